@@ -1,0 +1,208 @@
+/* ustrun.h -- C ABI of libustrun.so: the MI355X (gfx950) implementation of UST-RUN's
+ * 2D U-Net training hot path.
+ *
+ * The reference has no FFI: its boundary for this path is the torch.nn.Module API of
+ * networks/unet_model.py + utils/losses.py and the inline step in train.py.  Each entry point
+ * below names the reference code it replaces (file:line under the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, nonzero on error; ustrun_last_error() gives the
+ *     message (thread-local).  No exceptions cross the ABI, nothing is allocated or freed here,
+ *     no pointer is retained after return, nothing synchronises the device: all work is
+ *     enqueued on `stream` (a hipStream_t; NULL = default stream).
+ *   - all pointers are DEVICE pointers unless named host_*.
+ *   - activations inside the network are NHWC ("pixel-major": channels of one pixel are
+ *     contiguous); the network input and the logits are NCHW as in the reference.
+ *   - dtype selects the storage type of activations and packed weights: USTRUN_F32 (exact
+ *     f32 MFMA, the parity path) or USTRUN_BF16 (bf16 MFMA, f32 accumulate/statistics).
+ */
+#ifndef USTRUN_H
+#define USTRUN_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define USTRUN_VERSION 100
+enum { USTRUN_F32 = 0, USTRUN_BF16 = 1 };
+enum { USTRUN_LOSS_SOFTMAX = 0, USTRUN_LOSS_SIGMOID = 1 };
+
+typedef void* ustrun_stream_t;
+
+int ustrun_version(void);
+const char* ustrun_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Activation source of an implicit-GEMM loader.  The loader evaluates, per element,
+ *     a = relu?( x*scale[c] + shift[c] )   then, if pool, max over the 2x2 window,
+ * and zero outside the stored extent (conv zero padding, F.pad of the up path).  This is how
+ * BatchNorm+ReLU (unet_parts.py:17-18), MaxPool2d(2) (:34), F.pad (:62-63) and torch.cat (:67)
+ * are folded into the consumer's loads instead of being materialised.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ustrun_src {
+    const void*  ptr;        /* stored tensor                                              */
+    const float* scale;      /* per-channel affine, NULL = identity                        */
+    const float* shift;
+    int32_t C, H, W;         /* stored channels / extent                                   */
+    int64_t sN, sH, sW, sC;  /* element strides (NHWC: sC = 1; NCHW input: sW = 1)         */
+    int32_t relu;            /* max(0, .) after the affine                                 */
+    int32_t pool;            /* logical pixel (y,x) = max of stored (2y..2y+1, 2x..2x+1)   */
+    int32_t off_y, off_x;    /* logical (y,x) reads stored (y-off_y, x-off_x)              */
+} ustrun_src_t;
+
+/* ---- weight packing (done once per optimizer step) ---------------------------------------
+ * conv3x3: torch [Cout][Cin][3][3] -> fwd [9][Cin][Cout] and dgrad [9][Cout][Cin]
+ * convT2x2: torch [Cin][Cout][2][2] -> fwd [4][Cin][Cout] and dgrad [4][Cout][Cin]            */
+int ustrun_pack_conv3x3(const float* w, int Cout, int Cin, void* w_fwd, void* w_dgrad, int dtype, ustrun_stream_t s);
+int ustrun_pack_convT2x2(const float* w, int Cin, int Cout, void* w_fwd, void* w_dgrad, int dtype, ustrun_stream_t s);
+
+/* ---- conv3x3 (pad 1, no bias) forward: replaces nn.Conv2d at unet_parts.py:16,19 ----------
+ * y[N,H,W,Cout] (raw, pre-BN) = conv(loader(srcs)), plus per-channel partial sums of y and
+ * y*y per M-tile for the train-mode BatchNorm that follows: stat[mtile][2][Cout] (NULL = skip).
+ * ustrun_conv_mtiles gives the number of M-tiles the launch will use.                        */
+int ustrun_conv_mtiles(int N, int H, int W, int Cout);
+int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W,
+                       int Cout, void* y, float* stat, int dtype, ustrun_stream_t s);
+
+/* ---- train-mode BatchNorm statistics: replaces nn.BatchNorm2d at unet_parts.py:17,20 -------
+ * Reduces stat[mtiles][2][C] (fixed order, f64) to batch mean / biased variance, writes
+ * scale = gamma*rstd, shift = beta - mean*scale (consumed by the next loader), mean, rstd
+ * (kept for backward), and updates running_mean/var (unbiased var, momentum) and
+ * num_batches_tracked when update_running != 0.  eval mode: ustrun_bn_eval_affine.           */
+int ustrun_bn_finalize(const float* stat, int mtiles, int C, int64_t count, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, float momentum, float eps, int update_running,
+                       float* scale, float* shift, float* mean, float* rstd, ustrun_stream_t s);
+int ustrun_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, float* scale, float* shift,
+                          ustrun_stream_t s);
+/* materialise a = relu(y*scale+shift) as NHWC or NCHW f32 (block-level API and feature=True) */
+int ustrun_bn_relu_apply(const void* y, const float* scale, const float* shift, int64_t npix, int C,
+                         int HW, float* out, int out_nchw, int dtype, ustrun_stream_t s);
+
+/* ---- ConvTranspose2d(k=2,s=2,bias): replaces unet_parts.py:53 ------------------------------
+ * u[N,2H,2W,Cout] = convT(loader(src)) + bias.                                              */
+int ustrun_convT2x2_fwd(const ustrun_src_t* src, const void* w_fwd, const float* bias, int N, int H,
+                        int W, int Cout, void* u, int dtype, ustrun_stream_t s);
+
+/* ---- 1x1 head with bias: replaces OutConv, unet_parts.py:71-76 -----------------------------
+ * logits NCHW f32 [N,K,H,W] from y[N,H,W,C] through the loader affine (scale/shift/relu).    */
+int ustrun_head_fwd(const void* y, const float* scale, const float* shift, int64_t npix, int HW,
+                    int C, int K, const float* w, const float* bias, float* logits, int dtype,
+                    ustrun_stream_t s);
+/* backward: da[N,H,W,C] (grad wrt the activated input), dw[K][C], db[K] (accumulate != 0 adds) */
+int ustrun_head_bwd(const float* dlogits, const void* y, const float* scale, const float* shift,
+                    int64_t npix, int HW, int C, int K, const float* w, void* da, float* dw, float* db,
+                    int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s);
+
+/* ---- BatchNorm+ReLU (+MaxPool) backward: autograd of unet_parts.py:17-18,34 ------------------
+ * Inputs: da (grad wrt the activated output, may be NULL), dp (grad wrt the 2x2-pooled
+ * activated output, may be NULL; routed to the window arg-max recomputed from y), y and the
+ * forward scale/shift/mean/rstd.  Pass 1 (reduce) produces dgamma/dbeta and the coefficient
+ * table coef[3][C]; pass 2 (apply) writes dy = coef0*dz + coef1*y + coef2, dz = da_total*(a>0). */
+int64_t ustrun_bn_bwd_partials_bytes(int64_t npix, int C);
+int ustrun_bn_bwd_reduce(const void* da, const void* dp, const void* y, const float* scale,
+                         const float* shift, const float* mean, const float* rstd, const float* gamma,
+                         int N, int H, int W, int C, float* dgamma, float* dbeta, int accumulate,
+                         float* coef, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s);
+int ustrun_bn_bwd_apply(const void* da, const void* dp, const void* y, const float* scale,
+                        const float* shift, const float* coef, int N, int H, int W, int C, void* dy,
+                        int dtype, ustrun_stream_t s);
+
+/* ---- conv3x3 input gradient (autograd of unet_parts.py:16,19) ------------------------------
+ * da = conv3x3(dy, flipped/transposed w).  Channels [0,C0) go to da0[N,H,W,C0]; channels
+ * [C0,Cin) go to da1[N,H1,W1,Cin-C0] at pixel (y-o1y, x-o1x) (the cat/pad split of the up path). */
+int ustrun_conv3x3_dgrad(const void* dy, const void* w_dgrad, int N, int H, int W, int Cout, int Cin,
+                         void* da0, int C0, void* da1, int H1, int W1, int o1y, int o1x, int dtype,
+                         ustrun_stream_t s);
+/* ---- conv3x3 weight gradient: dw[Cout][Cin][3][3] (torch layout, f32) ---------------------- */
+int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int64_t npix);
+int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const void* dy, int N, int H, int W,
+                         int Cout, float* dw, int accumulate, float* partials, int64_t partials_bytes,
+                         int dtype, ustrun_stream_t s);
+/* ---- ConvTranspose2d backward --------------------------------------------------------------- */
+int ustrun_convT2x2_dgrad(const void* du, const void* w_dgrad, int N, int H, int W, int Cout, int Cin,
+                          void* da, int dtype, ustrun_stream_t s);
+int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, int N, int H, int W, int Cout,
+                          float* dw, float* db, int accumulate, float* partials, int64_t partials_bytes,
+                          int dtype, ustrun_stream_t s);
+
+/* ---- pseudo-labels: replaces train.py:648-667 (teacher) and :669-674 (student) ---------------
+ * softmax: conf,label = max(softmax(logits,1),1); mask = conf > th   (label int64, mask f32)
+ * sigmoid: label = (p >= .5); mask = (p >= th) + (p <= 1-th)          (both f32 [N,K,H,W])   */
+int ustrun_pseudo_label(const float* logits, int N, int K, int HW, float threshold, int mode,
+                        void* label, float* mask, ustrun_stream_t s);
+
+/* ---- ensemble/CutMix target algebra: replaces train.py:677-697 -------------------------------
+ * box[N,HW] in {0,1}; cut_label/cut_mask are already gathered by `choice`.                    */
+int ustrun_mix_targets(int mode, int N, int K, int HW, const float* box, const void* pl,
+                       const float* mask, const void* pl_w_ul, const float* mask_w_ul,
+                       const void* pl_w_lu, const float* mask_w_lu, const void* cut_label,
+                       const float* cut_mask, void* pl_w, float* mask_w, void* pl_ul, float* mask_ul,
+                       void* pl_lu, float* mask_lu, ustrun_stream_t s);
+/* CutMix image compositing out = a*(1-box) + b*box on NCHW images: train.py:644-646,688,691   */
+int ustrun_box_mix(const float* a, const float* b, const float* box, int N, int C, int HW,
+                   float* out, ustrun_stream_t s);
+
+/* ---- loss term ce + dice: replaces train.py:816-817,829-836 with utils/losses.py:236-268 -----
+ * softmax mode: target int64 [N,HW], mask f32 [N,HW] or NULL;  CE(reduction none)*mask, mean over
+ *   all pixels (Q5) + per-class masked Dice with the class-0 mask all ones (Q4).
+ * sigmoid mode: target/mask f32 [N,K,HW];  BCE-with-logits*mask mean + ONE global masked Dice.
+ * fwd writes out[0]=ce, out[1]=dice, out[2..] = the reduced sums the backward needs
+ * (USTRUN_LOSS_NSUMS(K) floats in all).  bwd writes dlogits = gscale * d(ce+dice)/dlogits.    */
+#define USTRUN_LOSS_NSUMS(K) (4 + 3 * (K))
+int64_t ustrun_loss_partials_bytes(int N, int K, int HW);
+int ustrun_seg_loss_fwd(const float* logits, const void* target, const float* mask, int N, int K,
+                        int HW, int mode, float* out, float* partials, int64_t partials_bytes,
+                        ustrun_stream_t s);
+int ustrun_seg_loss_bwd(const float* logits, const void* target, const float* mask, int N, int K,
+                        int HW, int mode, const float* sums, const float* gscale_dev, float gscale,
+                        float ce_weight, float dice_weight, float* dlogits, ustrun_stream_t s);
+
+/* ---- per-sample binary overlap counts for the numpy Dice of utils/metrics.py:114-146 ---------
+ * counts[n][c] = {|pred|, |gt|, |pred & gt|} with pred/gt binarised as (x == cls[c]) or (x != 0). */
+int ustrun_dice_counts(const void* pred, const void* gt, int pred_is_i64, int gt_is_i64, int N,
+                       int K, int HW, int by_class, int32_t* counts, ustrun_stream_t s);
+
+/* ---- SGD(momentum, weight decay) + EMA teacher over flat buffers: train.py:512,848,87-93 ------
+ * g += wd*p; v = first ? g : mu*v + g; p -= lr*v; t = alpha*t + (1-alpha)*p                    */
+int ustrun_sgd_ema(float* p, const float* g, float* v, float* t, int64_t n, float lr, float mu,
+                   float wd, int first, float alpha, float grad_scale, ustrun_stream_t s);
+
+/* ---- whole-network plan: replaces UNet.forward / autograd backward, unet_model.py:25-39 -------
+ * The plan is a host-side description (shapes + parameter pointers); the caller owns all device
+ * memory: params, packed-weight arena, forward workspace (kept for backward) and scratch.      */
+typedef struct ustrun_unet_desc {
+    int32_t N, C, H, W, K;       /* batch, input channels, extent, classes                    */
+    int32_t base;                /* 64 in the reference (unet_model.py:13)                    */
+    int32_t dtype;               /* storage dtype of activations                              */
+    int32_t train;               /* batch statistics (1) or running statistics (0)            */
+    int32_t update_running;      /* update BN running buffers (train mode)                    */
+    float   momentum, eps;
+    /* parameters/buffers, torch layouts, in state_dict order:                 */
+    const float* conv_w[18];     /* inc.0, inc.3, down1..4 (.0,.3), up1..4.conv (.0,.3)        */
+    const float* bn_w[18];  const float* bn_b[18];
+    float* bn_rm[18];       float* bn_rv[18];   int64_t* bn_nbt[18];
+    const float* up_w[4];   const float* up_b[4];
+    const float* head_w;    const float* head_b;
+    void* packed;                /* packed-weight arena, ustrun_unet_packed_bytes()           */
+} ustrun_unet_desc_t;
+
+int64_t ustrun_unet_packed_bytes(const ustrun_unet_desc_t* d);
+int64_t ustrun_unet_fwd_workspace_bytes(const ustrun_unet_desc_t* d);
+int64_t ustrun_unet_bwd_scratch_bytes(const ustrun_unet_desc_t* d);
+int ustrun_unet_pack(const ustrun_unet_desc_t* d, ustrun_stream_t s);
+/* x NCHW f32 [N,C,H,W] -> logits NCHW f32 [N,K,H,W]; feat (optional) NCHW f32 [N,base,H,W]  */
+int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, float* logits, float* feat,
+                        void* workspace, ustrun_stream_t s);
+/* grads[] follow the parameter order of the reference's model.parameters() (64 tensors for
+ * bilinear=False): accumulate != 0 adds into them.                                           */
+int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x, const float* dlogits,
+                         void* workspace, void* scratch, float* const* grads, int accumulate,
+                         ustrun_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USTRUN_H */

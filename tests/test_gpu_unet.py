@@ -1,0 +1,115 @@
+"""GPU parity: the HIP U-Net (through the C ABI) against the CPU oracle and the reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import unet_ref as U
+
+pytestmark = pytest.mark.gpu
+
+
+def build_model(sd, c, k, base=64):
+    from networks.unet_model import UNet
+    m = UNet(n_channels=c, n_classes=k, base_channels=base)
+    m.load_state_dict({kk: v.detach().clone() for kk, v in sd.items()})
+    return m.cuda()
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def run_pair(c, k, n, h, w, base, seed, train=True):
+    torch.manual_seed(seed)
+    sd = U.make_state_dict(c, k, base=base)
+    # non-trivial BN affine so that gamma/beta gradients and negative scales are exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    for key in sd:
+        if key.endswith(("1.weight", "4.weight")) and sd[key].dim() == 1:
+            sd[key] = 1 + 0.5 * torch.randn(sd[key].shape, generator=g)
+        if key.endswith(("1.bias", "4.bias")) and sd[key].dim() == 1 and "double_conv" in key:
+            sd[key] = 0.2 * torch.randn(sd[key].shape, generator=g)
+    x = torch.randn(n, c, h, w, generator=g)
+    model = build_model(sd, c, k, base)
+    model.train(train)
+    ref_sd = U.clone_sd(sd, requires_grad=True)
+    ref_logits = U.unet_forward(x, ref_sd, train=train)
+    logits = model(x.cuda())
+    return model, logits, ref_sd, ref_logits
+
+
+@pytest.mark.parametrize("c,k,n,h,w,base", [(3, 2, 2, 32, 32, 8), (1, 4, 3, 48, 32, 8), (3, 2, 1, 50, 38, 8),
+                                            (1, 2, 2, 32, 32, 64)])
+def test_forward_backward_vs_oracle(c, k, n, h, w, base):
+    model, logits, ref_sd, ref_logits = run_pair(c, k, n, h, w, base, seed=5)
+    assert rel_l2(logits.cpu(), ref_logits.detach()) < 1e-4
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref_logits.detach().numpy(), rtol=1e-3, atol=2e-4)
+    # BN running stats were updated in place by the kernels
+    msd = model.state_dict()
+    for key in ref_sd:
+        if "running" in key or "num_batches" in key:
+            np.testing.assert_allclose(msd[key].cpu().numpy(), ref_sd[key].numpy(), rtol=1e-4, atol=1e-5, err_msg=key)
+    # gradients of loss = mean(logits^2)
+    logits.square().mean().backward()
+    ref_logits.square().mean().backward()
+    for (name, p), key in zip(model.named_parameters(), U.param_keys(ref_sd)):
+        assert name == key
+        rg = ref_sd[key].grad
+        err = rel_l2(p.grad.cpu(), rg)
+        assert err < 2e-3, (key, err, float(rg.norm()))
+
+
+def test_eval_mode_uses_running_stats():
+    model, logits, ref_sd, ref_logits = run_pair(3, 2, 2, 32, 32, 8, seed=9, train=False)
+    assert rel_l2(logits.cpu(), ref_logits.detach()) < 1e-4
+
+
+def test_feature_output():
+    model, _, ref_sd, _ = run_pair(3, 2, 2, 32, 32, 8, seed=3)
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 32, 32)
+    with torch.no_grad():
+        lg, ft = model(x.cuda(), feature=True)
+        rl, rf = U.unet_forward(x, ref_sd, train=True, feature=True)
+    assert rel_l2(lg.cpu(), rl) < 1e-4 and rel_l2(ft.cpu(), rf) < 1e-4
+
+
+def test_reference_golden_small_spatial():
+    """Full-width UNet(1,2) on 2x1x32x32 against outputs captured from the reference itself."""
+    g = load_golden("g2_unet_1_2_n2_32")
+    torch.manual_seed(int(g["model_seed"]))
+    sd = U.make_state_dict(1, 2)
+    model = build_model(sd, 1, 2)
+    model.train()
+    logits = model(torch.from_numpy(g["x"]).cuda())
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], rtol=1e-3, atol=1e-4)
+    logits.square().mean().backward()
+    norms = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["g3_unet_3_2_n4_256", "g3_unet_1_4_n2_288"])
+def test_reference_golden_full_size(name):
+    g = load_golden(name)
+    n, c, h, _, k = [int(v) for v in g["shape"]]
+    torch.manual_seed(int(g["model_seed"]))
+    sd = U.make_state_dict(c, k)
+    gen = torch.Generator().manual_seed(int(g["input_seed"]))
+    x = torch.randint(0, 256, (n, c, h, h), generator=gen).float() / 127.5 - 1
+    model = build_model(sd, c, k)
+    model.train()
+    with torch.no_grad():
+        logits = model(x.cuda()).cpu()
+    flat = logits.flatten()
+    idx = torch.from_numpy(g["sample_idx"])
+    np.testing.assert_allclose(flat[idx].numpy(), g["sample_val"], rtol=1e-3, atol=1e-4)
+    assert abs(float(flat.double().norm()) - float(g["logit_l2"])) <= 1e-4 * float(g["logit_l2"])
+
+
+def test_cpu_tensor_is_refused():
+    from networks.unet_model import UNet
+    m = UNet(1, 2, base_channels=8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 32, 32))

@@ -1,0 +1,319 @@
+// bn.hip -- train-mode BatchNorm2d statistics, and the BatchNorm+ReLU(+MaxPool) backward passes.
+// All kernels here are HBM-bound streams over NHWC activations (4 channels = 16 B per lane) with
+// fixed-order two-level reductions (block partials, then an f64 finalize) so results are
+// reproducible run to run.
+#include "common.h"
+
+namespace ustrun {
+namespace {
+
+// ---- forward statistics -------------------------------------------------------------------
+// block = 32 channels x 8 row lanes; stat[row][2][C] -> mean, biased var -> scale/shift
+__global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* rm, float* rv, int64_t* nbt, float momentum, float eps, int update,
+                                   float* scale, float* shift, float* mean, float* rstd) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = rg; r < rows; r += 8) {
+            s1 += (double)stat[((long)r * 2 + 0) * C + c];
+            s2 += (double)stat[((long)r * 2 + 1) * C + c];
+        }
+    red[0][rg][cl] = s1; red[1][rg][cl] = s2;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+        const double m = s1 / count;
+        double var = s2 / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const double rs = 1.0 / sqrt(var + (double)eps);
+        const float sc = (float)((double)gamma[c] * rs);
+        scale[c] = sc;
+        shift[c] = (float)((double)beta[c] - m * (double)gamma[c] * rs);
+        mean[c] = (float)m; rstd[c] = (float)rs;
+        if (update) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rm[c] = (float)((1.0 - momentum) * (double)rm[c] + momentum * m);
+            rv[c] = (float)((1.0 - momentum) * (double)rv[c] + momentum * unb);
+        }
+    }
+    if (update && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+__global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float eps, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = gamma[c] * (1.0f / sqrtf(rv[c] + eps));
+        scale[c] = sc; shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+
+// a = relu(y*scale+shift) materialised (NHWC -> NHWC or NCHW)
+__global__ void bn_relu_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, long npix, int C, int HW,
+                                     float* __restrict__ out, int nchw) {
+    const long total = npix * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long p = e / C; const int c = (int)(e - p * C);
+        float v = y[e];
+        if (scale) v = fmaxf(v * scale[c] + shift[c], 0.f);
+        if (nchw) { const long n = p / HW; const long hw = p - n * HW; out[(n * C + c) * HW + hw] = v; }
+        else out[e] = v;
+    }
+}
+
+// ---- backward -------------------------------------------------------------------------------
+// One "window" = one pixel (POOL = false) or one 2x2 pooling window (POOL = true).  For each
+// element: a = relu(s*y+b); da_total = da + (dp routed to the window's first arg-max of a);
+// dz = da_total * (a > 0).
+template <bool POOL>
+struct Win {
+    static constexpr int NPX = POOL ? 4 : 1;
+};
+
+template <bool POOL>
+__device__ __forceinline__ void window_dz(const float* da, const float* __restrict__ dp,
+                                          const float* __restrict__ y, f32x4 sc, f32x4 sh, int n, int wy, int wx,
+                                          int H, int W, int C, int c, f32x4 (&yv)[Win<POOL>::NPX],
+                                          f32x4 (&dz)[Win<POOL>::NPX], bool (&ok)[Win<POOL>::NPX]) {
+    constexpr int NPX = Win<POOL>::NPX;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 av[NPX];
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) {
+        const int py = POOL ? 2 * wy + (q >> 1) : wy, px = POOL ? 2 * wx + (q & 1) : wx;
+        ok[q] = py < H && px < W;
+        yv[q] = zero; dz[q] = zero; av[q] = zero;
+        if (ok[q]) {
+            const long off = (((long)n * H + py) * W + px) * C + c;
+            yv[q] = *(const f32x4*)(y + off);
+            av[q] = yv[q] * sc + sh;
+            if (da) dz[q] = *(const f32x4*)(da + off);
+        }
+    }
+    if (POOL) {
+        const int PH = H / 2, PW = W / 2;
+        if (dp && wy < PH && wx < PW) {
+            const f32x4 g = *(const f32x4*)(dp + (((long)n * PH + wy) * PW + wx) * C + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int best = 0; float bv = fmaxf(av[0][j], 0.f);
+#pragma unroll
+                for (int q = 1; q < NPX; ++q) { const float t = fmaxf(av[q][j], 0.f); if (t > bv) { bv = t; best = q; } }
+#pragma unroll
+                for (int q = 0; q < NPX; ++q) if (q == best) dz[q][j] += g[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NPX; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (!(av[q][j] > 0.f)) dz[q][j] = 0.f;
+}
+
+// grid-stride over windows; thread = (channel quad, window lane).  partials[block][2][C]
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ dp,
+                                                           const float* __restrict__ y, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int N, int H, int W, int C,
+                                                           int G, float* __restrict__ partials) {
+    constexpr int NPX = Win<POOL>::NPX;
+    __shared__ f32x4 red[2][256];
+    const int C4 = C / 4, PL = 256 / G;
+    const int cq0 = threadIdx.x % G, pl = threadIdx.x / G;
+    const int WH = POOL ? (H + 1) / 2 : H, WW = POOL ? (W + 1) / 2 : W;
+    const long nwin = (long)N * WH * WW;
+    for (int cb = 0; cb < C4; cb += G) {      // uniform trip count: the body holds barriers
+        const int cq = cb + cq0;
+        const bool active = cq < C4;
+        const int c = active ? cq * 4 : 0;
+        const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (active)
+            for (long w = (long)blockIdx.x * PL + pl; w < nwin; w += (long)gridDim.x * PL) {
+                const int n = (int)(w / (WH * WW));
+                const int rem = (int)(w - (long)n * WH * WW);
+                const int wy = rem / WW, wx = rem - wy * WW;
+                f32x4 yv[NPX], dz[NPX]; bool ok[NPX];
+                window_dz<POOL>(da, dp, y, sc, sh, n, wy, wx, H, W, C, c, yv, dz, ok);
+#pragma unroll
+                for (int q = 0; q < NPX; ++q) { s1 += dz[q]; s2 += dz[q] * yv[q]; }
+            }
+        red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+        __syncthreads();
+        if (pl == 0 && active) {
+            for (int k = 1; k < PL; ++k) { s1 += red[0][k * G + cq0]; s2 += red[1][k * G + cq0]; }
+            *(f32x4*)(partials + ((long)blockIdx.x * 2 + 0) * C + c) = s1;
+            *(f32x4*)(partials + ((long)blockIdx.x * 2 + 1) * C + c) = s2;
+        }
+        __syncthreads();
+    }
+}
+
+// partials[rows][2][C] -> dgamma, dbeta, coef[3][C]
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int rows, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, float* dgamma, float* dbeta, int accumulate,
+                                       float* coef) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = rg; r < rows; r += 8) {
+            s1 += (double)partials[((long)r * 2 + 0) * C + c];
+            s2 += (double)partials[((long)r * 2 + 1) * C + c];
+        }
+    red[0][rg][cl] = s1; red[1][rg][cl] = s2;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+        const double mu = mean[c], rs = rstd[c], g = gamma[c];
+        const double dbe = s1, dga = rs * (s2 - mu * s1);
+        const double c0 = g * rs, m1 = dbe / count, m2 = dga / count;
+        const double c1 = -c0 * m2 * rs, c2 = -c0 * m1 - c1 * mu;
+        coef[c] = (float)c0; coef[C + c] = (float)c1; coef[2 * C + c] = (float)c2;
+        if (dgamma) {
+            dgamma[c] = accumulate ? dgamma[c] + (float)dga : (float)dga;
+            dbeta[c] = accumulate ? dbeta[c] + (float)dbe : (float)dbe;
+        }
+    }
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* da, const float* __restrict__ dp,
+                                                          const float* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ coef,
+                                                          int N, int H, int W, int C, int G, float* dy) {
+    constexpr int NPX = Win<POOL>::NPX;
+    const int C4 = C / 4, PL = 256 / G;
+    const int cq0 = threadIdx.x % G, pl = threadIdx.x / G;
+    const int WH = POOL ? (H + 1) / 2 : H, WW = POOL ? (W + 1) / 2 : W;
+    const long nwin = (long)N * WH * WW;
+    for (int cq = cq0; cq < C4; cq += G) {
+        const int c = cq * 4;
+        const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
+        const f32x4 k0 = *(const f32x4*)(coef + c), k1 = *(const f32x4*)(coef + C + c), k2 = *(const f32x4*)(coef + 2 * C + c);
+        for (long w = (long)blockIdx.x * PL + pl; w < nwin; w += (long)gridDim.x * PL) {
+            const int n = (int)(w / (WH * WW));
+            const int rem = (int)(w - (long)n * WH * WW);
+            const int wy = rem / WW, wx = rem - wy * WW;
+            f32x4 yv[NPX], dz[NPX]; bool ok[NPX];
+            window_dz<POOL>(da, dp, y, sc, sh, n, wy, wx, H, W, C, c, yv, dz, ok);
+#pragma unroll
+            for (int q = 0; q < NPX; ++q) {
+                if (!ok[q]) continue;
+                const int py = POOL ? 2 * wy + (q >> 1) : wy, px = POOL ? 2 * wx + (q & 1) : wx;
+                *(f32x4*)(dy + (((long)n * H + py) * W + px) * C + c) = k0 * dz[q] + k1 * yv[q] + k2;
+            }
+        }
+    }
+}
+
+int group_size(int C4) { int g = 1; while (g < C4 && g < 256) g <<= 1; return g; }
+
+int reduce_blocks(long nwin, int G) {
+    const int PL = 256 / G;
+    long b = (nwin + (long)PL * 8 - 1) / ((long)PL * 8);   // >= 8 windows per thread
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+}  // namespace ustrun
+
+using namespace ustrun;
+
+extern "C" int ustrun_bn_finalize(const float* stat, int mtiles, int C, int64_t count, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var,
+                                  int64_t* num_batches_tracked, float momentum, float eps, int update_running,
+                                  float* scale, float* shift, float* mean, float* rstd, ustrun_stream_t s) {
+    USTRUN_CHECK(stat && gamma && beta && scale && shift && mean && rstd, "bn_finalize: null pointer");
+    USTRUN_CHECK(!update_running || (running_mean && running_var), "bn_finalize: running buffers missing");
+    USTRUN_CHECK(mtiles > 0 && C > 0 && count > 0, "bn_finalize: empty");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)s, stat, mtiles, C,
+                       (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                       update_running, scale, shift, mean, rstd);
+    USTRUN_LAUNCH_CHECK("bn_finalize");
+    return 0;
+}
+
+extern "C" int ustrun_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                                     const float* running_var, float eps, float* scale, float* shift,
+                                     ustrun_stream_t s) {
+    USTRUN_CHECK(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_eval_affine: bad args");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)s, C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    USTRUN_LAUNCH_CHECK("bn_eval_affine");
+    return 0;
+}
+
+extern "C" int ustrun_bn_relu_apply(const void* y, const float* scale, const float* shift, int64_t npix, int C,
+                                    int HW, float* out, int out_nchw, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(dtype == USTRUN_F32, "bn_relu_apply: dtype %d not built", dtype);
+    USTRUN_CHECK(y && out && npix > 0 && C > 0 && HW > 0, "bn_relu_apply: bad args");
+    int blocks = cdiv(npix * C, 256 * 4);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)y, scale,
+                       shift, (long)npix, C, HW, out, out_nchw);
+    USTRUN_LAUNCH_CHECK("bn_relu_apply");
+    return 0;
+}
+
+extern "C" int64_t ustrun_bn_bwd_partials_bytes(int64_t npix, int C) {
+    (void)npix;
+    return (int64_t)1024 * 2 * C * sizeof(float);
+}
+
+extern "C" int ustrun_bn_bwd_reduce(const void* da, const void* dp, const void* y, const float* scale,
+                                    const float* shift, const float* mean, const float* rstd, const float* gamma,
+                                    int N, int H, int W, int C, float* dgamma, float* dbeta, int accumulate,
+                                    float* coef, float* partials, int64_t partials_bytes, int dtype,
+                                    ustrun_stream_t s) {
+    USTRUN_CHECK(dtype == USTRUN_F32, "bn_bwd_reduce: dtype %d not built", dtype);
+    USTRUN_CHECK((da || dp) && y && scale && shift && mean && rstd && gamma && coef && partials, "bn_bwd_reduce: null pointer");
+    USTRUN_CHECK(C % 4 == 0 && C > 0, "bn_bwd_reduce: C=%d must be a multiple of 4", C);
+    USTRUN_CHECK(partials_bytes >= ustrun_bn_bwd_partials_bytes((int64_t)N * H * W, C), "bn_bwd_reduce: partials too small");
+    const int G = group_size(C / 4);
+    const bool pool = dp != nullptr;
+    const long nwin = pool ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long)N * H * W;
+    const int blocks = reduce_blocks(nwin, G);
+    if (pool)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)da,
+                           (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)da,
+                           (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials);
+    USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)s, partials, blocks, C,
+                       (double)N * H * W, gamma, mean, rstd, dgamma, dbeta, accumulate, coef);
+    USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
+    return 0;
+}
+
+extern "C" int ustrun_bn_bwd_apply(const void* da, const void* dp, const void* y, const float* scale,
+                                   const float* shift, const float* coef, int N, int H, int W, int C, void* dy,
+                                   int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(dtype == USTRUN_F32, "bn_bwd_apply: dtype %d not built", dtype);
+    USTRUN_CHECK((da || dp) && y && scale && shift && coef && dy, "bn_bwd_apply: null pointer");
+    USTRUN_CHECK(C % 4 == 0 && C > 0, "bn_bwd_apply: C=%d must be a multiple of 4", C);
+    const int G = group_size(C / 4);
+    const bool pool = dp != nullptr;
+    const long nwin = pool ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long)N * H * W;
+    const int PL = 256 / G;
+    long blocks = (nwin + (long)PL * 4 - 1) / ((long)PL * 4);
+    if (blocks > 4096) blocks = 4096;
+    if (pool)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)da,
+                           (const float*)dp, (const float*)y, scale, shift, coef, N, H, W, C, G, (float*)dy);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)da,
+                           (const float*)dp, (const float*)y, scale, shift, coef, N, H, W, C, G, (float*)dy);
+    USTRUN_LAUNCH_CHECK("bn_bwd_apply");
+    return 0;
+}

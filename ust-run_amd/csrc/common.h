@@ -1,0 +1,106 @@
+// Shared host/device helpers for libustrun (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ustrun.h"
+
+namespace ustrun {
+
+void set_error(const char* fmt, ...);
+
+#define USTRUN_CHECK(cond, ...)                      \
+    do {                                             \
+        if (!(cond)) {                               \
+            ::ustrun::set_error(__VA_ARGS__);        \
+            return 1;                                \
+        }                                            \
+    } while (0)
+
+#define USTRUN_LAUNCH_CHECK(name)                                                   \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            ::ustrun::set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return 2;                                                               \
+        }                                                                           \
+    } while (0)
+
+#define USTRUN_TRY(expr)          \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_) return rc_;      \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device-side view of an activation source (ustrun_src_t + derived logical extent) ----
+struct SrcDev {
+    const float* ptr;
+    const float* scale;
+    const float* shift;
+    int C, H, W;
+    long sN, sH, sW, sC;
+    int relu, pool, off_y, off_x;
+    int LH, LW;  // logical extent (H/2 when pooled)
+};
+
+static inline SrcDev make_src(const ustrun_src_t& s) {
+    SrcDev d;
+    d.ptr = (const float*)s.ptr; d.scale = s.scale; d.shift = s.shift;
+    d.C = s.C; d.H = s.H; d.W = s.W;
+    d.sN = s.sN; d.sH = s.sH; d.sW = s.sW; d.sC = s.sC;
+    d.relu = s.relu; d.pool = s.pool; d.off_y = s.off_y; d.off_x = s.off_x;
+    d.LH = s.pool ? s.H / 2 : s.H;
+    d.LW = s.pool ? s.W / 2 : s.W;
+    return d;
+}
+
+// ---- generic implicit GEMM:  out[map_out(m)][n] = sum_seg sum_c A_seg[map_in(m,seg)][c] * W[seg][c][n]
+struct IgemmArgs {
+    SrcDev src[2];
+    int nsrc, Cin;
+    const float* W;          // [nslice][Cin][Cout]
+    int Cout;
+    int N, Hb, Wb, M;        // base grid; M = N*Hb*Wb
+    int s_in;                // input pixel = base*s_in + (dy,dx)
+    int nseg, segw, d0, dstep; // segment s: (dy,dx) = d0 + (s/segw, s%segw)*dstep, weight slice s
+    int nz;                  // grid.z: output parity classes z: out offset (z/2, z%2), weight slice z
+    int s_out;               // out pixel = base*s_out + (z/2, z%2)
+    float* out0; float* out1;
+    int C0;                  // channels [0,C0) -> out0, [C0,Cout) -> out1
+    int Ho, Wo;              // out0 extent
+    int H1, W1, o1y, o1x;    // out1 extent / offset
+    const float* bias;
+    float* stat;             // [mtiles][2][Cout] or null
+};
+int igemm_mtiles(int64_t M, int Cout);
+int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st);
+
+// ---- generic "TN" weight-gradient GEMM: dW[seg][ci][co] = sum_p A_seg[p][ci] * dY_seg[p][co]
+struct WgradArgs {
+    SrcDev src[2];
+    int nsrc, Cin;
+    const float* dy; int Cout;
+    int N, Hb, Wb; long M;   // base grid = pixels summed over
+    int nseg, segw, d0, astep; // A side: in pixel = base + d0 + (s/segw, s%segw)*astep
+    int dy_s;                  // dY pixel = base*dy_s + (dy_s == 2 ? (s/2, s%2) : (0,0))
+    int dyH, dyW;              // dY extent
+    float* partials;           // [ksplit][nseg][Cin][Cout]
+    int ksplit; long kchunk;   // block-level K splits; pixels per split (multiple of 32)
+};
+// slabs = total partial slabs written (ksplit x in-block K waves)
+int wgrad_plan(int nseg, int Cin, int Cout, int64_t M, int* ksplit, long* kchunk, int* slabs);
+int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);
+// reduce partial slabs [ksplit][rows] -> out (permuted): layout 0: conv3x3 torch [Cout][Cin][3][3];
+// layout 1: convT torch [Cin][Cout][2][2]; layout 2: plain [rows]
+int reduce_partials(const float* partials, int ksplit, int nseg, int Cin, int Cout, float* out,
+                    int layout, int accumulate, hipStream_t st);
+
+int reduce_rows(const float* part, int nslab, long stride, long offset, int count, float* out, int accumulate,
+                hipStream_t st);
+
+}  // namespace ustrun

@@ -1,0 +1,178 @@
+// head.hip -- the 1x1 classification head (OutConv) forward/backward.  AI ~ 1 flop/B: HBM-bound,
+// so it is a stream over the 64-channel NHWC feature map with the producer's BatchNorm+ReLU
+// applied on load; LPP lanes share one pixel (16 B of channels each, one coalesced line per pixel)
+// and combine their partial dot products with wavefront shuffles.  Logits are written NCHW.
+#include "common.h"
+
+namespace ustrun {
+namespace {
+
+constexpr int KMAX = 8;
+
+__device__ __forceinline__ f32x4 act4(f32x4 v, const float* scale, const float* shift, int c) {
+    if (scale) {
+        v = v * *(const f32x4*)(scale + c) + *(const f32x4*)(shift + c);
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, long npix, int HW, int C, int K,
+                                                      int LPP, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ logits) {
+    const int C4 = C / 4, PPB = 256 / LPP;
+    const int cq0 = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    for (long p0 = (long)blockIdx.x * PPB; p0 < npix; p0 += (long)gridDim.x * PPB) {
+        const long p = p0 + pl;
+        float acc[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+        if (p < npix)
+            for (int cq = cq0; cq < C4; cq += LPP) {
+                const f32x4 a = act4(*(const f32x4*)(y + p * C + cq * 4), scale, shift, cq * 4);
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K) {
+                        const f32x4 wk = *(const f32x4*)(w + k * C + cq * 4);
+                        acc[k] += a[0] * wk[0] + a[1] * wk[1] + a[2] * wk[2] + a[3] * wk[3];
+                    }
+            }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K)
+                for (int o = LPP >> 1; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+        if (cq0 == 0 && p < npix) {
+            const long n = p / HW, hw = p - n * HW;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) logits[(n * K + k) * HW + hw] = acc[k] + bias[k];
+        }
+    }
+}
+
+// da[p][c] = sum_k dl[k][p] w[k][c];  block partials of dW[k][c] = sum_p dl[k][p] a[p][c], db[k] = sum_p dl[k][p]
+// partials[block][K*C + K]
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ y,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      long npix, int HW, int C, int K, int LPP,
+                                                      const float* __restrict__ w, float* __restrict__ da,
+                                                      float* __restrict__ partials) {
+    extern __shared__ float red[];   // [PPB][K*C + K] would be large; reduce per k instead (below)
+    const int C4 = C / 4, PPB = 256 / LPP;
+    const int cq0 = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    const int row = K * C + K;
+    float* out = partials + (long)blockIdx.x * row;
+    for (int cb = 0; cb < C4; cb += LPP) {          // uniform trip count (barriers inside)
+        const int cq = cb + cq0;
+        const bool active = cq < C4;
+        const int c = active ? cq * 4 : 0;
+        f32x4 dwp[KMAX]; float dbp[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { dwp[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; dbp[k] = 0.f; }
+        f32x4 wk[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) wk[k] = (k < K) ? *(const f32x4*)(w + k * C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (active)
+            for (long p = (long)blockIdx.x * PPB + pl; p < npix; p += (long)gridDim.x * PPB) {
+                const long n = p / HW, hw = p - n * HW;
+                const f32x4 a = act4(*(const f32x4*)(y + p * C + c), scale, shift, c);
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K) {
+                        const float d = dl[(n * K + k) * HW + hw];
+                        g += d * wk[k];
+                        dwp[k] += d * a;
+                        dbp[k] += d;
+                    }
+                *(f32x4*)(da + p * C + c) = g;
+            }
+        // fixed-order block reduction over the PPB pixel lanes, one class at a time
+        for (int k = 0; k < K; ++k) {
+            f32x4 v = dwp[0]; float b = dbp[0];
+#pragma unroll
+            for (int kk = 1; kk < KMAX; ++kk) if (kk == k) { v = dwp[kk]; b = dbp[kk]; }
+            ((f32x4*)red)[threadIdx.x] = v;
+            red[1024 + threadIdx.x] = b;
+            __syncthreads();
+            if (pl == 0 && active) {
+                for (int q = 1; q < PPB; ++q) v += ((f32x4*)red)[q * LPP + cq0];
+                *(f32x4*)(out + k * C + c) = v;
+                if (cb == 0 && cq0 == 0) {
+                    for (int q = 1; q < PPB; ++q) b += red[1024 + q * LPP];
+                    out[K * C + k] = b;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void reduce_rows_kernel(const float* __restrict__ part, int nslab, long stride, long offset, int count,
+                                   float* __restrict__ out, int accumulate) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    double v = 0.0;
+    for (int k = 0; k < nslab; ++k) v += (double)part[(long)k * stride + offset + e];
+    out[e] = accumulate ? out[e] + (float)v : (float)v;
+}
+
+int lanes_per_pixel(int C4) { int g = 1; while (g < C4 && g < 64) g <<= 1; return g; }
+
+}  // namespace
+
+int reduce_rows(const float* part, int nslab, long stride, long offset, int count, float* out, int accumulate,
+                hipStream_t st) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(count, 256)), dim3(256), 0, st, part, nslab, stride, offset, count,
+                       out, accumulate);
+    USTRUN_LAUNCH_CHECK("reduce_rows");
+    return 0;
+}
+
+}  // namespace ustrun
+
+using namespace ustrun;
+
+static int head_blocks(int64_t npix, int LPP) {
+    const int PPB = 256 / LPP;
+    long b = (npix + (long)PPB * 16 - 1) / ((long)PPB * 16);
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* shift, int64_t npix, int HW, int C,
+                               int K, const float* w, const float* bias, float* logits, int dtype,
+                               ustrun_stream_t s) {
+    USTRUN_CHECK(dtype == USTRUN_F32, "head_fwd: dtype %d not built", dtype);
+    USTRUN_CHECK(y && w && bias && logits, "head_fwd: null pointer");
+    USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_fwd: C=%d K=%d unsupported", C, K);
+    USTRUN_CHECK(npix > 0 && HW > 0 && npix % HW == 0, "head_fwd: bad extent");
+    const int LPP = lanes_per_pixel(C / 4);
+    long blocks = (npix + (256 / LPP) * 4 - 1) / ((256 / LPP) * 4);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)y, scale, shift,
+                       (long)npix, HW, C, K, LPP, w, bias, logits);
+    USTRUN_LAUNCH_CHECK("head_fwd");
+    return 0;
+}
+
+extern "C" int ustrun_head_bwd(const float* dlogits, const void* y, const float* scale, const float* shift,
+                               int64_t npix, int HW, int C, int K, const float* w, void* da, float* dw, float* db,
+                               int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(dtype == USTRUN_F32, "head_bwd: dtype %d not built", dtype);
+    USTRUN_CHECK(dlogits && y && w && da && dw && db && partials, "head_bwd: null pointer");
+    USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_bwd: C=%d K=%d unsupported", C, K);
+    const int LPP = lanes_per_pixel(C / 4);
+    const int blocks = head_blocks(npix, LPP);
+    const long row = (long)K * C + K;
+    USTRUN_CHECK(partials_bytes >= (int64_t)(1024 * row * 4), "head_bwd: partials too small (%lld < %lld)",
+                 (long long)partials_bytes, (long long)(1024 * row * 4));
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), (1024 + 256) * sizeof(float), (hipStream_t)s, dlogits,
+                       (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials);
+    USTRUN_LAUNCH_CHECK("head_bwd");
+    USTRUN_TRY(reduce_rows(partials, blocks, row, 0, K * C, dw, accumulate, (hipStream_t)s));
+    USTRUN_TRY(reduce_rows(partials, blocks, row, (long)K * C, K, db, accumulate, (hipStream_t)s));
+    return 0;
+}

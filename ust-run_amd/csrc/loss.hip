@@ -1,0 +1,397 @@
+// loss.hip -- the `ce + dice` term of the step, forward (reductions) and backward (dlogits), and
+// the pseudo-label / target-mixing streams.  Everything is HBM-bound: one lane per pixel reads the
+// K logit planes (NCHW: coalesced per plane), reductions go wavefront shuffle -> LDS -> one
+// partial row per block -> single-block f64 finalize (fixed order: reproducible).
+#include "common.h"
+
+namespace ustrun {
+namespace {
+
+constexpr int KMAX = 8;
+constexpr int NS = 1 + 3 * KMAX;   // per-thread running sums: ce, I[k], Z[k], Y[k]
+constexpr float SMOOTH = 1e-10f;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// softmax mode: target int64 [N,HW], mask f32 [N,HW] or null.  sigmoid mode: target/mask f32 [N,K,HW].
+__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restrict__ logits, const void* __restrict__ target,
+                                                          const float* __restrict__ mask, int N, int K, int HW, int mode,
+                                                          float* __restrict__ partials) {
+    __shared__ float red[4][NS];
+    float acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] = 0.f;
+    const long npix = (long)N * HW;
+    if (mode == USTRUN_LOSS_SOFTMAX) {
+        const long long* tgt = (const long long*)target;
+        for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+            const long n = p / HW, hw = p - n * HW;
+            float l[KMAX], mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (k < K) { l[k] = logits[(n * K + k) * HW + hw]; mx = fmaxf(mx, l[k]); }
+            float se = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (k < K) { l[k] = expf(l[k] - mx); se += l[k]; }
+            const int t = (int)tgt[p];
+            const float m = mask ? mask[p] : 1.f;
+            const float m1 = mask ? (m == 1.f ? 1.f : 0.f) : 1.f;
+            const float inv = 1.f / se;
+            float lt = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) {
+                    const float pk = l[k] * inv;
+                    const float mk = (k == 0) ? 1.f : m1;          // class-0 mask channel is all ones (Q4)
+                    const float tk = (t == k) ? 1.f : 0.f;
+                    if (t == k) lt = logits[(n * K + k) * HW + hw] - mx;
+                    acc[1 + k] += pk * tk * mk;
+                    acc[1 + KMAX + k] += pk * pk * mk;
+                    acc[1 + 2 * KMAX + k] += tk * mk;
+                }
+            acc[0] += (logf(se) - lt) * m;
+        }
+    } else {
+        const float* tgt = (const float*)target;
+        const long total = npix * K;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const float x = logits[e], t = tgt[e], m = mask ? mask[e] : 1.f;
+            const float ea = expf(-fabsf(x));
+            acc[0] += (fmaxf(x, 0.f) - x * t + log1pf(ea)) * m;
+            const float p = x >= 0.f ? 1.f / (1.f + ea) : ea / (1.f + ea);
+            acc[1] += p * t * m;
+            acc[1 + KMAX] += p * p * m;
+            acc[1 + 2 * KMAX] += t * t * m;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { const float v = wave_sum(acc[i]); if (lane == 0) red[wave][i] = v; }
+    __syncthreads();
+    if (threadIdx.x < NS)
+        partials[(long)blockIdx.x * NS + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[0] = ce mean, out[1] = dice, out[2] = ce sum, out[3+k] = I, out[3+K+k] = Z, out[3+2K+k] = Y
+__global__ void seg_loss_finalize_kernel(const float* __restrict__ partials, int rows, int N, int K, int HW, int mode,
+                                         float* __restrict__ out) {
+    __shared__ double tot[NS];
+    if (threadIdx.x < NS) {
+        double v = 0.0;
+        for (int r = 0; r < rows; ++r) v += (double)partials[(long)r * NS + threadIdx.x];
+        tot[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int kk = mode == USTRUN_LOSS_SOFTMAX ? K : 1;
+        const double cnt = mode == USTRUN_LOSS_SOFTMAX ? (double)N * HW : (double)N * K * HW;
+        double dice = 0.0;
+        for (int k = 0; k < kk; ++k) {
+            const double I = tot[1 + k], Z = tot[1 + KMAX + k], Y = tot[1 + 2 * KMAX + k];
+            dice += 1.0 - (2.0 * I + (double)SMOOTH) / (Z + Y + (double)SMOOTH);
+            out[3 + k] = (float)I; out[3 + kk + k] = (float)Z; out[3 + 2 * kk + k] = (float)Y;
+        }
+        out[0] = (float)(tot[0] / cnt);
+        out[1] = (float)(dice / kk);
+        out[2] = (float)tot[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restrict__ logits, const void* __restrict__ target,
+                                                          const float* __restrict__ mask, int N, int K, int HW, int mode,
+                                                          const float* __restrict__ sums, const float* __restrict__ gdev,
+                                                          float gscale, float cw, float dw, float* __restrict__ dlogits) {
+    const float gs = gscale * (gdev ? *gdev : 1.f);
+    const long npix = (long)N * HW;
+    if (mode == USTRUN_LOSS_SOFTMAX) {
+        const long long* tgt = (const long long*)target;
+        float A[KMAX], Bc[KMAX];   // dDice/dp_k = A[k]*t_k*m_k + Bc[k]*p_k*m_k
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                const float I = sums[3 + k], D = sums[3 + K + k] + sums[3 + 2 * K + k] + SMOOTH;
+                A[k] = -2.f / D / K;
+                Bc[k] = 2.f * (2.f * I + SMOOTH) / (D * D) / K;
+            }
+        const float cen = cw / (float)npix;
+        for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+            const long n = p / HW, hw = p - n * HW;
+            float l[KMAX], mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (k < K) { l[k] = logits[(n * K + k) * HW + hw]; mx = fmaxf(mx, l[k]); }
+            float se = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (k < K) { l[k] = expf(l[k] - mx); se += l[k]; }
+            const float inv = 1.f / se;
+            const int t = (int)tgt[p];
+            const float m = mask ? mask[p] : 1.f;
+            const float m1 = mask ? (m == 1.f ? 1.f : 0.f) : 1.f;
+            float G[KMAX], gp = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) {
+                    l[k] *= inv;
+                    const float mk = (k == 0) ? 1.f : m1, tk = (t == k) ? 1.f : 0.f;
+                    G[k] = dw * (A[k] * tk * mk + Bc[k] * l[k] * mk);
+                    gp += G[k] * l[k];
+                }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) {
+                    const float tk = (t == k) ? 1.f : 0.f;
+                    dlogits[(n * K + k) * HW + hw] = gs * (cen * m * (l[k] - tk) + l[k] * (G[k] - gp));
+                }
+        }
+    } else {
+        const float* tgt = (const float*)target;
+        const long total = npix * K;
+        const float I = sums[3], D = sums[4] + sums[5] + SMOOTH;
+        const float A = -2.f / D, Bc = 2.f * (2.f * I + SMOOTH) / (D * D);
+        const float cen = cw / (float)total;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const float x = logits[e], t = tgt[e], m = mask ? mask[e] : 1.f;
+            const float ea = expf(-fabsf(x));
+            const float p = x >= 0.f ? 1.f / (1.f + ea) : ea / (1.f + ea);
+            const float G = dw * (A * t * m + Bc * p * m);
+            dlogits[e] = gs * (cen * m * (p - t) + G * p * (1.f - p));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ logits, int N, int K, int HW,
+                                                          float th, int mode, void* __restrict__ label,
+                                                          float* __restrict__ mask) {
+    const long npix = (long)N * HW;
+    if (mode == USTRUN_LOSS_SOFTMAX) {
+        long long* lab = (long long*)label;
+        for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+            const long n = p / HW, hw = p - n * HW;
+            float l[KMAX], mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (k < K) { l[k] = logits[(n * K + k) * HW + hw]; mx = fmaxf(mx, l[k]); }
+            float se = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (k < K) { l[k] = expf(l[k] - mx); se += l[k]; }
+            // max over the PROBABILITIES, first index on ties (torch.max semantics)
+            int best = 0; float bp = l[0] / se;
+#pragma unroll
+            for (int k = 1; k < KMAX; ++k) if (k < K) { const float pk = l[k] / se; if (pk > bp) { bp = pk; best = k; } }
+            lab[p] = best;
+            mask[p] = bp > th ? 1.f : 0.f;
+        }
+    } else {
+        float* lab = (float*)label;
+        const long total = npix * K;
+        const float lo = 1.f - th;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const float x = logits[e];
+            const float p = 1.f / (1.f + expf(-x));
+            lab[e] = p >= 0.5f ? 1.f : 0.f;
+            mask[e] = (p >= th ? 1.f : 0.f) + (p <= lo ? 1.f : 0.f);
+        }
+    }
+}
+
+// train.py:677-697 on the flattened tensors; cut_label/cut_mask already gathered by `choice`
+__global__ __launch_bounds__(256) void mix_targets_kernel(int mode, int N, int K, int HW, const float* __restrict__ box,
+                                                         const void* pl_, const float* mask, const void* plwul_,
+                                                         const float* mwul, const void* plwlu_, const float* mwlu,
+                                                         const void* cutl_, const float* cutm, void* plw_, float* mw,
+                                                         void* plul_, float* mul, void* pllu_, float* mlu) {
+    const int CH = mode == USTRUN_LOSS_SOFTMAX ? 1 : K;
+    const long total = (long)N * CH * HW;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long n = e / ((long)CH * HW), hw = e % HW;
+        const float b = box[n * HW + hw], nb = 1.f - b;
+        const float m = mask[e];
+        float mwv = mwul[e] * nb + mwlu[e] * b;
+        if (mode == USTRUN_LOSS_SOFTMAX) {
+            const long long pl = ((const long long*)pl_)[e], cl = ((const long long*)cutl_)[e];
+            const long long plw = (long long)((float)((const long long*)plwul_)[e] * nb + (float)((const long long*)plwlu_)[e] * b);
+            const float ens = (plw == pl ? 1.f : 0.f) * m;
+            if (ens == 0.f) mwv = 0.f;
+            ((long long*)plw_)[e] = plw;
+            ((long long*)plul_)[e] = (long long)((float)pl * nb + (float)cl * b);
+            ((long long*)pllu_)[e] = (long long)((float)cl * nb + (float)pl * b);
+        } else {
+            const float pl = ((const float*)pl_)[e], cl = ((const float*)cutl_)[e];
+            const float plw = (float)(long long)(((const float*)plwul_)[e] * nb + ((const float*)plwlu_)[e] * b);
+            const float ens = (plw == pl ? 1.f : 0.f) * m;
+            if (ens == 0.f) mwv = 0.f;
+            ((float*)plw_)[e] = plw;
+            ((float*)plul_)[e] = (float)(long long)(pl * nb + cl * b);
+            ((float*)pllu_)[e] = (float)(long long)(cl * nb + pl * b);
+        }
+        mw[e] = mwv;
+        mul[e] = b == 1.f ? cutm[e] : m;
+        mlu[e] = b == 0.f ? cutm[e] : m;
+    }
+}
+
+__global__ __launch_bounds__(256) void box_mix_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ box, int N, int C, int HW,
+                                                     float* __restrict__ out) {
+    const long total = (long)N * C * HW;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long n = e / ((long)C * HW), hw = e % HW;
+        const float bx = box[n * HW + hw];
+        out[e] = a[e] * (1.f - bx) + b[e] * bx;
+    }
+}
+
+// one block per (sample, class): exact integer counts {|pred|, |gt|, |pred & gt|}
+__global__ __launch_bounds__(256) void dice_counts_kernel(const void* pred, const void* gt, int pi64, int gi64, int K,
+                                                         int HW, int by_class, int* __restrict__ counts) {
+    __shared__ int red[4][3];
+    const int n = blockIdx.x / K, c = blockIdx.x % K;
+    const long base = by_class ? (long)n * HW : ((long)n * K + c) * HW;
+    int s = 0, g = 0, i = 0;
+    for (int e = threadIdx.x; e < HW; e += 256) {
+        bool pb, gb;
+        if (by_class) {
+            const long long pv = pi64 ? ((const long long*)pred)[base + e] : (long long)((const float*)pred)[base + e];
+            const long long gv = gi64 ? ((const long long*)gt)[base + e] : (long long)((const float*)gt)[base + e];
+            pb = pv == c + 1; gb = gv == c + 1;
+        } else {
+            pb = pi64 ? ((const long long*)pred)[base + e] != 0 : ((const float*)pred)[base + e] != 0.f;
+            gb = gi64 ? ((const long long*)gt)[base + e] != 0 : ((const float*)gt)[base + e] != 0.f;
+        }
+        s += pb; g += gb; i += pb && gb;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); g += __shfl_xor(g, o); i += __shfl_xor(i, o); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = s; red[wave][1] = g; red[wave][2] = i; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        counts[(long)blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// SGD(momentum, wd) + EMA over flat f32 buffers, 16 B per lane
+__global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
+                                                     float* __restrict__ t, long n, float lr, float mu, float wd, int first,
+                                                     float alpha, float gsc) {
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 pv = ((f32x4*)p)[i];
+        const f32x4 gv = ((const f32x4*)g)[i] * gsc + wd * pv;
+        const f32x4 vv = first ? gv : mu * ((f32x4*)v)[i] + gv;
+        ((f32x4*)v)[i] = vv;
+        pv = pv - lr * vv;
+        ((f32x4*)p)[i] = pv;
+        if (t) ((f32x4*)t)[i] = alpha * ((f32x4*)t)[i] + (1.f - alpha) * pv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = n4 * 4 + threadIdx.x;
+        float pv = p[i];
+        const float gv = g[i] * gsc + wd * pv;
+        const float vv = first ? gv : mu * v[i] + gv;
+        v[i] = vv; pv -= lr * vv; p[i] = pv;
+        if (t) t[i] = alpha * t[i] + (1.f - alpha) * pv;
+    }
+}
+
+int stream_blocks(long work_items) {
+    long b = (work_items + 256 * 4 - 1) / (256 * 4);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+}  // namespace ustrun
+
+using namespace ustrun;
+
+extern "C" int64_t ustrun_loss_partials_bytes(int N, int K, int HW) {
+    (void)N; (void)K; (void)HW;
+    return (int64_t)2048 * NS * sizeof(float);
+}
+
+extern "C" int ustrun_seg_loss_fwd(const float* logits, const void* target, const float* mask, int N, int K, int HW,
+                                   int mode, float* out, float* partials, int64_t partials_bytes, ustrun_stream_t s) {
+    USTRUN_CHECK(logits && target && out && partials, "seg_loss_fwd: null pointer");
+    USTRUN_CHECK(K >= 1 && K <= KMAX && N > 0 && HW > 0, "seg_loss_fwd: bad shape N=%d K=%d HW=%d", N, K, HW);
+    USTRUN_CHECK(mode == USTRUN_LOSS_SOFTMAX || mode == USTRUN_LOSS_SIGMOID, "seg_loss_fwd: bad mode %d", mode);
+    USTRUN_CHECK(partials_bytes >= ustrun_loss_partials_bytes(N, K, HW), "seg_loss_fwd: partials too small");
+    const long items = mode == USTRUN_LOSS_SOFTMAX ? (long)N * HW : (long)N * K * HW;
+    const int blocks = stream_blocks(items);
+    hipLaunchKernelGGL(seg_loss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, logits, target, mask, N, K, HW,
+                       mode, partials);
+    USTRUN_LAUNCH_CHECK("seg_loss_fwd");
+    hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partials, blocks, N, K, HW, mode, out);
+    USTRUN_LAUNCH_CHECK("seg_loss_finalize");
+    return 0;
+}
+
+extern "C" int ustrun_seg_loss_bwd(const float* logits, const void* target, const float* mask, int N, int K, int HW,
+                                   int mode, const float* sums, const float* gscale_dev, float gscale, float ce_weight,
+                                   float dice_weight, float* dlogits, ustrun_stream_t s) {
+    USTRUN_CHECK(logits && target && sums && dlogits, "seg_loss_bwd: null pointer");
+    USTRUN_CHECK(K >= 1 && K <= KMAX && N > 0 && HW > 0, "seg_loss_bwd: bad shape");
+    USTRUN_CHECK(mode == USTRUN_LOSS_SOFTMAX || mode == USTRUN_LOSS_SIGMOID, "seg_loss_bwd: bad mode %d", mode);
+    const long items = mode == USTRUN_LOSS_SOFTMAX ? (long)N * HW : (long)N * K * HW;
+    hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3(stream_blocks(items)), dim3(256), 0, (hipStream_t)s, logits, target,
+                       mask, N, K, HW, mode, sums, gscale_dev, gscale, ce_weight, dice_weight, dlogits);
+    USTRUN_LAUNCH_CHECK("seg_loss_bwd");
+    return 0;
+}
+
+extern "C" int ustrun_pseudo_label(const float* logits, int N, int K, int HW, float threshold, int mode, void* label,
+                                   float* mask, ustrun_stream_t s) {
+    USTRUN_CHECK(logits && label && mask, "pseudo_label: null pointer");
+    USTRUN_CHECK(K >= 1 && K <= KMAX && N > 0 && HW > 0, "pseudo_label: bad shape");
+    const long items = mode == USTRUN_LOSS_SOFTMAX ? (long)N * HW : (long)N * K * HW;
+    hipLaunchKernelGGL(pseudo_label_kernel, dim3(stream_blocks(items)), dim3(256), 0, (hipStream_t)s, logits, N, K, HW,
+                       threshold, mode, label, mask);
+    USTRUN_LAUNCH_CHECK("pseudo_label");
+    return 0;
+}
+
+extern "C" int ustrun_mix_targets(int mode, int N, int K, int HW, const float* box, const void* pl, const float* mask,
+                                  const void* pl_w_ul, const float* mask_w_ul, const void* pl_w_lu,
+                                  const float* mask_w_lu, const void* cut_label, const float* cut_mask, void* pl_w,
+                                  float* mask_w, void* pl_ul, float* mask_ul, void* pl_lu, float* mask_lu,
+                                  ustrun_stream_t s) {
+    USTRUN_CHECK(box && pl && mask && pl_w_ul && mask_w_ul && pl_w_lu && mask_w_lu && cut_label && cut_mask && pl_w &&
+                     mask_w && pl_ul && mask_ul && pl_lu && mask_lu, "mix_targets: null pointer");
+    const long items = (long)N * (mode == USTRUN_LOSS_SOFTMAX ? 1 : K) * HW;
+    hipLaunchKernelGGL(mix_targets_kernel, dim3(stream_blocks(items)), dim3(256), 0, (hipStream_t)s, mode, N, K, HW, box,
+                       pl, mask, pl_w_ul, mask_w_ul, pl_w_lu, mask_w_lu, cut_label, cut_mask, pl_w, mask_w, pl_ul,
+                       mask_ul, pl_lu, mask_lu);
+    USTRUN_LAUNCH_CHECK("mix_targets");
+    return 0;
+}
+
+extern "C" int ustrun_box_mix(const float* a, const float* b, const float* box, int N, int C, int HW, float* out,
+                              ustrun_stream_t s) {
+    USTRUN_CHECK(a && b && box && out && N > 0 && C > 0 && HW > 0, "box_mix: bad args");
+    hipLaunchKernelGGL(box_mix_kernel, dim3(stream_blocks((long)N * C * HW)), dim3(256), 0, (hipStream_t)s, a, b, box, N,
+                       C, HW, out);
+    USTRUN_LAUNCH_CHECK("box_mix");
+    return 0;
+}
+
+extern "C" int ustrun_dice_counts(const void* pred, const void* gt, int pred_is_i64, int gt_is_i64, int N, int K,
+                                  int HW, int by_class, int32_t* counts, ustrun_stream_t s) {
+    USTRUN_CHECK(pred && gt && counts && N > 0 && K > 0 && HW > 0, "dice_counts: bad args");
+    hipLaunchKernelGGL(dice_counts_kernel, dim3(N * K), dim3(256), 0, (hipStream_t)s, pred, gt, pred_is_i64, gt_is_i64, K,
+                       HW, by_class, counts);
+    USTRUN_LAUNCH_CHECK("dice_counts");
+    return 0;
+}
+
+extern "C" int ustrun_sgd_ema(float* p, const float* g, float* v, float* t, int64_t n, float lr, float mu, float wd,
+                              int first, float alpha, float grad_scale, ustrun_stream_t s) {
+    USTRUN_CHECK(p && g && v && n > 0, "sgd_ema: bad args");
+    USTRUN_CHECK(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                     (!t || (uintptr_t)t % 16 == 0), "sgd_ema: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(sgd_ema_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)s, p, g, v, t, (long)n,
+                       lr, mu, wd, first, alpha, grad_scale);
+    USTRUN_LAUNCH_CHECK("sgd_ema");
+    return 0;
+}

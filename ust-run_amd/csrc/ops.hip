@@ -1,0 +1,220 @@
+// ops.hip -- C-ABI wrappers that phrase each U-Net operator as one launch of the generic
+// implicit-GEMM / weight-gradient kernels, plus the weight packing kernels.
+#include "common.h"
+
+namespace ustrun {
+namespace {
+
+// torch conv weight [Cout][Cin][3][3] -> fwd [9][Cin][Cout], dgrad [9][Cout][Cin]
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ wf,
+                                    float* __restrict__ wd) {
+    const long total = (long)Cout * Cin * 9;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        // e indexes the fwd layout so that the stores are coalesced
+        const int co = (int)(e % Cout);
+        const long t = e / Cout;
+        const int ci = (int)(t % Cin), tap = (int)(t / Cin);
+        const float v = w[((long)co * Cin + ci) * 9 + tap];
+        wf[e] = v;
+        if (wd) wd[((long)tap * Cout + co) * Cin + ci] = v;
+    }
+}
+
+// torch convT weight [Cin][Cout][2][2] -> fwd [4][Cin][Cout], dgrad [4][Cout][Cin]
+__global__ void pack_convT_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wf,
+                                  float* __restrict__ wd) {
+    const long total = (long)Cin * Cout * 4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(e % Cout);
+        const long t = e / Cout;
+        const int ci = (int)(t % Cin), ij = (int)(t / Cin);
+        const float v = w[((long)ci * Cout + co) * 4 + ij];
+        wf[e] = v;
+        if (wd) wd[((long)ij * Cout + co) * Cin + ci] = v;
+    }
+}
+
+int pack_blocks(long total) { long b = (total + 1023) / 1024; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+}  // namespace ustrun
+
+using namespace ustrun;
+
+extern "C" int ustrun_pack_conv3x3(const float* w, int Cout, int Cin, void* w_fwd, void* w_dgrad, int dtype,
+                                   ustrun_stream_t s) {
+    USTRUN_CHECK(dtype == USTRUN_F32, "pack_conv3x3: dtype %d not built", dtype);
+    USTRUN_CHECK(w && w_fwd && Cout > 0 && Cin > 0, "pack_conv3x3: bad args");
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(pack_blocks((long)Cout * Cin * 9)), dim3(256), 0, (hipStream_t)s, w, Cout,
+                       Cin, (float*)w_fwd, (float*)w_dgrad);
+    USTRUN_LAUNCH_CHECK("pack_conv3x3");
+    return 0;
+}
+
+extern "C" int ustrun_pack_convT2x2(const float* w, int Cin, int Cout, void* w_fwd, void* w_dgrad, int dtype,
+                                    ustrun_stream_t s) {
+    USTRUN_CHECK(dtype == USTRUN_F32, "pack_convT2x2: dtype %d not built", dtype);
+    USTRUN_CHECK(w && w_fwd && Cout > 0 && Cin > 0, "pack_convT2x2: bad args");
+    hipLaunchKernelGGL(pack_convT_kernel, dim3(pack_blocks((long)Cout * Cin * 4)), dim3(256), 0, (hipStream_t)s, w, Cin,
+                       Cout, (float*)w_fwd, (float*)w_dgrad);
+    USTRUN_LAUNCH_CHECK("pack_convT2x2");
+    return 0;
+}
+
+extern "C" int ustrun_conv_mtiles(int N, int H, int W, int Cout) { return igemm_mtiles((int64_t)N * H * W, Cout); }
+
+static int check_srcs(const ustrun_src_t* srcs, int nsrc, const char* who) {
+    USTRUN_CHECK(srcs && (nsrc == 1 || nsrc == 2), "%s: nsrc must be 1 or 2", who);
+    for (int i = 0; i < nsrc; ++i) {
+        USTRUN_CHECK(srcs[i].ptr && srcs[i].C > 0 && srcs[i].H > 0 && srcs[i].W > 0, "%s: bad source %d", who, i);
+        USTRUN_CHECK((srcs[i].scale == nullptr) == (srcs[i].shift == nullptr), "%s: scale/shift must come together", who);
+        USTRUN_CHECK(!srcs[i].pool || srcs[i].relu, "%s: pooled sources must be ReLU-activated", who);
+    }
+    return 0;
+}
+
+extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W, int Cout,
+                                  void* y, float* stat, int dtype, ustrun_stream_t s) {
+    USTRUN_TRY(check_srcs(srcs, nsrc, "conv3x3_fwd"));
+    USTRUN_CHECK(w_fwd && y && N > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_fwd: bad args");
+    IgemmArgs a = {};
+    a.nsrc = nsrc; a.Cin = 0;
+    for (int i = 0; i < nsrc; ++i) { a.src[i] = make_src(srcs[i]); a.Cin += srcs[i].C; }
+    a.W = (const float*)w_fwd; a.Cout = Cout;
+    a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
+    a.s_in = 1; a.nseg = 9; a.segw = 3; a.d0 = -1; a.dstep = 1;
+    a.nz = 1; a.s_out = 1;
+    a.out0 = (float*)y; a.out1 = nullptr; a.C0 = Cout; a.Ho = H; a.Wo = W;
+    a.bias = nullptr; a.stat = stat;
+    return igemm_launch(a, dtype, (hipStream_t)s);
+}
+
+extern "C" int ustrun_conv3x3_dgrad(const void* dy, const void* w_dgrad, int N, int H, int W, int Cout, int Cin,
+                                    void* da0, int C0, void* da1, int H1, int W1, int o1y, int o1x, int dtype,
+                                    ustrun_stream_t s) {
+    USTRUN_CHECK(dy && w_dgrad && da0 && N > 0 && H > 0 && W > 0 && Cout > 0 && Cin > 0, "conv3x3_dgrad: bad args");
+    USTRUN_CHECK(C0 > 0 && C0 <= Cin && (C0 == Cin || da1), "conv3x3_dgrad: bad channel split %d/%d", C0, Cin);
+    IgemmArgs a = {};
+    ustrun_src_t sd = {};
+    sd.ptr = dy; sd.C = Cout; sd.H = H; sd.W = W;
+    sd.sC = 1; sd.sW = Cout; sd.sH = (int64_t)W * Cout; sd.sN = (int64_t)H * W * Cout;
+    a.nsrc = 1; a.src[0] = make_src(sd); a.Cin = Cout;
+    a.W = (const float*)w_dgrad; a.Cout = Cin;
+    a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
+    a.s_in = 1; a.nseg = 9; a.segw = 3; a.d0 = 1; a.dstep = -1;   // da[q] = sum_t dy[q - (t-1)] W[t]^T
+    a.nz = 1; a.s_out = 1;
+    a.out0 = (float*)da0; a.C0 = C0; a.Ho = H; a.Wo = W;
+    a.out1 = (float*)da1; a.H1 = H1; a.W1 = W1; a.o1y = o1y; a.o1x = o1x;
+    return igemm_launch(a, dtype, (hipStream_t)s);
+}
+
+extern "C" int ustrun_convT2x2_fwd(const ustrun_src_t* src, const void* w_fwd, const float* bias, int N, int H, int W,
+                                   int Cout, void* u, int dtype, ustrun_stream_t s) {
+    USTRUN_TRY(check_srcs(src, 1, "convT2x2_fwd"));
+    USTRUN_CHECK(w_fwd && u && N > 0 && H > 0 && W > 0 && Cout > 0, "convT2x2_fwd: bad args");
+    IgemmArgs a = {};
+    a.nsrc = 1; a.src[0] = make_src(*src); a.Cin = src->C;
+    USTRUN_CHECK(a.src[0].LH == H && a.src[0].LW == W, "convT2x2_fwd: source extent %dx%d != %dx%d", a.src[0].LH, a.src[0].LW, H, W);
+    a.W = (const float*)w_fwd; a.Cout = Cout;
+    a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
+    a.s_in = 1; a.nseg = 1; a.segw = 1; a.d0 = 0; a.dstep = 0;
+    a.nz = 4; a.s_out = 2;                                          // u[2p + (i,j)] = a[p] W[ij] + bias
+    a.out0 = (float*)u; a.C0 = Cout; a.Ho = 2 * H; a.Wo = 2 * W;
+    a.bias = bias;
+    return igemm_launch(a, dtype, (hipStream_t)s);
+}
+
+extern "C" int ustrun_convT2x2_dgrad(const void* du, const void* w_dgrad, int N, int H, int W, int Cout, int Cin,
+                                     void* da, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(du && w_dgrad && da && N > 0 && H > 0 && W > 0 && Cout > 0 && Cin > 0, "convT2x2_dgrad: bad args");
+    IgemmArgs a = {};
+    ustrun_src_t sd = {};
+    sd.ptr = du; sd.C = Cout; sd.H = 2 * H; sd.W = 2 * W;
+    sd.sC = 1; sd.sW = Cout; sd.sH = (int64_t)2 * W * Cout; sd.sN = (int64_t)4 * H * W * Cout;
+    a.nsrc = 1; a.src[0] = make_src(sd); a.Cin = Cout;
+    a.W = (const float*)w_dgrad; a.Cout = Cin;
+    a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
+    a.s_in = 2; a.nseg = 4; a.segw = 2; a.d0 = 0; a.dstep = 1;     // da[p] = sum_ij du[2p+(i,j)] W[ij]^T
+    a.nz = 1; a.s_out = 1;
+    a.out0 = (float*)da; a.C0 = Cin; a.Ho = H; a.Wo = W;
+    return igemm_launch(a, dtype, (hipStream_t)s);
+}
+
+extern "C" int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int64_t npix) {
+    int ks, slabs; long chunk;
+    wgrad_plan(nseg, Cin, Cout, npix, &ks, &chunk, &slabs);
+    return (int64_t)slabs * nseg * Cin * Cout * sizeof(float);
+}
+
+extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const void* dy, int N, int H, int W, int Cout,
+                                    float* dw, int accumulate, float* partials, int64_t partials_bytes, int dtype,
+                                    ustrun_stream_t s) {
+    USTRUN_TRY(check_srcs(srcs, nsrc, "conv3x3_wgrad"));
+    USTRUN_CHECK(dy && dw && partials && N > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_wgrad: bad args");
+    WgradArgs a = {};
+    a.nsrc = nsrc; a.Cin = 0;
+    for (int i = 0; i < nsrc; ++i) { a.src[i] = make_src(srcs[i]); a.Cin += srcs[i].C; }
+    a.dy = (const float*)dy; a.Cout = Cout;
+    a.N = N; a.Hb = H; a.Wb = W; a.M = (long)N * H * W;
+    a.nseg = 9; a.segw = 3; a.d0 = -1; a.astep = 1; a.dy_s = 1; a.dyH = H; a.dyW = W;
+    int slabs;
+    wgrad_plan(9, a.Cin, Cout, a.M, &a.ksplit, &a.kchunk, &slabs);
+    USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 9 * a.Cin * Cout * 4, "conv3x3_wgrad: partials too small");
+    a.partials = partials;
+    USTRUN_TRY(wgrad_launch(a, dtype, (hipStream_t)s));
+    return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 0, accumulate, (hipStream_t)s);
+}
+
+namespace ustrun {
+namespace {
+// db[co] = sum over all pixels of du[p][co]: block partials then reduce_rows
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ du, long npix, int C,
+                                                       float* __restrict__ partials) {
+    __shared__ float red[256];
+    // thread = (channel lane, pixel lane); C <= 256 handled per pass of 256/CL pixel lanes
+    int CL = 1; while (CL < C && CL < 256) CL <<= 1;
+    const int PL = 256 / CL, cl = threadIdx.x % CL, pl = threadIdx.x / CL;
+    for (int cb = 0; cb < C; cb += CL) {
+        const int c = cb + cl;
+        float s = 0.f;
+        if (c < C)
+            for (long p = (long)blockIdx.x * PL + pl; p < npix; p += (long)gridDim.x * PL) s += du[p * C + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (pl == 0 && c < C) {
+            for (int k = 1; k < PL; ++k) s += red[k * CL + cl];
+            partials[(long)blockIdx.x * C + c] = s;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+}  // namespace ustrun
+
+extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, int N, int H, int W, int Cout, float* dw,
+                                     float* db, int accumulate, float* partials, int64_t partials_bytes, int dtype,
+                                     ustrun_stream_t s) {
+    USTRUN_TRY(check_srcs(src, 1, "convT2x2_wgrad"));
+    USTRUN_CHECK(du && dw && partials && N > 0 && H > 0 && W > 0 && Cout > 0, "convT2x2_wgrad: bad args");
+    WgradArgs a = {};
+    a.nsrc = 1; a.src[0] = make_src(*src); a.Cin = src->C;
+    a.dy = (const float*)du; a.Cout = Cout;
+    a.N = N; a.Hb = H; a.Wb = W; a.M = (long)N * H * W;
+    a.nseg = 4; a.segw = 2; a.d0 = 0; a.astep = 0; a.dy_s = 2; a.dyH = 2 * H; a.dyW = 2 * W;
+    int slabs;
+    wgrad_plan(4, a.Cin, Cout, a.M, &a.ksplit, &a.kchunk, &slabs);
+    USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 4 * a.Cin * Cout * 4, "convT2x2_wgrad: partials too small");
+    a.partials = partials;
+    USTRUN_TRY(wgrad_launch(a, dtype, (hipStream_t)s));
+    USTRUN_TRY(reduce_partials(partials, slabs, 4, a.Cin, Cout, dw, 1, accumulate, (hipStream_t)s));
+    if (db) {
+        const long npix = (long)N * 4 * H * W;
+        int blocks = cdiv(npix, 512);
+        if (blocks > 512) blocks = 512;
+        USTRUN_CHECK(partials_bytes >= (int64_t)blocks * Cout * 4, "convT2x2_wgrad: partials too small for bias");
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)du, npix, Cout, partials);
+        USTRUN_LAUNCH_CHECK("bias_grad");
+        USTRUN_TRY(reduce_rows(partials, blocks, Cout, 0, Cout, db, accumulate, (hipStream_t)s));
+    }
+    return 0;
+}

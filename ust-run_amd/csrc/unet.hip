@@ -1,0 +1,279 @@
+// unet.hip -- whole-network forward/backward sequencing (host code): the counterpart of
+// UNet.forward (reference networks/unet_model.py:25-39) and of autograd's backward through it.
+//
+// Nothing is materialised between operators except the raw (pre-BatchNorm) conv outputs y_i and
+// the ConvTranspose outputs u_j, which are also exactly what backward needs:
+//   activated tensor  = loader(y_i, scale_i, shift_i, relu)         (BatchNorm + ReLU on load)
+//   Down input        = loader(..., pool)                           (MaxPool2d on load)
+//   Up input          = loader(skip y_s) ++ loader(u_j, offset)     (pad + cat on load)
+#include "common.h"
+#include <string.h>
+
+namespace ustrun {
+namespace {
+
+struct Plan {
+    int N, C, H, W, K, base;
+    int Hs[5], Ws[5];            // extent per level
+    int cin[18], cout[18], lvl[18];
+    int up_cin[4], up_cout[4];   // convT j: level of its input = 4-j (j = 0..3), output level 3-j
+    // element offsets
+    long y_off[18], aff_off[18]; // aff: scale, shift, mean, rstd (4*cout)
+    long u_off[4];
+    long stat_off, fwd_total;
+    long wf_off[18], wd_off[18], uf_off[4], ud_off[4], pack_total;
+    long da_off[18], du_off[4], dp_off[4], coef_off, part_off, bwd_total, part_bytes;
+    long y_elems(int i) const { return (long)N * Hs[lvl[i]] * Ws[lvl[i]] * cout[i]; }
+    long u_elems(int j) const { return (long)N * (2 * Hs[4 - j]) * (2 * Ws[4 - j]) * up_cout[j]; }
+};
+
+long align_up(long v, long a) { return (v + a - 1) / a * a; }
+
+int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
+    USTRUN_CHECK(d, "unet: null descriptor");
+    USTRUN_CHECK(d->N > 0 && d->C > 0 && d->K > 0 && d->K <= 8 && d->base >= 4 && d->base % 4 == 0,
+                 "unet: bad N=%d C=%d K=%d base=%d", d->N, d->C, d->K, d->base);
+    USTRUN_CHECK(d->H >= 16 && d->W >= 16, "unet: extent %dx%d too small for 4 poolings", d->H, d->W);
+    USTRUN_CHECK(d->dtype == USTRUN_F32, "unet: dtype %d not built", d->dtype);
+    p.N = d->N; p.C = d->C; p.H = d->H; p.W = d->W; p.K = d->K; p.base = d->base;
+    p.Hs[0] = d->H; p.Ws[0] = d->W;
+    for (int l = 1; l < 5; ++l) { p.Hs[l] = p.Hs[l - 1] / 2; p.Ws[l] = p.Ws[l - 1] / 2; }
+    const int b = d->base;
+    const int ch[5] = {b, 2 * b, 4 * b, 8 * b, 16 * b};
+    for (int l = 0; l < 5; ++l) {                 // encoder double convs
+        p.cin[2 * l] = l == 0 ? d->C : ch[l - 1]; p.cout[2 * l] = ch[l];
+        p.cin[2 * l + 1] = ch[l]; p.cout[2 * l + 1] = ch[l];
+        p.lvl[2 * l] = p.lvl[2 * l + 1] = l;
+    }
+    for (int j = 0; j < 4; ++j) {                 // decoder: up(j+1) works at level 3-j
+        const int l = 3 - j;
+        p.up_cin[j] = ch[l + 1]; p.up_cout[j] = ch[l + 1] / 2;
+        p.cin[10 + 2 * j] = ch[l] + p.up_cout[j]; p.cout[10 + 2 * j] = ch[l];
+        p.cin[11 + 2 * j] = ch[l]; p.cout[11 + 2 * j] = ch[l];
+        p.lvl[10 + 2 * j] = p.lvl[11 + 2 * j] = l;
+    }
+    long o = 0;
+    long stat_max = 0;
+    for (int i = 0; i < 18; ++i) {
+        p.y_off[i] = o; o = align_up(o + p.y_elems(i), 64);
+        p.aff_off[i] = o; o = align_up(o + 4L * p.cout[i], 64);
+        const long st = (long)igemm_mtiles((long)p.N * p.Hs[p.lvl[i]] * p.Ws[p.lvl[i]], p.cout[i]) * 2 * p.cout[i];
+        if (st > stat_max) stat_max = st;
+    }
+    for (int j = 0; j < 4; ++j) { p.u_off[j] = o; o = align_up(o + p.u_elems(j), 64); }
+    p.stat_off = o; o = align_up(o + stat_max, 64);
+    p.fwd_total = o;
+
+    o = 0;
+    for (int i = 0; i < 18; ++i) {
+        const long n = 9L * p.cin[i] * p.cout[i];
+        p.wf_off[i] = o; o = align_up(o + n, 64);
+        p.wd_off[i] = o; o = align_up(o + n, 64);
+    }
+    for (int j = 0; j < 4; ++j) {
+        const long n = 4L * p.up_cin[j] * p.up_cout[j];
+        p.uf_off[j] = o; o = align_up(o + n, 64);
+        p.ud_off[j] = o; o = align_up(o + n, 64);
+    }
+    p.pack_total = o;
+
+    o = 0;
+    long part = ustrun_loss_partials_bytes(1, 1, 1);
+    for (int i = 0; i < 18; ++i) {
+        p.da_off[i] = o; o = align_up(o + p.y_elems(i), 64);
+        const long npix = (long)p.N * p.Hs[p.lvl[i]] * p.Ws[p.lvl[i]];
+        long b1 = ustrun_bn_bwd_partials_bytes(npix, p.cout[i]);
+        long b2 = ustrun_wgrad_partials_bytes(9, p.cin[i], p.cout[i], npix);
+        if (b1 > part) part = b1;
+        if (b2 > part) part = b2;
+    }
+    for (int j = 0; j < 4; ++j) {
+        p.du_off[j] = o; o = align_up(o + p.u_elems(j), 64);
+        const int l = 3 - j;                                     // pooled grad of the skip at level l
+        p.dp_off[j] = o; o = align_up(o + (long)p.N * p.Hs[l + 1] * p.Ws[l + 1] * ch[l], 64);
+        const long npix = (long)p.N * p.Hs[l + 1] * p.Ws[l + 1];
+        long b2 = ustrun_wgrad_partials_bytes(4, p.up_cin[j], p.up_cout[j], npix);
+        if (b2 > part) part = b2;
+        long b3 = 512L * p.up_cout[j] * 4;
+        if (b3 > part) part = b3;
+    }
+    long bh = 1024L * ((long)p.K * b + p.K) * 4;
+    if (bh > part) part = bh;
+    p.coef_off = o; o = align_up(o + 3L * 16 * b, 64);
+    p.part_off = o; p.part_bytes = align_up(part, 256);
+    o += p.part_bytes / 4;
+    p.bwd_total = o;
+    return 0;
+}
+
+ustrun_src_t nhwc_src(const float* ptr, const float* aff, int C, int H, int W, int relu, int pool) {
+    ustrun_src_t s = {};
+    s.ptr = ptr; s.scale = aff; s.shift = aff ? aff + C : nullptr;
+    s.C = C; s.H = H; s.W = W;
+    s.sC = 1; s.sW = C; s.sH = (int64_t)W * C; s.sN = (int64_t)H * W * C;
+    s.relu = relu; s.pool = pool;
+    return s;
+}
+
+// sources of conv i (forward input), from the saved workspace
+int conv_sources(const Plan& p, const float* x, const float* ws, int i, ustrun_src_t* srcs) {
+    auto act = [&](int k, int pool) {
+        return nhwc_src(ws + p.y_off[k], ws + p.aff_off[k], p.cout[k], p.Hs[p.lvl[k]], p.Ws[p.lvl[k]], 1, pool);
+    };
+    if (i == 0) {   // network input, NCHW
+        ustrun_src_t s = {};
+        s.ptr = x; s.C = p.C; s.H = p.H; s.W = p.W;
+        s.sW = 1; s.sH = p.W; s.sC = (int64_t)p.H * p.W; s.sN = (int64_t)p.C * p.H * p.W;
+        srcs[0] = s;
+        return 1;
+    }
+    if (i < 10) {
+        srcs[0] = (i % 2 == 1) ? act(i - 1, 0) : act(i - 1, 1);
+        return 1;
+    }
+    if (i % 2 == 1) { srcs[0] = act(i - 1, 0); return 1; }
+    const int j = (i - 10) / 2, l = 3 - j;
+    const int skip = 2 * l + 1;
+    srcs[0] = act(skip, 0);
+    ustrun_src_t u = nhwc_src(ws + p.u_off[j], nullptr, p.up_cout[j], 2 * p.Hs[l + 1], 2 * p.Ws[l + 1], 0, 0);
+    u.off_y = (p.Hs[l] - 2 * p.Hs[l + 1]) / 2;       // F.pad(diff//2, ...) of the reference
+    u.off_x = (p.Ws[l] - 2 * p.Ws[l + 1]) / 2;
+    srcs[1] = u;
+    return 2;
+}
+
+int grad_index_conv(int i) {    // index of conv i's weight in model.parameters() order; +1 gamma, +2 beta
+    if (i < 10) return (i / 2) * 6 + (i % 2) * 3;
+    const int j = (i - 10) / 2;
+    return 30 + j * 8 + 2 + (i % 2) * 3;
+}
+
+}  // namespace
+}  // namespace ustrun
+
+using namespace ustrun;
+
+extern "C" int64_t ustrun_unet_packed_bytes(const ustrun_unet_desc_t* d) {
+    Plan p; if (make_plan(d, p)) return -1;
+    return p.pack_total * 4;
+}
+extern "C" int64_t ustrun_unet_fwd_workspace_bytes(const ustrun_unet_desc_t* d) {
+    Plan p; if (make_plan(d, p)) return -1;
+    return p.fwd_total * 4;
+}
+extern "C" int64_t ustrun_unet_bwd_scratch_bytes(const ustrun_unet_desc_t* d) {
+    Plan p; if (make_plan(d, p)) return -1;
+    return p.bwd_total * 4;
+}
+
+extern "C" int ustrun_unet_pack(const ustrun_unet_desc_t* d, ustrun_stream_t s) {
+    Plan p; USTRUN_TRY(make_plan(d, p));
+    USTRUN_CHECK(d->packed, "unet_pack: packed arena missing");
+    float* pk = (float*)d->packed;
+    for (int i = 0; i < 18; ++i) {
+        USTRUN_CHECK(d->conv_w[i], "unet_pack: conv weight %d missing", i);
+        USTRUN_TRY(ustrun_pack_conv3x3(d->conv_w[i], p.cout[i], p.cin[i], pk + p.wf_off[i], pk + p.wd_off[i], d->dtype, s));
+    }
+    for (int j = 0; j < 4; ++j) {
+        USTRUN_CHECK(d->up_w[j], "unet_pack: up weight %d missing", j);
+        USTRUN_TRY(ustrun_pack_convT2x2(d->up_w[j], p.up_cin[j], p.up_cout[j], pk + p.uf_off[j], pk + p.ud_off[j], d->dtype, s));
+    }
+    return 0;
+}
+
+extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, float* logits, float* feat,
+                                   void* workspace, ustrun_stream_t s) {
+    Plan p; USTRUN_TRY(make_plan(d, p));
+    USTRUN_CHECK(x && logits && workspace && d->packed, "unet_forward: null pointer");
+    float* ws = (float*)workspace;
+    const float* pk = (const float*)d->packed;
+    float* stat = ws + p.stat_off;
+    for (int i = 0; i < 18; ++i) {
+        if (i >= 10 && i % 2 == 0) {   // Up: ConvTranspose of the previous level's output first
+            const int j = (i - 10) / 2, l = 3 - j;
+            const int prev = (j == 0) ? 9 : i - 1;
+            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], ws + p.aff_off[prev], p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0);
+            USTRUN_TRY(ustrun_convT2x2_fwd(&a, pk + p.uf_off[j], d->up_b[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
+                                           ws + p.u_off[j], d->dtype, s));
+        }
+        ustrun_src_t srcs[2];
+        const int ns = conv_sources(p, x, ws, i, srcs);
+        const int H = p.Hs[p.lvl[i]], W = p.Ws[p.lvl[i]];
+        USTRUN_TRY(ustrun_conv3x3_fwd(srcs, ns, pk + p.wf_off[i], p.N, H, W, p.cout[i], ws + p.y_off[i],
+                                      d->train ? stat : nullptr, d->dtype, s));
+        float* aff = ws + p.aff_off[i];
+        const int C = p.cout[i];
+        if (d->train) {
+            USTRUN_TRY(ustrun_bn_finalize(stat, ustrun_conv_mtiles(p.N, H, W, C), C, (int64_t)p.N * H * W, d->bn_w[i],
+                                          d->bn_b[i], d->bn_rm[i], d->bn_rv[i], d->bn_nbt[i], d->momentum, d->eps,
+                                          d->update_running, aff, aff + C, aff + 2 * C, aff + 3 * C, s));
+        } else {
+            USTRUN_TRY(ustrun_bn_eval_affine(C, d->bn_w[i], d->bn_b[i], d->bn_rm[i], d->bn_rv[i], d->eps, aff, aff + C, s));
+        }
+    }
+    const int C = p.cout[17];
+    const long npix = (long)p.N * p.H * p.W;
+    USTRUN_TRY(ustrun_head_fwd(ws + p.y_off[17], ws + p.aff_off[17], ws + p.aff_off[17] + C, npix, p.H * p.W, C, p.K,
+                               d->head_w, d->head_b, logits, d->dtype, s));
+    if (feat)
+        USTRUN_TRY(ustrun_bn_relu_apply(ws + p.y_off[17], ws + p.aff_off[17], ws + p.aff_off[17] + C, npix, C, p.H * p.W,
+                                        feat, 1, d->dtype, s));
+    return 0;
+}
+
+extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x, const float* dlogits, void* workspace,
+                                    void* scratch, float* const* grads, int accumulate, ustrun_stream_t s) {
+    Plan p; USTRUN_TRY(make_plan(d, p));
+    USTRUN_CHECK(x && dlogits && workspace && scratch && grads && d->packed, "unet_backward: null pointer");
+    USTRUN_CHECK(d->train, "unet_backward: forward must have run in train mode");
+    const float* ws = (const float*)workspace;
+    float* sc = (float*)scratch;
+    const float* pk = (const float*)d->packed;
+    float* coef = sc + p.coef_off;
+    float* part = sc + p.part_off;
+    const int dt = d->dtype;
+
+    {   // head
+        const int C = p.cout[17];
+        USTRUN_TRY(ustrun_head_bwd(dlogits, ws + p.y_off[17], ws + p.aff_off[17], ws + p.aff_off[17] + C,
+                                   (long)p.N * p.H * p.W, p.H * p.W, C, p.K, d->head_w, sc + p.da_off[17], grads[62],
+                                   grads[63], accumulate, part, p.part_bytes, dt, s));
+    }
+    for (int i = 17; i >= 0; --i) {
+        const int l = p.lvl[i], H = p.Hs[l], W = p.Ws[l], C = p.cout[i];
+        const float* aff = ws + p.aff_off[i];
+        const int gi = grad_index_conv(i);
+        // the encoder outputs x1..x4 (convs 1,3,5,7) also feed a MaxPool: add the routed pooled grad
+        const bool pooled = (i < 8) && (i % 2 == 1);
+        const float* dp = pooled ? sc + p.dp_off[3 - l] : nullptr;
+        float* da = sc + p.da_off[i];
+        USTRUN_TRY(ustrun_bn_bwd_reduce(da, dp, ws + p.y_off[i], aff, aff + C, aff + 2 * C, aff + 3 * C, d->bn_w[i], p.N, H,
+                                        W, C, grads[gi + 1], grads[gi + 2], accumulate, coef, part, p.part_bytes, dt, s));
+        USTRUN_TRY(ustrun_bn_bwd_apply(da, dp, ws + p.y_off[i], aff, aff + C, coef, p.N, H, W, C, da, dt, s));
+        ustrun_src_t srcs[2];
+        const int ns = conv_sources(p, x, ws, i, srcs);
+        USTRUN_TRY(ustrun_conv3x3_wgrad(srcs, ns, da, p.N, H, W, C, grads[gi], accumulate, part, p.part_bytes, dt, s));
+        if (i == 0) break;
+        const float* wd = pk + p.wd_off[i];
+        if (i < 10 && i % 2 == 0) {            // Down conv: grad wrt the pooled activation of conv i-1
+            USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, p.cin[i], sc + p.dp_off[3 - (l - 1)], p.cin[i], nullptr, 0,
+                                            0, 0, 0, dt, s));
+        } else if (i >= 10 && i % 2 == 0) {    // Up conv: split into the skip grad and the ConvTranspose-output grad
+            const int j = (i - 10) / 2, skip = 2 * l + 1;
+            const int uh = 2 * p.Hs[l + 1], uw = 2 * p.Ws[l + 1];
+            USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, p.cin[i], sc + p.da_off[skip], p.cout[skip],
+                                            sc + p.du_off[j], uh, uw, (H - uh) / 2, (W - uw) / 2, dt, s));
+            const int prev = (j == 0) ? 9 : i - 1;
+            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], ws + p.aff_off[prev], p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0);
+            const int ub = 30 + j * 8;
+            USTRUN_TRY(ustrun_convT2x2_wgrad(&a, sc + p.du_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], grads[ub],
+                                             grads[ub + 1], accumulate, part, p.part_bytes, dt, s));
+            USTRUN_TRY(ustrun_convT2x2_dgrad(sc + p.du_off[j], pk + p.ud_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
+                                             p.up_cin[j], sc + p.da_off[prev], dt, s));
+        } else {                               // second conv of a DoubleConv
+            USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, p.cin[i], sc + p.da_off[i - 1], p.cin[i], nullptr, 0, 0, 0,
+                                            0, dt, s));
+        }
+    }
+    return 0;
+}
