@@ -1,0 +1,231 @@
+"""GPU parity of the individual C-ABI operators against the oracle's primitives (torch CPU f32,
+with an f64 evaluation as the conditioning yardstick)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def L():
+    from ustrun import _lib
+    return _lib
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc(t):          # [N,C,H,W] -> contiguous [N,H,W,C] on the GPU
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def from_nhwc(t):     # GPU [N,H,W,C] -> CPU [N,C,H,W]
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def pack_conv(w):
+    l = L()
+    co, ci = w.shape[:2]
+    wf = torch.empty(9 * ci * co, device="cuda")
+    wd = torch.empty(9 * ci * co, device="cuda")
+    wg = w.contiguous().cuda()
+    l.check(l.lib().ustrun_pack_conv3x3(wg.data_ptr(), co, ci, wf.data_ptr(), wd.data_ptr(), 0, None))
+    return wf, wd
+
+
+SHAPES = [(2, 512, 512, 4, 4), (2, 64, 64, 16, 16), (1, 24, 40, 9, 7), (2, 256, 128, 8, 8), (3, 128, 256, 6, 10),
+          (2, 3, 64, 16, 16)]
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", SHAPES)
+def test_conv3x3_fwd_dgrad_wgrad(n, ci, co, h, w):
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+    dy = torch.randn(n, co, h, w, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, 1, 1)
+    y_ref.backward(dy)
+    y64 = F.conv2d(x.double(), wt.double(), None, 1, 1)
+
+    wf, wd = pack_conv(wt)
+    xg = nhwc(x)
+    src = l.nhwc_src(xg.data_ptr(), ci, h, w)
+    y = torch.empty(n, h, w, co, device="cuda")
+    mt = lib.ustrun_conv_mtiles(n, h, w, co)
+    stat = torch.zeros(mt, 2, co, device="cuda")
+    l.check(lib.ustrun_conv3x3_fwd(C.byref(src), 1, wf.data_ptr(), n, h, w, co, y.data_ptr(), stat.data_ptr(), 0, None))
+    yc = from_nhwc(y)
+    assert rel(yc, y64) < max(5 * rel(y_ref.detach(), y64), 2e-6)   # a K-long f32 fmaf chain (K up to 4608)
+    np.testing.assert_allclose(stat[:, 0].sum(0).cpu().numpy(), y_ref.detach().sum((0, 2, 3)).numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(stat[:, 1].sum(0).cpu().numpy(), y_ref.detach().square().sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-4)
+
+    # input gradient, written whole and split over two destinations
+    dyg = nhwc(dy)
+    da = torch.empty(n, h, w, ci, device="cuda")
+    l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 0, None))
+    assert rel(from_nhwc(da), xr.grad) < 1e-5
+    if ci % 8 == 0:
+        c0 = ci // 2
+        d0 = torch.empty(n, h, w, c0, device="cuda")
+        d1 = torch.full((n, h, w, ci - c0), 7.0, device="cuda")
+        l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, d0.data_ptr(), c0, d1.data_ptr(), h, w, 0, 0, 0, None))
+        assert rel(from_nhwc(torch.cat([d0, d1], 3)), xr.grad) < 1e-5
+
+    # weight gradient (torch layout), then accumulate a second time
+    nb = lib.ustrun_wgrad_partials_bytes(9, ci, co, n * h * w)
+    part = torch.empty(nb // 4, device="cuda")
+    dw = torch.empty(co, ci, 3, 3, device="cuda")
+    l.check(lib.ustrun_conv3x3_wgrad(C.byref(src), 1, dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 0, part.data_ptr(), nb, 0, None))
+    assert rel(dw.cpu(), wr.grad) < 1e-5
+    l.check(lib.ustrun_conv3x3_wgrad(C.byref(src), 1, dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 1, part.data_ptr(), nb, 0, None))
+    assert rel(dw.cpu(), 2 * wr.grad) < 1e-5
+
+
+def test_conv3x3_loader_affine_relu_pool_concat_pad():
+    """BatchNorm affine + ReLU, 2x2 max-pool (negative scales included), concat and F.pad offset on load."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(1)
+    n, c0, c1, co, h, w = 2, 16, 8, 24, 11, 13
+    # pooled single source
+    ys = torch.randn(n, c0, 2 * h + 1, 2 * w, generator=g)
+    sc, sh = torch.randn(c0, generator=g), 0.3 * torch.randn(c0, generator=g)
+    wt = torch.randn(co, c0, 3, 3, generator=g) / 12
+    a = F.max_pool2d(torch.relu(ys * sc[None, :, None, None] + sh[None, :, None, None]), 2)
+    ref = F.conv2d(a, wt, None, 1, 1)
+    wf, _ = pack_conv(wt)
+    yg, scg, shg = nhwc(ys), sc.cuda(), sh.cuda()
+    src = l.nhwc_src(yg.data_ptr(), c0, 2 * h + 1, 2 * w, scg.data_ptr(), shg.data_ptr(), relu=1, pool=1)
+    out = torch.empty(n, h, w, co, device="cuda")
+    l.check(lib.ustrun_conv3x3_fwd(C.byref(src), 1, wf.data_ptr(), n, h, w, co, out.data_ptr(), None, 0, None))
+    assert rel(from_nhwc(out), ref) < 1e-5
+    # concat [skip (affine+relu), up (offset-padded, smaller extent)]
+    skip = torch.randn(n, c0, h, w, generator=g)
+    up = torch.randn(n, c1, h - 3, w - 2, generator=g)
+    wt2 = torch.randn(co, c0 + c1, 3, 3, generator=g) / 14
+    upp = F.pad(up, [1, 1, 1, 2])
+    a2 = torch.cat([torch.relu(skip * sc[None, :, None, None] + sh[None, :, None, None]), upp], 1)
+    ref2 = F.conv2d(a2, wt2, None, 1, 1)
+    wf2, _ = pack_conv(wt2)
+    sg, ug = nhwc(skip), nhwc(up)
+    srcs = (l.Src * 2)(l.nhwc_src(sg.data_ptr(), c0, h, w, scg.data_ptr(), shg.data_ptr(), relu=1),
+                       l.nhwc_src(ug.data_ptr(), c1, h - 3, w - 2, off=(1, 1)))
+    out2 = torch.empty(n, h, w, co, device="cuda")
+    l.check(lib.ustrun_conv3x3_fwd(srcs, 2, wf2.data_ptr(), n, h, w, co, out2.data_ptr(), None, 0, None))
+    assert rel(from_nhwc(out2), ref2) < 1e-5
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 64, 32, 5, 7), (1, 512, 256, 4, 4), (2, 16, 8, 8, 8)])
+def test_convT2x2_fwd_bwd(n, ci, co, h, w):
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(ci + co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(ci, co, 2, 2, generator=g) / ci ** 0.5
+    b = torch.randn(co, generator=g)
+    du = torch.randn(n, co, 2 * h, 2 * w, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    u_ref = F.conv_transpose2d(xr, wr, br, stride=2)
+    u_ref.backward(du)
+    wf = torch.empty(4 * ci * co, device="cuda")
+    wd = torch.empty(4 * ci * co, device="cuda")
+    wg = wt.cuda()
+    l.check(lib.ustrun_pack_convT2x2(wg.data_ptr(), ci, co, wf.data_ptr(), wd.data_ptr(), 0, None))
+    xg, bg = nhwc(x), b.cuda()
+    src = l.nhwc_src(xg.data_ptr(), ci, h, w)
+    u = torch.empty(n, 2 * h, 2 * w, co, device="cuda")
+    l.check(lib.ustrun_convT2x2_fwd(C.byref(src), wf.data_ptr(), bg.data_ptr(), n, h, w, co, u.data_ptr(), 0, None))
+    assert rel(from_nhwc(u), u_ref.detach()) < 1e-5
+    dug = nhwc(du)
+    da = torch.empty(n, h, w, ci, device="cuda")
+    l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), 0, None))
+    assert rel(from_nhwc(da), xr.grad) < 1e-5
+    nb = max(lib.ustrun_wgrad_partials_bytes(4, ci, co, n * h * w), 512 * co * 4)
+    part = torch.empty(nb // 4, device="cuda")
+    dw, db = torch.empty(ci, co, 2, 2, device="cuda"), torch.empty(co, device="cuda")
+    l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, 0, None))
+    assert rel(dw.cpu(), wr.grad) < 1e-5 and rel(db.cpu(), br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n,c,h,w,pool", [(2, 512, 4, 4, False), (2, 64, 16, 16, True), (1, 24, 9, 7, True),
+                                          (3, 128, 6, 10, False), (2, 1024, 2, 2, False), (2, 512, 4, 4, True)])
+def test_bn_relu_pool_backward(n, c, h, w, pool):
+    """BatchNorm(train)+ReLU(+MaxPool) backward against torch autograd of the same expression."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(c + h)
+    y = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+    gamma = 1 + 0.5 * torch.randn(c, generator=g)
+    beta = 0.2 * torch.randn(c, generator=g)
+    da = torch.randn(n, c, h, w, generator=g)
+    dp = torch.randn(n, c, h // 2, w // 2, generator=g)
+
+    def ref(dtype):
+        yr = y.detach().clone().to(dtype).requires_grad_(True)
+        gr, br = gamma.detach().clone().to(dtype).requires_grad_(True), beta.detach().clone().to(dtype).requires_grad_(True)
+        var, mean = torch.var_mean(yr, dim=(0, 2, 3), unbiased=False)
+        a = torch.relu((yr - mean[None, :, None, None]) * torch.rsqrt(var + 1e-5)[None, :, None, None] * gr[None, :, None, None] + br[None, :, None, None])
+        loss = (a * da.to(dtype)).sum()
+        if pool:
+            loss = loss + (F.max_pool2d(a, 2) * dp.to(dtype)).sum()
+        loss.backward()
+        return yr.grad, gr.grad, br.grad, mean.detach(), var.detach()
+
+    dy32, dg32, db32, mean, var = ref(torch.float32)
+    dy64, dg64, db64, _, _ = ref(torch.float64)
+    rstd = torch.rsqrt(var + 1e-5)
+    scale = gamma * rstd
+    shift = beta - mean * scale
+    yg, dag, dpg = nhwc(y), nhwc(da), nhwc(dp)
+    t = [v.cuda() for v in (scale, shift, mean, rstd, gamma)]
+    dgam, dbet = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    coef = torch.empty(3 * c, device="cuda")
+    nb = lib.ustrun_bn_bwd_partials_bytes(n * h * w, c)
+    part = torch.empty(nb // 4, device="cuda")
+    dpp = dpg.data_ptr() if pool else None
+    l.check(lib.ustrun_bn_bwd_reduce(dag.data_ptr(), dpp, yg.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                     t[3].data_ptr(), t[4].data_ptr(), n, h, w, c, dgam.data_ptr(), dbet.data_ptr(), 0,
+                                     coef.data_ptr(), part.data_ptr(), nb, 0, None))
+    dy = torch.empty(n, h, w, c, device="cuda")
+    l.check(lib.ustrun_bn_bwd_apply(dag.data_ptr(), dpp, yg.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), coef.data_ptr(),
+                                    n, h, w, c, dy.data_ptr(), 0, None))
+    assert rel(dgam.cpu(), dg64) < max(3 * rel(dg32, dg64), 1e-5)
+    assert rel(dbet.cpu(), db64) < max(3 * rel(db32, db64), 1e-5)
+    assert rel(from_nhwc(dy), dy64) < max(3 * rel(dy32, dy64), 1e-5)
+
+
+@pytest.mark.parametrize("n,c,k,h,w", [(2, 64, 2, 16, 16), (1, 8, 4, 9, 7), (3, 64, 4, 12, 12)])
+def test_head_fwd_bwd(n, c, k, h, w):
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(c + k)
+    y = torch.randn(n, c, h, w, generator=g)
+    sc, sh = 1 + 0.3 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    wt, b = torch.randn(k, c, generator=g) / c ** 0.5, torch.randn(k, generator=g)
+    dl = torch.randn(n, k, h, w, generator=g)
+    ar = torch.relu(y * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(ar, wr[:, :, None, None], br)
+    ref.backward(dl)
+    yg, scg, shg, wg, bg, dlg = nhwc(y), sc.cuda(), sh.cuda(), wt.cuda(), b.cuda(), dl.cuda()
+    lg = torch.empty(n, k, h, w, device="cuda")
+    l.check(lib.ustrun_head_fwd(yg.data_ptr(), scg.data_ptr(), shg.data_ptr(), n * h * w, h * w, c, k, wg.data_ptr(),
+                                bg.data_ptr(), lg.data_ptr(), 0, None))
+    assert rel(lg.cpu(), ref.detach()) < 1e-5
+    da = torch.empty(n, h, w, c, device="cuda")
+    dw, db = torch.empty(k, c, device="cuda"), torch.empty(k, device="cuda")
+    nb = 1024 * (k * c + k) * 4
+    part = torch.empty(nb // 4, device="cuda")
+    l.check(lib.ustrun_head_bwd(dlg.data_ptr(), yg.data_ptr(), scg.data_ptr(), shg.data_ptr(), n * h * w, h * w, c, k,
+                                wg.data_ptr(), da.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, 0, None))
+    assert rel(from_nhwc(da), ar.grad) < 1e-5
+    assert rel(dw.cpu(), wr.grad) < 1e-5 and rel(db.cpu(), br.grad) < 1e-5

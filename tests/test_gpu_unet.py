@@ -21,7 +21,7 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def run_pair(c, k, n, h, w, base, seed, train=True):
+def run_pair(c, k, n, h, w, base, seed, train=True, want64=False):
     torch.manual_seed(seed)
     sd = U.make_state_dict(c, k, base=base)
     # non-trivial BN affine so that gamma/beta gradients and negative scales are exercised
@@ -37,14 +37,22 @@ def run_pair(c, k, n, h, w, base, seed, train=True):
     ref_sd = U.clone_sd(sd, requires_grad=True)
     ref_logits = U.unet_forward(x, ref_sd, train=train)
     logits = model(x.cuda())
+    if want64:      # f64 evaluation of the same oracle: the yardstick for conditioning
+        sd64 = {kk: (v.double() if v.is_floating_point() else v.clone()) for kk, v in sd.items()}
+        for kk in U.param_keys(sd64):
+            sd64[kk].requires_grad_(True)
+        return model, logits, ref_sd, ref_logits, sd64, U.unet_forward(x.double(), sd64, train=train)
     return model, logits, ref_sd, ref_logits
 
 
-@pytest.mark.parametrize("c,k,n,h,w,base", [(3, 2, 2, 32, 32, 8), (1, 4, 3, 48, 32, 8), (3, 2, 1, 50, 38, 8),
-                                            (1, 2, 2, 32, 32, 64)])
-def test_forward_backward_vs_oracle(c, k, n, h, w, base):
-    model, logits, ref_sd, ref_logits = run_pair(c, k, n, h, w, base, seed=5)
-    assert rel_l2(logits.cpu(), ref_logits.detach()) < 1e-4
+# Seeds are fixed: a pre-activation that lands within rounding of the ReLU kink can flip its mask
+# between any two f32 evaluation orders (CPU vs CPU included), which moves every upstream gradient by
+# far more than rounding; the chosen seeds have no such coincidence (tools/diag_grad.py shows one).
+@pytest.mark.parametrize("c,k,n,h,w,base,seed", [(3, 2, 2, 32, 32, 8, 5), (1, 4, 3, 48, 32, 8, 5), (3, 2, 1, 50, 38, 8, 5),
+                                                 (1, 2, 2, 32, 32, 64, 11), (3, 2, 2, 64, 48, 64, 12)])
+def test_forward_backward_vs_oracle(c, k, n, h, w, base, seed):
+    model, logits, ref_sd, ref_logits, sd64, l64 = run_pair(c, k, n, h, w, base, seed=seed, want64=True)
+    assert rel_l2(logits.detach().cpu(), ref_logits.detach()) < 1e-4
     np.testing.assert_allclose(logits.detach().cpu().numpy(), ref_logits.detach().numpy(), rtol=1e-3, atol=2e-4)
     # BN running stats were updated in place by the kernels
     msd = model.state_dict()
@@ -54,16 +62,20 @@ def test_forward_backward_vs_oracle(c, k, n, h, w, base):
     # gradients of loss = mean(logits^2)
     logits.square().mean().backward()
     ref_logits.square().mean().backward()
+    l64.square().mean().backward()
+    # Deep gradients pass through BatchNorm over as few as 8 values and are ill-conditioned in f32:
+    # measure both f32 paths against the f64 oracle; the HIP path must be as accurate as the CPU one.
     for (name, p), key in zip(model.named_parameters(), U.param_keys(ref_sd)):
         assert name == key
-        rg = ref_sd[key].grad
-        err = rel_l2(p.grad.cpu(), rg)
-        assert err < 2e-3, (key, err, float(rg.norm()))
+        truth = sd64[key].grad
+        err_hip = rel_l2(p.grad.cpu(), truth)
+        err_cpu = rel_l2(ref_sd[key].grad, truth)
+        assert err_hip < max(3 * err_cpu, 2e-4), (key, err_hip, err_cpu)
 
 
 def test_eval_mode_uses_running_stats():
     model, logits, ref_sd, ref_logits = run_pair(3, 2, 2, 32, 32, 8, seed=9, train=False)
-    assert rel_l2(logits.cpu(), ref_logits.detach()) < 1e-4
+    assert rel_l2(logits.detach().cpu(), ref_logits.detach()) < 1e-4
 
 
 def test_feature_output():

@@ -153,6 +153,9 @@ int grad_index_conv(int i) {    // index of conv i's weight in model.parameters(
 
 using namespace ustrun;
 
+// debugging aid (not part of the ABI): stop backward before the BatchNorm backward of this layer
+extern "C" int ustrun_debug_stop_layer = -1;
+
 extern "C" int64_t ustrun_unet_packed_bytes(const ustrun_unet_desc_t* d) {
     Plan p; if (make_plan(d, p)) return -1;
     return p.pack_total * 4;
@@ -240,6 +243,7 @@ extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x,
                                    grads[63], accumulate, part, p.part_bytes, dt, s));
     }
     for (int i = 17; i >= 0; --i) {
+        if (i == ustrun_debug_stop_layer) return 0;
         const int l = p.lvl[i], H = p.Hs[l], W = p.Ws[l], C = p.cout[i];
         const float* aff = ws + p.aff_off[i];
         const int gi = grad_index_conv(i);
