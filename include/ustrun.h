@@ -150,7 +150,9 @@ int ustrun_box_mix(const float* a, const float* b, const float* box, int N, int 
  *   all pixels (Q5) + per-class masked Dice with the class-0 mask all ones (Q4).
  * sigmoid mode: target/mask f32 [N,K,HW];  BCE-with-logits*mask mean + ONE global masked Dice.
  * fwd writes out[0]=ce, out[1]=dice, out[2..] = the reduced sums the backward needs
- * (USTRUN_LOSS_NSUMS(K) floats in all).  bwd writes dlogits = gscale * d(ce+dice)/dlogits.    */
+ * (USTRUN_LOSS_NSUMS(K) floats in all).  bwd writes
+ *   dlogits = gscale * (ce_weight*g[0] * dce/dlogits + dice_weight*g[1] * ddice/dlogits),
+ * g = gscale_dev (two device floats: upstream grads of ce and dice) or {1,1} when NULL.          */
 #define USTRUN_LOSS_NSUMS(K) (4 + 3 * (K))
 int64_t ustrun_loss_partials_bytes(int N, int K, int HW);
 int ustrun_seg_loss_fwd(const float* logits, const void* target, const float* mask, int N, int K,

@@ -1,0 +1,134 @@
+"""GPU parity of the loss / pseudo-label / mixing / optimizer kernels (C ABI via ustrun.functional)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import host_ref as H
+from oracle import losses_ref as L
+
+pytestmark = pytest.mark.gpu
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def F():
+    from ustrun import functional
+    return functional
+
+
+@pytest.mark.parametrize("K", [2, 4])
+def test_dice_loss_module_matches_reference_goldens(K):
+    """utils.losses.DiceLossWithMask on the GPU vs values/grads captured from the reference."""
+    from utils.losses import DiceLossWithMask
+    g = load_golden("g4_losses")
+    dl = DiceLossWithMask(K)
+    cases = {"sm": dict(target=t(g[f"K{K}.tgt"]).cuda(), softmax=True),
+             "sm_mask": dict(target=t(g[f"K{K}.tgt"]).cuda(), mask=t(g[f"K{K}.mask"]).cuda(), softmax=True),
+             "sg": dict(target=t(g[f"K{K}.tgt_ml"]).unsqueeze(1).cuda(), sigmoid=True, multi=True),
+             "sg_mask": dict(target=t(g[f"K{K}.tgt_ml"]).unsqueeze(1).cuda(), mask=t(g[f"K{K}.mask_ml"]).cuda(), sigmoid=True, multi=True)}
+    for tag, kw in cases.items():
+        lg = t(g[f"K{K}.logits"]).cuda().requires_grad_(True)
+        val = dl(lg, **kw)
+        val.backward()
+        np.testing.assert_allclose(float(val), float(g[f"K{K}.{tag}.val"]), rtol=2e-5)
+        np.testing.assert_allclose(lg.grad.cpu().numpy(), g[f"K{K}.{tag}.grad"], rtol=2e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("mode,K,N,H", [("softmax", 2, 3, 40), ("softmax", 4, 2, 33), ("sigmoid", 2, 3, 40)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_seg_loss_vs_oracle(mode, K, N, H, masked):
+    g = torch.Generator().manual_seed(K + N + H)
+    logits = 3 * torch.randn(N, K, H, H, generator=g)
+    if mode == "softmax":
+        tgt = torch.randint(0, K, (N, H, H), generator=g)
+        mask = (torch.rand(N, 1, H, H, generator=g) > 0.4).float() if masked else None
+    else:
+        tgt = (torch.rand(N, K, H, H, generator=g) > 0.5).float()
+        mask = (torch.rand(N, K, H, H, generator=g) > 0.4).float() if masked else None
+    lr = logits.clone().requires_grad_(True)
+    ce, dc = L.seg_loss(lr, tgt, mask, mode, K)
+    (ce + 0.7 * dc).backward()
+    lg = logits.cuda().requires_grad_(True)
+    ce_g, dc_g = F().seg_loss(lg, tgt.cuda(), None if mask is None else mask.cuda(), mode)
+    (ce_g + 0.7 * dc_g).backward()
+    np.testing.assert_allclose(float(ce_g), float(ce), rtol=2e-5)
+    np.testing.assert_allclose(float(dc_g), float(dc), rtol=2e-5)
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), lr.grad.numpy(), rtol=2e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("mode,K", [("softmax", 2), ("softmax", 4), ("sigmoid", 2)])
+def test_pseudo_label_bit_exact(mode, K):
+    g = torch.Generator().manual_seed(17 + K)
+    logits = 4 * torch.randn(4, K, 64, 64, generator=g)
+    logits[0, :, :4] = 0.0                                   # exact ties -> first index
+    logits[1, 0, :8] = logits[1, K - 1, :8]
+    label, mask = L.pseudo_label(logits, 0.95, mode)
+    lab_g, mask_g = F().pseudo_label(logits.cuda(), 0.95, mode)
+    assert lab_g.dtype == label.dtype and lab_g.shape == label.shape and mask_g.shape == mask.shape
+    assert torch.equal(lab_g.cpu(), label)                   # argmax / >=0.5 masks: bit-exact
+    # confidence masks are ulp-sensitive exactly at the threshold: exclude |p - th| < 1e-6 and report
+    p = torch.softmax(logits, 1).max(1)[0][:, None] if mode == "softmax" else torch.sigmoid(logits)
+    near = ((p - 0.95).abs() < 1e-6) | ((p - 0.05).abs() < 1e-6)
+    assert int(near.sum()) < 10
+    assert torch.equal(mask_g.cpu()[~near], mask[~near])
+
+
+@pytest.mark.parametrize("mode", ["softmax", "sigmoid"])
+def test_mix_targets_and_box_mix_exact(mode):
+    g = torch.Generator().manual_seed(23)
+    N, K, H = 3, 2, 24
+    box = torch.zeros(N, H, H)
+    box[0, 3:11, 5:20] = 1
+    box[2, :, :7] = 1
+
+    def lab():
+        return torch.randint(0, K, (N, H, H), generator=g) if mode == "softmax" else (torch.rand(N, K, H, H, generator=g) > 0.5).float()
+
+    def msk():
+        return (torch.rand(N, 1 if mode == "softmax" else K, H, H, generator=g) > 0.3).float()
+
+    args = [lab(), msk(), lab(), msk(), lab(), msk()]
+    cut_label, cut_mask = lab(), msk()
+    ref = L.mix_targets(mode, *args, box, cut_label, cut_mask)
+    got = F().mix_targets(mode, box.cuda(), *[a.cuda() for a in args], cut_label.cuda(), cut_mask.cuda())
+    for r, o in zip(ref, got):
+        assert r.dtype == o.dtype and torch.equal(o.cpu(), r)
+    a, b = torch.randn(N, 3, H, H, generator=g), torch.randn(N, 3, H, H, generator=g)
+    ib = box[:, None]
+    assert torch.equal(F().box_mix(a.cuda(), b.cuda(), box.cuda()).cpu(), a * (1 - ib) + b * ib)
+
+
+def test_dice_counts_match_numpy_dice():
+    from utils import metrics
+    g = load_golden("g6_metrics")
+    p2, t2 = t(g["l2.pred"]).cuda(), t(g["l2.tgt"]).cuda()
+    c = F().dice_counts(p2, t2).cpu().numpy().astype(np.float64)
+    d = metrics.dice_from_counts(c[..., 0], c[..., 1], c[..., 2])
+    np.testing.assert_allclose(d.T, g["l2.arr"], rtol=1e-12)
+    p3, t3 = t(g["l3.pred"]).cuda(), t(g["l3.tgt"]).cuda()
+    c = F().dice_counts(p3, t3, by_class=True, n_classes=3).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(metrics.dice_from_counts(c[..., 0], c[..., 1], c[..., 2]).T, g["l3.arr"], rtol=1e-12)
+    a, b = t(g["bin.pred"].astype(np.int64)).cuda(), t(g["bin.tgt"].astype(np.int64)).cuda()
+    c = F().dice_counts(a, b).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(metrics.dice_from_counts(c[..., 0], c[..., 1], c[..., 2])[:, 0], g["bin.each"], rtol=1e-12)
+
+
+def test_sgd_ema_matches_torch_sgd_trajectory():
+    g = load_golden("g8_sgd")
+    p = torch.zeros(36, device="cuda")
+    p[:35] = t(g["p0"]).flatten().cuda()
+    v, tt = torch.zeros_like(p), torch.zeros_like(p)
+    tt[:35] = 1.0
+    lr = 0.03
+    for s in range(3):
+        gr = torch.zeros_like(p)
+        gr[:35] = t(g[f"g{s}"]).flatten().cuda()
+        alpha = H.ema_alpha(s, 0.99)
+        t_prev = tt.clone()
+        F().sgd_ema(p, gr, v, tt, lr, 0.9, 1e-4, s == 0, alpha)
+        np.testing.assert_allclose(p[:35].cpu().numpy(), g[f"p{s + 1}"].flatten(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(tt.cpu().numpy(), (alpha * t_prev + (1 - alpha) * p).cpu().numpy(), rtol=1e-6, atol=1e-7)
+        lr = H.poly_lr(0.03, s, 30000)

@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
                                                           const float* __restrict__ mask, int N, int K, int HW, int mode,
                                                           const float* __restrict__ sums, const float* __restrict__ gdev,
                                                           float gscale, float cw, float dw, float* __restrict__ dlogits) {
-    const float gs = gscale * (gdev ? *gdev : 1.f);
+    // gdev (optional) = upstream gradients of the two outputs {d/d ce, d/d dice} on the device
+    const float gs = gscale;
+    cw *= gdev ? gdev[0] : 1.f;
+    dw *= gdev ? gdev[1] : 1.f;
     const long npix = (long)N * HW;
     if (mode == USTRUN_LOSS_SOFTMAX) {
         const long long* tgt = (const long long*)target;

@@ -1,0 +1,164 @@
+"""Python wrappers of the loss / pseudo-label / target-mixing / optimizer entry points."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .engine import stream_ptr
+
+_MODE = {"softmax": L.LOSS_SOFTMAX, "sigmoid": L.LOSS_SIGMOID}
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a float32 HIP tensor, got {t.dtype} on {t.device}")
+    return t.contiguous()
+
+
+def _shape(logits):
+    N, K = logits.shape[:2]
+    HW = logits[0, 0].numel()
+    return N, K, HW
+
+
+def _check_targets(logits, target, mask, mode):
+    N, K, HW = _shape(logits)
+    if mode == "softmax":
+        if target.dtype != torch.int64 or target.numel() != N * HW:
+            raise RuntimeError(f"softmax target must be int64 [N,H,W], got {target.dtype} {tuple(target.shape)}")
+        if mask is not None and mask.numel() != N * HW:
+            raise RuntimeError(f"softmax mask must have N*H*W elements, got {tuple(mask.shape)}")
+    else:
+        if target.dtype != torch.float32 or target.numel() != N * K * HW:
+            raise RuntimeError(f"sigmoid target must be float32 [N,K,H,W], got {target.dtype} {tuple(target.shape)}")
+        if mask is not None and mask.numel() != N * K * HW:
+            raise RuntimeError(f"sigmoid mask must have N*K*H*W elements, got {tuple(mask.shape)}")
+
+
+def seg_loss_fwd(logits, target, mask, mode):
+    """-> out tensor: [0]=ce mean, [1]=dice, [2:]=reduced sums kept for the backward."""
+    lib = L.lib()
+    logits = _f32c(logits, "logits")
+    target = target.contiguous()
+    mask = None if mask is None else _f32c(mask, "mask")
+    _check_targets(logits, target, mask, mode)
+    N, K, HW = _shape(logits)
+    out = torch.empty(4 + 3 * K, dtype=torch.float32, device=logits.device)
+    nb = lib.ustrun_loss_partials_bytes(N, K, HW)
+    part = torch.empty(nb // 4, dtype=torch.float32, device=logits.device)
+    L.check(lib.ustrun_seg_loss_fwd(logits.data_ptr(), target.data_ptr(), L.ptr(mask), N, K, HW, _MODE[mode],
+                                    out.data_ptr(), part.data_ptr(), nb, stream_ptr()), "ustrun_seg_loss_fwd")
+    return out
+
+
+def seg_loss_bwd(logits, target, mask, mode, sums, gscale=1.0, ce_weight=1.0, dice_weight=1.0, gdev=None):
+    lib = L.lib()
+    logits = _f32c(logits, "logits")
+    target = target.contiguous()
+    mask = None if mask is None else _f32c(mask, "mask")
+    N, K, HW = _shape(logits)
+    dl = torch.empty_like(logits)
+    L.check(lib.ustrun_seg_loss_bwd(logits.data_ptr(), target.data_ptr(), L.ptr(mask), N, K, HW, _MODE[mode],
+                                    sums.data_ptr(), L.ptr(gdev), float(gscale), float(ce_weight), float(dice_weight),
+                                    dl.data_ptr(), stream_ptr()), "ustrun_seg_loss_bwd")
+    return dl
+
+
+class _SegLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, mask, mode, ce_weight, dice_weight):
+        out = seg_loss_fwd(logits, target, mask, mode)
+        ctx.save_for_backward(logits, target, out) if mask is None else ctx.save_for_backward(logits, target, out, mask)
+        ctx.cfg = (mode, ce_weight, dice_weight, mask is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        mode, cw, dw, has_mask = ctx.cfg
+        saved = ctx.saved_tensors
+        logits, target, out = saved[:3]
+        mask = saved[3] if has_mask else None
+        g = gout.contiguous()
+        dl = seg_loss_bwd(logits, target, mask, mode, out, 1.0, cw, dw, gdev=g)
+        return dl, None, None, None, None, None
+
+
+def seg_loss(logits, target, mask, mode, ce_weight=1.0, dice_weight=1.0):
+    """(ce, dice) of one loss term (train.py:816-817,829-836); differentiable w.r.t. logits."""
+    out = _SegLossFn.apply(logits, target, mask, mode, float(ce_weight), float(dice_weight))
+    return out[0], out[1]
+
+
+def pseudo_label(logits, threshold, mode):
+    """train.py:648-667.  softmax -> (label int64 [N,H,W], mask f32 [N,1,H,W]); sigmoid -> f32 [N,K,H,W] x2."""
+    lib = L.lib()
+    logits = _f32c(logits, "logits")
+    N, K, HW = _shape(logits)
+    sp = logits.shape[2:]
+    if mode == "softmax":
+        label = torch.empty((N,) + tuple(sp), dtype=torch.int64, device=logits.device)
+        mask = torch.empty((N, 1) + tuple(sp), dtype=torch.float32, device=logits.device)
+    else:
+        label = torch.empty_like(logits)
+        mask = torch.empty_like(logits)
+    L.check(lib.ustrun_pseudo_label(logits.data_ptr(), N, K, HW, float(threshold), _MODE[mode], label.data_ptr(),
+                                    mask.data_ptr(), stream_ptr()), "ustrun_pseudo_label")
+    return label, mask
+
+
+def mix_targets(mode, box, pl, mask, pl_w_ul, mask_w_ul, pl_w_lu, mask_w_lu, cut_label, cut_mask):
+    """train.py:677-697 -> (pl_w, mask_w, pl_ul, mask_ul, pl_lu, mask_lu)."""
+    lib = L.lib()
+    ts = [t.contiguous() for t in (pl, mask, pl_w_ul, mask_w_ul, pl_w_lu, mask_w_lu, cut_label, cut_mask)]
+    box = _f32c(box, "box")
+    N = box.shape[0]
+    HW = box[0].numel()
+    K = mask.shape[1] if mode == "sigmoid" else 1
+    want = torch.float32 if mode == "sigmoid" else torch.int64
+    for t in (ts[0], ts[2], ts[4], ts[6]):
+        if t.dtype != want or t.numel() != ts[0].numel():
+            raise RuntimeError("mix_targets: label tensors must share dtype/shape")
+    for t in (ts[1], ts[3], ts[5], ts[7]):
+        if t.dtype != torch.float32 or t.numel() != ts[1].numel():
+            raise RuntimeError("mix_targets: mask tensors must be float32 of one shape")
+    outs = [torch.empty_like(ts[0]), torch.empty_like(ts[1]), torch.empty_like(ts[0]), torch.empty_like(ts[1]),
+            torch.empty_like(ts[0]), torch.empty_like(ts[1])]
+    L.check(lib.ustrun_mix_targets(_MODE[mode], N, K, HW, box.data_ptr(), *[t.data_ptr() for t in ts],
+                                   *[t.data_ptr() for t in outs], stream_ptr()), "ustrun_mix_targets")
+    return tuple(outs)
+
+
+def box_mix(a, b, box):
+    """a*(1-box) + b*box with box [N,H,W] broadcast over channels (train.py:644-646,688,691)."""
+    lib = L.lib()
+    a, b, box = _f32c(a, "a"), _f32c(b, "b"), _f32c(box, "box")
+    N, C = a.shape[:2]
+    out = torch.empty_like(a)
+    L.check(lib.ustrun_box_mix(a.data_ptr(), b.data_ptr(), box.data_ptr(), N, C, a[0, 0].numel(), out.data_ptr(),
+                               stream_ptr()), "ustrun_box_mix")
+    return out
+
+
+def dice_counts(pred, gt, by_class=False, n_classes=1):
+    """Per-sample {|pred|, |gt|, |pred&gt|} as int32 [N,K,3] (inputs of utils/metrics.py:114-146)."""
+    lib = L.lib()
+    pred, gt = pred.contiguous(), gt.contiguous()
+    N = pred.shape[0]
+    if by_class:
+        K, HW = n_classes, pred[0].numel()
+    else:
+        K = pred.shape[1] if pred.dim() == 4 else 1
+        HW = pred[0].numel() // K
+    counts = torch.empty((N, K, 3), dtype=torch.int32, device=pred.device)
+    L.check(lib.ustrun_dice_counts(pred.data_ptr(), gt.data_ptr(), int(pred.dtype == torch.int64),
+                                   int(gt.dtype == torch.int64), N, K, HW, int(by_class), counts.data_ptr(),
+                                   stream_ptr()), "ustrun_dice_counts")
+    return counts
+
+
+def sgd_ema(p, g, v, t, lr, momentum, weight_decay, first, alpha, grad_scale=1.0):
+    """Fused SGD(momentum, wd) step on flat f32 buffers + EMA teacher update (train.py:512,848,87-93)."""
+    lib = L.lib()
+    L.check(lib.ustrun_sgd_ema(p.data_ptr(), g.data_ptr(), v.data_ptr(), L.ptr(t), p.numel(), float(lr), float(momentum),
+                               float(weight_decay), int(first), float(alpha), float(grad_scale), stream_ptr()),
+            "ustrun_sgd_ema")

@@ -1,0 +1,306 @@
+"""One semi-supervised training iteration on MI355X -- the counterpart of the reference's inline
+loop body train.py:577-858 (twin train_mnms.py:535-791), minus data loading and logging.
+
+Every tensor op of the iteration runs in libustrun.so (U-Net forward/backward, pseudo-labels,
+target mixing, CutMix compositing, losses, SGD+EMA); this module only sequences the calls, draws
+the reference's random numbers in the reference's order, and keeps the reference's cross-iteration
+state (memory bank, low-quality sample, choice threshold).  Quirks reproduced: Q2-Q7, Q10, Q11, Q13,
+Q16, Q17.  Deliberate deviations: batch sizes are honoured (Q1); precision is the
+model's compute dtype rather than fp16 autocast (Q12).
+"""
+from __future__ import annotations
+
+import math
+import random
+
+import numpy as np
+import torch
+
+from utils import metrics, ramps
+
+from . import engine
+from . import functional as F
+
+DATASETS = {
+    # name: (in_channels, patch, classes, loss mode, parts, max_iterations)   train.py:404-436, train_mnms.py:397-404
+    "fundus": (3, 256, 2, "sigmoid", 2, 30000),
+    "prostate": (1, 384, 2, "softmax", 1, 60000),
+    "BUSI": (1, 256, 2, "softmax", 1, 30000),
+    "MNMS": (1, 288, 4, "softmax", 3, 60000),
+}
+
+
+def decode_labels(dataset, y):
+    """train.py:590-608, train_mnms.py:549-556."""
+    if dataset == "fundus":
+        return torch.stack([y.eq(0).float(), y.le(128).float()], dim=1)
+    if dataset == "prostate":
+        return y.eq(0).long()
+    if dataset == "BUSI":
+        return y.eq(255).long()
+    m = y[..., 0].eq(255).float()
+    m[y[..., 1].eq(255)] = 2
+    m[y[..., 2].eq(255)] = 3
+    return m.long()
+
+
+def cutmix_box(img_size, p=0.5, size_min=0.02, size_max=0.4, ratio_1=0.3, ratio_2=1 / 0.3):
+    """train.py:222-240 on the host (numpy {0,1} map); same RNG streams and draw order."""
+    box = np.zeros((img_size, img_size), dtype=np.float32)
+    if random.random() > p:
+        return box
+    size = np.random.uniform(size_min, size_max) * img_size * img_size
+    while True:
+        ratio = np.random.uniform(ratio_1, ratio_2)
+        w = int(np.sqrt(size / ratio))
+        h = int(np.sqrt(size * ratio))
+        x = np.random.randint(0, img_size)
+        y = np.random.randint(0, img_size)
+        if x + w <= img_size and y + h <= img_size:
+            break
+    box[y:y + h, x:x + w] = 1
+    return box
+
+
+def all_cover_box(region):
+    """train.py:242-251: bounding box of the nonzero pixels (rows from scan order, cols min/max)."""
+    loc = np.argwhere(region != 0)
+    if len(loc) == 0:
+        return cutmix_box(region.shape[0], p=1.0)
+    box = np.zeros(region.shape, dtype=np.float32)
+    box[loc[0, 0]:loc[-1, 0] + 1, loc[:, 1].min():loc[:, 1].max() + 1] = 1
+    return box
+
+
+def freq_mix_host(src_img, trg_img, L, ratio):
+    """train.py:158-207 (numpy FFT on the host, as the reference does)."""
+    amp_trg = np.abs(np.fft.fft2(trg_img, axes=(-2, -1)))
+    f = np.fft.fft2(src_img, axes=(-2, -1))
+    amp, pha = np.abs(f), np.angle(f)
+    a_s = np.fft.fftshift(amp, axes=(-2, -1))
+    a_t = np.fft.fftshift(amp_trg, axes=(-2, -1))
+    _, h, w = a_s.shape
+    b = int(np.floor(min(h, w) * L))
+    ch, cw = int(np.floor(h / 2.0)), int(np.floor(w / 2.0))
+    sl = (slice(None), slice(ch - b, ch + b + 1), slice(cw - b, cw + b + 1))
+    a_s[sl] = a_s[sl] * (1 - ratio) + a_t[sl] * ratio
+    a_s = np.fft.ifftshift(a_s, axes=(-2, -1))
+    return np.real(np.fft.ifft2(a_s * np.exp(1j * pha), axes=(-2, -1)))
+
+
+def flatten_parameters(model):
+    """Re-home all parameters in one contiguous f32 buffer (views keep their names/shapes)."""
+    params = list(model.parameters())
+    total = sum((p.numel() + 3) // 4 * 4 for p in params)
+    flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
+    views, o = [], 0
+    for p in params:
+        v = flat[o:o + p.numel()].view_as(p)
+        v.copy_(p.data)
+        p.data = v
+        views.append(v)
+        o += (p.numel() + 3) // 4 * 4
+    return flat, views
+
+
+def flat_like(flat, params):
+    buf = torch.zeros_like(flat)
+    views, o = [], 0
+    for p in params:
+        views.append(buf[o:o + p.numel()].view_as(p))
+        o += (p.numel() + 3) // 4 * 4
+    return buf, views
+
+
+class SSLTrainer:
+    def __init__(self, dataset, model, ema_model, base_lr=0.03, max_iterations=None, threshold=0.95,
+                 ema_decay=0.99, consistency=1.0, consistency_rampup=200.0, cutmix_prob=1.0, LB=0.01,
+                 increase=1.0005, queue_len=10, num_eval_iter=500, momentum=0.9, weight_decay=1e-4,
+                 patch_size=None, grad_allreduce=None, world_size=1, fft="host"):
+        cfg = DATASETS[dataset]
+        self.dataset = dataset
+        self.n_classes, self.mode, self.n_part = cfg[2], cfg[3], cfg[4]
+        self.patch = patch_size or cfg[1]
+        self.max_iterations = max_iterations or cfg[5]
+        self.model, self.ema_model = model, ema_model
+        for p in ema_model.parameters():
+            p.detach_()                                  # train.py:501-502
+        model.train()
+        ema_model.train()                                # teacher stays in train mode (train.py:566, Q11)
+        self.flat_p, _ = flatten_parameters(model)
+        self.flat_t, _ = flatten_parameters(ema_model)
+        params = list(model.parameters())
+        self.flat_g, self.grad_views = flat_like(self.flat_p, params)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        model._ustrun_grad_sink = self.grad_views        # backward accumulates straight into flat_g
+        engine.invalidate_packed(model)
+        engine.invalidate_packed(ema_model)
+        self.base_lr, self.lr = base_lr, base_lr
+        self.momentum, self.wd = momentum, weight_decay
+        self.threshold, self.ema_decay = threshold, ema_decay
+        self.consistency, self.rampup = consistency, consistency_rampup
+        self.cutmix_prob, self.LB, self.increase, self.queue_len = cutmix_prob, LB, increase, queue_len
+        self.num_eval_iter = num_eval_iter
+        self.grad_allreduce = grad_allreduce             # callable(flat_g): SUM over ranks (RCCL all-reduce)
+        self.world_size = world_size
+        self.fft = fft
+        self.iter_num = 0
+        self.first_step = True
+        # memory bank + low-quality sample state (train.py:554-561,576)
+        self.simple_ulb = None
+        self.cor_pl = self.cor_gt = self.cor_mask = None
+        self.cor_hardness = []
+        self.choice_th = 0.1
+        self.lq_u = self.lq_pl = self.lq_mask = None
+        self.last = {}
+
+    # ---------------------------------------------------------------------------------------
+    def _pl(self, logits):
+        return F.pseudo_label(logits, self.threshold, self.mode)
+
+    def _sample_dice(self, pred, gt):
+        """Per-sample Dice (numpy array [n_part, B]) from device overlap counts: one small D2H copy."""
+        if self.dataset == "MNMS":
+            cnt = F.dice_counts(pred, gt, by_class=True, n_classes=3)
+        else:
+            cnt = F.dice_counts(pred, gt)
+        c = cnt.cpu().numpy().astype(np.float64)          # [B, parts, 3]
+        return metrics.dice_from_counts(c[..., 0], c[..., 1], c[..., 2]).T
+
+    def _freq_mix(self, mix_img, ulb_x_w, n):
+        degree = self.iter_num / self.max_iterations
+        ratios = [random.uniform(0, degree) for _ in range(n)]     # one draw per image (train.py:182)
+        if self.fft == "host":
+            src = ((mix_img[:n] + 1) * 127.5).cpu().numpy()
+            trg = ((ulb_x_w[:n] + 1) * 127.5).cpu().numpy()
+            out = [np.clip(freq_mix_host(src[i], trg[i], self.LB, ratios[i]), 0, 255).astype(np.float32) for i in range(n)]
+            return (torch.tensor(np.array(out), dtype=torch.float32) / 127.5 - 1).to(mix_img.device)
+        from . import fftmix
+        return fftmix.freq_mix_device(mix_img[:n], ulb_x_w[:n], self.LB, ratios)
+
+    # ---------------------------------------------------------------------------------------
+    def step(self, lb_x_w, lb_y, ulb_x_w, ulb_x_s, ulb_y, epoch_start=False):
+        ds, mode, K = self.dataset, self.mode, self.n_classes
+        model, ema = self.model, self.ema_model
+        dev = lb_x_w.device
+        B = len(ulb_x_s)
+        epoch_num = self.iter_num // self.num_eval_iter
+        if epoch_start:
+            self.lq_u = self.lq_pl = self.lq_mask = None
+        lb_mask = decode_labels(ds, lb_y)
+        ulb_mask = decode_labels(ds, ulb_y)
+        mshape = [len(lb_x_w), K if ds == "fundus" else 1, self.patch, self.patch]
+
+        # CutMix partner selection (train.py:612-627)
+        ones = torch.ones(mshape, device=dev)
+        if self.simple_ulb is None or len(self.simple_ulb) == 0:
+            cut_img, cut_label, cut_mask = lb_x_w, lb_mask, ones
+            choice = np.random.randint(0, len(lb_x_w), B)
+        else:
+            cut_img = torch.cat((lb_x_w, self.simple_ulb), 0)
+            cut_label = torch.cat((lb_mask, self.cor_pl), 0)
+            cut_mask = torch.cat((ones, self.cor_mask), 0)
+            n_s = min(int(B * 0.5), len(self.simple_ulb))
+            c_lb = np.random.randint(0, len(lb_x_w), B - n_s)
+            c_s = np.random.randint(len(lb_x_w), len(lb_x_w) + len(self.simple_ulb), n_s)
+            choice = np.random.permutation(np.concatenate((c_lb, c_s)))
+        idx = torch.as_tensor(choice, device=dev, dtype=torch.long)
+        mix_img = cut_img.index_select(0, idx)
+        cut_label_c, cut_mask_c = cut_label.index_select(0, idx), cut_mask.index_select(0, idx)
+
+        # FFT low-frequency amplitude mix (train.py:628-636, Q13)
+        move_transx = self._freq_mix(mix_img, ulb_x_w, len(lb_x_w))
+
+        with torch.no_grad():
+            box = torch.from_numpy(np.stack([cutmix_box(self.patch, p=self.cutmix_prob) for _ in range(B)])).to(dev)
+            # teacher: three train-mode forwards (train.py:638-667, Q11)
+            pl, mask = self._pl(ema(ulb_x_w))
+            pl_w_ul, mask_w_ul = self._pl(ema(F.box_mix(ulb_x_w, mix_img, box)))
+            pl_w_lu, mask_w_lu = self._pl(ema(F.box_mix(mix_img, ulb_x_w, box)))
+            # student forward on the weak view: only its pseudo-label is used (Q3)
+            stu_pl, _ = self._pl(model(ulb_x_w))
+            pl_w, mask_w, pl_ul, mask_ul, pl_lu, mask_lu = F.mix_targets(
+                mode, box, pl, mask, pl_w_ul, mask_w_ul, pl_w_lu, mask_w_lu, cut_label_c, cut_mask_c)
+            x_s_ul = F.box_mix(ulb_x_s, move_transx, box)
+            x_s_lu = F.box_mix(move_transx, ulb_x_s, box)
+
+        # student: four forwards that carry gradient (train.py:699-702)
+        lg_lb, lg_ul, lg_lu, lg_s = model(lb_x_w), model(x_s_ul), model(x_s_lu), model(ulb_x_s)
+
+        # hardness and the low-quality sample forward (train.py:705-747, Q2, Q7)
+        d = self._sample_dice(stu_pl, pl)
+        hardness = 1 - d.sum(0) / self.n_part
+        if epoch_num == 0:
+            hardness[:] = 1
+        lq_idx = int(np.argmax(hardness))
+        if self.lq_u is not None:
+            new_choice = np.random.randint(0, len(lb_x_w))
+            if ds == "fundus":
+                region = self.lq_pl[0, 1].clone()
+                region[self.lq_pl[0, 0].long() == 1] = 1
+                region[lb_mask[new_choice, 0].long() == 1] = 1
+                region[lb_mask[new_choice, 1].long() == 1] = 1
+            else:
+                region = self.lq_pl[0].clone()
+                region[lb_mask[new_choice].long() > 0] = 1
+            ib_lq = torch.from_numpy(all_cover_box(region.cpu().numpy()))[None].to(dev)
+            with torch.no_grad():                 # result unused (Q2); student BN running stats still move
+                model(F.box_mix(self.lq_u, lb_x_w[[new_choice]], ib_lq))
+        self.lq_u = ulb_x_w[[lq_idx]].clone()
+        self.lq_pl = pl[[lq_idx]].clone()
+        self.lq_mask = mask[[lq_idx]].clone()
+
+        # memory bank of easy unlabelled samples (train.py:749-782)
+        simple = hardness < self.choice_th
+        n_cur = int(simple.sum())
+        sel = torch.from_numpy(simple).to(dev)
+        if self.simple_ulb is None or len(self.simple_ulb) == 0:
+            self.simple_ulb, self.cor_pl = ulb_x_w[sel].clone(), pl[sel].clone()
+            self.cor_gt, self.cor_mask = ulb_mask[sel].clone(), mask[sel].clone()
+            self.cor_hardness = hardness[simple].copy()
+            if len(self.simple_ulb) > 0:
+                self.choice_th = min(self.choice_th, self.cor_hardness.max())
+        elif n_cur > 0:
+            keep = self.queue_len - n_cur if len(self.simple_ulb) + n_cur > self.queue_len else len(self.simple_ulb)
+            self.simple_ulb = torch.cat((ulb_x_w[sel], self.simple_ulb[:keep]), 0)
+            self.cor_pl = torch.cat((pl[sel], self.cor_pl[:keep]), 0)
+            self.cor_gt = torch.cat((ulb_mask[sel], self.cor_gt[:keep]), 0)
+            self.cor_mask = torch.cat((mask[sel], self.cor_mask[:keep]), 0)
+            self.cor_hardness = np.concatenate((hardness[simple], self.cor_hardness[:keep]))
+            self.choice_th = min(self.choice_th, self.cor_hardness.max())
+        else:
+            self.choice_th = min(self.increase * self.choice_th, 0.1)
+
+        # losses and backward (train.py:816-848; Q5, Q6): loss = sup + w*(ul + lu + w*s)
+        w = self.consistency * ramps.sigmoid_rampup(self.iter_num // (self.max_iterations / self.rampup), self.rampup)
+        terms = ((lg_lb, lb_mask, None, 1.0), (lg_ul, pl_ul, mask_ul, w), (lg_lu, pl_lu, mask_lu, w), (lg_s, pl_w, mask_w, w * w))
+        outs = []
+        model._ustrun_sink_fresh = True
+        for lg, tgt, msk, coef in terms:
+            out = F.seg_loss_fwd(lg.detach(), tgt, msk, mode)
+            outs.append(out)
+            dl = F.seg_loss_bwd(lg.detach(), tgt, msk, mode, out, gscale=coef)
+            lg.backward(dl)
+        if self.grad_allreduce is not None:
+            self.grad_allreduce(self.flat_g)
+
+        # SGD + EMA (train.py:848-851; alpha from the pre-increment iter_num, Q10), poly LR for the NEXT step
+        alpha = min(1 - 1 / (self.iter_num + 1), self.ema_decay)
+        F.sgd_ema(self.flat_p, self.flat_g, self.flat_v, self.flat_t, self.lr, self.momentum, self.wd,
+                  self.first_step, alpha, grad_scale=1.0 / self.world_size)
+        self.first_step = False
+        engine.invalidate_packed(model)
+        engine.invalidate_packed(ema)
+        self.lr = self.base_lr * (1.0 - self.iter_num / self.max_iterations) ** 0.9
+        self.iter_num += 1
+        self.last = {"outs": outs, "w": w, "pl": pl, "ulb_mask": ulb_mask, "mask": mask}
+        return self.last
+
+    def scalars(self):
+        """Loss values of the last step as python floats (one D2H copy; logging only)."""
+        o = torch.stack([t[:2] for t in self.last["outs"]]).cpu().numpy().astype(np.float64)
+        w = self.last["w"]
+        sup, ul, lu, s = (float(o[i, 0] + o[i, 1]) for i in range(4))
+        d = self._sample_dice(self.last["pl"], self.last["ulb_mask"]).mean(1)
+        return {"loss": sup + w * (ul + lu + w * s), "sup": sup, "ul": ul, "lu": lu, "s": s, "w": w,
+                "ulb_dice": [float(v) for v in d], "mask_ratio": float(self.last["mask"].mean())}
