@@ -145,6 +145,14 @@ int ustrun_mix_targets(int mode, int N, int K, int HW, const float* box, const v
 int ustrun_box_mix(const float* a, const float* b, const float* box, int N, int C, int HW,
                    float* out, ustrun_stream_t s);
 
+/* ---- FFT low-frequency amplitude mix: replaces train.py:158-207,628-636 (numpy on the host) --------
+ * src/trg/out are normalised NCHW images (k/127.5-1); per image n the (2b+1)^2 window of src's
+ * fft-shifted amplitude is blended towards trg's with ratio ratios[n] (device array), phase kept;
+ * out = clip(result,0,255)/127.5-1.  b = floor(min(H,W)*L).                                       */
+int64_t ustrun_freq_mix_work_bytes(int n, int C, int b);
+int ustrun_freq_mix(const float* src, const float* trg, const float* ratios, int n, int C, int H, int W,
+                    int b, float* out, void* work, int64_t work_bytes, ustrun_stream_t s);
+
 /* ---- loss term ce + dice: replaces train.py:816-817,829-836 with utils/losses.py:236-268 -----
  * softmax mode: target int64 [N,HW], mask f32 [N,HW] or NULL;  CE(reduction none)*mask, mean over
  *   all pixels (Q5) + per-class masked Dice with the class-0 mask all ones (Q4).
@@ -203,6 +211,13 @@ int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, float* logi
 int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x, const float* dlogits,
                          void* workspace, void* scratch, float* const* grads, int accumulate,
                          ustrun_stream_t s);
+
+/* ---- optional launch profiler (bench.py): HIP events recorded on the launch stream around every
+ * implicit-GEMM (kind 0) / weight-gradient (kind 1) launch while enabled; collect synchronises on
+ * the recorded events, returns the sums and resets that kind.                                   */
+int ustrun_profile_enable(int on);
+int ustrun_profile_collect(int kind, double* host_ms, double* host_flops, double* host_bytes,
+                           int64_t* host_launches);
 
 #ifdef __cplusplus
 }

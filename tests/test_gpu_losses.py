@@ -132,3 +132,24 @@ def test_sgd_ema_matches_torch_sgd_trajectory():
         np.testing.assert_allclose(p[:35].cpu().numpy(), g[f"p{s + 1}"].flatten(), rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(tt.cpu().numpy(), (alpha * t_prev + (1 - alpha) * p).cpu().numpy(), rtol=1e-6, atol=1e-7)
         lr = H.poly_lr(0.03, s, 30000)
+
+
+@pytest.mark.parametrize("C,S,LB", [(3, 32, 0.1), (1, 64, 0.05), (3, 256, 0.01)])
+def test_freq_mix_device_matches_numpy_fft(C, S, LB):
+    """Device amplitude mix vs the oracle's numpy FFT restatement (pinned to the reference by G7)."""
+    from ustrun.fftmix import freq_mix_device
+    g = torch.Generator().manual_seed(C + S)
+    n = 3
+    src = torch.randint(0, 256, (n, C, S, S), generator=g).float() / 127.5 - 1
+    trg = torch.randint(0, 256, (n, C, S, S), generator=g).float() / 127.5 - 1
+    ratios = [0.0, 0.37, 1.0]
+    got = freq_mix_device(src.cuda(), trg.cuda(), LB, ratios).cpu().numpy()
+    for i in range(n):
+        amp = H_amp(((trg[i] + 1) * 127.5).numpy())
+        ref = H.freq_mix(((src[i] + 1) * 127.5).numpy().astype(np.float64), amp, L=LB, ratio=ratios[i])
+        ref = np.clip(ref, 0, 255).astype(np.float32) / 127.5 - 1
+        np.testing.assert_allclose(got[i], ref, rtol=0, atol=2e-5)
+
+
+def H_amp(x):
+    return H.amp_spectrum(x.astype(np.float64))

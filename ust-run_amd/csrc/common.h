@@ -100,6 +100,11 @@ int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);
 int reduce_partials(const float* partials, int ksplit, int nseg, int Cin, int Cout, float* out,
                     int layout, int accumulate, hipStream_t st);
 
+// ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg) ----
+// kind 0: implicit-GEMM (conv3x3 fwd/dgrad, convT fwd/dgrad), kind 1: weight-gradient GEMM
+void prof_begin(int kind, double flops, double bytes, hipStream_t st);
+void prof_end(hipStream_t st);
+
 int reduce_rows(const float* part, int nslab, long stride, long offset, int count, float* out, int accumulate,
                 hipStream_t st);
 

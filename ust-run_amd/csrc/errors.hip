@@ -9,3 +9,46 @@ const char* get_error() { return g_err; }
 }
 extern "C" int ustrun_version(void) { return USTRUN_VERSION; }
 extern "C" const char* ustrun_last_error(void) { return ustrun::get_error(); }
+
+// ---- launch profiler -----------------------------------------------------------------------
+#include <vector>
+namespace ustrun {
+namespace {
+struct Slot { hipEvent_t a, b; double flops, bytes; int kind; };
+bool g_prof_on = false;
+std::vector<Slot> g_slots;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}  // namespace
+void prof_begin(int kind, double flops, double bytes, hipStream_t st) {
+    if (!g_prof_on) return;
+    Slot s; s.a = get_event(); s.b = get_event(); s.flops = flops; s.bytes = bytes; s.kind = kind;
+    (void)hipEventRecord(s.a, st);
+    g_slots.push_back(s);
+}
+void prof_end(hipStream_t st) {
+    if (!g_prof_on || g_slots.empty()) return;
+    (void)hipEventRecord(g_slots.back().b, st);
+}
+}  // namespace ustrun
+
+extern "C" int ustrun_profile_enable(int on) { ustrun::g_prof_on = on != 0; return 0; }
+
+extern "C" int ustrun_profile_collect(int kind, double* ms, double* flops, double* bytes, int64_t* launches) {
+    using namespace ustrun;
+    double t = 0, f = 0, b = 0; int64_t n = 0;
+    std::vector<Slot> keep;
+    for (auto& s : g_slots) {
+        if (s.kind != kind) { keep.push_back(s); continue; }
+        if (hipEventSynchronize(s.b) != hipSuccess) { set_error("profile_collect: event sync failed"); return 2; }
+        float e = 0.f; (void)hipEventElapsedTime(&e, s.a, s.b);
+        t += e; f += s.flops; b += s.bytes; ++n;
+        g_pool.push_back(s.a); g_pool.push_back(s.b);
+    }
+    g_slots.swap(keep);
+    if (ms) *ms = t; if (flops) *flops = f; if (bytes) *bytes = b; if (launches) *launches = n;
+    return 0;
+}

@@ -287,15 +287,20 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     for (int i = 0; i < a.nsrc; ++i) { csum += a.src[i].C; pool |= a.src[i].pool != 0; }
     USTRUN_CHECK(csum == a.Cin, "igemm: source channels %d != Cin %d", csum, a.Cin);
     USTRUN_CHECK(!pool || a.nsrc == 1, "igemm: pooled source cannot be concatenated");
-    if (pick_bm(a.Cout) == 128) {
-        if (pool) return launch_cfg<2, 2, true>(a, st);
-        return launch_cfg<2, 2, false>(a, st);
+    // algorithmic cost of this launch: every stored input/weight/output element touched once
+    double in_elems = 0;
+    for (int i = 0; i < a.nsrc; ++i) in_elems += (double)a.N * a.src[i].H * a.src[i].W * a.src[i].C;
+    const double out_elems = (double)a.M * a.nz * a.Cout;
+    const double w_elems = (double)a.nseg * a.nz * a.Cin * a.Cout;
+    prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, 4.0 * (in_elems + out_elems + w_elems), st);
+    int rc;
+    if (pick_bm(a.Cout) == 128 || pool) {   // (narrow outputs with a pooled source only occur in tiny test nets)
+        rc = pool ? launch_cfg<2, 2, true>(a, st) : launch_cfg<2, 2, false>(a, st);
+    } else {
+        rc = launch_cfg<4, 1, false>(a, st);
     }
-    if (pool) {
-        // narrow outputs with a pooled source only occur in tiny test nets: run the 128-row tile
-        return launch_cfg<2, 2, true>(a, st);
-    }
-    return launch_cfg<4, 1, false>(a, st);
+    prof_end(st);
+    return rc;
 }
 
 }  // namespace ustrun

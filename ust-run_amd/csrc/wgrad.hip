@@ -229,6 +229,11 @@ int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
     const bool pool = a.src[0].pool != 0;
     USTRUN_CHECK(!pool || a.nsrc == 1, "wgrad: pooled source cannot be concatenated");
     const bool m128 = a.Cin > 64, n128 = a.Cout > 64;
+    double in_elems = 0;
+    for (int i = 0; i < a.nsrc; ++i) in_elems += (double)a.N * a.src[i].H * a.src[i].W * a.src[i].C;
+    prof_begin(1, 2.0 * a.M * a.nseg * a.Cin * a.Cout,
+               4.0 * (in_elems + (double)a.N * a.dyH * a.dyW * a.Cout + (double)a.nseg * a.Cin * a.Cout), st);
+    struct End { hipStream_t s; ~End() { prof_end(s); } } end_{st};
     if (pool) {
         if (m128 && n128) return launch_cfg<128, 128, true>(a, st);
         if (m128) return launch_cfg<128, 64, true>(a, st);

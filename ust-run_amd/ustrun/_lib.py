@@ -57,11 +57,15 @@ SIGNATURES = {
     "ustrun_pseudo_label": (i32, [fp, i32, i32, i32, f32, i32, vp, fp, vp]),
     "ustrun_mix_targets": (i32, [i32, i32, i32, i32, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp]),
     "ustrun_box_mix": (i32, [fp, fp, fp, i32, i32, i32, fp, vp]),
+    "ustrun_freq_mix_work_bytes": (i64, [i32, i32, i32]),
+    "ustrun_freq_mix": (i32, [fp, fp, fp, i32, i32, i32, i32, i32, fp, vp, i64, vp]),
     "ustrun_loss_partials_bytes": (i64, [i32, i32, i32]),
     "ustrun_seg_loss_fwd": (i32, [fp, vp, fp, i32, i32, i32, i32, fp, fp, i64, vp]),
     "ustrun_seg_loss_bwd": (i32, [fp, vp, fp, i32, i32, i32, i32, fp, fp, f32, f32, f32, fp, vp]),
     "ustrun_dice_counts": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ustrun_sgd_ema": (i32, [fp, fp, fp, fp, i64, f32, f32, f32, i32, f32, f32, vp]),
+    "ustrun_profile_enable": (i32, [i32]),
+    "ustrun_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ustrun_unet_packed_bytes": (i64, [PDesc]),
     "ustrun_unet_fwd_workspace_bytes": (i64, [PDesc]),
     "ustrun_unet_bwd_scratch_bytes": (i64, [PDesc]),

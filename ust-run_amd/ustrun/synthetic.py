@@ -1,0 +1,48 @@
+"""Seeded synthetic batches with the value domains the reference's data pipeline emits
+(SURVEY.md 8d): images on the 256-level grid k/127.5-1 (Normalize_tf, custom_transforms.py:650-684),
+labels as float tensors holding uint8 values (ToTensor, :728-753)."""
+import torch
+
+
+def _discs(B, H, g, radii):
+    """Concentric random discs per sample -> list of boolean maps, outermost first."""
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(H), indexing="ij")
+    cy = (0.3 + 0.4 * torch.rand(B, generator=g)) * H
+    cx = (0.3 + 0.4 * torch.rand(B, generator=g)) * H
+    r0 = (0.15 + 0.15 * torch.rand(B, generator=g)) * H
+    d2 = (yy[None] - cy[:, None, None]) ** 2 + (xx[None] - cx[:, None, None]) ** 2
+    return [d2 <= (r0 * f)[:, None, None] ** 2 for f in radii]
+
+
+def images(B, C, H, g):
+    x = torch.randint(0, 256, (B, C, H, H), generator=g).float()
+    # 3x3 box low-pass so that predictions are not pure noise, re-quantised to the 256-level grid
+    x = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="replicate"), 3, 1).round()
+    return x / 127.5 - 1
+
+
+def labels(dataset, B, H, g):
+    if dataset == "fundus":                      # 0 = cup, 128 = disc rim, 255 = background
+        disc, cup = _discs(B, H, g, (1.0, 0.5))
+        y = torch.full((B, H, H), 255.0)
+        y[disc] = 128.0
+        y[cup] = 0.0
+        return y
+    if dataset == "prostate":                    # foreground = 0 (train.py:600)
+        (fg,) = _discs(B, H, g, (1.0,))
+        return torch.where(fg, torch.tensor(0.0), torch.tensor(255.0))
+    if dataset == "BUSI":                        # foreground = 255 (train.py:605)
+        (fg,) = _discs(B, H, g, (1.0,))
+        return torch.where(fg, torch.tensor(255.0), torch.tensor(0.0))
+    a, b, c = _discs(B, H, g, (1.0, 0.7, 0.4))   # MNMS: channel c == 255 <=> class c+1, disjoint rings
+    y = torch.zeros(B, H, H, 3)
+    y[..., 0][a & ~b] = 255.0
+    y[..., 1][b & ~c] = 255.0
+    y[..., 2][c] = 255.0
+    return y
+
+
+def batch(dataset, B, C, H, seed):
+    """(lb_x_w, lb_y, ulb_x_w, ulb_x_s, ulb_y) on the CPU."""
+    g = torch.Generator().manual_seed(seed)
+    return images(B, C, H, g), labels(dataset, B, H, g), images(B, C, H, g), images(B, C, H, g), labels(dataset, B, H, g)
