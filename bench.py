@@ -49,13 +49,14 @@ def cpu_baseline(dataset):
     from oracle.step_ref import DATASETS, RefTrainer
     from ustrun import synthetic
     C, H, K = DATASETS[dataset][:3]
-    cores = os.cpu_count() or 1
+    cores = min(len(os.sched_getaffinity(0)), 16)     # the GPU box gives one GPU a 16-CPU share
     torch.set_num_threads(cores)
     torch.manual_seed(1337)
     sd = U.make_state_dict(C, K)
     tr = RefTrainer(dataset, sd)
     random.seed(1212); np.random.seed(1337)
     b = synthetic.batch(dataset, 4, C, H, 1337)
+    print(f"[bench] cpu_baseline: timing one oracle step on {cores} threads ...", file=sys.stderr, flush=True)
     t0 = time.time()
     tr.step(*b, epoch_start=True)
     dt = time.time() - t0
@@ -75,7 +76,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        from ustrun import ddp
+        ddp.init("nccl", device=dev)              # "nccl" is RCCL on ROCm
 
     from networks.unet_model import UNet
     from ustrun import _lib, synthetic
@@ -85,10 +87,9 @@ def main():
     model = UNet(C, K, dtype=a.dtype).to(dev)
     ema = UNet(C, K, dtype=a.dtype).to(dev)
 
-    def allreduce(flat):
-        dist.all_reduce(flat)                     # SUM over ranks on RCCL; 1/world folded into the SGD kernel
-
-    tr = SSLTrainer(a.dataset, model, ema, grad_allreduce=allreduce if world > 1 else None, world_size=world, fft=a.fft)
+    # one SUM all-reduce of the flat 124 MB gradient buffer per step; 1/world is folded into the SGD kernel
+    from ustrun.ddp import make_grad_allreduce
+    tr = SSLTrainer(a.dataset, model, ema, grad_allreduce=make_grad_allreduce(world), world_size=world, fft=a.fft)
     random.seed(1212 + rank); np.random.seed(1337 + rank)
     nb = 4                                        # a few distinct resident batches, cycled
     batches = []

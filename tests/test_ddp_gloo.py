@@ -1,0 +1,82 @@
+"""world_size-2 gloo test of the data-parallel exchange (CPU, no GPU): the flat-gradient all-reduce of
+ustrun.ddp + the 1/world scale folded into the SGD update reproduces the average of R independent
+replicas' gradients, and keeps parameters bit-identical across ranks."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _sgd(p, g, v, lr, mu, wd, first, gscale):
+    """same update as ustrun_sgd_ema (loss.hip) / torch.optim.SGD"""
+    g = g * gscale + wd * p
+    v = g.clone() if first else mu * v + g
+    return p - lr * v, v
+
+
+def _worker(rank, world, port, bucket, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "ust-run_amd")]
+    from ustrun import ddp
+    r, _, w = ddp.init("gloo")
+    assert (r, w) == (rank, world)
+    n = 10007
+    torch.manual_seed(1337)                                # identical initial parameters on every rank
+    p = torch.randn(n)
+    v = torch.zeros(n)
+    ar = ddp.make_grad_allreduce(world, bucket_elems=bucket)
+    for step in range(3):
+        g = torch.Generator().manual_seed(ddp.rank_seed(100 * step, rank))
+        grad = torch.randn(n, generator=g)                 # this rank's local gradient
+        local = grad.clone()
+        ar(grad)                                           # SUM over ranks, in place
+        # reference: mean of the R replicas' gradients
+        tot = sum(torch.randn(n, generator=torch.Generator().manual_seed(ddp.rank_seed(100 * step, k))) for k in range(world))
+        assert torch.allclose(grad, tot, rtol=0, atol=1e-6)
+        assert not torch.equal(grad, local)
+        p, v = _sgd(p, grad, v, 0.03, 0.9, 1e-4, step == 0, 1.0 / world)
+        p_ref, _ = None, None
+        assert ddp.params_identical_across_ranks(p)        # deterministic update => no drift, no extra traffic
+    q.put((rank, float(p.double().sum())))
+    dist.destroy_process_group()
+
+
+def _run(bucket):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get() for _ in range(2))
+    assert res[0] == res[1]
+
+
+def test_flat_gradient_allreduce_world2():
+    _run(bucket=0)
+
+
+def test_bucketed_allreduce_world2():
+    _run(bucket=4096)
+
+
+def test_single_process_needs_no_collective():
+    from ustrun import ddp
+    assert ddp.make_grad_allreduce(1) is None

@@ -229,3 +229,87 @@ def test_head_fwd_bwd(n, c, k, h, w):
                                 wg.data_ptr(), da.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, 0, None))
     assert rel(from_nhwc(da), ar.grad) < 1e-5
     assert rel(dw.cpu(), wr.grad) < 1e-5 and rel(db.cpu(), br.grad) < 1e-5
+
+
+# ---- bf16 matrix-core variants (dtype = 1): f32 storage, bf16 MFMA operands, f32 accumulate -------
+def pack_conv_bf16(w):
+    l = L()
+    co, ci = w.shape[:2]
+    n = 9 * ((ci + 7) // 8 * 8) * ((co + 7) // 8 * 8)
+    wf = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    wd = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    wg = w.contiguous().cuda()
+    l.check(l.lib().ustrun_pack_conv3x3(wg.data_ptr(), co, ci, wf.data_ptr(), wd.data_ptr(), 1, None))
+    return wf, wd
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 64, 64, 16, 16), (1, 24, 40, 9, 7), (2, 256, 128, 8, 8), (2, 128, 256, 6, 10),
+                                         (2, 3, 64, 16, 16), (1, 192, 64, 12, 12)])
+@pytest.mark.parametrize("exact", [True, False])
+def test_conv3x3_bf16_mfma(n, ci, co, h, w, exact):
+    """exact=True: small-integer data is exactly representable in bf16 and sums exactly in f32, so any
+    fragment-layout or indexing slip shows as an O(1) error; exact=False: random data, bf16 rounding."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(ci * 3 + co)
+    if exact:
+        x = torch.randint(-3, 4, (n, ci, h, w), generator=g).float()
+        wt = torch.randint(-2, 3, (co, ci, 3, 3), generator=g).float()
+        dy = torch.randint(-3, 4, (n, co, h, w), generator=g).float()
+        tol = 1e-6
+    else:
+        x = torch.randn(n, ci, h, w, generator=g)
+        wt = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+        dy = torch.randn(n, co, h, w, generator=g)
+        tol = 1e-2
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, 1, 1)
+    y_ref.backward(dy)
+    wf, wd = pack_conv_bf16(wt)
+    xg, dyg = nhwc(x), nhwc(dy)
+    src = l.nhwc_src(xg.data_ptr(), ci, h, w)
+    y = torch.empty(n, h, w, co, device="cuda")
+    stat = torch.zeros(lib.ustrun_conv_mtiles(n, h, w, co), 2, co, device="cuda")
+    l.check(lib.ustrun_conv3x3_fwd(C.byref(src), 1, wf.data_ptr(), n, h, w, co, y.data_ptr(), stat.data_ptr(), 1, None))
+    assert rel(from_nhwc(y), y_ref.detach()) < tol
+    np.testing.assert_allclose(stat[:, 0].sum(0).cpu().numpy(), from_nhwc(y).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-2)
+    da = torch.empty(n, h, w, ci, device="cuda")
+    l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 1, None))
+    assert rel(from_nhwc(da), xr.grad) < tol
+    nb = lib.ustrun_wgrad_partials_bytes(9, ci, co, n * h * w)
+    part = torch.empty(nb // 4, device="cuda")
+    dw = torch.empty(co, ci, 3, 3, device="cuda")
+    l.check(lib.ustrun_conv3x3_wgrad(C.byref(src), 1, dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 0, part.data_ptr(), nb, 1, None))
+    assert rel(dw.cpu(), wr.grad) < tol
+
+
+def test_convT2x2_bf16_mfma_exact():
+    l = L()
+    lib = l.lib()
+    n, ci, co, h, w = 2, 128, 64, 5, 7
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (n, ci, h, w), generator=g).float()
+    wt = torch.randint(-2, 3, (ci, co, 2, 2), generator=g).float()
+    b = torch.randint(-2, 3, (co,), generator=g).float()
+    du = torch.randint(-3, 4, (n, co, 2 * h, 2 * w), generator=g).float()
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    u_ref = F.conv_transpose2d(xr, wr, br, stride=2)
+    u_ref.backward(du)
+    nel = 4 * ci * co
+    wf = torch.zeros(nel, dtype=torch.bfloat16, device="cuda")
+    wd = torch.zeros(nel, dtype=torch.bfloat16, device="cuda")
+    wg = wt.cuda()
+    l.check(lib.ustrun_pack_convT2x2(wg.data_ptr(), ci, co, wf.data_ptr(), wd.data_ptr(), 1, None))
+    xg, bg, dug = nhwc(x), b.cuda(), nhwc(du)
+    src = l.nhwc_src(xg.data_ptr(), ci, h, w)
+    u = torch.empty(n, 2 * h, 2 * w, co, device="cuda")
+    l.check(lib.ustrun_convT2x2_fwd(C.byref(src), wf.data_ptr(), bg.data_ptr(), n, h, w, co, u.data_ptr(), 1, None))
+    assert rel(from_nhwc(u), u_ref.detach()) < 1e-6
+    da = torch.empty(n, h, w, ci, device="cuda")
+    l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), 1, None))
+    assert rel(from_nhwc(da), xr.grad) < 1e-6
+    nb = max(lib.ustrun_wgrad_partials_bytes(4, ci, co, n * h * w), 512 * co * 4)
+    part = torch.empty(nb // 4, device="cuda")
+    dw, db = torch.empty(ci, co, 2, 2, device="cuda"), torch.empty(co, device="cuda")
+    l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, 1, None))
+    assert rel(dw.cpu(), wr.grad) < 1e-6 and rel(db.cpu(), br.grad) < 1e-6

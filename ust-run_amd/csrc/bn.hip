@@ -13,19 +13,19 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* rm, float* rv, int64_t* nbt, float momentum, float eps, int update,
                                    float* scale, float* shift, float* mean, float* rstd) {
-    __shared__ double red[2][8][32];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    __shared__ double red[2][32][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 channels x 32 row lanes
     const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int r = rg; r < rows; r += 8) {
+        for (int r = rg; r < rows; r += 32) {
             s1 += (double)stat[((long)r * 2 + 0) * C + c];
             s2 += (double)stat[((long)r * 2 + 1) * C + c];
         }
     red[0][rg][cl] = s1; red[1][rg][cl] = s2;
     __syncthreads();
     if (rg == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+        for (int k = 1; k < 32; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
         const double m = s1 / count;
         double var = s2 / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -159,19 +159,19 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int r
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, float* dgamma, float* dbeta, int accumulate,
                                        float* coef) {
-    __shared__ double red[2][8][32];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    __shared__ double red[2][32][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 channels x 32 row lanes
     const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int r = rg; r < rows; r += 8) {
+        for (int r = rg; r < rows; r += 32) {
             s1 += (double)partials[((long)r * 2 + 0) * C + c];
             s2 += (double)partials[((long)r * 2 + 1) * C + c];
         }
     red[0][rg][cl] = s1; red[1][rg][cl] = s2;
     __syncthreads();
     if (rg == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+        for (int k = 1; k < 32; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
         const double mu = mean[c], rs = rstd[c], g = gamma[c];
         const double dbe = s1, dga = rs * (s2 - mu * s1);
         const double c0 = g * rs, m1 = dbe / count, m2 = dga / count;
@@ -236,7 +236,7 @@ extern "C" int ustrun_bn_finalize(const float* stat, int mtiles, int C, int64_t 
     USTRUN_CHECK(stat && gamma && beta && scale && shift && mean && rstd, "bn_finalize: null pointer");
     USTRUN_CHECK(!update_running || (running_mean && running_var), "bn_finalize: running buffers missing");
     USTRUN_CHECK(mtiles > 0 && C > 0 && count > 0, "bn_finalize: empty");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)s, stat, mtiles, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)s, stat, mtiles, C,
                        (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                        update_running, scale, shift, mean, rstd);
     USTRUN_LAUNCH_CHECK("bn_finalize");
@@ -255,7 +255,7 @@ extern "C" int ustrun_bn_eval_affine(int C, const float* gamma, const float* bet
 
 extern "C" int ustrun_bn_relu_apply(const void* y, const float* scale, const float* shift, int64_t npix, int C,
                                     int HW, float* out, int out_nchw, int dtype, ustrun_stream_t s) {
-    USTRUN_CHECK(dtype == USTRUN_F32, "bn_relu_apply: dtype %d not built", dtype);
+    USTRUN_CHECK(dtype_ok(dtype), "bn_relu_apply: dtype %d not built", dtype);
     USTRUN_CHECK(y && out && npix > 0 && C > 0 && HW > 0, "bn_relu_apply: bad args");
     int blocks = cdiv(npix * C, 256 * 4);
     if (blocks > 8192) blocks = 8192;
@@ -275,7 +275,7 @@ extern "C" int ustrun_bn_bwd_reduce(const void* da, const void* dp, const void* 
                                     int N, int H, int W, int C, float* dgamma, float* dbeta, int accumulate,
                                     float* coef, float* partials, int64_t partials_bytes, int dtype,
                                     ustrun_stream_t s) {
-    USTRUN_CHECK(dtype == USTRUN_F32, "bn_bwd_reduce: dtype %d not built", dtype);
+    USTRUN_CHECK(dtype_ok(dtype), "bn_bwd_reduce: dtype %d not built", dtype);
     USTRUN_CHECK((da || dp) && y && scale && shift && mean && rstd && gamma && coef && partials, "bn_bwd_reduce: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0, "bn_bwd_reduce: C=%d must be a multiple of 4", C);
     USTRUN_CHECK(partials_bytes >= ustrun_bn_bwd_partials_bytes((int64_t)N * H * W, C), "bn_bwd_reduce: partials too small");
@@ -290,7 +290,7 @@ extern "C" int ustrun_bn_bwd_reduce(const void* da, const void* dp, const void* 
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)da,
                            (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials);
     USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)s, partials, blocks, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)s, partials, blocks, C,
                        (double)N * H * W, gamma, mean, rstd, dgamma, dbeta, accumulate, coef);
     USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
     return 0;
@@ -299,7 +299,7 @@ extern "C" int ustrun_bn_bwd_reduce(const void* da, const void* dp, const void* 
 extern "C" int ustrun_bn_bwd_apply(const void* da, const void* dp, const void* y, const float* scale,
                                    const float* shift, const float* coef, int N, int H, int W, int C, void* dy,
                                    int dtype, ustrun_stream_t s) {
-    USTRUN_CHECK(dtype == USTRUN_F32, "bn_bwd_apply: dtype %d not built", dtype);
+    USTRUN_CHECK(dtype_ok(dtype), "bn_bwd_apply: dtype %d not built", dtype);
     USTRUN_CHECK((da || dp) && y && scale && shift && coef && dy, "bn_bwd_apply: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0, "bn_bwd_apply: C=%d must be a multiple of 4", C);
     const int G = group_size(C / 4);

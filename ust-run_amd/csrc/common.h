@@ -79,6 +79,9 @@ struct IgemmArgs {
 };
 int igemm_mtiles(int64_t M, int Cout);
 int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st);
+int igemm_launch_bf16(const IgemmArgs& a, hipStream_t st);
+int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, void* wf, void* wd, hipStream_t st);
+static inline bool dtype_ok(int dtype) { return dtype == USTRUN_F32 || dtype == USTRUN_BF16; }
 
 // ---- generic "TN" weight-gradient GEMM: dW[seg][ci][co] = sum_p A_seg[p][ci] * dY_seg[p][co]
 struct WgradArgs {
@@ -95,6 +98,7 @@ struct WgradArgs {
 // slabs = total partial slabs written (ksplit x in-block K waves)
 int wgrad_plan(int nseg, int Cin, int Cout, int64_t M, int* ksplit, long* kchunk, int* slabs);
 int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);
+int wgrad_launch_bf16(const WgradArgs& a, hipStream_t st);
 // reduce partial slabs [ksplit][rows] -> out (permuted): layout 0: conv3x3 torch [Cout][Cin][3][3];
 // layout 1: convT torch [Cin][Cout][2][2]; layout 2: plain [rows]
 int reduce_partials(const float* partials, int ksplit, int nseg, int Cin, int Cout, float* out,

@@ -10,52 +10,73 @@
 namespace ustrun {
 namespace {
 
-constexpr int MAXNB = 9;            // (2b+1) <= 9
+constexpr int MAXNB = 7;            // (2b+1) <= 7 (b = 2 at 256/288, 3 at 384)
 constexpr float TWO_PI = 6.283185307179586f;
 
-// bins[(img*C + c)*2 + which][u][v] = sum_{y,x} I[y,x] e^{-2 pi j (fu y/H + fv x/W)}, fu = u-b, fv = v-b
-// grid = n*C*2 blocks; images are given normalised (k/127.5 - 1) and evaluated as (x+1)*127.5
+// bins[((img*C + c)*2 + which)*RS + rs][u][v] = sum over the block's rows of I[y,x] e^{-2 pi j (fu y/H + fv x/W)},
+// fu = u-b, fv = v-b.  grid = (n*C*2, RS row splits); every thread keeps all (2b+1)^2 bins in registers and
+// makes ONE pass over its pixels; the RS partial rows are summed by the consumer.
+constexpr int RS = 8;
+
+template <int NB>
 __global__ __launch_bounds__(256) void dft_bins_kernel(const float* __restrict__ src, const float* __restrict__ trg,
-                                                      int C, int H, int W, int b, float2* __restrict__ bins) {
-    extern __shared__ float2 tw[];     // [nb][H] then [nb][W]
-    __shared__ double red[4][2];
-    const int nb = 2 * b + 1;
-    float2* twy = tw; float2* twx = tw + nb * H;
+                                                      int C, int H, int W, float2* __restrict__ bins) {
+    extern __shared__ float2 tw[];     // [NB][H] then [NB][W]
+    __shared__ float red[4][2 * NB * NB];
+    constexpr int b = NB / 2;
+    float2* twy = tw; float2* twx = tw + NB * H;
     const int ic = blockIdx.x >> 1, which = blockIdx.x & 1;
     const float* img = (which ? trg : src) + (long)ic * H * W;
-    for (int t = threadIdx.x; t < nb * H; t += 256) {
+    for (int t = threadIdx.x; t < NB * H; t += 256) {
         const int u = t / H, y = t % H;
         float s, c; sincosf(-TWO_PI * (float)(((long)(u - b) * y) % H) / (float)H, &s, &c);
         twy[t] = make_float2(c, s);
     }
-    for (int t = threadIdx.x; t < nb * W; t += 256) {
+    for (int t = threadIdx.x; t < NB * W; t += 256) {
         const int v = t / W, x = t % W;
         float s, c; sincosf(-TWO_PI * (float)(((long)(v - b) * x) % W) / (float)W, &s, &c);
         twx[t] = make_float2(c, s);
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int u = 0; u < nb; ++u)
-        for (int v = 0; v < nb; ++v) {
-            float re = 0.f, im = 0.f;
-            for (int p = threadIdx.x; p < H * W; p += 256) {
-                const int y = p / W, x = p - y * W;
-                const float val = (img[p] + 1.f) * 127.5f;
-                const float2 a = twy[u * H + y], c2 = twx[v * W + x];
-                re += val * (a.x * c2.x - a.y * c2.y);
-                im += val * (a.x * c2.y + a.y * c2.x);
-            }
-            double dre = re, dim = im;
+    float2 acc[NB][NB];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { dre += __shfl_xor(dre, o); dim += __shfl_xor(dim, o); }
-            if (lane == 0) { red[wave][0] = dre; red[wave][1] = dim; }
-            __syncthreads();
-            if (threadIdx.x == 0)
-                bins[((long)blockIdx.x * nb + u) * nb + v] =
-                    make_float2((float)(red[0][0] + red[1][0] + red[2][0] + red[3][0]),
-                                (float)(red[0][1] + red[1][1] + red[2][1] + red[3][1]));
-            __syncthreads();
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int v = 0; v < NB; ++v) acc[u][v] = make_float2(0.f, 0.f);
+    const int rows = (H + RS - 1) / RS, y0 = blockIdx.y * rows, y1 = min(H, y0 + rows);
+    for (int p = y0 * W + threadIdx.x; p < y1 * W; p += 256) {
+        const int y = p / W, x = p - y * W;
+        const float val = (img[p] + 1.f) * 127.5f;
+        float2 tx[NB];
+#pragma unroll
+        for (int v = 0; v < NB; ++v) { const float2 c2 = twx[v * W + x]; tx[v] = make_float2(val * c2.x, val * c2.y); }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const float2 a = twy[u * H + y];
+#pragma unroll
+            for (int v = 0; v < NB; ++v) {
+                acc[u][v].x += a.x * tx[v].x - a.y * tx[v].y;
+                acc[u][v].y += a.x * tx[v].y + a.y * tx[v].x;
+            }
         }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int v = 0; v < NB; ++v) {
+            float re = acc[u][v].x, im = acc[u][v].y;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { re += __shfl_xor(re, o); im += __shfl_xor(im, o); }
+            if (lane == 0) { red[wave][2 * (u * NB + v)] = re; red[wave][2 * (u * NB + v) + 1] = im; }
+        }
+    __syncthreads();
+    if (threadIdx.x < NB * NB) {
+        const int t = threadIdx.x;
+        bins[((long)blockIdx.x * RS + blockIdx.y) * NB * NB + t] =
+            make_float2(red[0][2 * t] + red[1][2 * t] + red[2][2 * t] + red[3][2 * t],
+                        red[0][2 * t + 1] + red[1][2 * t + 1] + red[2][2 * t + 1] + red[3][2 * t + 1]);
+    }
 }
 
 // out = clip(S + corr, 0, 255)/127.5 - 1;  grid = (row tiles, n*C)
@@ -69,7 +90,11 @@ __global__ __launch_bounds__(256) void freq_apply_kernel(const float* __restrict
     const float r = ratios[n];
     const float inv = 1.f / ((float)H * (float)W);
     for (int t = threadIdx.x; t < nb * nb; t += 256) {
-        const float2 fs = bins[((long)ic * 2 + 0) * nb * nb + t], ft = bins[((long)ic * 2 + 1) * nb * nb + t];
+        float2 fs = make_float2(0.f, 0.f), ft = make_float2(0.f, 0.f);
+        for (int r2 = 0; r2 < RS; ++r2) {        // fixed-order sum of the row-split partials
+            const float2 p0 = bins[(((long)ic * 2 + 0) * RS + r2) * nb * nb + t], p1 = bins[(((long)ic * 2 + 1) * RS + r2) * nb * nb + t];
+            fs.x += p0.x; fs.y += p0.y; ft.x += p1.x; ft.y += p1.y;
+        }
         const float as = sqrtf(fs.x * fs.x + fs.y * fs.y), at = sqrtf(ft.x * ft.x + ft.y * ft.y);
         const float2 ph = as > 0.f ? make_float2(fs.x / as, fs.y / as) : make_float2(1.f, 0.f);   // np.angle(0) = 0
         const float g = r * (at - as) * inv;
@@ -112,7 +137,7 @@ using namespace ustrun;
 
 extern "C" int64_t ustrun_freq_mix_work_bytes(int n, int C, int b) {
     const int nb = 2 * b + 1;
-    return (int64_t)n * C * 2 * nb * nb * sizeof(float2);
+    return (int64_t)n * C * 2 * RS * nb * nb * sizeof(float2);
 }
 
 extern "C" int ustrun_freq_mix(const float* src, const float* trg, const float* ratios, int n, int C, int H, int W,
@@ -124,7 +149,13 @@ extern "C" int ustrun_freq_mix(const float* src, const float* trg, const float* 
     const size_t lds1 = (size_t)nb * (H + W) * sizeof(float2);
     const size_t lds2 = lds1 + (size_t)nb * nb * sizeof(float2);
     USTRUN_CHECK(lds2 <= 64 * 1024, "freq_mix: extent %dx%d too large for the twiddle tables", H, W);
-    hipLaunchKernelGGL(dft_bins_kernel, dim3(n * C * 2), dim3(256), lds1, (hipStream_t)s, src, trg, C, H, W, b, (float2*)work);
+    dim3 g1(n * C * 2, RS);
+    switch (nb) {
+        case 1: hipLaunchKernelGGL(dft_bins_kernel<1>, g1, dim3(256), lds1, (hipStream_t)s, src, trg, C, H, W, (float2*)work); break;
+        case 3: hipLaunchKernelGGL(dft_bins_kernel<3>, g1, dim3(256), lds1, (hipStream_t)s, src, trg, C, H, W, (float2*)work); break;
+        case 5: hipLaunchKernelGGL(dft_bins_kernel<5>, g1, dim3(256), lds1, (hipStream_t)s, src, trg, C, H, W, (float2*)work); break;
+        default: hipLaunchKernelGGL(dft_bins_kernel<7>, g1, dim3(256), lds1, (hipStream_t)s, src, trg, C, H, W, (float2*)work); break;
+    }
     USTRUN_LAUNCH_CHECK("dft_bins");
     int tiles = cdiv((long)H * W, 256 * 8);
     hipLaunchKernelGGL(freq_apply_kernel, dim3(tiles, n * C), dim3(256), lds2, (hipStream_t)s, src, (const float2*)work, ratios,

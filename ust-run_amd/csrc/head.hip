@@ -145,7 +145,7 @@ static int head_blocks(int64_t npix, int LPP) {
 extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* shift, int64_t npix, int HW, int C,
                                int K, const float* w, const float* bias, float* logits, int dtype,
                                ustrun_stream_t s) {
-    USTRUN_CHECK(dtype == USTRUN_F32, "head_fwd: dtype %d not built", dtype);
+    USTRUN_CHECK(dtype_ok(dtype), "head_fwd: dtype %d not built", dtype);
     USTRUN_CHECK(y && w && bias && logits, "head_fwd: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_fwd: C=%d K=%d unsupported", C, K);
     USTRUN_CHECK(npix > 0 && HW > 0 && npix % HW == 0, "head_fwd: bad extent");
@@ -161,7 +161,7 @@ extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* s
 extern "C" int ustrun_head_bwd(const float* dlogits, const void* y, const float* scale, const float* shift,
                                int64_t npix, int HW, int C, int K, const float* w, void* da, float* dw, float* db,
                                int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s) {
-    USTRUN_CHECK(dtype == USTRUN_F32, "head_bwd: dtype %d not built", dtype);
+    USTRUN_CHECK(dtype_ok(dtype), "head_bwd: dtype %d not built", dtype);
     USTRUN_CHECK(dlogits && y && w && da && dw && db && partials, "head_bwd: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_bwd: C=%d K=%d unsupported", C, K);
     const int LPP = lanes_per_pixel(C / 4);

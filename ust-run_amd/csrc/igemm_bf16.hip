@@ -1,47 +1,36 @@
-// igemm.hip -- generic implicit-GEMM kernel on the exact-f32 matrix cores of gfx950.
-//
-//   out[map_out(m)][n] = bias[n] + sum_{seg} sum_{c} A_seg[m][c] * W[seg][c][n]
-//
-// m runs over a base pixel grid (N,Hb,Wb); A_seg[m][c] is the loader's view of the activation
-// sources at pixel base*s_in + (dy,dx)_seg (BatchNorm affine + ReLU, 2x2 max-pool, concat of two
-// sources and zero padding are all evaluated on the fly, never materialised); W is the packed
-// weight [slice][Cin][Cout].  conv3x3 forward / input-gradient use 9 segments, ConvTranspose
-// forward uses 4 output parity classes (grid.z) with one segment each, its input-gradient 4
-// segments with s_in = 2.
-//
-// Tile: 256 threads = 4 waves, each wave owns a 64x64 output tile as 2x2 v_mfma_f32_32x32x2_f32
-// accumulators (bitwise an f32 fmaf chain, MI355X_MICROARCH "Matrix cores").  K is consumed in
-// stages of 32 channels: global -> registers (prefetched under the previous stage's MFMAs) ->
-// transform -> LDS (A stored k-major so that lanes read consecutive pixels, B row-major) -> MFMA.
+// igemm_bf16.hip -- the implicit-GEMM kernel of igemm.hip on the bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16, f32 accumulate).  Activations stay f32 in HBM this round: the loader
+// applies the BatchNorm/ReLU/pool/concat transform in f32, rounds to bf16 (RNE) and stores a
+// K-contiguous, XOR-swizzled A tile in LDS; weights are pre-packed in bf16 as [slice][K/8][N][8] so
+// that a lane's 8 consecutive K values are one 16-byte LDS read with no conflicts.
 #include "common.h"
 #include "loader.h"
 
 namespace ustrun {
-
 namespace {
 
-constexpr int BK = 32;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 struct RowInfo { int n; int yx; };
 
 template <int WM, int WN, bool POOL>
-__global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, const int mt_total, const int nt_total) {
+__global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IgemmArgs a, const int mt_total, const int nt_total) {
     constexpr int BM = WM * 64, BN = WN * 64;
-    constexpr int LDA = BM + 1;
-    constexpr int AR = BM / 32;         // A rows per thread per stage
-    constexpr int NP = POOL ? 4 : 1;    // stored pixels per logical pixel
-    constexpr int BQ = BN / 4;          // float4 per B row
-    constexpr int BPASS = 256 / BQ;     // B rows covered per pass
-    constexpr int BR = BK / BPASS;      // B float4 per thread per stage
-    constexpr int A_FLOATS = (BK * LDA + 3) & ~3;
+    constexpr int BK = POOL ? 32 : 64;
+    constexpr int CPR = BK / 4;            // 4-channel groups per row
+    constexpr int RPP = 256 / CPR;         // rows per pass
+    constexpr int AR = BM / RPP;           // rows per thread per stage
+    constexpr int NP = POOL ? 4 : 1;
+    constexpr int ROWB = BK * 2;           // bytes per A row in LDS
+    constexpr int BCH = (BK / 8) * BN;     // 16-byte chunks in the B tile
+    constexpr int BR = BCH / 256;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* As = (float*)smem;
-    float* Bs = As + A_FLOATS;
-    RowInfo* rowinfo = (RowInfo*)(Bs + BK * BN);
+    char* As = smem;                        // [BM][BK] bf16, 16-B chunks XOR-swizzled by row
+    char* Bs = smem + BM * ROWB;            // [BK/8][BN][8] bf16
+    RowInfo* rowinfo = (RowInfo*)(Bs + BCH * 16);
 
-    // ---- XCD-aware tile id: consecutive hardware block ids round-robin over the 8 XCDs, so give
-    // each XCD a contiguous run of tiles (n-tiles of one m-tile adjacent -> A panel shared in L2).
     const int ntiles = mt_total * nt_total;
     int bid = blockIdx.x;
     {
@@ -51,7 +40,6 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
     const int mtile = bid / nt_total, ntile = bid % nt_total;
     const int z = blockIdx.y;
     const int n0 = ntile * BN;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
@@ -69,18 +57,20 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
     }
     __syncthreads();
 
-    const int a_c4 = tid & 7, a_r0 = tid >> 3;
-    const int b_n4 = tid % BQ, b_k0 = tid / BQ;
+    auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+
+    const int a_c4 = tid % CPR, a_r0 = tid / CPR;
     const bool vecA = sources_vectorizable(a.src[0], a.src[1], a.nsrc);
-    const bool vecB = (a.Cout & 3) == 0;
     const int nchunk = (a.Cin + BK - 1) / BK;
     const int nstage = a.nseg * nchunk;
+    const int K8 = (a.Cin + 7) / 8;         // packed K octets per slice
+    const __bf16* Wp = (const __bf16*)a.W;
 
     f32x4 av[AR][NP];
     f32x4 asc, ash;
     unsigned aok;
     int a_relu;
-    f32x4 bv[BR];
+    bf16x8 bv[BR];
 
     auto load_stage = [&](int s) {
         const int seg = s / nchunk, c0 = (s - seg * nchunk) * BK;
@@ -97,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
             a_relu = S.relu;
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
-                RowInfo ri = rowinfo[a_r0 + 32 * i];
+                RowInfo ri = rowinfo[a_r0 + RPP * i];
                 const int ly = (ri.yx >> 16) * a.s_in + dy - S.off_y;
                 const int lx = (ri.yx & 0xffff) * a.s_in + dx - S.off_x;
                 const bool ok = cok && ri.n >= 0 && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
@@ -115,11 +105,9 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
                 }
             }
         } else {
-            // scalar path (first layer with C = 1/3, tiny test nets): the transform is applied
-            // here and the write pass only copies.
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
-                RowInfo ri = rowinfo[a_r0 + 32 * i];
+                RowInfo ri = rowinfo[a_r0 + RPP * i];
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (ri.n >= 0) {
                     const int iy = (ri.yx >> 16) * a.s_in + dy, ix = (ri.yx & 0xffff) * a.s_in + dx;
@@ -130,20 +118,16 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
                 av[i][0] = v;
             }
         }
-        // B tile: W[slice][c0 + k][n0 + 4*b_n4 ..]
-        const float* wb = a.W + ((long)(seg + z) * a.Cin) * a.Cout;
+        // B tile: packed bf16 weights [slice][K8][Cout][8]
+        const __bf16* wb = Wp + ((long)(seg + z) * K8) * a.Cout * 8;
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const int k = c0 + b_k0 + BPASS * i, n = n0 + 4 * b_n4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < a.Cin) {
-                const float* p = wb + (long)k * a.Cout + n;
-                if (vecB) { if (n < a.Cout) v = *(const f32x4*)p; }
-                else {
+            const int idx = tid + 256 * i, o = idx / BN, n = idx % BN;
+            bf16x8 v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (n + j < a.Cout) v[j] = p[j];
-                }
-            }
+            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+            const int ko = c0 / 8 + o;
+            if (ko < K8 && n0 + n < a.Cout) v = *(const bf16x8*)(wb + ((long)ko * a.Cout + n0 + n) * 8);
             bv[i] = v;
         }
     };
@@ -165,13 +149,13 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
                 }
                 if (!((aok >> i) & 1u)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            const int row = a_r0 + 32 * i;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) As[(4 * a_c4 + j) * LDA + row] = v[j];
+            const int row = a_r0 + RPP * i;
+            bf16x4 h;
+            h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+            *(bf16x4*)(As + row * ROWB + (((a_c4 >> 1) ^ swz(row)) * 16) + (a_c4 & 1) * 8) = h;
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i)
-            *(f32x4*)(Bs + (b_k0 + BPASS * i) * BN + 4 * b_n4) = bv[i];
+        for (int i = 0; i < BR; ++i) *(bf16x8*)(Bs + (tid + 256 * i) * 16) = bv[i];
     };
 
     f32x16 acc[2][2];
@@ -183,8 +167,11 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    const float* Ap = As + lh * LDA + wm * 64 + l31;
-    const float* Bp = Bs + lh * BN + wn * 64 + l31;
+    const int rowA = wm * 64 + l31;
+    const char* Ap0 = As + rowA * ROWB;
+    const char* Ap1 = As + (rowA + 32) * ROWB;
+    const int sw0 = swz(rowA), sw1 = swz(rowA + 32);
+    const char* Bp = Bs + (lh * BN + wn * 64 + l31) * 16;
 
     load_stage(0);
     for (int s = 0; s < nstage; ++s) {
@@ -192,18 +179,21 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
         __syncthreads();
         if (s + 1 < nstage) load_stage(s + 1);
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const float a0 = Ap[2 * kk * LDA], a1 = Ap[2 * kk * LDA + 32];
-            const float b0 = Bp[2 * kk * BN], b1 = Bp[2 * kk * BN + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int ch = 2 * ks + lh;
+            const bf16x8 a0 = *(const bf16x8*)(Ap0 + ((ch ^ sw0) * 16));
+            const bf16x8 a1 = *(const bf16x8*)(Ap1 + ((ch ^ sw1) * 16));
+            const bf16x8 b0 = *(const bf16x8*)(Bp + (2 * ks * BN) * 16);
+            const bf16x8 b1 = *(const bf16x8*)(Bp + (2 * ks * BN + 32) * 16);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
     }
 
-    // ---- epilogue: D[row = pixel][col = channel]; col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue (identical to the f32 kernel: f32 outputs, BN-statistics partials) ----
     const int oyz = z >> 1, oxz = z & 1;
     const int C1 = a.Cout - a.C0;
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -234,8 +224,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
         }
     }
     if (a.stat) {
-        // fixed-order tree: lane halves, then the WM waves that share these columns
-        float* red = As;  // [WM][2][BN], free after the final barrier of the main loop
+        float* red = (float*)As;   // [WM][2][BN]
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             s1[j] += __shfl_xor(s1[j], 32);
@@ -246,8 +235,6 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
             }
         }
         __syncthreads();
-        // one stat row per 128 pixels whatever the tile height, so that the row count does not
-        // depend on the tile configuration (ustrun_conv_mtiles)
         constexpr int HALVES = WM / 2;
         const int stat_rows = (int)((a.M + 127) / 128);
         for (int t = tid; t < HALVES * 2 * BN; t += 256) {
@@ -261,48 +248,57 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const IgemmArgs a, co
 
 template <int WM, int WN, bool POOL>
 int launch_cfg(const IgemmArgs& a, hipStream_t st) {
-    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int BM = WM * 64, BN = WN * 64, BK = POOL ? 32 : 64;
     const int mt = cdiv(a.M, BM), nt = cdiv(a.Cout, BN);
-    const size_t lds = (size_t)(((BK * (BM + 1) + 3) & ~3) + BK * BN) * 4 + (size_t)BM * sizeof(RowInfo);
+    const size_t lds = (size_t)BM * BK * 2 + (size_t)BK * BN * 2 + (size_t)BM * sizeof(RowInfo);
     dim3 grid(mt * nt, a.nz), block(256);
-    hipLaunchKernelGGL((igemm_f32_kernel<WM, WN, POOL>), grid, block, lds, st, a, mt, nt);
-    USTRUN_LAUNCH_CHECK("igemm");
+    hipLaunchKernelGGL((igemm_bf16_kernel<WM, WN, POOL>), grid, block, lds, st, a, mt, nt);
+    USTRUN_LAUNCH_CHECK("igemm_bf16");
     return 0;
+}
+
+// torch conv weight [Cout][Cin][taps] (taps = 9) or convT weight [Cin][Cout][taps] (taps = 4)
+// -> fwd [tap][ceil(Cin/8)][Cout][8] and dgrad [tap][ceil(Cout/8)][Cin][8], bf16, zero padded
+__global__ void pack_bf16_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int transposed_src,
+                                 __bf16* __restrict__ wf, __bf16* __restrict__ wd) {
+    const int Ki = (Cin + 7) / 8, Ko = (Cout + 7) / 8;
+    const long nf = (long)taps * Ki * Cout * 8, nd = (long)taps * Ko * Cin * 8;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nf + nd; e += (long)gridDim.x * blockDim.x) {
+        int tap, ci, co;
+        if (e < nf) {
+            const int j = (int)(e & 7); long t = e >> 3;
+            co = (int)(t % Cout); t /= Cout;
+            ci = (int)(t % Ki) * 8 + j; tap = (int)(t / Ki);
+        } else {
+            const long f = e - nf;
+            const int j = (int)(f & 7); long t = f >> 3;
+            ci = (int)(t % Cin); t /= Cin;
+            co = (int)(t % Ko) * 8 + j; tap = (int)(t / Ko);
+        }
+        float v = 0.f;
+        if (ci < Cin && co < Cout)
+            v = transposed_src ? w[((long)ci * Cout + co) * taps + tap] : w[((long)co * Cin + ci) * taps + tap];
+        if (e < nf) wf[e] = (__bf16)v; else if (wd) wd[e - nf] = (__bf16)v;
+    }
 }
 
 }  // namespace
 
-// M-tile height the launcher will pick for this problem (must agree with igemm_launch)
-static int pick_bm(int Cout) { return (Cout > 64) ? 128 : 256; }
-
-int igemm_mtiles(int64_t M, int Cout) { (void)Cout; return cdiv(M, 128); }
-
-int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
-    USTRUN_CHECK(dtype_ok(dtype), "igemm: dtype %d not built", dtype);
-    USTRUN_CHECK(a.M > 0 && a.Cout > 0 && a.Cin > 0, "igemm: empty problem");
-    USTRUN_CHECK(a.Hb < 65536 && a.Wb < 65536, "igemm: extent too large");
-    USTRUN_CHECK(a.nseg >= 1 && a.nseg <= 9 && a.nz >= 1 && a.nz <= 4, "igemm: bad segment/parity count");
-    int csum = 0;
+int igemm_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     bool pool = false;
-    for (int i = 0; i < a.nsrc; ++i) { csum += a.src[i].C; pool |= a.src[i].pool != 0; }
-    USTRUN_CHECK(csum == a.Cin, "igemm: source channels %d != Cin %d", csum, a.Cin);
-    USTRUN_CHECK(!pool || a.nsrc == 1, "igemm: pooled source cannot be concatenated");
-    // algorithmic cost of this launch: every stored input/weight/output element touched once
-    double in_elems = 0;
-    for (int i = 0; i < a.nsrc; ++i) in_elems += (double)a.N * a.src[i].H * a.src[i].W * a.src[i].C;
-    const double out_elems = (double)a.M * a.nz * a.Cout;
-    const double w_elems = (double)a.nseg * a.nz * a.Cin * a.Cout;
-    prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, 4.0 * (in_elems + out_elems + w_elems), st);
-    int rc;
-    if (dtype == USTRUN_BF16) {
-        rc = igemm_launch_bf16(a, st);
-    } else if (pick_bm(a.Cout) == 128 || pool) {   // (narrow outputs with a pooled source only occur in tiny test nets)
-        rc = pool ? launch_cfg<2, 2, true>(a, st) : launch_cfg<2, 2, false>(a, st);
-    } else {
-        rc = launch_cfg<4, 1, false>(a, st);
-    }
-    prof_end(st);
-    return rc;
+    for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
+    if (a.Cout > 64 || pool) return pool ? launch_cfg<2, 2, true>(a, st) : launch_cfg<2, 2, false>(a, st);
+    return launch_cfg<4, 1, false>(a, st);
+}
+
+int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, void* wf, void* wd, hipStream_t st) {
+    const long total = (long)taps * (((Cin + 7) / 8) * (long)Cout + ((Cout + 7) / 8) * (long)Cin) * 8;
+    long b = (total + 1023) / 1024;
+    if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((int)b), dim3(256), 0, st, w, Cout, Cin, taps, transposed_src, (__bf16*)wf,
+                       (__bf16*)wd);
+    USTRUN_LAUNCH_CHECK("pack_bf16");
+    return 0;
 }
 
 }  // namespace ustrun

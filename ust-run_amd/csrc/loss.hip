@@ -80,10 +80,17 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
 __global__ void seg_loss_finalize_kernel(const float* __restrict__ partials, int rows, int N, int K, int HW, int mode,
                                          float* __restrict__ out) {
     __shared__ double tot[NS];
+    __shared__ double red[8][32];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 columns (NS used) x 8 row lanes
+    double v = 0.0;
+    if (col < NS)
+        for (int r = rg; r < rows; r += 8) v += (double)partials[(long)r * NS + col];
+    red[rg][col] = v;
+    __syncthreads();
     if (threadIdx.x < NS) {
-        double v = 0.0;
-        for (int r = 0; r < rows; ++r) v += (double)partials[(long)r * NS + threadIdx.x];
-        tot[threadIdx.x] = v;
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        tot[threadIdx.x] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ p, con
 
 int stream_blocks(long work_items) {
     long b = (work_items + 256 * 4 - 1) / (256 * 4);
-    if (b > 2048) b = 2048;
+    if (b > 1024) b = 1024;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -326,7 +333,7 @@ extern "C" int ustrun_seg_loss_fwd(const float* logits, const void* target, cons
     hipLaunchKernelGGL(seg_loss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, logits, target, mask, N, K, HW,
                        mode, partials);
     USTRUN_LAUNCH_CHECK("seg_loss_fwd");
-    hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partials, blocks, N, K, HW, mode, out);
+    hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, partials, blocks, N, K, HW, mode, out);
     USTRUN_LAUNCH_CHECK("seg_loss_finalize");
     return 0;
 }

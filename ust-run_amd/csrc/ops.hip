@@ -43,8 +43,9 @@ using namespace ustrun;
 
 extern "C" int ustrun_pack_conv3x3(const float* w, int Cout, int Cin, void* w_fwd, void* w_dgrad, int dtype,
                                    ustrun_stream_t s) {
-    USTRUN_CHECK(dtype == USTRUN_F32, "pack_conv3x3: dtype %d not built", dtype);
+    USTRUN_CHECK(dtype_ok(dtype), "pack_conv3x3: dtype %d not built", dtype);
     USTRUN_CHECK(w && w_fwd && Cout > 0 && Cin > 0, "pack_conv3x3: bad args");
+    if (dtype == USTRUN_BF16) return pack_bf16(w, Cout, Cin, 9, 0, w_fwd, w_dgrad, (hipStream_t)s);
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(pack_blocks((long)Cout * Cin * 9)), dim3(256), 0, (hipStream_t)s, w, Cout,
                        Cin, (float*)w_fwd, (float*)w_dgrad);
     USTRUN_LAUNCH_CHECK("pack_conv3x3");
@@ -53,8 +54,9 @@ extern "C" int ustrun_pack_conv3x3(const float* w, int Cout, int Cin, void* w_fw
 
 extern "C" int ustrun_pack_convT2x2(const float* w, int Cin, int Cout, void* w_fwd, void* w_dgrad, int dtype,
                                     ustrun_stream_t s) {
-    USTRUN_CHECK(dtype == USTRUN_F32, "pack_convT2x2: dtype %d not built", dtype);
+    USTRUN_CHECK(dtype_ok(dtype), "pack_convT2x2: dtype %d not built", dtype);
     USTRUN_CHECK(w && w_fwd && Cout > 0 && Cin > 0, "pack_convT2x2: bad args");
+    if (dtype == USTRUN_BF16) return pack_bf16(w, Cout, Cin, 4, 1, w_fwd, w_dgrad, (hipStream_t)s);
     hipLaunchKernelGGL(pack_convT_kernel, dim3(pack_blocks((long)Cout * Cin * 4)), dim3(256), 0, (hipStream_t)s, w, Cin,
                        Cout, (float*)w_fwd, (float*)w_dgrad);
     USTRUN_LAUNCH_CHECK("pack_convT2x2");

@@ -34,7 +34,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     USTRUN_CHECK(d->N > 0 && d->C > 0 && d->K > 0 && d->K <= 8 && d->base >= 4 && d->base % 4 == 0,
                  "unet: bad N=%d C=%d K=%d base=%d", d->N, d->C, d->K, d->base);
     USTRUN_CHECK(d->H >= 16 && d->W >= 16, "unet: extent %dx%d too small for 4 poolings", d->H, d->W);
-    USTRUN_CHECK(d->dtype == USTRUN_F32, "unet: dtype %d not built", d->dtype);
+    USTRUN_CHECK(dtype_ok(d->dtype), "unet: dtype %d not built", d->dtype);
     p.N = d->N; p.C = d->C; p.H = d->H; p.W = d->W; p.K = d->K; p.base = d->base;
     p.Hs[0] = d->H; p.Ws[0] = d->W;
     for (int l = 1; l < 5; ++l) { p.Hs[l] = p.Hs[l - 1] / 2; p.Ws[l] = p.Ws[l - 1] / 2; }
@@ -66,12 +66,12 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
 
     o = 0;
     for (int i = 0; i < 18; ++i) {
-        const long n = 9L * p.cin[i] * p.cout[i];
+        const long n = 9L * align_up(p.cin[i], 8) * align_up(p.cout[i], 8);   // covers f32 and the K-padded bf16 layout
         p.wf_off[i] = o; o = align_up(o + n, 64);
         p.wd_off[i] = o; o = align_up(o + n, 64);
     }
     for (int j = 0; j < 4; ++j) {
-        const long n = 4L * p.up_cin[j] * p.up_cout[j];
+        const long n = 4L * align_up(p.up_cin[j], 8) * align_up(p.up_cout[j], 8);
         p.uf_off[j] = o; o = align_up(o + n, 64);
         p.ud_off[j] = o; o = align_up(o + n, 64);
     }

@@ -1,28 +1,48 @@
-// wgrad.hip -- weight-gradient "TN" GEMM on the exact-f32 matrix cores:
-//
-//   dW[seg][ci][co] = sum_{p in base grid} A_seg[p][ci] * dY_seg[p][co]
-//
-// A_seg is the loader's view of the layer input (same on-the-fly BatchNorm/ReLU/pool/concat as the
-// forward) at pixel p + tap(seg); dY_seg is the raw output gradient at p (conv3x3) or at
-// 2p + (seg/2, seg%2) (ConvTranspose).  The contraction runs over pixels, so both operands are
-// consumed in their natural NHWC layout: lanes read consecutive channels of one pixel from LDS.
-// Work split: grid = (ci-tile x co-tile x seg) x ksplit; every block (and, for narrow tiles, every
-// K-wave inside it) writes its own partial slab, summed in a fixed order by reduce_partials.
+// wgrad_bf16.hip -- the weight-gradient "TN" GEMM of wgrad.hip on the bf16 matrix cores.
+// The contraction runs over pixels while both operands are stored pixel-major (NHWC), so each lane
+// needs 8 consecutive PIXELS of one channel: the LDS tiles keep the natural [pixel][channel] layout
+// (coalesced fills, 8-byte stores) and the fragments are fetched with the transposing LDS read
+// ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major).
 #include "common.h"
 #include "loader.h"
 
 namespace ustrun {
 namespace {
 
-constexpr int KP = 32;  // pixels per stage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+
+// 64-byte segments of a row are XOR-permuted by the row index so that the 4 rows of a transposed
+// read fall on different bank segments
+template <int RB> __device__ __forceinline__ int seg_swz(int row) { return RB >= 256 ? (row & 3) : ((row >> 1) & 1); }
+
+template <int RB> __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, int lane) {
+    // lane l of the wave: rows k0 + 8*(l>>5) + {0..3 | 4..7}, columns col0 + 16*((l>>4)&1) + ...
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int colb = (col0 + 16 * ((lane >> 4) & 1) + 4 * p) * 2;
+    const int r0 = k0 + 8 * (lane >> 5) + q, r1 = r0 + 4;
+    const char* a0 = tile + r0 * RB + (colb ^ (seg_swz<RB>(r0) << 6));
+    const char* a1 = tile + r1 * RB + (colb ^ (seg_swz<RB>(r1) << 6));
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
 
 template <int TM, int TN, bool POOL>
-__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a, const int mtn, const int ntn) {
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, const int mtn, const int ntn) {
     constexpr int WTM = TM / 64, WTN = TN / 64, KW = 4 / (WTM * WTN);
+    constexpr int KP = 16 * (KW > 2 ? KW : 2);   // pixels per stage: every K-wave owns >= one 16-deep MFMA step
     constexpr int AQ = TM / 4, APASS = 256 / AQ, AR = KP / APASS;
     constexpr int BQ = TN / 4, BPASS = 256 / BQ, BR = KP / BPASS;
-    __shared__ __attribute__((aligned(16))) float As[KP * TM];
-    __shared__ __attribute__((aligned(16))) float Bs[KP * TN];
+    constexpr int RBA = TM * 2, RBB = TN * 2;
+    constexpr int NP = POOL ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) char As[KP * RBA];
+    __shared__ __attribute__((aligned(16))) char Bs[KP * RBB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kw = wave % KW, wt = wave / KW, wm = wt / WTN, wn = wt % WTN;
@@ -50,7 +70,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a, co
     f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
     if (vecA && cg < a.Cin && S.scale) { asc = *(const f32x4*)(S.scale + cl); ash = *(const f32x4*)(S.shift + cl); }
 
-    constexpr int NP = POOL ? 4 : 1;
     f32x4 av[AR][NP];
     unsigned aok;
     f32x4 bv[BR];
@@ -60,8 +79,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a, co
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const long m = k0 + a_r0 + APASS * i;
-            f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            av[i][0] = z4;
+            av[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (m < kend) {
                 const int n = (int)(m / hw);
                 const int rem = (int)(m - (long)n * hw);
@@ -109,6 +127,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a, co
         }
     };
 
+    auto to_bf16 = [](f32x4 v) {
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        return h;
+    };
+
     auto write_stage = [&]() {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
@@ -126,10 +150,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a, co
                 }
                 if (!((aok >> i) & 1u)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            *(f32x4*)(As + (a_r0 + APASS * i) * TM + 4 * a_q) = v;
+            const int row = a_r0 + APASS * i;
+            *(bf16x4*)(As + row * RBA + ((a_q * 8) ^ (seg_swz<RBA>(row) << 6))) = to_bf16(v);
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) *(f32x4*)(Bs + (b_r0 + BPASS * i) * TN + 4 * b_q) = bv[i];
+        for (int i = 0; i < BR; ++i) {
+            const int row = b_r0 + BPASS * i;
+            *(bf16x4*)(Bs + row * RBB + ((b_q * 8) ^ (seg_swz<RBB>(row) << 6))) = to_bf16(bv[i]);
+        }
     };
 
     f32x16 acc[2][2];
@@ -140,30 +168,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int l31 = lane & 31, lh = lane >> 5;
-    const float* Ap = As + lh * TM + wm * 64 + l31;
-    const float* Bp = Bs + lh * TN + wn * 64 + l31;
-
     if (kbeg < kend) load_stage(kbeg);
     for (long k0 = kbeg; k0 < kend; k0 += KP) {
         write_stage();
         __syncthreads();
         if (k0 + KP < kend) load_stage(k0 + KP);
 #pragma unroll
-        for (int t = 0; t < KP / 2 / KW; ++t) {
-            const int kk = t * KW + kw;
-            const float a0 = Ap[2 * kk * TM], a1 = Ap[2 * kk * TM + 32];
-            const float b0 = Bp[2 * kk * TN], b1 = Bp[2 * kk * TN + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int t = 0; t < KP / 16 / KW; ++t) {
+            const int kk = t * KW + kw;          // 16-pixel step owned by this wave
+            const bf16x8 a0 = tr_frag<RBA>(As, kk * 16, wm * 64, lane);
+            const bf16x8 a1 = tr_frag<RBA>(As, kk * 16, wm * 64 + 32, lane);
+            const bf16x8 b0 = tr_frag<RBB>(Bs, kk * 16, wn * 64, lane);
+            const bf16x8 b1 = tr_frag<RBB>(Bs, kk * 16, wn * 64 + 32, lane);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
     }
 
-    // slab (ks*KW + kw): [nseg][Cin][Cout]
     float* slab = a.partials + ((long)(ks * KW + kw) * a.nseg + seg) * a.Cin * a.Cout;
+    const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int co = co0 + wn * 64 + j * 32 + l31;
@@ -177,65 +203,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a, co
     }
 }
 
-// out[...] (+)= sum_k partials[k][...]; grid-stride over the nseg*Cin*Cout elements
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int nslab, int nseg, int Cin, int Cout,
-                                       float* __restrict__ out, int layout, int accumulate) {
-    const long total = (long)nseg * Cin * Cout;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int k = 0; k < nslab; ++k) v += part[(long)k * total + e];
-        const int co = (int)(e % Cout);
-        const long t = e / Cout;
-        const int ci = (int)(t % Cin), seg = (int)(t / Cin);
-        long o;
-        if (layout == 0) o = ((long)co * Cin + ci) * nseg + seg;        // [Cout][Cin][3][3]
-        else if (layout == 1) o = ((long)ci * Cout + co) * nseg + seg;  // [Cin][Cout][2][2]
-        else o = e;
-        out[o] = accumulate ? out[o] + v : v;
-    }
-}
-
 template <int TM, int TN, bool POOL>
 int launch_cfg(const WgradArgs& a, hipStream_t st) {
     const int mtn = cdiv(a.Cin, TM), ntn = cdiv(a.Cout, TN);
     dim3 grid(mtn * ntn * a.nseg, a.ksplit), block(256);
-    hipLaunchKernelGGL((wgrad_f32_kernel<TM, TN, POOL>), grid, block, 0, st, a, mtn, ntn);
-    USTRUN_LAUNCH_CHECK("wgrad");
+    hipLaunchKernelGGL((wgrad_bf16_kernel<TM, TN, POOL>), grid, block, 0, st, a, mtn, ntn);
+    USTRUN_LAUNCH_CHECK("wgrad_bf16");
     return 0;
 }
 
 }  // namespace
 
-int wgrad_plan(int nseg, int Cin, int Cout, int64_t M, int* ksplit, long* kchunk, int* slabs) {
-    const int TM = Cin > 64 ? 128 : 64, TN = Cout > 64 ? 128 : 64;
-    const int KW = 4 / ((TM / 64) * (TN / 64));
-    const long tiles = (long)cdiv(Cin, TM) * cdiv(Cout, TN) * nseg;
-    long ks = (1024 + tiles - 1) / tiles;          // aim at ~4 blocks per CU
-    const long maxks = (M + 4 * KP - 1) / (4 * KP); // at least 4 stages per block
-    if (ks > maxks) ks = maxks;
-    if (ks < 1) ks = 1;
-    long chunk = ((M + ks - 1) / ks + 63) / 64 * 64;   // multiple of every kernel's stage depth
-    ks = (M + chunk - 1) / chunk;
-    *ksplit = (int)ks; *kchunk = chunk; *slabs = (int)ks * KW;
-    return 0;
-}
-
-int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
-    USTRUN_CHECK(dtype_ok(dtype), "wgrad: dtype %d not built", dtype);
-    USTRUN_CHECK(a.M > 0 && a.Cin > 0 && a.Cout > 0, "wgrad: empty problem");
-    int csum = 0;
-    for (int i = 0; i < a.nsrc; ++i) csum += a.src[i].C;
-    USTRUN_CHECK(csum == a.Cin, "wgrad: source channels %d != Cin %d", csum, a.Cin);
+int wgrad_launch_bf16(const WgradArgs& a, hipStream_t st) {
     const bool pool = a.src[0].pool != 0;
-    USTRUN_CHECK(!pool || a.nsrc == 1, "wgrad: pooled source cannot be concatenated");
-    USTRUN_CHECK(a.kchunk % 64 == 0, "wgrad: K chunk must be a multiple of 64");
     const bool m128 = a.Cin > 64, n128 = a.Cout > 64;
-    double in_elems = 0;
-    for (int i = 0; i < a.nsrc; ++i) in_elems += (double)a.N * a.src[i].H * a.src[i].W * a.src[i].C;
-    prof_begin(1, 2.0 * a.M * a.nseg * a.Cin * a.Cout,
-               4.0 * (in_elems + (double)a.N * a.dyH * a.dyW * a.Cout + (double)a.nseg * a.Cin * a.Cout), st);
-    struct End { hipStream_t s; ~End() { prof_end(s); } } end_{st};
-    if (dtype == USTRUN_BF16) return wgrad_launch_bf16(a, st);
     if (pool) {
         if (m128 && n128) return launch_cfg<128, 128, true>(a, st);
         if (m128) return launch_cfg<128, 64, true>(a, st);
@@ -246,17 +227,6 @@ int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
     if (m128) return launch_cfg<128, 64, false>(a, st);
     if (n128) return launch_cfg<64, 128, false>(a, st);
     return launch_cfg<64, 64, false>(a, st);
-}
-
-int reduce_partials(const float* partials, int nslab, int nseg, int Cin, int Cout, float* out, int layout,
-                    int accumulate, hipStream_t st) {
-    const long total = (long)nseg * Cin * Cout;
-    int blocks = cdiv(total, 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, partials, nslab, nseg, Cin, Cout, out,
-                       layout, accumulate);
-    USTRUN_LAUNCH_CHECK("reduce_partials");
-    return 0;
 }
 
 }  // namespace ustrun

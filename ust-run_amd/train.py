@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""train.py -- MI355X build of the reference's training driver for the U-Net hot path.
+
+Keeps the reference's command line (train.py:38-79: same flag names and defaults); new flags are
+additive (--synthetic, --backend_dtype, --data_root, --fft, --log_every).  The step itself is
+ustrun.trainer.SSLTrainer (HIP kernels through libustrun.so).  Data loading, augmentation,
+validation with medpy and tensorboard logging are outside this build's scope: batches
+come from the seeded synthetic generator unless a loader is plugged in through `make_loaders`.
+
+Single GPU:   python train.py --dataset fundus --save_name run0 --synthetic 1
+Data parallel: python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...
+"""
+import argparse
+import logging
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+parser = argparse.ArgumentParser()
+parser.add_argument('--dataset', type=str, default='BUSI', choices=['fundus', 'prostate', 'BUSI'])
+parser.add_argument("--save_name", type=str, default="debug", help="experiment_name")
+parser.add_argument("--overwrite", action='store_true')
+parser.add_argument("--model", type=str, default="unet", help="model_name")
+parser.add_argument("--max_iterations", type=int, default=60000, help="maximum epoch number to train")
+parser.add_argument('--num_eval_iter', type=int, default=500)
+parser.add_argument("--deterministic", type=int, default=1, help="whether use deterministic training")
+parser.add_argument("--base_lr", type=float, default=0.03, help="segmentation network learning rate")
+parser.add_argument("--seed", type=int, default=1337, help="random seed")
+parser.add_argument("--gpu", type=str, default='0')
+parser.add_argument('--load', action='store_true')
+parser.add_argument('--eval', action='store_true')
+parser.add_argument('--load_path', type=str, default='../checkpoints/label_0.2/Prostate/ours_v0_d1/checkpoint.pth')
+parser.add_argument("--threshold", type=float, default=0.95, help="confidence threshold for using pseudo-labels")
+parser.add_argument('--amp', type=int, default=1, help='use mixed precision training or not')
+parser.add_argument("--label_bs", type=int, default=4, help="labeled_batch_size per gpu")
+parser.add_argument("--unlabel_bs", type=int, default=4)
+parser.add_argument("--test_bs", type=int, default=1)
+parser.add_argument('--domain_num', type=int, default=6)
+parser.add_argument('--lb_domain', type=int, default=1)
+parser.add_argument('--lb_num', type=int, default=40)
+parser.add_argument('--lb_ratio', type=float, default=0)
+parser.add_argument("--ema_decay", type=float, default=0.99, help="ema_decay")
+parser.add_argument("--consistency_type", type=str, default="mse", help="consistency_type")
+parser.add_argument("--consistency", type=float, default=1.0, help="consistency")
+parser.add_argument("--consistency_rampup", type=float, default=200.0, help="consistency_rampup")
+parser.add_argument('--depth', type=int, default=28)
+parser.add_argument('--widen_factor', type=int, default=2)
+parser.add_argument('--leaky_slope', type=float, default=0.1)
+parser.add_argument('--bn_momentum', type=float, default=0.1)
+parser.add_argument('--dropout', type=float, default=0.0)
+parser.add_argument('--cutmix_prob', default=1.0, type=float)
+parser.add_argument('--LB', default=0.01, type=float)
+parser.add_argument('--increase', default=1.0005, type=float)
+parser.add_argument('--queue_len', default=10, type=int)
+# additive flags of this build
+parser.add_argument('--synthetic', type=int, default=1, help='seeded synthetic batches (SURVEY.md 8d)')
+parser.add_argument('--backend_dtype', default='f32', choices=['f32', 'bf16'])
+parser.add_argument('--fft', default='device', choices=['host', 'device'])
+parser.add_argument('--data_root', type=str, default='../../data')
+parser.add_argument('--log_every', type=int, default=50)
+
+
+def make_loaders(args, C, H):
+    """-> iterator of (lb_x_w, lb_y, ulb_x_w, ulb_x_s, ulb_y) CPU tensors."""
+    if not args.synthetic:
+        raise SystemExit("the PIL/scipy dataset pipeline of the reference (dataloaders/) is outside this build's scope; "
+                         "run with --synthetic 1 or plug a loader in here")
+    from ustrun import synthetic
+    from ustrun.ddp import env_world
+    rank = env_world()[0]
+    step = 0
+    while True:
+        yield synthetic.batch(args.dataset, args.label_bs, C, H, args.seed + 100003 * rank + step)
+        step += 1
+
+
+def train(args, snapshot_path):
+    from networks.unet_model import UNet
+    from ustrun import ddp
+    from ustrun.trainer import DATASETS, SSLTrainer
+    rank, local, world = ddp.env_world()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ddp.init(device=dev)
+    C, H, K, _, _, max_it = DATASETS[args.dataset]
+    args.max_iterations = max_it                       # per-dataset schedule of the reference (train.py:412,423,434)
+
+    def create_model(ema=False):
+        if args.model != 'unet':
+            raise SystemExit("only --model unet exists on the reference's path (train.py:496-503)")
+        model = UNet(n_channels=C, n_classes=K, dtype=args.backend_dtype)
+        if ema:
+            for p in model.parameters():
+                p.detach_()
+        return model.to(dev)
+
+    model, ema_model = create_model(), create_model(ema=True)
+    trainer = SSLTrainer(args.dataset, model, ema_model, base_lr=args.base_lr, max_iterations=args.max_iterations,
+                         threshold=args.threshold, ema_decay=args.ema_decay, consistency=args.consistency,
+                         consistency_rampup=args.consistency_rampup, cutmix_prob=args.cutmix_prob, LB=args.LB,
+                         increase=args.increase, queue_len=args.queue_len, num_eval_iter=args.num_eval_iter,
+                         grad_allreduce=ddp.make_grad_allreduce(world), world_size=world, fft=args.fft)
+    loader = make_loaders(args, C, H)
+    max_epoch = args.max_iterations // args.num_eval_iter
+    logging.info("%d iterations per epoch, %d epochs", args.num_eval_iter, max_epoch)
+    t0 = time.time()
+    for epoch in range(max_epoch):
+        for i in range(args.num_eval_iter):
+            batch = [t.to(dev, non_blocking=True) for t in next(loader)]
+            trainer.step(*batch, epoch_start=(i == 0))
+            if rank == 0 and trainer.iter_num % args.log_every == 0:
+                s = trainer.scalars()
+                ips = (args.label_bs + args.unlabel_bs) * world * args.log_every / (time.time() - t0)
+                t0 = time.time()
+                logging.info("iteration %d: loss:%.4f sup:%.4f ul:%.4f lu:%.4f s:%.4f cons_w:%.4f mask:%.4f ulb_dice:%s  %.1f img/s",
+                             trainer.iter_num, s["loss"], s["sup"], s["ul"], s["lu"], s["s"], s["w"], s["mask_ratio"],
+                             ["%.4f" % v for v in s["ulb_dice"]], ips)
+        if rank == 0:
+            torch.save({"epoch": epoch + 1, "ema_state_dict": ema_model.state_dict(), "state_dict": model.state_dict()},
+                       os.path.join(snapshot_path, "checkpoint.pth"))
+
+
+if __name__ == "__main__":
+    args = parser.parse_args()
+    snapshot_path = "../model/" + args.dataset + "/" + args.save_name + "/"
+    if "LOCAL_RANK" not in os.environ:
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)
+    from ustrun.ddp import env_world
+    rank = env_world()[0]
+    random.seed(args.seed)
+    np.random.seed(args.seed + rank)
+    torch.manual_seed(args.seed)                       # same initial weights on every rank
+    if rank == 0:
+        if os.path.exists(snapshot_path) and not args.overwrite:
+            raise Exception('file {} is exist!'.format(snapshot_path))
+        os.makedirs(snapshot_path, exist_ok=True)
+    logging.basicConfig(level=logging.INFO, format='[%(asctime)s.%(msecs)03d] %(message)s', datefmt='%H:%M:%S',
+                        handlers=[logging.StreamHandler(sys.stdout)])
+    logging.info(str(args))
+    train(args, snapshot_path)
