@@ -313,3 +313,53 @@ def test_convT2x2_bf16_mfma_exact():
     dw, db = torch.empty(ci, co, 2, 2, device="cuda"), torch.empty(co, device="cuda")
     l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, 1, None))
     assert rel(dw.cpu(), wr.grad) < 1e-6 and rel(db.cpu(), br.grad) < 1e-6
+
+
+def test_halo_bf16_pool_concat_pad_and_split_dgrad():
+    """The halo-tiled bf16 kernel with a pooled source, with a two-source concat + pad offset, with
+    statistics on an extent that is not a multiple of the tile, and with the split input-gradient."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(3)
+    n, c0, c1, co, h, w = 2, 64, 64, 128, 11, 21
+    sc, sh = torch.randint(-2, 3, (c0,), generator=g).float(), torch.randint(-2, 3, (c0,), generator=g).float()
+    scg, shg = sc.cuda(), sh.cuda()
+    ri = lambda *s: torch.randint(-2, 3, s, generator=g).float()
+    # pooled source (integers stay exact through affine/relu/max and bf16)
+    ys = ri(n, c0, 2 * h + 1, 2 * w)
+    wt = ri(co, c0, 3, 3)
+    a = F.max_pool2d(torch.relu(ys * sc[None, :, None, None] + sh[None, :, None, None]), 2)
+    ref = F.conv2d(a, wt, None, 1, 1)
+    wf, _ = pack_conv_bf16(wt)
+    yg = nhwc(ys)
+    src = l.nhwc_src(yg.data_ptr(), c0, 2 * h + 1, 2 * w, scg.data_ptr(), shg.data_ptr(), relu=1, pool=1)
+    out = torch.empty(n, h, w, co, device="cuda")
+    rows = lib.ustrun_conv_mtiles(n, h, w, co)
+    stat = torch.full((rows, 2, co), 9.0, device="cuda")
+    l.check(lib.ustrun_conv3x3_fwd(C.byref(src), 1, wf.data_ptr(), n, h, w, co, out.data_ptr(), stat.data_ptr(), 1, None))
+    assert rel(from_nhwc(out), ref) < 1e-6
+    np.testing.assert_allclose(stat[:, 0].sum(0).cpu().numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(stat[:, 1].sum(0).cpu().numpy(), ref.square().sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    # concat [skip (affine+relu), up (offset-padded, smaller extent)]
+    skip, up = ri(n, c0, h, w), ri(n, c1, h - 3, w - 2)
+    wt2 = ri(co, c0 + c1, 3, 3)
+    a2 = torch.cat([torch.relu(skip * sc[None, :, None, None] + sh[None, :, None, None]), F.pad(up, [1, 1, 1, 2])], 1)
+    a2r = a2.clone().requires_grad_(True)
+    ref2 = F.conv2d(a2r, wt2, None, 1, 1)
+    dy = ri(n, co, h, w)
+    ref2.backward(dy)
+    wf2, wd2 = pack_conv_bf16(wt2)
+    sg, ug = nhwc(skip), nhwc(up)
+    srcs = (l.Src * 2)(l.nhwc_src(sg.data_ptr(), c0, h, w, scg.data_ptr(), shg.data_ptr(), relu=1),
+                       l.nhwc_src(ug.data_ptr(), c1, h - 3, w - 2, off=(1, 1)))
+    out2 = torch.empty(n, h, w, co, device="cuda")
+    l.check(lib.ustrun_conv3x3_fwd(srcs, 2, wf2.data_ptr(), n, h, w, co, out2.data_ptr(), None, 1, None))
+    assert rel(from_nhwc(out2), ref2.detach()) < 1e-6
+    # input gradient split into the skip part and the (offset, smaller) up part
+    dyg = nhwc(dy)
+    d0 = torch.empty(n, h, w, c0, device="cuda")
+    d1 = torch.empty(n, h - 3, w - 2, c1, device="cuda")
+    l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd2.data_ptr(), n, h, w, co, c0 + c1, d0.data_ptr(), c0, d1.data_ptr(),
+                                     h - 3, w - 2, 1, 1, 1, None))
+    assert rel(from_nhwc(d0), a2r.grad[:, :c0]) < 1e-6
+    assert rel(from_nhwc(d1), a2r.grad[:, c0:, 1:h - 2, 1:w - 1]) < 1e-6

@@ -78,8 +78,12 @@ struct IgemmArgs {
     float* stat;             // [mtiles][2][Cout] or null
 };
 int igemm_mtiles(int64_t M, int Cout);
+int igemm_stat_rows_used(const IgemmArgs& a, int dtype);
 int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st);
 int igemm_launch_bf16(const IgemmArgs& a, hipStream_t st);
+bool halo_supported(const IgemmArgs& a);
+int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st);
+int halo_stat_rows(int N, int H, int W);
 int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, void* wf, void* wd, hipStream_t st);
 static inline bool dtype_ok(int dtype) { return dtype == USTRUN_F32 || dtype == USTRUN_BF16; }
 

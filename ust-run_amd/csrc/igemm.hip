@@ -277,6 +277,17 @@ static int pick_bm(int Cout) { return (Cout > 64) ? 128 : 256; }
 
 int igemm_mtiles(int64_t M, int Cout) { (void)Cout; return cdiv(M, 128); }
 
+// stat rows actually written by the kernel igemm_launch will pick
+int igemm_stat_rows_used(const IgemmArgs& a, int dtype) {
+    if (dtype == USTRUN_BF16 && halo_supported(a)) {
+        bool pool = false;
+        for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
+        const bool th16 = !pool && (a.Cout % 128 != 0);
+        return th16 ? a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16) : a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
+    }
+    return cdiv(a.M, 128);
+}
+
 int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     USTRUN_CHECK(dtype_ok(dtype), "igemm: dtype %d not built", dtype);
     USTRUN_CHECK(a.M > 0 && a.Cout > 0 && a.Cin > 0, "igemm: empty problem");
@@ -295,7 +306,7 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, 4.0 * (in_elems + out_elems + w_elems), st);
     int rc;
     if (dtype == USTRUN_BF16) {
-        rc = igemm_launch_bf16(a, st);
+        rc = halo_supported(a) ? conv3x3_halo_launch_bf16(a, st) : igemm_launch_bf16(a, st);
     } else if (pick_bm(a.Cout) == 128 || pool) {   // (narrow outputs with a pooled source only occur in tiny test nets)
         rc = pool ? launch_cfg<2, 2, true>(a, st) : launch_cfg<2, 2, false>(a, st);
     } else {

@@ -63,7 +63,12 @@ extern "C" int ustrun_pack_convT2x2(const float* w, int Cin, int Cout, void* w_f
     return 0;
 }
 
-extern "C" int ustrun_conv_mtiles(int N, int H, int W, int Cout) { return igemm_mtiles((int64_t)N * H * W, Cout); }
+// upper bound of the BatchNorm-statistics rows over every kernel that may serve the launch; the
+// wrapper zero-fills the buffer when the chosen kernel writes fewer (extents not multiples of 16)
+extern "C" int ustrun_conv_mtiles(int N, int H, int W, int Cout) {
+    const int lin = igemm_mtiles((int64_t)N * H * W, Cout), tiled = N * cdiv(H, 16) * 2 * cdiv(W, 16);
+    return lin > tiled ? lin : tiled;
+}
 
 static int check_srcs(const ustrun_src_t* srcs, int nsrc, const char* who) {
     USTRUN_CHECK(srcs && (nsrc == 1 || nsrc == 2), "%s: nsrc must be 1 or 2", who);
@@ -88,6 +93,13 @@ extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void
     a.nz = 1; a.s_out = 1;
     a.out0 = (float*)y; a.out1 = nullptr; a.C0 = Cout; a.Ho = H; a.Wo = W;
     a.bias = nullptr; a.stat = stat;
+    if (stat) {
+        const int rows = ustrun_conv_mtiles(N, H, W, Cout);
+        if (igemm_stat_rows_used(a, dtype) < rows) {
+            hipError_t e = hipMemsetAsync(stat, 0, (size_t)rows * 2 * Cout * sizeof(float), (hipStream_t)s);
+            USTRUN_CHECK(e == hipSuccess, "conv3x3_fwd: memset failed: %s", hipGetErrorString(e));
+        }
+    }
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
 

@@ -57,7 +57,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     for (int i = 0; i < 18; ++i) {
         p.y_off[i] = o; o = align_up(o + p.y_elems(i), 64);
         p.aff_off[i] = o; o = align_up(o + 4L * p.cout[i], 64);
-        const long st = (long)igemm_mtiles((long)p.N * p.Hs[p.lvl[i]] * p.Ws[p.lvl[i]], p.cout[i]) * 2 * p.cout[i];
+        const long st = (long)ustrun_conv_mtiles(p.N, p.Hs[p.lvl[i]], p.Ws[p.lvl[i]], p.cout[i]) * 2 * p.cout[i];
         if (st > stat_max) stat_max = st;
     }
     for (int j = 0; j < 4; ++j) { p.u_off[j] = o; o = align_up(o + p.u_elems(j), 64); }
