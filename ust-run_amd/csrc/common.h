@@ -103,6 +103,9 @@ struct WgradArgs {
 int wgrad_plan(int nseg, int Cin, int Cout, int64_t M, int* ksplit, long* kchunk, int* slabs);
 int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);
 int wgrad_launch_bf16(const WgradArgs& a, hipStream_t st);
+bool wgrad_halo_supported(const WgradArgs& a);
+int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per);
+int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t st);
 // reduce partial slabs [ksplit][rows] -> out (permuted): layout 0: conv3x3 torch [Cout][Cin][3][3];
 // layout 1: convT torch [Cin][Cout][2][2]; layout 2: plain [rows]
 int reduce_partials(const float* partials, int ksplit, int nseg, int Cin, int Cout, float* out,

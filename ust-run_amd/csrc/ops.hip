@@ -157,6 +157,11 @@ extern "C" int ustrun_convT2x2_dgrad(const void* du, const void* w_dgrad, int N,
 extern "C" int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int64_t npix) {
     int ks, slabs; long chunk;
     wgrad_plan(nseg, Cin, Cout, npix, &ks, &chunk, &slabs);
+    if (nseg == 9 && Cin % 64 == 0 && Cout % 64 == 0) {          // the all-taps bf16 kernel may split further
+        const long pairs = (long)(Cin / 64) * (Cout / 64);
+        const int halo = (int)((768 + pairs - 1) / pairs) + 1;
+        if (halo > slabs) slabs = halo;
+    }
     return (int64_t)slabs * nseg * Cin * Cout * sizeof(float);
 }
 
@@ -172,9 +177,19 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
     a.N = N; a.Hb = H; a.Wb = W; a.M = (long)N * H * W;
     a.nseg = 9; a.segw = 3; a.d0 = -1; a.astep = 1; a.dy_s = 1; a.dyH = H; a.dyW = W;
     int slabs;
+    a.partials = partials;
+    if (dtype == USTRUN_BF16 && wgrad_halo_supported(a)) {
+        int per;
+        wgrad_halo_plan(a, &slabs, &per);
+        USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 9 * a.Cin * Cout * 4, "conv3x3_wgrad: partials too small");
+        prof_begin(1, 2.0 * a.M * 9 * a.Cin * Cout, 0.0, (hipStream_t)s);
+        const int rc = wgrad_halo_launch_bf16(a, slabs, per, (hipStream_t)s);
+        prof_end((hipStream_t)s);
+        USTRUN_TRY(rc);
+        return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 0, accumulate, (hipStream_t)s);
+    }
     wgrad_plan(9, a.Cin, Cout, a.M, &a.ksplit, &a.kchunk, &slabs);
     USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 9 * a.Cin * Cout * 4, "conv3x3_wgrad: partials too small");
-    a.partials = partials;
     USTRUN_TRY(wgrad_launch(a, dtype, (hipStream_t)s));
     return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 0, accumulate, (hipStream_t)s);
 }

@@ -1,0 +1,184 @@
+// wgrad_halo_bf16.hip -- 3x3 weight gradient on the bf16 matrix cores with all nine taps per block:
+//
+//   dW[tap][ci][co] = sum_{pixels p} A[p + tap][ci] * dY[p][co]        (64 ci x 64 co per block)
+//
+// Per 4x16-pixel tile the block stages ONE 6x18-pixel input patch (BatchNorm affine + ReLU / concat /
+// zero padding applied in f32, rounded to bf16) and ONE dY tile in LDS, both pixel-major; the nine
+// taps are nine shifted views of the same patch.  Each wave owns a 32x32 (ci,co) quadrant with nine
+// accumulators (one per tap): per 16-pixel row it fetches one dY fragment and nine shifted A fragments
+// with the transposing LDS read (ds_read_b64_tr_b16) and issues nine MFMAs.  The block walks a range
+// of tiles (split-K over space) and writes one f32 slab, reduced in fixed order by reduce_partials.
+#include "common.h"
+#include "loader.h"
+
+namespace ustrun {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr int TH = 4, TW = 16, HW2 = TW + 2, HP = (TH + 2) * HW2;   // 108 halo pixels
+constexpr int RB = 192;   // LDS row pitch: 64 channels x bf16 = 128 B + 64 B pad, so that the 4 rows of a
+                          // transposed read fall on disjoint bank quarters and every address is base + immediate
+
+// lane_base = per-lane byte offset ((8*(l>>5) + q) * RB + column bytes), k0 = first pixel row of the fragment
+__device__ __forceinline__ bf16x8 tr_frag(const char* lane_base, int k0) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lane_base + k0 * RB));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lane_base + (k0 + 4) * RB));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+// grid = (ci tiles * co tiles, ksplit); tiles_per = spatial tiles per split
+__global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs a, const int ntn, const int tiles_x,
+                                                                 const int tiles_y, const int tiles_per) {
+    constexpr int AIT = (HP * 16 + 255) / 256;     // 7 float4 per thread for the A patch
+    constexpr int BIT = (TH * TW * 16) / 256;      // 4 float4 per thread for the dY tile
+    __shared__ __attribute__((aligned(16))) char As[HP * RB];
+    __shared__ __attribute__((aligned(16))) char Bs[TH * TW * RB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int mtile = blockIdx.x / ntn, ntile = blockIdx.x % ntn;
+    const int ci0 = mtile * 64, co0 = ntile * 64;
+    const int ttotal = a.N * tiles_y * tiles_x;
+    const int tbeg = blockIdx.y * tiles_per;
+    const int tend = min(ttotal, tbeg + tiles_per);
+
+    const int c4 = tid & 15;                        // 4-channel group of this thread (same for A and dY)
+    const int cg = ci0 + 4 * c4;
+    const bool second = (a.nsrc == 2 && cg >= a.src[0].C);
+    const SrcDev S = pick_src(a.src[0], a.src[1], second);
+    const int cl = cg - (second ? a.src[0].C : 0);
+    f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+    if (S.scale) { asc = *(const f32x4*)(S.scale + cl); ash = *(const f32x4*)(S.shift + cl); }
+
+    f32x4 av[AIT], bv[BIT];
+    unsigned aok;
+
+    auto load_tile = [&](int t) {
+        const int img = t / (tiles_y * tiles_x);
+        const int rem = t - img * tiles_y * tiles_x;
+        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+        aok = 0;
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int hp = (tid + 256 * i) >> 4;
+            av[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (hp < HP) {
+                const int hy = hp / HW2, hx = hp - hy * HW2;
+                const int ly = y0 + hy - 1 - S.off_y, lx = x0 + hx - 1 - S.off_x;
+                if (ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW) {
+                    aok |= 1u << i;
+                    av[i] = *(const f32x4*)(S.ptr + img * S.sN + (long)ly * S.sH + (long)lx * S.sW + cl);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            const int p = (tid + 256 * i) >> 4;              // 0..63 inside the tile
+            const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
+            bv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (oy < a.dyH && ox < a.dyW)
+                bv[i] = *(const f32x4*)(a.dy + (((long)img * a.dyH + oy) * a.dyW + ox) * a.Cout + co0 + 4 * c4);
+        }
+    };
+    auto to_bf16 = [](f32x4 v) {
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        return h;
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int hp = (tid + 256 * i) >> 4;
+            if (hp < HP) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((aok >> i) & 1u) {
+                    v = av[i] * asc + ash;
+                    if (S.relu) v = relu4(v);
+                }
+                *(bf16x4*)(As + hp * RB + c4 * 8) = to_bf16(v);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            const int p = (tid + 256 * i) >> 4;
+            *(bf16x4*)(Bs + p * RB + c4 * 8) = to_bf16(bv[i]);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // per-lane fragment bases: rows 8*(l>>5) + q, columns quadrant + 16*((l>>4)&1) + 4p
+    const int lrow = 8 * (lane >> 5) + ((lane & 15) >> 2), lcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const char* Abase = As + lrow * RB + (wi * 32 + lcol) * 2;
+    const char* Bbase = Bs + lrow * RB + (wj * 32 + lcol) * 2;
+
+    if (tbeg < tend) load_tile(tbeg);
+    for (int t = tbeg; t < tend; ++t) {
+        write_tile();
+        __syncthreads();
+        if (t + 1 < tend) load_tile(t + 1);
+#pragma unroll
+        for (int r = 0; r < TH; ++r) {
+            const bf16x8 b = tr_frag(Bbase, r * TW);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {       // tap (kh,kw) reads the patch at (+kh-1, +kw-1): constant offsets
+                const bf16x8 af = tr_frag(Abase, (r + tap / 3) * HW2 + tap % 3);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, acc[tap], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    float* slab = a.partials + (long)blockIdx.y * 9 * a.Cin * a.Cout;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int co = co0 + wj * 32 + l31;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            slab[((long)tap * a.Cin + ci) * a.Cout + co] = acc[tap][r];
+        }
+}
+
+}  // namespace
+
+bool wgrad_halo_supported(const WgradArgs& a) {
+    if (a.nseg != 9 || a.segw != 3 || a.dy_s != 1 || a.astep != 1 || a.d0 != -1) return false;
+    for (int i = 0; i < a.nsrc; ++i)
+        if (a.src[i].sC != 1 || a.src[i].pool || (a.src[i].C % 64)) return false;
+    if (a.Cin % 64 || a.Cout % 64) return false;
+    if (a.Hb < 4 || a.Wb < 8) return false;
+    return true;
+}
+
+// split-K plan of the halo kernel: slabs == ksplit
+int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
+    const int ttotal = a.N * cdiv(a.Hb, TH) * cdiv(a.Wb, TW);
+    const long pairs = (long)(a.Cin / 64) * (a.Cout / 64);
+    long ks = (768 + pairs - 1) / pairs;           // ~3 blocks per CU
+    if (ks > ttotal / 2) ks = ttotal / 2;          // at least two tiles per block
+    if (ks < 1) ks = 1;
+    const int per = cdiv(ttotal, ks);
+    *tiles_per = per; *ksplit = cdiv(ttotal, per);
+    return 0;
+}
+
+int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t st) {
+    dim3 grid((a.Cin / 64) * (a.Cout / 64), ksplit), block(256);
+    hipLaunchKernelGGL(wgrad_halo_bf16_kernel, grid, block, 0, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
+    USTRUN_LAUNCH_CHECK("wgrad_halo_bf16");
+    return 0;
+}
+
+}  // namespace ustrun
