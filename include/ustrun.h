@@ -70,7 +70,7 @@ int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, in
  * scale = gamma*rstd, shift = beta - mean*scale (consumed by the next loader), mean, rstd
  * (kept for backward), and updates running_mean/var (unbiased var, momentum) and
  * num_batches_tracked when update_running != 0.  eval mode: ustrun_bn_eval_affine.           */
-int ustrun_bn_finalize(const float* stat, int mtiles, int C, int64_t count, const float* gamma,
+int ustrun_bn_finalize(float* stat /* scratch: may be overwritten */, int mtiles, int C, int64_t count, const float* gamma,
                        const float* beta, float* running_mean, float* running_var,
                        int64_t* num_batches_tracked, float momentum, float eps, int update_running,
                        float* scale, float* shift, float* mean, float* rstd, ustrun_stream_t s);

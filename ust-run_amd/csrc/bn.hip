@@ -9,7 +9,33 @@ namespace {
 
 // ---- forward statistics -------------------------------------------------------------------
 // block = 32 channels x 8 row lanes; stat[row][2][C] -> mean, biased var -> scale/shift
-__global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int C, double count,
+// Stage 1 for long statistics tables: block (cb, sp) sums its row range [sp*R, sp*R+R) of its 32 columns
+// in f64 and parks the two sums IN PLACE, each as a (hi, lo) float pair, in its OWN cells: row sp*R holds
+// the sum (q=0 cell: hi, q=1 cell: lo), row sp*R+1 the sum of squares.  Only this block reads those cells,
+// and it does so before the barrier that precedes the writes.
+__global__ __launch_bounds__(256) void bn_stat_stage1_kernel(float* stat, int rows, int C, int R) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl, r0 = blockIdx.y * R, r1 = min(rows, r0 + R);
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int r = r0 + rg; r < r1; r += 8) {
+            s1 += (double)stat[((long)r * 2 + 0) * C + c];
+            s2 += (double)stat[((long)r * 2 + 1) * C + c];
+        }
+    red[0][rg][cl] = s1; red[1][rg][cl] = s2;
+    __syncthreads();
+    if (rg < 2 && c < C) {                   // rg 0 -> sum into row r0, rg 1 -> sum of squares into row r0+1
+        double v = 0.0;
+        for (int k = 0; k < 8; ++k) v += red[rg][k][cl];
+        const float hi = (float)v, lo = (float)(v - (double)hi);
+        stat[((long)(r0 + rg) * 2 + 0) * C + c] = hi;
+        stat[((long)(r0 + rg) * 2 + 1) * C + c] = lo;
+    }
+}
+
+template <bool PRE>
+__global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int C, double count, int R,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* rm, float* rv, int64_t* nbt, float momentum, float eps, int update,
                                    float* scale, float* shift, float* mean, float* rstd) {
@@ -17,11 +43,20 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 channels x 32 row lanes
     const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int r = rg; r < rows; r += 32) {
-            s1 += (double)stat[((long)r * 2 + 0) * C + c];
-            s2 += (double)stat[((long)r * 2 + 1) * C + c];
+    if (c < C) {
+        if (PRE) {       // stage-1 doubles parked at rows sp*R / sp*R+1, columns of this channel block
+            for (int sp = rg; sp * R < rows; sp += 32) {
+                const long a0 = (long)(sp * R) * 2 * C + c, a1 = (long)(sp * R + 1) * 2 * C + c;
+                s1 += (double)stat[a0] + (double)stat[a0 + C];
+                s2 += (double)stat[a1] + (double)stat[a1 + C];
+            }
+        } else {
+            for (int r = rg; r < rows; r += 32) {
+                s1 += (double)stat[((long)r * 2 + 0) * C + c];
+                s2 += (double)stat[((long)r * 2 + 1) * C + c];
+            }
         }
+    }
     red[0][rg][cl] = s1; red[1][rg][cl] = s2;
     __syncthreads();
     if (rg == 0 && c < C) {
@@ -229,16 +264,27 @@ int reduce_blocks(long nwin, int G) {
 
 using namespace ustrun;
 
-extern "C" int ustrun_bn_finalize(const float* stat, int mtiles, int C, int64_t count, const float* gamma,
+extern "C" int ustrun_bn_finalize(float* stat, int mtiles, int C, int64_t count, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var,
                                   int64_t* num_batches_tracked, float momentum, float eps, int update_running,
                                   float* scale, float* shift, float* mean, float* rstd, ustrun_stream_t s) {
     USTRUN_CHECK(stat && gamma && beta && scale && shift && mean && rstd, "bn_finalize: null pointer");
     USTRUN_CHECK(!update_running || (running_mean && running_var), "bn_finalize: running buffers missing");
     USTRUN_CHECK(mtiles > 0 && C > 0 && count > 0, "bn_finalize: empty");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)s, stat, mtiles, C,
-                       (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
-                       update_running, scale, shift, mean, rstd);
+    if (mtiles >= 512 && C % 32 == 0) {     // long table: two stages (the first one rewrites `stat` in place)
+        int R = cdiv(mtiles, 32);
+        while (mtiles % R == 1) ++R;         // every split needs two rows to park its sums in
+        hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(mtiles, R)), dim3(256), 0, (hipStream_t)s, (float*)stat,
+                           mtiles, C, R);
+        USTRUN_LAUNCH_CHECK("bn_stat_stage1");
+        hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3(C / 32), dim3(1024), 0, (hipStream_t)s, stat, mtiles, C, (double)count,
+                           R, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, update_running,
+                           scale, shift, mean, rstd);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)s, stat, mtiles, C,
+                           (double)count, 0, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                           update_running, scale, shift, mean, rstd);
+    }
     USTRUN_LAUNCH_CHECK("bn_finalize");
     return 0;
 }

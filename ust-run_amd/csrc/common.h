@@ -116,6 +116,14 @@ int reduce_partials(const float* partials, int ksplit, int nseg, int Cin, int Co
 void prof_begin(int kind, double flops, double bytes, hipStream_t st);
 void prof_end(hipStream_t st);
 
+// first convolution (C <= 4 input channels, 64 outputs): conv_first.hip
+bool conv_first_supported(const ustrun_src_t& s, int Cout);
+int conv_first_stat_rows(int N, int H, int W);
+int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, float* y, float* stat, hipStream_t st);
+int64_t conv_first_wgrad_partials_bytes();
+int conv_first_wgrad(const ustrun_src_t& s, const float* dy, int N, float* dw, int accumulate, float* partials,
+                     int64_t partials_bytes, hipStream_t st);
+
 int reduce_rows(const float* part, int nslab, long stride, long offset, int count, float* out, int accumulate,
                 hipStream_t st);
 

@@ -1,0 +1,217 @@
+// conv_first.hip -- the network's first convolution (inc.conv0: C = 1..4 input channels, NCHW input,
+// 64 outputs) and its weight gradient.  With K = 9*C <= 36 this layer is not a matrix-core problem:
+// forward is HBM-bound on its 64-channel output (268 B/pixel written vs 12 B read), the weight gradient
+// on reading dY once.
+//
+//  * forward: direct f32 stencil on the VALU.  8x16-pixel tile per block, lane = pixel, wave = group of
+//    16 output channels; the 10x18xC input patch sits in LDS, the 27x16 weights of a wave are wave-uniform
+//    (scalar loads, SGPR operands of v_fma).  Epilogue: NHWC f32 store + BatchNorm-statistics partials.
+//  * weight gradient (bf16 MFMA): dW[(c,kh,kw)][co] = sum_p x[c][p+(kh,kw)-1] * dY[p][co] as a
+//    [32 x pixels] x [pixels x 64] GEMM; the im2col rows are built in LDS from the NCHW patch (three
+//    kw-shifted copies keep the 16-byte fragment reads aligned), dY tiles are read transposed.
+#include "common.h"
+
+namespace ustrun {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr int FTH = 8, FTW = 16, FHW = FTW + 2, FHP = (FTH + 2) * FHW;   // 10 x 18 patch
+constexpr int CMAX = 4;
+
+// x NCHW [N,C,H,W] (strides given), w = packed forward weights (f32 [9][C][64] or bf16 [9][C/8][64][8]),
+// y NHWC [N,H,W,64], stat [tiles][2][64]
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, long sN, long sC, long sH, long sW,
+                                                            int C, int H, int W, const void* __restrict__ w, int wbf16,
+                                                            float* __restrict__ y, float* __restrict__ stat,
+                                                            int tiles_x, int tiles_y) {
+    __shared__ float patch[CMAX][FHP];
+    __shared__ __attribute__((aligned(16))) float wl[CMAX * 9][64];   // weights as [c*9+t][co]
+    __shared__ float red[4][2][16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 16 output channels per wave
+    const int img = blockIdx.x / (tiles_y * tiles_x);
+    const int rem = blockIdx.x - img * tiles_y * tiles_x;
+    const int y0 = (rem / tiles_x) * FTH, x0 = (rem % tiles_x) * FTW;
+    for (int t = tid; t < C * FHP; t += 256) {
+        const int c = t / FHP, hp = t - c * FHP;
+        const int iy = y0 + hp / FHW - 1, ix = x0 + hp % FHW - 1;
+        patch[c][hp] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[img * sN + c * sC + iy * sH + ix * sW] : 0.f;
+    }
+    for (int t = tid; t < C * 9 * 64; t += 256) {                    // packed forward weights -> [c*9+tap][co]
+        const int co = t & 63, k = t >> 6, c = k / 9, tap = k - c * 9;
+        wl[k][co] = wbf16 ? (float)((const __bf16*)w)[(((long)tap * ((C + 7) / 8) + c / 8) * 64 + co) * 8 + (c & 7)]
+                          : ((const float*)w)[((long)tap * C + c) * 64 + co];
+    }
+    __syncthreads();
+    float s1[16], s2[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {                                   // two 4x16 pixel groups per block
+        const int py = g * 4 + (lane >> 4), px = lane & 15;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float v = patch[c][(py + t / 3) * FHW + px + t % 3];
+                const float* wk = &wl[c * 9 + t][wave * 16];          // wave-uniform address: LDS broadcast
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w4 = *(const f32x4*)(wk + 4 * q);
+                    acc[4 * q] = fmaf(v, w4[0], acc[4 * q]); acc[4 * q + 1] = fmaf(v, w4[1], acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(v, w4[2], acc[4 * q + 2]); acc[4 * q + 3] = fmaf(v, w4[3], acc[4 * q + 3]);
+                }
+            }
+        const int oy = y0 + py, ox = x0 + px;
+        if (oy < H && ox < W) {
+            float* o = y + (((long)img * H + oy) * W + ox) * 64 + wave * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(o + 4 * q) = (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
+        }
+    }
+    if (stat) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float a = s1[j], b = s2[j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            if (lane == 0) { red[wave][0][j] = a; red[wave][1][j] = b; }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int q = tid >> 6, c = tid & 63;
+            stat[((long)blockIdx.x * 2 + q) * 64 + c] = red[c >> 4][q][c & 15];
+        }
+    }
+}
+
+// ---- weight gradient -----------------------------------------------------------------------
+// block: a range of 8x16 tiles; wave w owns tile rows {2w, 2w+1}: D[32 im2col rows][64 co] per wave,
+// waves summed through LDS at the end, one slab per block: slab[(c*9 + t)][co] (rows >= 9C unused)
+constexpr int WRB = 192;     // dY LDS row pitch (64 bf16 + pad: conflict-free transposed reads)
+
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, long sN, long sC, long sH, long sW,
+                                                              int C, int H, int W, const float* __restrict__ dy,
+                                                              float* __restrict__ partials, int tiles_x, int tiles_y,
+                                                              int ttotal, int tiles_per) {
+    // im2col source: xs[c][kw][hy][16] bf16 = patch shifted by kw so that 8 consecutive pixels are 16-B aligned
+    __shared__ __attribute__((aligned(16))) __bf16 xs[CMAX][3][FTH + 2][FTW];
+    __shared__ __attribute__((aligned(16))) char dys[FTH * FTW * WRB];
+    __shared__ float accs[4][32][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // this lane's im2col row i = l31 -> (c, kh, kw); rows >= 9C are zero
+    const int irow = l31, ic = irow / 9, it = irow % 9, ikh = it / 3, ikw = it % 3;
+    const bool ivalid = irow < 9 * C;
+    const int lrow = 8 * lh + ((lane & 15) >> 2), lcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+    const int tbeg = blockIdx.x * tiles_per, tend = min(ttotal, tbeg + tiles_per);
+    for (int t = tbeg; t < tend; ++t) {
+        const int img = t / (tiles_y * tiles_x);
+        const int rem = t - img * tiles_y * tiles_x;
+        const int y0 = (rem / tiles_x) * FTH, x0 = (rem % tiles_x) * FTW;
+        __syncthreads();
+        for (int e = tid; e < C * 3 * (FTH + 2) * FTW; e += 256) {
+            const int px = e % FTW, hy = (e / FTW) % (FTH + 2), kw = (e / (FTW * (FTH + 2))) % 3, c = e / (FTW * (FTH + 2) * 3);
+            const int iy = y0 + hy - 1, ix = x0 + px + kw - 1;
+            const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[img * sN + c * sC + iy * sH + ix * sW] : 0.f;
+            xs[c][kw][hy][px] = (__bf16)v;
+        }
+        for (int e = tid; e < FTH * FTW * 16; e += 256) {
+            const int p = e >> 4, c4 = e & 15;
+            const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (oy < H && ox < W) v = *(const f32x4*)(dy + (((long)img * H + oy) * W + ox) * 64 + 4 * c4);
+            bf16x4 h;
+            h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+            *(bf16x4*)(dys + p * WRB + c4 * 8) = h;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = wave * 2 + rr;                              // tile row = 16 pixels = one MFMA k-step
+            bf16x8 a;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = (__bf16)0.f;
+            if (ivalid) a = *(const bf16x8*)&xs[ic][ikw][r + ikh][8 * lh];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const char* base = dys + (r * FTW + lrow) * WRB + (j * 32 + lcol) * 2;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)base);
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + 4 * WRB));
+                bf16x8 b;
+                b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3]; b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // sum the four waves (fixed order) and write the block's slab
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][j * 32 + l31] = acc[j][r];
+    __syncthreads();
+    float* slab = partials + (long)blockIdx.x * 32 * 64;
+    for (int e = tid; e < 32 * 64; e += 256) {
+        const int i = e >> 6, co = e & 63;
+        slab[e] = accs[0][i][co] + accs[1][i][co] + accs[2][i][co] + accs[3][i][co];
+    }
+}
+
+// dw[co][c][t] (+)= sum_k partials[k][c*9+t][co]
+__global__ void conv_first_wgrad_reduce_kernel(const float* __restrict__ partials, int nslab, int C, float* __restrict__ dw,
+                                               int accumulate) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 64 * C * 9) return;
+    const int co = e / (C * 9), i = e % (C * 9);
+    double v = 0.0;
+    for (int k = 0; k < nslab; ++k) v += (double)partials[((long)k * 32 + i) * 64 + co];
+    dw[e] = accumulate ? dw[e] + (float)v : (float)v;
+}
+
+}  // namespace
+
+bool conv_first_supported(const ustrun_src_t& s, int Cout) {
+    return s.C <= CMAX && Cout == 64 && !s.pool && !s.scale && !s.relu && s.off_y == 0 && s.off_x == 0;
+}
+int conv_first_stat_rows(int N, int H, int W) { return N * cdiv(H, FTH) * cdiv(W, FTW); }
+
+int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, float* y, float* stat, hipStream_t st) {
+    const int tx = cdiv(s.W, FTW), ty = cdiv(s.H, FTH);
+    hipLaunchKernelGGL(conv_first_fwd_kernel, dim3(N * ty * tx), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
+                       (long)s.sH, (long)s.sW, s.C, s.H, s.W, w_fwd, dtype == USTRUN_BF16 ? 1 : 0, y, stat, tx, ty);
+    USTRUN_LAUNCH_CHECK("conv_first_fwd");
+    return 0;
+}
+
+int64_t conv_first_wgrad_partials_bytes() { return (int64_t)1024 * 32 * 64 * sizeof(float); }
+
+int conv_first_wgrad(const ustrun_src_t& s, const float* dy, int N, float* dw, int accumulate, float* partials,
+                     int64_t partials_bytes, hipStream_t st) {
+    USTRUN_CHECK(partials_bytes >= conv_first_wgrad_partials_bytes(), "conv_first_wgrad: partials too small");
+    const int tx = cdiv(s.W, FTW), ty = cdiv(s.H, FTH), ttotal = N * ty * tx;
+    int blocks = ttotal < 1024 ? ttotal : 1024;
+    const int per = cdiv(ttotal, blocks);
+    blocks = cdiv(ttotal, per);
+    hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
+                       (long)s.sH, (long)s.sW, s.C, s.H, s.W, dy, partials, tx, ty, ttotal, per);
+    USTRUN_LAUNCH_CHECK("conv_first_wgrad");
+    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(cdiv(64 * s.C * 9, 256)), dim3(256), 0, st, partials, blocks, s.C, dw,
+                       accumulate);
+    USTRUN_LAUNCH_CHECK("conv_first_wgrad_reduce");
+    return 0;
+}
+
+}  // namespace ustrun

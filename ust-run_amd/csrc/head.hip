@@ -109,13 +109,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ part, int nslab, long stride, long offset, int count,
-                                   float* __restrict__ out, int accumulate) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= count) return;
+// block = 32 outputs x 8 slab lanes, fixed-order f64 combine
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int nslab, long stride, long offset,
+                                                         int count, float* __restrict__ out, int accumulate) {
+    __shared__ double red[8][32];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
     double v = 0.0;
-    for (int k = 0; k < nslab; ++k) v += (double)part[(long)k * stride + offset + e];
-    out[e] = accumulate ? out[e] + (float)v : (float)v;
+    if (e < count)
+        for (int k = sl; k < nslab; k += 8) v += (double)part[(long)k * stride + offset + e];
+    red[sl][el] = v;
+    __syncthreads();
+    if (sl == 0 && e < count) {
+        for (int k = 1; k < 8; ++k) v += red[k][el];
+        out[e] = accumulate ? out[e] + (float)v : (float)v;
+    }
 }
 
 int lanes_per_pixel(int C4) { int g = 1; while (g < C4 && g < 64) g <<= 1; return g; }
@@ -124,7 +132,7 @@ int lanes_per_pixel(int C4) { int g = 1; while (g < C4 && g < 64) g <<= 1; retur
 
 int reduce_rows(const float* part, int nslab, long stride, long offset, int count, float* out, int accumulate,
                 hipStream_t st) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(count, 256)), dim3(256), 0, st, part, nslab, stride, offset, count,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(count, 32)), dim3(256), 0, st, part, nslab, stride, offset, count,
                        out, accumulate);
     USTRUN_LAUNCH_CHECK("reduce_rows");
     return 0;

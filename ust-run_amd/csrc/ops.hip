@@ -93,12 +93,19 @@ extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void
     a.nz = 1; a.s_out = 1;
     a.out0 = (float*)y; a.out1 = nullptr; a.C0 = Cout; a.Ho = H; a.Wo = W;
     a.bias = nullptr; a.stat = stat;
+    const bool first = nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W;
     if (stat) {
         const int rows = ustrun_conv_mtiles(N, H, W, Cout);
-        if (igemm_stat_rows_used(a, dtype) < rows) {
+        if ((first ? conv_first_stat_rows(N, H, W) : igemm_stat_rows_used(a, dtype)) < rows) {
             hipError_t e = hipMemsetAsync(stat, 0, (size_t)rows * 2 * Cout * sizeof(float), (hipStream_t)s);
             USTRUN_CHECK(e == hipSuccess, "conv3x3_fwd: memset failed: %s", hipGetErrorString(e));
         }
+    }
+    if (first) {     // C <= 4 input channels: direct f32 stencil, HBM-bound on its output
+        prof_begin(0, 2.0 * a.M * Cout * 9 * a.Cin, 4.0 * ((double)a.M * (a.Cin + Cout) + 9.0 * a.Cin * Cout), (hipStream_t)s);
+        const int rc = conv_first_fwd(srcs[0], w_fwd, dtype, N, (float*)y, stat, (hipStream_t)s);
+        prof_end((hipStream_t)s);
+        return rc;
     }
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
@@ -162,7 +169,9 @@ extern "C" int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int6
         const int halo = (int)((768 + pairs - 1) / pairs) + 1;
         if (halo > slabs) slabs = halo;
     }
-    return (int64_t)slabs * nseg * Cin * Cout * sizeof(float);
+    int64_t b = (int64_t)slabs * nseg * Cin * Cout * sizeof(float);
+    if (nseg == 9 && Cin <= 4 && Cout == 64 && conv_first_wgrad_partials_bytes() > b) b = conv_first_wgrad_partials_bytes();
+    return b;
 }
 
 extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const void* dy, int N, int H, int W, int Cout,
@@ -178,6 +187,8 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
     a.nseg = 9; a.segw = 3; a.d0 = -1; a.astep = 1; a.dy_s = 1; a.dyH = H; a.dyW = W;
     int slabs;
     a.partials = partials;
+    if (dtype == USTRUN_BF16 && nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W)
+        return conv_first_wgrad(srcs[0], (const float*)dy, N, dw, accumulate, partials, partials_bytes, (hipStream_t)s);
     if (dtype == USTRUN_BF16 && wgrad_halo_supported(a)) {
         int per;
         wgrad_halo_plan(a, &slabs, &per);
@@ -186,7 +197,7 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
         const int rc = wgrad_halo_launch_bf16(a, slabs, per, (hipStream_t)s);
         prof_end((hipStream_t)s);
         USTRUN_TRY(rc);
-        return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 0, accumulate, (hipStream_t)s);
+        return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 2, accumulate, (hipStream_t)s);   // slabs are in torch layout
     }
     wgrad_plan(9, a.Cin, Cout, a.M, &a.ksplit, &a.kchunk, &slabs);
     USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 9 * a.Cin * Cout * 4, "conv3x3_wgrad: partials too small");

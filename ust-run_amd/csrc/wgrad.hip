@@ -177,21 +177,74 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a, co
     }
 }
 
-// out[...] (+)= sum_k partials[k][...]; grid-stride over the nseg*Cin*Cout elements
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int nslab, int nseg, int Cin, int Cout,
-                                       float* __restrict__ out, int layout, int accumulate) {
-    const long total = (long)nseg * Cin * Cout;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+// In-place pre-reduction of long slab lists: group g (blockIdx.y) sums slabs [g*GRP, g*GRP+GRP) into
+// slab g*GRP.  Every thread reads and writes only its own elements, so no ordering is needed.
+constexpr int GRP = 16;
+__global__ __launch_bounds__(256) void reduce_groups_kernel(float* part, int nslab, long total, long sstride) {
+    const int k0 = blockIdx.y * GRP, k1 = min(nslab, k0 + GRP);
+    const long n4 = total / 4;
+    float* base = part + (long)k0 * sstride;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = ((const f32x4*)base)[i];
+        for (int k = k0 + 1; k < k1; ++k) v += ((const f32x4*)(part + (long)k * sstride))[i];
+        ((f32x4*)base)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {
+        const long e = n4 * 4 + threadIdx.x;
         float v = 0.f;
-        for (int k = 0; k < nslab; ++k) v += part[(long)k * total + e];
-        const int co = (int)(e % Cout);
-        const long t = e / Cout;
-        const int ci = (int)(t % Cin), seg = (int)(t / Cin);
-        long o;
-        if (layout == 0) o = ((long)co * Cin + ci) * nseg + seg;        // [Cout][Cin][3][3]
-        else if (layout == 1) o = ((long)ci * Cout + co) * nseg + seg;  // [Cin][Cout][2][2]
-        else o = e;
-        out[o] = accumulate ? out[o] + v : v;
+        for (int k = k0; k < k1; ++k) v += part[(long)k * sstride + e];
+        base[e] = v;
+    }
+}
+
+// out (+)= sum_k partials[k*sstride ...]  (same layout, 16 B per lane)
+__global__ __launch_bounds__(256) void reduce_plain_kernel(const float* __restrict__ part, int nslab, long total, long sstride,
+                                                          float* __restrict__ out, int accumulate) {
+    const long n4 = total / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = ((const f32x4*)part)[i];
+        for (int k = 1; k < nslab; ++k) v += ((const f32x4*)(part + (long)k * sstride))[i];
+        if (accumulate) v += ((f32x4*)out)[i];
+        ((f32x4*)out)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {
+        const long e = n4 * 4 + threadIdx.x;
+        float v = 0.f;
+        for (int k = 0; k < nslab; ++k) v += part[(long)k * sstride + e];
+        out[e] = accumulate ? out[e] + v : v;
+    }
+}
+
+// partials [k][seg][ci][co] -> torch conv layout [co][ci][seg] (layout 0) or convT layout [ci][co][seg]
+// (layout 1): one 32(ci) x 32(co) x nseg tile per block goes through LDS so that both the reads (along co)
+// and the writes (along the destination's inner dimensions) are coalesced.
+__global__ __launch_bounds__(256) void reduce_transpose_kernel(const float* __restrict__ part, int nslab, long sstride, int nseg,
+                                                              int Cin, int Cout, float* __restrict__ out, int layout,
+                                                              int accumulate) {
+    __shared__ float tile[9][32][33];
+    const int cit = blockIdx.x % ((Cin + 31) / 32), cot = blockIdx.x / ((Cin + 31) / 32);
+    const int ci0 = cit * 32, co0 = cot * 32;
+    const long total = (long)nseg * Cin * Cout;
+    for (int e = threadIdx.x; e < nseg * 32 * 32; e += 256) {
+        const int co = e & 31, ci = (e >> 5) & 31, seg = e >> 10;
+        float v = 0.f;
+        if (ci0 + ci < Cin && co0 + co < Cout) {
+            const long idx = ((long)seg * Cin + ci0 + ci) * Cout + co0 + co;
+            for (int k = 0; k < nslab; ++k) v += part[(long)k * sstride + idx];
+        }
+        tile[seg][ci][co] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nseg * 32 * 32; e += 256) {
+        int seg, ci, co;
+        if (layout == 0) { seg = e % nseg; ci = (e / nseg) & 31; co = e / (nseg * 32); }   // [co][ci][seg]
+        else { seg = e % nseg; co = (e / nseg) & 31; ci = e / (nseg * 32); }               // [ci][co][seg]
+        if (ci0 + ci < Cin && co0 + co < Cout) {
+            const long o = layout == 0 ? ((long)(co0 + co) * Cin + ci0 + ci) * nseg + seg
+                                       : ((long)(ci0 + ci) * Cout + co0 + co) * nseg + seg;
+            const float v = tile[seg][ci][co];
+            out[o] = accumulate ? out[o] + v : v;
+        }
     }
 }
 
@@ -251,10 +304,23 @@ int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
 int reduce_partials(const float* partials, int nslab, int nseg, int Cin, int Cout, float* out, int layout,
                     int accumulate, hipStream_t st) {
     const long total = (long)nseg * Cin * Cout;
-    int blocks = cdiv(total, 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, partials, nslab, nseg, Cin, Cout, out,
-                       layout, accumulate);
+    int eblocks = cdiv(total / 4 + 1, 256);
+    if (eblocks > 2048) eblocks = 2048;
+    long sstride = total;
+    while (nslab > GRP) {                      // parallel fixed-order tree over long slab lists (in place)
+        const int groups = cdiv(nslab, GRP);
+        hipLaunchKernelGGL(reduce_groups_kernel, dim3(eblocks, groups), dim3(256), 0, st, const_cast<float*>(partials), nslab,
+                           total, sstride);
+        USTRUN_LAUNCH_CHECK("reduce_groups");
+        nslab = groups; sstride *= GRP;
+    }
+    if (layout == 2) {
+        hipLaunchKernelGGL(reduce_plain_kernel, dim3(eblocks), dim3(256), 0, st, partials, nslab, total, sstride, out, accumulate);
+    } else {
+        USTRUN_CHECK(nseg <= 9, "reduce_partials: nseg %d > 9", nseg);
+        hipLaunchKernelGGL(reduce_transpose_kernel, dim3(cdiv(Cin, 32) * cdiv(Cout, 32)), dim3(256), 0, st, partials, nslab,
+                           sstride, nseg, Cin, Cout, out, layout, accumulate);
+    }
     USTRUN_LAUNCH_CHECK("reduce_partials");
     return 0;
 }

@@ -7,7 +7,8 @@
 // taps are nine shifted views of the same patch.  Each wave owns a 32x32 (ci,co) quadrant with nine
 // accumulators (one per tap): per 16-pixel row it fetches one dY fragment and nine shifted A fragments
 // with the transposing LDS read (ds_read_b64_tr_b16) and issues nine MFMAs.  The block walks a range
-// of tiles (split-K over space) and writes one f32 slab, reduced in fixed order by reduce_partials.
+// of tiles (split-K over space) and writes one f32 slab already in the torch [Cout][Cin][3][3] layout,
+// summed in fixed order by a plain streaming reduce.
 #include "common.h"
 #include "loader.h"
 
@@ -133,22 +134,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {       // tap (kh,kw) reads the patch at (+kh-1, +kw-1): constant offsets
                 const bf16x8 af = tr_frag(Abase, (r + tap / 3) * HW2 + tap % 3);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, af, acc[tap], 0, 0, 0);   // D[co][ci]
             }
         }
         __syncthreads();
     }
 
+    // slab in the torch weight layout [Cout][Cin][3][3]: rows of D are co, lanes are ci, and a lane
+    // holds all nine taps of its (co, ci) pairs -> nine consecutive floats
     float* slab = a.partials + (long)blockIdx.y * 9 * a.Cin * a.Cout;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int co = co0 + wj * 32 + l31;
+    const int ci = ci0 + wi * 32 + l31;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float* o = slab + ((long)co * a.Cin + ci) * 9;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            slab[((long)tap * a.Cin + ci) * a.Cout + co] = acc[tap][r];
-        }
+        for (int tap = 0; tap < 9; ++tap) o[tap] = acc[tap][r];
+    }
 }
 
 }  // namespace
