@@ -129,3 +129,27 @@ def test_cpu_tensor_is_refused():
     m = UNet(1, 2, base_channels=8)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 1, 32, 32))
+
+
+@pytest.mark.parametrize("c,k,n,h,w,base", [(3, 2, 2, 64, 64, 64), (1, 4, 2, 48, 32, 16)])
+def test_bf16_compute_tracks_f32(c, k, n, h, w, base):
+    """dtype='bf16' (bf16 matrix-core operands, f32 accumulate/statistics/storage) against the f32 oracle:
+    bf16 has an 8-bit mantissa: logits agree to ~1e-2; on a random-init net the deep gradients (through
+    train-mode BatchNorm over a handful of values) are noise-amplified, so they are only required to stay
+    correlated here -- the training-trajectory gate is tools/parity_200.py (Dice within 1e-3 after 200 steps)."""
+    from networks.unet_model import UNet
+    torch.manual_seed(21)
+    sd = U.make_state_dict(c, k, base=base)
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(n, c, h, w, generator=g)
+    m = UNet(c, k, base_channels=base, dtype="bf16")
+    m.load_state_dict({kk: v.clone() for kk, v in sd.items()})
+    m = m.cuda().train()
+    ref_sd = U.clone_sd(sd, requires_grad=True)
+    ref = U.unet_forward(x, ref_sd, train=True)
+    lg = m(x.cuda())
+    assert rel_l2(lg.detach().cpu(), ref.detach()) < 3e-2
+    lg.square().mean().backward()
+    ref.square().mean().backward()
+    errs = [rel_l2(p.grad.cpu(), ref_sd[key].grad) for (name, p), key in zip(m.named_parameters(), U.param_keys(ref_sd))]
+    assert max(errs) < 0.8 and float(np.median(errs)) < 0.4, (max(errs), float(np.median(errs)))

@@ -14,11 +14,25 @@ def _discs(B, H, g, radii):
     return [d2 <= (r0 * f)[:, None, None] ** 2 for f in radii]
 
 
-def images(B, C, H, g):
+def images(B, C, H, g, fg=None):
+    """Noise on the 256-level grid, 3x3 box low-passed; when a foreground map [B,H,H] in [0,1] is given the
+    foreground is brightened so that the segmentation task is learnable (Dice is then a meaningful gate)."""
     x = torch.randint(0, 256, (B, C, H, H), generator=g).float()
-    # 3x3 box low-pass so that predictions are not pure noise, re-quantised to the 256-level grid
-    x = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="replicate"), 3, 1).round()
-    return x / 127.5 - 1
+    x = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="replicate"), 3, 1)
+    if fg is not None:
+        x = 0.6 * x + 100.0 * fg[:, None]
+    return x.round().clamp(0, 255) / 127.5 - 1
+
+
+def foreground(dataset, y):
+    """[B,H,H] map in [0,1] of how 'bright' each pixel's class is."""
+    if dataset == "fundus":
+        return (y <= 128).float() * 0.5 + (y == 0).float() * 0.5
+    if dataset == "prostate":
+        return (y == 0).float()
+    if dataset == "BUSI":
+        return (y == 255).float()
+    return (y[..., 0] == 255).float() * 0.33 + (y[..., 1] == 255).float() * 0.66 + (y[..., 2] == 255).float()
 
 
 def labels(dataset, B, H, g):
@@ -45,4 +59,6 @@ def labels(dataset, B, H, g):
 def batch(dataset, B, C, H, seed):
     """(lb_x_w, lb_y, ulb_x_w, ulb_x_s, ulb_y) on the CPU."""
     g = torch.Generator().manual_seed(seed)
-    return images(B, C, H, g), labels(dataset, B, H, g), images(B, C, H, g), images(B, C, H, g), labels(dataset, B, H, g)
+    lb_y, ulb_y = labels(dataset, B, H, g), labels(dataset, B, H, g)
+    f_lb, f_ulb = foreground(dataset, lb_y), foreground(dataset, ulb_y)
+    return images(B, C, H, g, f_lb), lb_y, images(B, C, H, g, f_ulb), images(B, C, H, g, f_ulb), ulb_y
