@@ -166,7 +166,7 @@ extern "C" int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int6
     wgrad_plan(nseg, Cin, Cout, npix, &ks, &chunk, &slabs);
     if (nseg == 9 && Cin % 64 == 0 && Cout % 64 == 0) {          // the all-taps bf16 kernel may split further
         const long pairs = (long)(Cin / 64) * (Cout / 64);
-        const int halo = (int)((768 + pairs - 1) / pairs) + 1;
+        const int halo = (int)((1024 + pairs - 1) / pairs) + 1;
         if (halo > slabs) slabs = halo;
     }
     int64_t b = (int64_t)slabs * nseg * Cin * Cout * sizeof(float);

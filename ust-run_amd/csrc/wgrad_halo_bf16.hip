@@ -34,6 +34,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lane_base, int k0) {
 }
 
 // grid = (ci tiles * co tiles, ksplit); tiles_per = spatial tiles per split
+template <bool POOL>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs a, const int ntn, const int tiles_x,
                                                                  const int tiles_y, const int tiles_per) {
     constexpr int AIT = (HP * 16 + 255) / 256;     // 7 float4 per thread for the A patch
@@ -59,22 +60,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
 
     f32x4 av[AIT], bv[BIT];
     unsigned aok;
+    // patch coordinates of this thread's A items are tile-invariant: (hy << 8) | hx, hp >= HP -> 0xffff
+    int hyx[AIT];
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+        const int hp = (tid + 256 * i) >> 4;
+        hyx[i] = hp < HP ? (((hp / HW2) << 8) | (hp % HW2)) : 0xffff;
+    }
 
     auto load_tile = [&](int t) {
         const int img = t / (tiles_y * tiles_x);
         const int rem = t - img * tiles_y * tiles_x;
         const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
         aok = 0;
+        const int by = y0 - 1 - S.off_y, bx = x0 - 1 - S.off_x;
+        const float* base = S.ptr + img * S.sN + cl;
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            const int hp = (tid + 256 * i) >> 4;
             av[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (hp < HP) {
-                const int hy = hp / HW2, hx = hp - hy * HW2;
-                const int ly = y0 + hy - 1 - S.off_y, lx = x0 + hx - 1 - S.off_x;
-                if (ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW) {
-                    aok |= 1u << i;
-                    av[i] = *(const f32x4*)(S.ptr + img * S.sN + (long)ly * S.sH + (long)lx * S.sW + cl);
+            const int ly = by + (hyx[i] >> 8), lx = bx + (hyx[i] & 0xff);
+            if (hyx[i] != 0xffff && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW) {
+                aok |= 1u << i;
+                if (POOL) {          // 2x2 max of the activated source, evaluated right here (no raw prefetch)
+                    const float* p = base + (long)(2 * ly) * S.sH + (long)(2 * lx) * S.sW;
+                    f32x4 v = relu4(*(const f32x4*)p * asc + ash);
+                    v = max4(v, relu4(*(const f32x4*)(p + S.sW) * asc + ash));
+                    v = max4(v, relu4(*(const f32x4*)(p + S.sH) * asc + ash));
+                    av[i] = max4(v, relu4(*(const f32x4*)(p + S.sH + S.sW) * asc + ash));
+                } else {
+                    av[i] = *(const f32x4*)(base + (long)ly * S.sH + (long)lx * S.sW);
                 }
             }
         }
@@ -99,8 +113,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
             if (hp < HP) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if ((aok >> i) & 1u) {
-                    v = av[i] * asc + ash;
-                    if (S.relu) v = relu4(v);
+                    if (POOL) v = av[i];
+                    else {
+                        v = av[i] * asc + ash;
+                        if (S.relu) v = relu4(v);
+                    }
                 }
                 *(bf16x4*)(As + hp * RB + c4 * 8) = to_bf16(v);
             }
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
 bool wgrad_halo_supported(const WgradArgs& a) {
     if (a.nseg != 9 || a.segw != 3 || a.dy_s != 1 || a.astep != 1 || a.d0 != -1) return false;
     for (int i = 0; i < a.nsrc; ++i)
-        if (a.src[i].sC != 1 || a.src[i].pool || (a.src[i].C % 64)) return false;
+        if (a.src[i].sC != 1 || (a.src[i].C % 64) || (a.src[i].pool && (a.nsrc != 1 || !a.src[i].relu))) return false;
     if (a.Cin % 64 || a.Cout % 64) return false;
     if (a.Hb < 4 || a.Wb < 8) return false;
     return true;
@@ -169,8 +186,8 @@ bool wgrad_halo_supported(const WgradArgs& a) {
 int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
     const int ttotal = a.N * cdiv(a.Hb, TH) * cdiv(a.Wb, TW);
     const long pairs = (long)(a.Cin / 64) * (a.Cout / 64);
-    long ks = (768 + pairs - 1) / pairs;           // ~3 blocks per CU
-    if (ks > ttotal / 2) ks = ttotal / 2;          // at least two tiles per block
+    long ks = (1024 + pairs - 1) / pairs;          // whole waves of 512 resident blocks (2 per CU)
+    if (ks > ttotal / 4) ks = ttotal / 4;          // at least four tiles per block
     if (ks < 1) ks = 1;
     const int per = cdiv(ttotal, ks);
     *tiles_per = per; *ksplit = cdiv(ttotal, per);
@@ -179,7 +196,10 @@ int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
 
 int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t st) {
     dim3 grid((a.Cin / 64) * (a.Cout / 64), ksplit), block(256);
-    hipLaunchKernelGGL(wgrad_halo_bf16_kernel, grid, block, 0, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
+    if (a.src[0].pool)
+        hipLaunchKernelGGL(wgrad_halo_bf16_kernel<true>, grid, block, 0, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
+    else
+        hipLaunchKernelGGL(wgrad_halo_bf16_kernel<false>, grid, block, 0, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
     USTRUN_LAUNCH_CHECK("wgrad_halo_bf16");
     return 0;
 }
