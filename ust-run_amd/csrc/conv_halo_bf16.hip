@@ -7,9 +7,11 @@
 // (global_load_lds_dwordx4, no VGPRs) into a double buffer, one tap ahead of the MFMAs.
 //
 // Tile: TH x 16 output pixels x BN channels per 256-thread block; every wave owns 4 rows x 16 pixels
-// x 64 channels = 2x2 v_mfma_f32_32x32x16_bf16 accumulators.  (TH,BN) = (8,128) or (16,64).
+// x 64 channels = 2x2 v_mfma_f32_32x32x16_bf16 accumulators (MI = 2), or 8 rows x 16 pixels x 64 channels
+// = 4x2 accumulators (MI = 4: 0.75 LDS fragment reads per MFMA instead of 1, half the weight traffic per flop).
 #include "common.h"
 #include "loader.h"
+#include <stdlib.h>
 
 namespace ustrun {
 namespace {
@@ -21,11 +23,12 @@ typedef __attribute__((address_space(3))) void lptr_t;
 
 constexpr int TW = 16, HW2 = TW + 2;
 
-template <int TH, int BN, int BK, bool POOL>
+// MI = 32-pixel (2 rows x 16) MFMA sub-tiles per wave along M: the wave tile is (2*MI rows x 16 px) x 64 channels
+template <int TH, int BN, int BK, int MI, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
-    constexpr bool EARLY_A = !POOL;             // prefetch the next A patch into registers under tap 8's MFMAs
-    constexpr int WM = TH / 4, WN = 4 / WM;
+    constexpr int WM = TH / (2 * MI), WN = 4 / WM;
+    static_assert(WM * WN == 4 && BN == WN * 64, "4 waves, 64 channels per wave");
     constexpr int HP = (TH + 2) * HW2;          // halo pixels
     constexpr int CPR = BK / 4;                 // 4-channel groups per pixel
     constexpr int AIT = (HP * CPR + 255) / 256; // A items per thread per chunk
@@ -35,9 +38,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     constexpr int BIT = BCH / 256;
     static_assert(BCH % 256 == 0, "B tile must be a whole number of wave-instructions per wave");
 
+    constexpr int BATCH = (AIT + 8) / 9;        // A items staged per tap (the next patch is spread over the 9 taps)
+    constexpr int ABYTES = (HP * ROWB + 15) & ~15;
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                            // [HP][BK] bf16
-    char* Bs = smem + ((HP * ROWB + 15) & ~15); // 2 x [BK/8][BN][8] bf16
+    char* As = smem;                            // 2 x [HP][BK] bf16 (current patch / patch being staged)
+    char* Bs = smem + 2 * ABYTES;               // 2 x [BK/8][BN][8] bf16
 
     const int mt_total = a.N * tiles_y * tiles_x;
     const int ntiles = mt_total * nt_total;
@@ -62,66 +68,71 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     const int K8 = a.Cin / 8;
     const __bf16* Wp = (const __bf16*)a.W;
 
-    f32x4 av[AIT][NP];
+    // ---- A patch staging, BATCH items per call: global -> registers (raw) ... -> transform -> bf16 -> LDS ----
+    f32x4 av[BATCH][NP];
     f32x4 asc, ash;
-    unsigned aok;
-    int a_relu;
-
-    // ---- A halo: global -> registers (raw), registers -> transform -> bf16 -> LDS ----
-    auto load_A = [&](int c) {
-        const int c0 = c * BK;
-        const int c4 = tid % CPR;                    // constant per thread: 256 % CPR == 0
-        const int cg = c0 + 4 * c4;
+    int a_relu = 0;
+    unsigned aok = 0;
+    const int c4 = tid % CPR;                       // constant per thread: 256 % CPR == 0
+    const float* abase = nullptr;
+    int aLH = 0, aLW = 0, aby = 0, abx = 0;
+    long asH = 0, asW = 0;
+    auto stage_begin = [&](int c) {                 // per-chunk constants: source, affine, origin
+        const int cg = c * BK + 4 * c4;
         const bool second = (a.nsrc == 2 && cg >= a.src[0].C);
         const SrcDev S = pick_src(a.src[0], a.src[1], second);
         const int cl = cg - (second ? a.src[0].C : 0);
         asc = (f32x4){1.f, 1.f, 1.f, 1.f}; ash = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (S.scale) { asc = *(const f32x4*)(S.scale + cl); ash = *(const f32x4*)(S.shift + cl); }
         a_relu = S.relu;
+        abase = S.ptr + img * S.sN + cl;
+        aLH = S.LH; aLW = S.LW; asH = S.sH; asW = S.sW;
+        aby = y0 - 1 - S.off_y; abx = x0 - 1 - S.off_x;
+    };
+    auto stage_load = [&](int t) {                  // items t*BATCH .. t*BATCH+BATCH-1
         aok = 0;
 #pragma unroll
-        for (int i = 0; i < AIT; ++i) {
-            const int hp = (tid + 256 * i) / CPR;
-            if (hp < HP) {
+        for (int b = 0; b < BATCH; ++b) {
+            const int hp = (tid + 256 * (t * BATCH + b)) / CPR;
+            if (t * BATCH + b < AIT && hp < HP) {
                 const int hy = hp / HW2, hx = hp - hy * HW2;
-                const int ly = y0 + hy - 1 - S.off_y, lx = x0 + hx - 1 - S.off_x;
-                if (ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW) {
-                    aok |= 1u << i;
+                const int ly = aby + hy, lx = abx + hx;
+                if (ly >= 0 && ly < aLH && lx >= 0 && lx < aLW) {
+                    aok |= 1u << b;
                     if (POOL) {
-                        const float* p = S.ptr + img * S.sN + (long)(2 * ly) * S.sH + (long)(2 * lx) * S.sW + cl;
-                        av[i][0] = *(const f32x4*)p;
-                        av[i][1 % NP] = *(const f32x4*)(p + S.sW);
-                        av[i][2 % NP] = *(const f32x4*)(p + S.sH);
-                        av[i][3 % NP] = *(const f32x4*)(p + S.sH + S.sW);
+                        const float* p = abase + (long)(2 * ly) * asH + (long)(2 * lx) * asW;
+                        av[b][0] = *(const f32x4*)p;
+                        av[b][1 % NP] = *(const f32x4*)(p + asW);
+                        av[b][2 % NP] = *(const f32x4*)(p + asH);
+                        av[b][3 % NP] = *(const f32x4*)(p + asH + asW);
                     } else {
-                        av[i][0] = *(const f32x4*)(S.ptr + img * S.sN + (long)ly * S.sH + (long)lx * S.sW + cl);
+                        av[b][0] = *(const f32x4*)(abase + (long)ly * asH + (long)lx * asW);
                     }
                 }
             }
         }
     };
-    auto write_A = [&]() {
-        const int c4 = tid % CPR;
+    auto stage_write = [&](int t, char* Adst) {
 #pragma unroll
-        for (int i = 0; i < AIT; ++i) {
-            const int hp = (tid + 256 * i) / CPR;
-            if (hp < HP) {
+        for (int b = 0; b < BATCH; ++b) {
+            const int hp = (tid + 256 * (t * BATCH + b)) / CPR;
+            if (t * BATCH + b < AIT && hp < HP) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((aok >> i) & 1u) {
-                    v = av[i][0] * asc + ash;
+                if ((aok >> b) & 1u) {
+                    v = av[b][0] * asc + ash;
                     if (a_relu) v = relu4(v);
                     if (POOL) {
 #pragma unroll
                         for (int q = 1; q < NP; ++q) {
-                            f32x4 t = av[i][q] * asc + ash;
-                            if (a_relu) t = relu4(t);
-                            v = max4(v, t);
+                            f32x4 u = av[b][q] * asc + ash;
+                            if (a_relu) u = relu4(u);
+                            v = max4(v, u);
                         }
                     }
                 }
                 bf16x4 h;
                 h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-                *(bf16x4*)(As + hp * ROWB + (((c4 >> 1) ^ swz(hp)) * 16) + (c4 & 1) * 8) = h;
+                *(bf16x4*)(Adst + hp * ROWB + (((c4 >> 1) ^ swz(hp)) * 16) + (c4 & 1) * 8) = h;
             }
         }
     };
@@ -138,55 +149,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // halo pixel (before the tap shift) of this lane's two A rows: subtile i covers tile rows
-    // wm*4 + 2i + (l31>>4), column l31&15
-    const int hpb0 = (wm * 4 + (l31 >> 4) + 1) * HW2 + (l31 & 15) + 1;
-    const int hpb1 = hpb0 + 2 * HW2;
+    // halo pixel (before the tap shift) of this lane's A rows: subtile i covers tile rows
+    // wm*2*MI + 2i + (l31>>4), column l31&15
+    const int hpb0 = (wm * 2 * MI + (l31 >> 4) + 1) * HW2 + (l31 & 15) + 1;
     const int nstage = nchunk * 9;
 
-    load_A(0);
     dma_B(0, 0);
-    write_A();
+    stage_begin(0);
+    for (int t = 0; t * BATCH < AIT; ++t) { stage_load(t); stage_write(t, As); }
     __syncthreads();
     int buf = 0;
     for (int c = 0; c < nchunk; ++c) {
+        const char* Acur = As + (c & 1) * ABYTES;
+        char* Anext = As + ((c + 1) & 1) * ABYTES;
+        const bool more = c + 1 < nchunk;
+        if (more) stage_begin(c + 1);
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int s = c * 9 + tap;
             if (s + 1 < nstage) dma_B(s + 1, buf ^ 1);
-            if (EARLY_A && tap == 8 && c + 1 < nchunk) load_A(c + 1);
+            const bool stg = more && tap * BATCH < AIT;
+            if (stg) stage_load(tap);                      // raw loads of the next patch fly under this tap's MFMAs
             const int dy = a.d0 + (tap / 3) * a.dstep, dx = a.d0 + (tap % 3) * a.dstep;
-            const int hp0 = hpb0 + dy * HW2 + dx, hp1 = hpb1 + dy * HW2 + dx;
-            const char* Ap0 = As + hp0 * ROWB;
-            const char* Ap1 = As + hp1 * ROWB;
-            const int sw0 = swz(hp0), sw1 = swz(hp1);
+            const int hp0 = hpb0 + dy * HW2 + dx;
             const char* Bp = Bs + buf * (BCH * 16) + (lh * BN + wn * 64 + l31) * 16;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 const int ch = 2 * ks + lh;
-                const bf16x8 a0 = *(const bf16x8*)(Ap0 + ((ch ^ sw0) * 16));
-                const bf16x8 a1 = *(const bf16x8*)(Ap1 + ((ch ^ sw1) * 16));
                 const bf16x8 b0 = *(const bf16x8*)(Bp + (2 * ks * BN) * 16);
                 const bf16x8 b1 = *(const bf16x8*)(Bp + (2 * ks * BN + 32) * 16);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int hp = hp0 + 2 * i * HW2;
+                    const bf16x8 af = *(const bf16x8*)(Acur + hp * ROWB + ((ch ^ swz(hp)) * 16));
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[i][1], 0, 0, 0);
+                }
             }
-            __syncthreads();             // B[buf] and (at tap 8) the A patch are free; DMA of B[buf^1] has landed
-            if (tap == 8 && c + 1 < nchunk) {
-                if (!EARLY_A) load_A(c + 1);
-                write_A();
-                __syncthreads();
-            }
+            if (stg) stage_write(tap, Anext);              // the other patch buffer: no reader until the next chunk
+            __syncthreads();                               // B[buf] is free; DMA of B[buf^1] has landed
             buf ^= 1;
         }
     }
@@ -199,11 +208,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         const int col = n0 + wn * 64 + j * 32 + l31;
         const float bias = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;          // 0..31 inside the 2x16 subtile
-                const int oy = y0 + wm * 4 + 2 * i + (row >> 4), ox = x0 + (row & 15);
+                const int oy = y0 + wm * 2 * MI + 2 * i + (row >> 4), ox = x0 + (row & 15);
                 if (oy < a.Ho && ox < a.Wo) {
                     const float v = acc[i][j][r] + bias;
                     if (col < a.C0) {
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         }
     }
     if (a.stat) {
-        float* red = (float*)As;   // [WM][2][BN]; the A patch is dead after the last barrier
+        float* red = (float*)As;   // [WM][2][BN]; the A patches are dead after the last barrier
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             s1[j] += __shfl_xor(s1[j], 32);
@@ -230,21 +239,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             }
         }
         __syncthreads();
-        constexpr int HALVES = WM / 2;              // one stat row per 8 tile rows (128 pixels)
-        for (int t = tid; t < HALVES * 2 * BN; t += 256) {
+        constexpr int SROWS = TH / 8;               // one stat row per 8 tile rows (128 pixels)
+        constexpr int WPS = WM / SROWS;             // waves (along M) that share a stat row
+        for (int t = tid; t < SROWS * 2 * BN; t += 256) {
             const int h = t / (2 * BN), q = (t / BN) % 2, cc = t % BN;
-            const float v = red[((2 * h) * 2 + q) * BN + cc] + red[((2 * h + 1) * 2 + q) * BN + cc];
-            a.stat[((long)(mtile * HALVES + h) * 2 + q) * a.Cout + n0 + cc] = v;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPS; ++w) v += red[((h * WPS + w) * 2 + q) * BN + cc];
+            a.stat[((long)(mtile * SROWS + h) * 2 + q) * a.Cout + n0 + cc] = v;
         }
     }
 }
 
-template <int TH, int BN, int BK, bool POOL>
+template <int TH, int BN, int BK, int MI, bool POOL>
 int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
-    const size_t lds = (size_t)(((TH + 2) * HW2 * BK * 2 + 15) & ~15) + 2 * (size_t)(BK / 8) * BN * 16;
+    const size_t lds = 2 * (size_t)(((TH + 2) * HW2 * BK * 2 + 15) & ~15) + 2 * (size_t)(BK / 8) * BN * 16;
     dim3 grid(a.N * ty * tx * nt), block(256);
-    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, BN, BK, POOL>), grid, block, lds, st, a, tx, ty, nt);
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, BN, BK, MI, POOL>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;
 }
@@ -262,7 +274,7 @@ bool halo_supported(const IgemmArgs& a) {
         if (a.src[i].sC != 1 || (a.src[i].C & 3)) return false;
         pool |= a.src[i].pool != 0;
     }
-    const int BK = (pool || a.Cout % 128) ? 32 : 64;
+    const int BK = 32;
     if (a.Cin % BK || a.Cout % 64) return false;
     if (a.nsrc == 2 && (a.src[0].C % BK)) return false;
     if (pool && (a.nsrc != 1 || a.Cout % 128)) return false;
@@ -270,12 +282,21 @@ bool halo_supported(const IgemmArgs& a) {
     return true;
 }
 
+// 16-row tiles (256 px x 128 ch per block) read fewer LDS/weight bytes per flop but need >= 2 blocks per CU
+bool halo_tall_tile(const IgemmArgs& a) {
+    return (long)a.N * cdiv(a.Hb, 16) * cdiv(a.Wb, 16) * (a.Cout / 128) >= 512;
+}
+
 int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     bool pool = false;
     for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
-    if (pool) return launch_cfg<8, 128, 32, true>(a, st);
-    if (a.Cout % 128 == 0) return launch_cfg<8, 128, 64, false>(a, st);
-    return launch_cfg<16, 64, 32, false>(a, st);
+    if (pool) return launch_cfg<8, 128, 32, 2, true>(a, st);
+    if (a.Cout % 128 == 0) {
+        if (halo_tall_tile(a)) return launch_cfg<16, 128, 32, 4, false>(a, st);   // wave tile 128 px x 64 ch
+        if (a.Cin % 64 == 0) return launch_cfg<8, 128, 64, 2, false>(a, st);
+        return launch_cfg<8, 128, 32, 2, false>(a, st);
+    }
+    return launch_cfg<16, 64, 32, 2, false>(a, st);
 }
 
 }  // namespace ustrun

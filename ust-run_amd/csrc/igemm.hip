@@ -15,6 +15,7 @@
 // transform -> LDS (A stored k-major so that lanes read consecutive pixels, B row-major) -> MFMA.
 #include "common.h"
 #include "loader.h"
+#include <stdlib.h>
 
 namespace ustrun {
 
@@ -282,7 +283,7 @@ int igemm_stat_rows_used(const IgemmArgs& a, int dtype) {
     if (dtype == USTRUN_BF16 && halo_supported(a)) {
         bool pool = false;
         for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
-        const bool th16 = !pool && (a.Cout % 128 != 0);
+        const bool th16 = !pool && (a.Cout % 128 != 0 || halo_tall_tile(a));
         return th16 ? a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16) : a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
     }
     return cdiv(a.M, 128);
