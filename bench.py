@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--dataset", default="fundus", choices=["fundus", "prostate", "BUSI", "MNMS"])
     ap.add_argument("--label_bs", type=int, default=16)
     ap.add_argument("--unlabel_bs", type=int, default=16)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+                    help="bf16 = bf16 matrix-core operands, f32 accumulate/statistics (configs[1]); f32 = the exact parity path")
     ap.add_argument("--fft", default="device", choices=["host", "device"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event roofline leg")
@@ -125,7 +126,8 @@ def main():
         lib.ustrun_profile_collect(0, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
         peak = 157.3 if a.dtype == "f32" else 2500.0
         ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        roof = {"kernel": "igemm (conv3x3 fwd/dgrad + ConvTranspose fwd/dgrad)", "bound": "mfma", "achieved": round(ach, 2),
+        roof = {"kernel": "DoubleConv convolutions: conv3x3 forward + input-gradient (halo-tiled implicit GEMM) and ConvTranspose",
+                "bound": "mfma", "achieved": round(ach, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "launches_per_step": n.value // max(a.steps, 1), "avg_launch_ms": round(ms.value / max(n.value, 1), 4),
                 "alg_flops_per_launch": fl.value / max(n.value, 1), "alg_bytes_per_launch": by.value / max(n.value, 1),
@@ -135,7 +137,16 @@ def main():
         lib.ustrun_profile_collect(1, ctypes.byref(ms2), ctypes.byref(fl2), None, ctypes.byref(n2))
         if ms2.value > 0:
             roof["wgrad"] = {"achieved": round(fl2.value / (ms2.value * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                             "frac": round(fl2.value / (ms2.value * 1e-3) / 1e12 / peak, 4),
                              "time_share_of_step": round(ms2.value * 1e-3 / dt, 3)}
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured offline with
+        # rocprofv3 --pmc on this same command and committed under profiles/ (bench.py cannot run under two profilers)
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{a.dtype}.json")
+        if os.path.exists(tpath):
+            try:
+                roof["traffic"] = json.load(open(tpath))["hbm_bytes_per_launch"]
+            except Exception:
+                pass
     if rank == 0:
         imgs = (a.label_bs + a.unlabel_bs) * world * a.steps
         out = {"metric": "train images/sec (256x256 U-Net, mixed lb+ulb batch)", "value": round(imgs / dt, 3),
