@@ -13,8 +13,10 @@
  *   - all pointers are DEVICE pointers unless named host_*.
  *   - activations inside the network are NHWC ("pixel-major": channels of one pixel are
  *     contiguous); the network input and the logits are NCHW as in the reference.
- *   - dtype selects the storage type of activations and packed weights: USTRUN_F32 (exact
- *     f32 MFMA, the parity path) or USTRUN_BF16 (bf16 MFMA, f32 accumulate/statistics).
+ *   - dtype selects the storage type of activations, activation gradients and packed weights:
+ *     USTRUN_F32 (exact f32 MFMA, the parity path) or USTRUN_BF16 (bf16 tensors in HBM, bf16 MFMA,
+ *     f32 accumulate / BatchNorm statistics / losses / optimizer).  `void*` activation arguments
+ *     follow it; the network input, logits, parameters and gradients of parameters are always f32.
  */
 #ifndef USTRUN_H
 #define USTRUN_H
@@ -49,6 +51,8 @@ typedef struct ustrun_src {
     int32_t relu;            /* max(0, .) after the affine                                 */
     int32_t pool;            /* logical pixel (y,x) = max of stored (2y..2y+1, 2x..2x+1)   */
     int32_t off_y, off_x;    /* logical (y,x) reads stored (y-off_y, x-off_x)              */
+    int32_t f32;             /* 1: this tensor is f32 even when dtype is USTRUN_BF16 (the    */
+                             /*    network input); otherwise its element type follows dtype  */
 } ustrun_src_t;
 
 /* ---- weight packing (done once per optimizer step) ---------------------------------------

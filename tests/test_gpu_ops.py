@@ -231,7 +231,14 @@ def test_head_fwd_bwd(n, c, k, h, w):
     assert rel(dw.cpu(), wr.grad) < 1e-5 and rel(db.cpu(), br.grad) < 1e-5
 
 
-# ---- bf16 matrix-core variants (dtype = 1): f32 storage, bf16 MFMA operands, f32 accumulate -------
+# ---- dtype = 1: bf16 tensors in HBM, bf16 MFMA operands, f32 accumulate/statistics -------------
+def nhwc16(t):
+    return nhwc(t).bfloat16()
+
+
+def r16(t):          # what an exact f32 result reads back as after bf16 storage
+    return t.bfloat16().float()
+
 def pack_conv_bf16(w):
     l = L()
     co, ci = w.shape[:2]
@@ -258,24 +265,24 @@ def test_conv3x3_bf16_mfma(n, ci, co, h, w, exact):
         dy = torch.randint(-3, 4, (n, co, h, w), generator=g).float()
         tol = 1e-6
     else:
-        x = torch.randn(n, ci, h, w, generator=g)
+        x = torch.randn(n, ci, h, w, generator=g).bfloat16().float()
         wt = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
-        dy = torch.randn(n, co, h, w, generator=g)
+        dy = torch.randn(n, co, h, w, generator=g).bfloat16().float()
         tol = 1e-2
     xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
     y_ref = F.conv2d(xr, wr, None, 1, 1)
     y_ref.backward(dy)
     wf, wd = pack_conv_bf16(wt)
-    xg, dyg = nhwc(x), nhwc(dy)
+    xg, dyg = nhwc16(x), nhwc16(dy)
     src = l.nhwc_src(xg.data_ptr(), ci, h, w)
-    y = torch.empty(n, h, w, co, device="cuda")
+    y = torch.empty(n, h, w, co, device="cuda", dtype=torch.bfloat16)
     stat = torch.zeros(lib.ustrun_conv_mtiles(n, h, w, co), 2, co, device="cuda")
     l.check(lib.ustrun_conv3x3_fwd(C.byref(src), 1, wf.data_ptr(), n, h, w, co, y.data_ptr(), stat.data_ptr(), 1, None))
-    assert rel(from_nhwc(y), y_ref.detach()) < tol
-    np.testing.assert_allclose(stat[:, 0].sum(0).cpu().numpy(), from_nhwc(y).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-2)
-    da = torch.empty(n, h, w, ci, device="cuda")
+    assert rel(from_nhwc(y.float()), r16(y_ref.detach())) < tol
+    np.testing.assert_allclose(stat[:, 0].sum(0).cpu().numpy(), from_nhwc(y.float()).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-2)
+    da = torch.empty(n, h, w, ci, device="cuda", dtype=torch.bfloat16)
     l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 1, None))
-    assert rel(from_nhwc(da), xr.grad) < tol
+    assert rel(from_nhwc(da.float()), r16(xr.grad)) < tol
     nb = lib.ustrun_wgrad_partials_bytes(9, ci, co, n * h * w)
     part = torch.empty(nb // 4, device="cuda")
     dw = torch.empty(co, ci, 3, 3, device="cuda")
@@ -300,14 +307,14 @@ def test_convT2x2_bf16_mfma_exact():
     wd = torch.zeros(nel, dtype=torch.bfloat16, device="cuda")
     wg = wt.cuda()
     l.check(lib.ustrun_pack_convT2x2(wg.data_ptr(), ci, co, wf.data_ptr(), wd.data_ptr(), 1, None))
-    xg, bg, dug = nhwc(x), b.cuda(), nhwc(du)
+    xg, bg, dug = nhwc16(x), b.cuda(), nhwc16(du)
     src = l.nhwc_src(xg.data_ptr(), ci, h, w)
-    u = torch.empty(n, 2 * h, 2 * w, co, device="cuda")
+    u = torch.empty(n, 2 * h, 2 * w, co, device="cuda", dtype=torch.bfloat16)
     l.check(lib.ustrun_convT2x2_fwd(C.byref(src), wf.data_ptr(), bg.data_ptr(), n, h, w, co, u.data_ptr(), 1, None))
-    assert rel(from_nhwc(u), u_ref.detach()) < 1e-6
-    da = torch.empty(n, h, w, ci, device="cuda")
+    assert rel(from_nhwc(u.float()), r16(u_ref.detach())) < 1e-6
+    da = torch.empty(n, h, w, ci, device="cuda", dtype=torch.bfloat16)
     l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), 1, None))
-    assert rel(from_nhwc(da), xr.grad) < 1e-6
+    assert rel(from_nhwc(da.float()), r16(xr.grad)) < 1e-6
     nb = max(lib.ustrun_wgrad_partials_bytes(4, ci, co, n * h * w), 512 * co * 4)
     part = torch.empty(nb // 4, device="cuda")
     dw, db = torch.empty(ci, co, 2, 2, device="cuda"), torch.empty(co, device="cuda")
@@ -331,15 +338,15 @@ def test_halo_bf16_pool_concat_pad_and_split_dgrad():
     a = F.max_pool2d(torch.relu(ys * sc[None, :, None, None] + sh[None, :, None, None]), 2)
     ref = F.conv2d(a, wt, None, 1, 1)
     wf, _ = pack_conv_bf16(wt)
-    yg = nhwc(ys)
+    yg = nhwc16(ys)
     src = l.nhwc_src(yg.data_ptr(), c0, 2 * h + 1, 2 * w, scg.data_ptr(), shg.data_ptr(), relu=1, pool=1)
-    out = torch.empty(n, h, w, co, device="cuda")
+    out = torch.empty(n, h, w, co, device="cuda", dtype=torch.bfloat16)
     rows = lib.ustrun_conv_mtiles(n, h, w, co)
     stat = torch.full((rows, 2, co), 9.0, device="cuda")
     l.check(lib.ustrun_conv3x3_fwd(C.byref(src), 1, wf.data_ptr(), n, h, w, co, out.data_ptr(), stat.data_ptr(), 1, None))
-    assert rel(from_nhwc(out), ref) < 1e-6
-    np.testing.assert_allclose(stat[:, 0].sum(0).cpu().numpy(), ref.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
-    np.testing.assert_allclose(stat[:, 1].sum(0).cpu().numpy(), ref.square().sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    assert rel(from_nhwc(out.float()), r16(ref)) < 1e-6
+    np.testing.assert_allclose(stat[:, 0].sum(0).cpu().numpy(), r16(ref).sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(stat[:, 1].sum(0).cpu().numpy(), r16(ref).square().sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
     # concat [skip (affine+relu), up (offset-padded, smaller extent)]
     skip, up = ri(n, c0, h, w), ri(n, c1, h - 3, w - 2)
     wt2 = ri(co, c0 + c1, 3, 3)
@@ -349,17 +356,53 @@ def test_halo_bf16_pool_concat_pad_and_split_dgrad():
     dy = ri(n, co, h, w)
     ref2.backward(dy)
     wf2, wd2 = pack_conv_bf16(wt2)
-    sg, ug = nhwc(skip), nhwc(up)
+    sg, ug = nhwc16(skip), nhwc16(up)
     srcs = (l.Src * 2)(l.nhwc_src(sg.data_ptr(), c0, h, w, scg.data_ptr(), shg.data_ptr(), relu=1),
                        l.nhwc_src(ug.data_ptr(), c1, h - 3, w - 2, off=(1, 1)))
-    out2 = torch.empty(n, h, w, co, device="cuda")
+    out2 = torch.empty(n, h, w, co, device="cuda", dtype=torch.bfloat16)
     l.check(lib.ustrun_conv3x3_fwd(srcs, 2, wf2.data_ptr(), n, h, w, co, out2.data_ptr(), None, 1, None))
-    assert rel(from_nhwc(out2), ref2.detach()) < 1e-6
+    assert rel(from_nhwc(out2.float()), r16(ref2.detach())) < 1e-6
     # input gradient split into the skip part and the (offset, smaller) up part
-    dyg = nhwc(dy)
-    d0 = torch.empty(n, h, w, c0, device="cuda")
-    d1 = torch.empty(n, h - 3, w - 2, c1, device="cuda")
+    dyg = nhwc16(dy)
+    d0 = torch.empty(n, h, w, c0, device="cuda", dtype=torch.bfloat16)
+    d1 = torch.empty(n, h - 3, w - 2, c1, device="cuda", dtype=torch.bfloat16)
     l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd2.data_ptr(), n, h, w, co, c0 + c1, d0.data_ptr(), c0, d1.data_ptr(),
                                      h - 3, w - 2, 1, 1, 1, None))
-    assert rel(from_nhwc(d0), a2r.grad[:, :c0]) < 1e-6
-    assert rel(from_nhwc(d1), a2r.grad[:, c0:, 1:h - 2, 1:w - 1]) < 1e-6
+    assert rel(from_nhwc(d0.float()), r16(a2r.grad[:, :c0])) < 1e-6
+    assert rel(from_nhwc(d1.float()), r16(a2r.grad[:, c0:, 1:h - 2, 1:w - 1])) < 1e-6
+
+
+def test_bf16_storage_bn_head_backward():
+    """BatchNorm/ReLU/pool backward and the head on bf16 tensors: same math as the f32 kernels, inputs and
+    outputs rounded to bf16 (compared against the f32 kernels run on the rounded inputs)."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(8)
+    n, c, h, w, k = 2, 64, 12, 16, 2
+    y = (torch.randn(n, c, h, w, generator=g) * 2 + 0.5).bfloat16().float()
+    da = torch.randn(n, c, h, w, generator=g).bfloat16().float()
+    dp = torch.randn(n, c, h // 2, w // 2, generator=g).bfloat16().float()
+    var, mean = torch.var_mean(y, dim=(0, 2, 3), unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    gamma, beta = 1 + 0.3 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    t = [v.cuda() for v in (gamma * rstd, beta - mean * gamma * rstd, mean, rstd, gamma)]
+    nb = lib.ustrun_bn_bwd_partials_bytes(n * h * w, c)
+    part = torch.empty(nb // 4, device="cuda")
+    outs = {}
+    for dt, cast in ((0, lambda v: v), (1, lambda v: v.bfloat16())):
+        yg, dag, dpg = cast(nhwc(y)), cast(nhwc(da)), cast(nhwc(dp))
+        dgam, dbet, coef = torch.empty(c, device="cuda"), torch.empty(c, device="cuda"), torch.empty(3 * c, device="cuda")
+        l.check(lib.ustrun_bn_bwd_reduce(dag.data_ptr(), dpg.data_ptr(), yg.data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
+                                         t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), n, h, w, c, dgam.data_ptr(),
+                                         dbet.data_ptr(), 0, coef.data_ptr(), part.data_ptr(), nb, dt, None))
+        dy = torch.empty_like(yg)
+        l.check(lib.ustrun_bn_bwd_apply(dag.data_ptr(), dpg.data_ptr(), yg.data_ptr(), t[0].data_ptr(), t[1].data_ptr(),
+                                        coef.data_ptr(), n, h, w, c, dy.data_ptr(), dt, None))
+        wt, b = torch.randn(k, c, generator=torch.Generator().manual_seed(1)).cuda() / 8, torch.zeros(k).cuda()
+        lg = torch.empty(n, k, h, w, device="cuda")
+        l.check(lib.ustrun_head_fwd(yg.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), n * h * w, h * w, c, k, wt.data_ptr(),
+                                    b.data_ptr(), lg.data_ptr(), dt, None))
+        outs[dt] = (dgam.cpu(), dbet.cpu(), dy.float().cpu(), lg.cpu())
+    assert rel(outs[1][0], outs[0][0]) < 1e-5 and rel(outs[1][1], outs[0][1]) < 1e-5
+    assert rel(outs[1][2], outs[0][2].bfloat16().float()) < 1e-5
+    assert rel(outs[1][3], outs[0][3]) < 1e-6

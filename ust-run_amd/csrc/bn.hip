@@ -3,6 +3,7 @@
 // fixed-order two-level reductions (block partials, then an f64 finalize) so results are
 // reproducible run to run.
 #include "common.h"
+#include "loader.h"
 
 namespace ustrun {
 namespace {
@@ -88,13 +89,13 @@ __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* be
 }
 
 // a = relu(y*scale+shift) materialised (NHWC -> NHWC or NCHW)
-__global__ void bn_relu_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+__global__ void bn_relu_apply_kernel(const float* __restrict__ y, int esz, const float* __restrict__ scale,
                                      const float* __restrict__ shift, long npix, int C, int HW,
                                      float* __restrict__ out, int nchw) {
     const long total = npix * C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long p = e / C; const int c = (int)(e - p * C);
-        float v = y[e];
+        float v = ld1(y, e, esz);
         if (scale) v = fmaxf(v * scale[c] + shift[c], 0.f);
         if (nchw) { const long n = p / HW; const long hw = p - n * HW; out[(n * C + c) * HW + hw] = v; }
         else out[e] = v;
@@ -110,7 +111,7 @@ struct Win {
     static constexpr int NPX = POOL ? 4 : 1;
 };
 
-template <bool POOL>
+template <bool POOL, int ESZ>
 __device__ __forceinline__ void window_dz(const float* da, const float* __restrict__ dp,
                                           const float* __restrict__ y, f32x4 sc, f32x4 sh, int n, int wy, int wx,
                                           int H, int W, int C, int c, f32x4 (&yv)[Win<POOL>::NPX],
@@ -125,15 +126,15 @@ __device__ __forceinline__ void window_dz(const float* da, const float* __restri
         yv[q] = zero; dz[q] = zero; av[q] = zero;
         if (ok[q]) {
             const long off = (((long)n * H + py) * W + px) * C + c;
-            yv[q] = *(const f32x4*)(y + off);
+            yv[q] = ld4t<ESZ>(y, off);
             av[q] = yv[q] * sc + sh;
-            if (da) dz[q] = *(const f32x4*)(da + off);
+            if (da) dz[q] = ld4t<ESZ>(da, off);
         }
     }
     if (POOL) {
         const int PH = H / 2, PW = W / 2;
         if (dp && wy < PH && wx < PW) {
-            const f32x4 g = *(const f32x4*)(dp + (((long)n * PH + wy) * PW + wx) * C + c);
+            const f32x4 g = ld4t<ESZ>(dp, (((long)n * PH + wy) * PW + wx) * C + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int best = 0; float bv = fmaxf(av[0][j], 0.f);
@@ -151,7 +152,7 @@ __device__ __forceinline__ void window_dz(const float* da, const float* __restri
 }
 
 // grid-stride over windows; thread = (channel quad, window lane).  partials[block][2][C]
-template <bool POOL>
+template <bool POOL, int ESZ>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ dp,
                                                            const float* __restrict__ y, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int N, int H, int W, int C,
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 const int rem = (int)(w - (long)n * WH * WW);
                 const int wy = rem / WW, wx = rem - wy * WW;
                 f32x4 yv[NPX], dz[NPX]; bool ok[NPX];
-                window_dz<POOL>(da, dp, y, sc, sh, n, wy, wx, H, W, C, c, yv, dz, ok);
+                window_dz<POOL, ESZ>(da, dp, y, sc, sh, n, wy, wx, H, W, C, c, yv, dz, ok);
 #pragma unroll
                 for (int q = 0; q < NPX; ++q) { s1 += dz[q]; s2 += dz[q] * yv[q]; }
             }
@@ -219,7 +220,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int r
     }
 }
 
-template <bool POOL>
+template <bool POOL, int ESZ>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* da, const float* __restrict__ dp,
                                                           const float* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ coef,
@@ -238,12 +239,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* da, cons
             const int rem = (int)(w - (long)n * WH * WW);
             const int wy = rem / WW, wx = rem - wy * WW;
             f32x4 yv[NPX], dz[NPX]; bool ok[NPX];
-            window_dz<POOL>(da, dp, y, sc, sh, n, wy, wx, H, W, C, c, yv, dz, ok);
+            window_dz<POOL, ESZ>(da, dp, y, sc, sh, n, wy, wx, H, W, C, c, yv, dz, ok);
 #pragma unroll
             for (int q = 0; q < NPX; ++q) {
                 if (!ok[q]) continue;
                 const int py = POOL ? 2 * wy + (q >> 1) : wy, px = POOL ? 2 * wx + (q & 1) : wx;
-                *(f32x4*)(dy + (((long)n * H + py) * W + px) * C + c) = k0 * dz[q] + k1 * yv[q] + k2;
+                st4t<ESZ>(dy, (((long)n * H + py) * W + px) * C + c, k0 * dz[q] + k1 * yv[q] + k2);
             }
         }
     }
@@ -305,7 +306,7 @@ extern "C" int ustrun_bn_relu_apply(const void* y, const float* scale, const flo
     USTRUN_CHECK(y && out && npix > 0 && C > 0 && HW > 0, "bn_relu_apply: bad args");
     int blocks = cdiv(npix * C, 256 * 4);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)y, scale,
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)y, act_esz(dtype), scale,
                        shift, (long)npix, C, HW, out, out_nchw);
     USTRUN_LAUNCH_CHECK("bn_relu_apply");
     return 0;
@@ -329,12 +330,12 @@ extern "C" int ustrun_bn_bwd_reduce(const void* da, const void* dp, const void* 
     const bool pool = dp != nullptr;
     const long nwin = pool ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long)N * H * W;
     const int blocks = reduce_blocks(nwin, G);
-    if (pool)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)da,
-                           (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)da,
-                           (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials);
+#define USTRUN_BN_REDUCE(P, E)                                                                                         \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<P, E>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)da, \
+                       (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials)
+    if (dtype == USTRUN_BF16) { if (pool) USTRUN_BN_REDUCE(true, 2); else USTRUN_BN_REDUCE(false, 2); }
+    else { if (pool) USTRUN_BN_REDUCE(true, 4); else USTRUN_BN_REDUCE(false, 4); }
+#undef USTRUN_BN_REDUCE
     USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)s, partials, blocks, C,
                        (double)N * H * W, gamma, mean, rstd, dgamma, dbeta, accumulate, coef);
@@ -354,12 +355,12 @@ extern "C" int ustrun_bn_bwd_apply(const void* da, const void* dp, const void* y
     const int PL = 256 / G;
     long blocks = (nwin + (long)PL * 4 - 1) / ((long)PL * 4);
     if (blocks > 4096) blocks = 4096;
-    if (pool)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)da,
-                           (const float*)dp, (const float*)y, scale, shift, coef, N, H, W, C, G, (float*)dy);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)da,
-                           (const float*)dp, (const float*)y, scale, shift, coef, N, H, W, C, G, (float*)dy);
+#define USTRUN_BN_APPLY(P, E)                                                                                               \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<P, E>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)da, \
+                       (const float*)dp, (const float*)y, scale, shift, coef, N, H, W, C, G, (float*)dy)
+    if (dtype == USTRUN_BF16) { if (pool) USTRUN_BN_APPLY(true, 2); else USTRUN_BN_APPLY(false, 2); }
+    else { if (pool) USTRUN_BN_APPLY(true, 4); else USTRUN_BN_APPLY(false, 4); }
+#undef USTRUN_BN_APPLY
     USTRUN_LAUNCH_CHECK("bn_bwd_apply");
     return 0;
 }

@@ -46,10 +46,14 @@ struct SrcDev {
     long sN, sH, sW, sC;
     int relu, pool, off_y, off_x;
     int LH, LW;  // logical extent (H/2 when pooled)
+    int esz;     // element size of the stored tensor: 4 (f32) or 2 (bf16); strides are in elements
 };
 
-static inline SrcDev make_src(const ustrun_src_t& s) {
+static inline int act_esz(int dtype) { return dtype == USTRUN_BF16 ? 2 : 4; }
+
+static inline SrcDev make_src(const ustrun_src_t& s, int dtype) {
     SrcDev d;
+    d.esz = (s.f32 || dtype != USTRUN_BF16) ? 4 : 2;
     d.ptr = (const float*)s.ptr; d.scale = s.scale; d.shift = s.shift;
     d.C = s.C; d.H = s.H; d.W = s.W;
     d.sN = s.sN; d.sH = s.sH; d.sW = s.sW; d.sC = s.sC;
@@ -76,6 +80,7 @@ struct IgemmArgs {
     int H1, W1, o1y, o1x;    // out1 extent / offset
     const float* bias;
     float* stat;             // [mtiles][2][Cout] or null
+    int out_esz;             // element size of out0/out1 (4 or 2)
 };
 int igemm_mtiles(int64_t M, int Cout);
 int igemm_stat_rows_used(const IgemmArgs& a, int dtype);
@@ -92,7 +97,7 @@ static inline bool dtype_ok(int dtype) { return dtype == USTRUN_F32 || dtype == 
 struct WgradArgs {
     SrcDev src[2];
     int nsrc, Cin;
-    const float* dy; int Cout;
+    const float* dy; int Cout; int dy_esz;
     int N, Hb, Wb; long M;   // base grid = pixels summed over
     int nseg, segw, d0, astep; // A side: in pixel = base + d0 + (s/segw, s%segw)*astep
     int dy_s;                  // dY pixel = base*dy_s + (dy_s == 2 ? (s/2, s%2) : (0,0))
@@ -120,9 +125,9 @@ void prof_end(hipStream_t st);
 // first convolution (C <= 4 input channels, 64 outputs): conv_first.hip
 bool conv_first_supported(const ustrun_src_t& s, int Cout);
 int conv_first_stat_rows(int N, int H, int W);
-int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, float* y, float* stat, hipStream_t st);
+int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, void* y, float* stat, hipStream_t st);
 int64_t conv_first_wgrad_partials_bytes();
-int conv_first_wgrad(const ustrun_src_t& s, const float* dy, int N, float* dw, int accumulate, float* partials,
+int conv_first_wgrad(const ustrun_src_t& s, const void* dy, int dy_esz, int N, float* dw, int accumulate, float* partials,
                      int64_t partials_bytes, hipStream_t st);
 
 int reduce_rows(const float* part, int nslab, long stride, long offset, int count, float* out, int accumulate,

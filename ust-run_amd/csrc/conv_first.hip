@@ -10,6 +10,7 @@
 //    [32 x pixels] x [pixels x 64] GEMM; the im2col rows are built in LDS from the NCHW patch (three
 //    kw-shifted copies keep the 16-byte fragment reads aligned), dY tiles are read transposed.
 #include "common.h"
+#include "loader.h"
 
 namespace ustrun {
 namespace {
@@ -23,6 +24,7 @@ constexpr int CMAX = 4;
 
 // x NCHW [N,C,H,W] (strides given), w = packed forward weights (f32 [9][C][64] or bf16 [9][C/8][64][8]),
 // y NHWC [N,H,W,64], stat [tiles][2][64]
+template <int ESZ>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, long sN, long sC, long sH, long sW,
                                                             int C, int H, int W, const void* __restrict__ w, int wbf16,
                                                             float* __restrict__ y, float* __restrict__ stat,
@@ -69,9 +71,11 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
             }
         const int oy = y0 + py, ox = x0 + px;
         if (oy < H && ox < W) {
-            float* o = y + (((long)img * H + oy) * W + ox) * 64 + wave * 16;
+            const long o = (((long)img * H + oy) * W + ox) * 64 + wave * 16;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *(f32x4*)(o + 4 * q) = (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            for (int j = 0; j < 16; ++j) acc[j] = rndt<ESZ>(acc[j]);        // statistics see the stored value
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st4t<ESZ>(y, o + 4 * q, (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
 #pragma unroll
             for (int j = 0; j < 16; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
         }
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
 // waves summed through LDS at the end, one slab per block: slab[(c*9 + t)][co] (rows >= 9C unused)
 constexpr int WRB = 192;     // dY LDS row pitch (64 bf16 + pad: conflict-free transposed reads)
 
+template <int ESZ>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, long sN, long sC, long sH, long sW,
                                                               int C, int H, int W, const float* __restrict__ dy,
                                                               float* __restrict__ partials, int tiles_x, int tiles_y,
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
             const int p = e >> 4, c4 = e & 15;
             const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < H && ox < W) v = *(const f32x4*)(dy + (((long)img * H + oy) * W + ox) * 64 + 4 * c4);
+            if (oy < H && ox < W) v = ld4t<ESZ>(dy, (((long)img * H + oy) * W + ox) * 64 + 4 * c4);
             bf16x4 h;
             h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
             *(bf16x4*)(dys + p * WRB + c4 * 8) = h;
@@ -171,14 +176,22 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
 }
 
 // dw[co][c][t] (+)= sum_k partials[k][c*9+t][co]
-__global__ void conv_first_wgrad_reduce_kernel(const float* __restrict__ partials, int nslab, int C, float* __restrict__ dw,
-                                               int accumulate) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 64 * C * 9) return;
-    const int co = e / (C * 9), i = e % (C * 9);
+__global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const float* __restrict__ partials, int nslab, int C,
+                                                                     float* __restrict__ dw, int accumulate) {
+    __shared__ double red[8][32];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;         // 32 outputs x 8 slab lanes
+    const int e = blockIdx.x * 32 + el;
     double v = 0.0;
-    for (int k = 0; k < nslab; ++k) v += (double)partials[((long)k * 32 + i) * 64 + co];
-    dw[e] = accumulate ? dw[e] + (float)v : (float)v;
+    if (e < 64 * C * 9) {
+        const int co = e / (C * 9), i = e % (C * 9);
+        for (int k = sl; k < nslab; k += 8) v += (double)partials[((long)k * 32 + i) * 64 + co];
+    }
+    red[sl][el] = v;
+    __syncthreads();
+    if (sl == 0 && e < 64 * C * 9) {
+        for (int k = 1; k < 8; ++k) v += red[k][el];
+        dw[e] = accumulate ? dw[e] + (float)v : (float)v;
+    }
 }
 
 }  // namespace
@@ -188,27 +201,35 @@ bool conv_first_supported(const ustrun_src_t& s, int Cout) {
 }
 int conv_first_stat_rows(int N, int H, int W) { return N * cdiv(H, FTH) * cdiv(W, FTW); }
 
-int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, float* y, float* stat, hipStream_t st) {
+int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, void* y, float* stat, hipStream_t st) {
     const int tx = cdiv(s.W, FTW), ty = cdiv(s.H, FTH);
-    hipLaunchKernelGGL(conv_first_fwd_kernel, dim3(N * ty * tx), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
-                       (long)s.sH, (long)s.sW, s.C, s.H, s.W, w_fwd, dtype == USTRUN_BF16 ? 1 : 0, y, stat, tx, ty);
+    if (dtype == USTRUN_BF16)
+        hipLaunchKernelGGL(conv_first_fwd_kernel<2>, dim3(N * ty * tx), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
+                           (long)s.sH, (long)s.sW, s.C, s.H, s.W, w_fwd, 1, (float*)y, stat, tx, ty);
+    else
+        hipLaunchKernelGGL(conv_first_fwd_kernel<4>, dim3(N * ty * tx), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
+                           (long)s.sH, (long)s.sW, s.C, s.H, s.W, w_fwd, 0, (float*)y, stat, tx, ty);
     USTRUN_LAUNCH_CHECK("conv_first_fwd");
     return 0;
 }
 
 int64_t conv_first_wgrad_partials_bytes() { return (int64_t)1024 * 32 * 64 * sizeof(float); }
 
-int conv_first_wgrad(const ustrun_src_t& s, const float* dy, int N, float* dw, int accumulate, float* partials,
+int conv_first_wgrad(const ustrun_src_t& s, const void* dy, int dy_esz, int N, float* dw, int accumulate, float* partials,
                      int64_t partials_bytes, hipStream_t st) {
     USTRUN_CHECK(partials_bytes >= conv_first_wgrad_partials_bytes(), "conv_first_wgrad: partials too small");
     const int tx = cdiv(s.W, FTW), ty = cdiv(s.H, FTH), ttotal = N * ty * tx;
     int blocks = ttotal < 1024 ? ttotal : 1024;
     const int per = cdiv(ttotal, blocks);
     blocks = cdiv(ttotal, per);
-    hipLaunchKernelGGL(conv_first_wgrad_kernel, dim3(blocks), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
-                       (long)s.sH, (long)s.sW, s.C, s.H, s.W, dy, partials, tx, ty, ttotal, per);
+    if (dy_esz == 2)
+        hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(blocks), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
+                           (long)s.sH, (long)s.sW, s.C, s.H, s.W, (const float*)dy, partials, tx, ty, ttotal, per);
+    else
+        hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(blocks), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
+                           (long)s.sH, (long)s.sW, s.C, s.H, s.W, (const float*)dy, partials, tx, ty, ttotal, per);
     USTRUN_LAUNCH_CHECK("conv_first_wgrad");
-    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(cdiv(64 * s.C * 9, 256)), dim3(256), 0, st, partials, blocks, s.C, dw,
+    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(cdiv(64 * s.C * 9, 32)), dim3(256), 0, st, partials, blocks, s.C, dw,
                        accumulate);
     USTRUN_LAUNCH_CHECK("conv_first_wgrad_reduce");
     return 0;

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     constexpr int WM = TH / (2 * MI), WN = 4 / WM;
     static_assert(WM * WN == 4 && BN == WN * 64, "4 waves, 64 channels per wave");
     constexpr int HP = (TH + 2) * HW2;          // halo pixels
-    constexpr int CPR = BK / 4;                 // 4-channel groups per pixel
+    constexpr int CPR = BK / 8;                 // 8-channel (16-byte) groups per pixel
     constexpr int AIT = (HP * CPR + 255) / 256; // A items per thread per chunk
     constexpr int NP = POOL ? 4 : 1;
     constexpr int ROWB = BK * 2;
@@ -68,27 +68,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     const int K8 = a.Cin / 8;
     const __bf16* Wp = (const __bf16*)a.W;
 
-    // ---- A patch staging, BATCH items per call: global -> registers (raw) ... -> transform -> bf16 -> LDS ----
-    f32x4 av[BATCH][NP];
-    f32x4 asc, ash;
-    int a_relu = 0;
+    // ---- A patch staging, BATCH items per call; an item = 8 channels (16 B of bf16) of one patch pixel:
+    // global -> registers (raw bf16) ... -> [affine + ReLU (+ 2x2 max) in f32] -> bf16 -> LDS.  Sources without an
+    // affine (dY in the input-gradient, the ConvTranspose output in a concat) are copied through untouched.
+    bf16x8 av[BATCH][NP];
+    f32x4 asc0, asc1, ash0, ash1;
+    int a_relu = 0, a_aff = 0;
     unsigned aok = 0;
-    const int c4 = tid % CPR;                       // constant per thread: 256 % CPR == 0
-    const float* abase = nullptr;
+    const int c8 = tid % CPR;                       // constant per thread: 256 % CPR == 0
+    const float* aptr = nullptr;
+    long abase = 0;
     int aLH = 0, aLW = 0, aby = 0, abx = 0;
     long asH = 0, asW = 0;
     auto stage_begin = [&](int c) {                 // per-chunk constants: source, affine, origin
-        const int cg = c * BK + 4 * c4;
+        const int cg = c * BK + 8 * c8;
         const bool second = (a.nsrc == 2 && cg >= a.src[0].C);
         const SrcDev S = pick_src(a.src[0], a.src[1], second);
         const int cl = cg - (second ? a.src[0].C : 0);
-        asc = (f32x4){1.f, 1.f, 1.f, 1.f}; ash = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (S.scale) { asc = *(const f32x4*)(S.scale + cl); ash = *(const f32x4*)(S.shift + cl); }
+        a_aff = S.scale != nullptr;
+        asc0 = asc1 = (f32x4){1.f, 1.f, 1.f, 1.f}; ash0 = ash1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a_aff) {
+            asc0 = *(const f32x4*)(S.scale + cl); asc1 = *(const f32x4*)(S.scale + cl + 4);
+            ash0 = *(const f32x4*)(S.shift + cl); ash1 = *(const f32x4*)(S.shift + cl + 4);
+        }
         a_relu = S.relu;
-        abase = S.ptr + img * S.sN + cl;
+        aptr = S.ptr; abase = img * S.sN + cl;
         aLH = S.LH; aLW = S.LW; asH = S.sH; asW = S.sW;
         aby = y0 - 1 - S.off_y; abx = x0 - 1 - S.off_x;
     };
+    auto ld8 = [&](long idx) { return *(const bf16x8*)((const __bf16*)aptr + idx); };
     auto stage_load = [&](int t) {                  // items t*BATCH .. t*BATCH+BATCH-1
         aok = 0;
 #pragma unroll
@@ -100,39 +108,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                 if (ly >= 0 && ly < aLH && lx >= 0 && lx < aLW) {
                     aok |= 1u << b;
                     if (POOL) {
-                        const float* p = abase + (long)(2 * ly) * asH + (long)(2 * lx) * asW;
-                        av[b][0] = *(const f32x4*)p;
-                        av[b][1 % NP] = *(const f32x4*)(p + asW);
-                        av[b][2 % NP] = *(const f32x4*)(p + asH);
-                        av[b][3 % NP] = *(const f32x4*)(p + asH + asW);
+                        const long p = abase + (long)(2 * ly) * asH + (long)(2 * lx) * asW;
+                        av[b][0] = ld8(p);
+                        av[b][1 % NP] = ld8(p + asW);
+                        av[b][2 % NP] = ld8(p + asH);
+                        av[b][3 % NP] = ld8(p + asH + asW);
                     } else {
-                        av[b][0] = *(const f32x4*)(abase + (long)ly * asH + (long)lx * asW);
+                        av[b][0] = ld8(abase + (long)ly * asH + (long)lx * asW);
                     }
                 }
             }
         }
+    };
+    auto act8 = [&](bf16x8 r, f32x4& lo, f32x4& hi) {     // bf16 raw -> activated f32
+        lo = (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * asc0 + ash0;
+        hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
+        if (a_relu) { lo = relu4(lo); hi = relu4(hi); }
     };
     auto stage_write = [&](int t, char* Adst) {
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
             const int hp = (tid + 256 * (t * BATCH + b)) / CPR;
             if (t * BATCH + b < AIT && hp < HP) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((aok >> b) & 1u) {
-                    v = av[b][0] * asc + ash;
-                    if (a_relu) v = relu4(v);
-                    if (POOL) {
+                bf16x8 h;
 #pragma unroll
-                        for (int q = 1; q < NP; ++q) {
-                            f32x4 u = av[b][q] * asc + ash;
-                            if (a_relu) u = relu4(u);
-                            v = max4(v, u);
+                for (int q = 0; q < 8; ++q) h[q] = (__bf16)0.f;
+                if ((aok >> b) & 1u) {
+                    if (a_aff || POOL) {
+                        f32x4 lo, hi;
+                        act8(av[b][0], lo, hi);
+                        if (POOL) {
+#pragma unroll
+                            for (int q = 1; q < NP; ++q) {
+                                f32x4 l2, h2;
+                                act8(av[b][q], l2, h2);
+                                lo = max4(lo, l2); hi = max4(hi, h2);
+                            }
                         }
+                        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+                        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+                    } else {
+                        h = av[b][0];
                     }
                 }
-                bf16x4 h;
-                h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-                *(bf16x4*)(Adst + hp * ROWB + (((c4 >> 1) ^ swz(hp)) * 16) + (c4 & 1) * 8) = h;
+                *(bf16x8*)(Adst + hp * ROWB + ((c8 ^ swz(hp)) * 16)) = h;
             }
         }
     };
@@ -214,13 +233,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;          // 0..31 inside the 2x16 subtile
                 const int oy = y0 + wm * 2 * MI + 2 * i + (row >> 4), ox = x0 + (row & 15);
                 if (oy < a.Ho && ox < a.Wo) {
-                    const float v = acc[i][j][r] + bias;
+                    const float v = rndt<2>(acc[i][j][r] + bias);   // statistics see the stored value
                     if (col < a.C0) {
-                        a.out0[(((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col] = v;
+                        st1t<2>(a.out0, (((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col, v);
                     } else {
                         const int y1 = oy - a.o1y, x1 = ox - a.o1x;
                         if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
-                            a.out1[(((long)img * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0)] = v;
+                            st1t<2>(a.out1, (((long)img * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0), v);
                     }
                     s1[j] += v; s2[j] += v * v;
                 }
@@ -270,8 +289,9 @@ int halo_stat_rows(int N, int H, int W) { return N * cdiv(H, 8) * cdiv(W, 16); }
 bool halo_supported(const IgemmArgs& a) {
     if (a.nseg != 9 || a.nz != 1 || a.s_in != 1 || a.s_out != 1 || a.segw != 3) return false;
     bool pool = false;
+    if (a.out_esz != 2) return false;
     for (int i = 0; i < a.nsrc; ++i) {
-        if (a.src[i].sC != 1 || (a.src[i].C & 3)) return false;
+        if (a.src[i].sC != 1 || (a.src[i].C & 7) || a.src[i].esz != 2) return false;
         pool |= a.src[i].pool != 0;
     }
     const int BK = 32;

@@ -3,6 +3,7 @@
 // applied on load; LPP lanes share one pixel (16 B of channels each, one coalesced line per pixel)
 // and combine their partial dot products with wavefront shuffles.  Logits are written NCHW.
 #include "common.h"
+#include "loader.h"
 
 namespace ustrun {
 namespace {
@@ -17,6 +18,7 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, const float* scale, const float* 
     return v;
 }
 
+template <int ESZ>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, long npix, int HW, int C, int K,
                                                       int LPP, const float* __restrict__ w, const float* __restrict__ bias,
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
         if (p < npix)
             for (int cq = cq0; cq < C4; cq += LPP) {
-                const f32x4 a = act4(*(const f32x4*)(y + p * C + cq * 4), scale, shift, cq * 4);
+                const f32x4 a = act4(ld4t<ESZ>(y, p * C + cq * 4), scale, shift, cq * 4);
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
                     if (k < K) {
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 
 // da[p][c] = sum_k dl[k][p] w[k][c];  block partials of dW[k][c] = sum_p dl[k][p] a[p][c], db[k] = sum_p dl[k][p]
 // partials[block][K*C + K]
+template <int ESZ>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ y,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       long npix, int HW, int C, int K, int LPP,
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         if (active)
             for (long p = (long)blockIdx.x * PPB + pl; p < npix; p += (long)gridDim.x * PPB) {
                 const long n = p / HW, hw = p - n * HW;
-                const f32x4 a = act4(*(const f32x4*)(y + p * C + c), scale, shift, c);
+                const f32x4 a = act4(ld4t<ESZ>(y, p * C + c), scale, shift, c);
                 f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                         dwp[k] += d * a;
                         dbp[k] += d;
                     }
-                *(f32x4*)(da + p * C + c) = g;
+                st4t<ESZ>(da, p * C + c, g);
             }
         // fixed-order block reduction over the PPB pixel lanes, one class at a time
         for (int k = 0; k < K; ++k) {
@@ -160,8 +163,12 @@ extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* s
     const int LPP = lanes_per_pixel(C / 4);
     long blocks = (npix + (256 / LPP) * 4 - 1) / ((256 / LPP) * 4);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)y, scale, shift,
-                       (long)npix, HW, C, K, LPP, w, bias, logits);
+    if (dtype == USTRUN_BF16)
+        hipLaunchKernelGGL(head_fwd_kernel<2>, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)y, scale, shift,
+                           (long)npix, HW, C, K, LPP, w, bias, logits);
+    else
+        hipLaunchKernelGGL(head_fwd_kernel<4>, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)y, scale, shift,
+                           (long)npix, HW, C, K, LPP, w, bias, logits);
     USTRUN_LAUNCH_CHECK("head_fwd");
     return 0;
 }
@@ -177,8 +184,12 @@ extern "C" int ustrun_head_bwd(const float* dlogits, const void* y, const float*
     const long row = (long)K * C + K;
     USTRUN_CHECK(partials_bytes >= (int64_t)(1024 * row * 4), "head_bwd: partials too small (%lld < %lld)",
                  (long long)partials_bytes, (long long)(1024 * row * 4));
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), (1024 + 256) * sizeof(float), (hipStream_t)s, dlogits,
-                       (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials);
+    if (dtype == USTRUN_BF16)
+        hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(blocks), dim3(256), (1024 + 256) * sizeof(float), (hipStream_t)s, dlogits,
+                           (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials);
+    else
+        hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(blocks), dim3(256), (1024 + 256) * sizeof(float), (hipStream_t)s, dlogits,
+                           (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials);
     USTRUN_LAUNCH_CHECK("head_bwd");
     USTRUN_TRY(reduce_rows(partials, blocks, row, 0, K * C, dw, accumulate, (hipStream_t)s));
     USTRUN_TRY(reduce_rows(partials, blocks, row, (long)K * C, K, db, accumulate, (hipStream_t)s));

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IgemmArgs a, c
     auto swz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
     const int a_c4 = tid % CPR, a_r0 = tid / CPR;
-    const bool vecA = sources_vectorizable(a.src[0], a.src[1], a.nsrc);
+    const bool vecA = sources_vectorizable(a.src[0], a.src[1], a.nsrc, 2);
     const int nchunk = (a.Cin + BK - 1) / BK;
     const int nstage = a.nseg * nchunk;
     const int K8 = (a.Cin + 7) / 8;         // packed K octets per slice
@@ -94,13 +94,13 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IgemmArgs a, c
                 if (ok) {
                     aok |= 1u << i;
                     if (POOL) {
-                        const float* p = S.ptr + ri.n * S.sN + (long)(2 * ly) * S.sH + (long)(2 * lx) * S.sW + cl;
-                        av[i][0] = *(const f32x4*)p;
-                        av[i][1 % NP] = *(const f32x4*)(p + S.sW);
-                        av[i][2 % NP] = *(const f32x4*)(p + S.sH);
-                        av[i][3 % NP] = *(const f32x4*)(p + S.sH + S.sW);
+                        const long p = ri.n * S.sN + (long)(2 * ly) * S.sH + (long)(2 * lx) * S.sW + cl;
+                        av[i][0] = ld4t<2>(S.ptr, p);
+                        av[i][1 % NP] = ld4t<2>(S.ptr, p + S.sW);
+                        av[i][2 % NP] = ld4t<2>(S.ptr, p + S.sH);
+                        av[i][3 % NP] = ld4t<2>(S.ptr, p + S.sH + S.sW);
                     } else {
-                        av[i][0] = *(const f32x4*)(S.ptr + ri.n * S.sN + (long)ly * S.sH + (long)lx * S.sW + cl);
+                        av[i][0] = ld4t<2>(S.ptr, ri.n * S.sN + (long)ly * S.sH + (long)lx * S.sW + cl);
                     }
                 }
             }
@@ -209,14 +209,14 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IgemmArgs a, c
                 const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const RowInfo ri = rowinfo[row];
                 if (ri.n >= 0 && cok) {
-                    const float v = acc[i][j][r] + bias;
+                    const float v = rndt<2>(acc[i][j][r] + bias);   // statistics see the stored value
                     const int oy = (ri.yx >> 16) * a.s_out + oyz, ox = (ri.yx & 0xffff) * a.s_out + oxz;
                     if (col < a.C0) {
-                        a.out0[(((long)ri.n * a.Ho + oy) * a.Wo + ox) * a.C0 + col] = v;
+                        st1t<2>(a.out0, (((long)ri.n * a.Ho + oy) * a.Wo + ox) * a.C0 + col, v);
                     } else {
                         const int y1 = oy - a.o1y, x1 = ox - a.o1x;
                         if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
-                            a.out1[(((long)ri.n * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0)] = v;
+                            st1t<2>(a.out1, (((long)ri.n * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0), v);
                     }
                     s1[j] += v; s2[j] += v * v;
                 }

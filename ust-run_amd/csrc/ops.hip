@@ -86,14 +86,15 @@ extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void
     USTRUN_CHECK(w_fwd && y && N > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_fwd: bad args");
     IgemmArgs a = {};
     a.nsrc = nsrc; a.Cin = 0;
-    for (int i = 0; i < nsrc; ++i) { a.src[i] = make_src(srcs[i]); a.Cin += srcs[i].C; }
+    for (int i = 0; i < nsrc; ++i) { a.src[i] = make_src(srcs[i], dtype); a.Cin += srcs[i].C; }
     a.W = (const float*)w_fwd; a.Cout = Cout;
     a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
     a.s_in = 1; a.nseg = 9; a.segw = 3; a.d0 = -1; a.dstep = 1;
     a.nz = 1; a.s_out = 1;
     a.out0 = (float*)y; a.out1 = nullptr; a.C0 = Cout; a.Ho = H; a.Wo = W;
-    a.bias = nullptr; a.stat = stat;
-    const bool first = nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W;
+    a.bias = nullptr; a.stat = stat; a.out_esz = act_esz(dtype);
+    const bool first = nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W &&
+                       (srcs[0].f32 || dtype == USTRUN_F32);
     if (stat) {
         const int rows = ustrun_conv_mtiles(N, H, W, Cout);
         if ((first ? conv_first_stat_rows(N, H, W) : igemm_stat_rows_used(a, dtype)) < rows) {
@@ -103,7 +104,7 @@ extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void
     }
     if (first) {     // C <= 4 input channels: direct f32 stencil, HBM-bound on its output
         prof_begin(0, 2.0 * a.M * Cout * 9 * a.Cin, 4.0 * ((double)a.M * (a.Cin + Cout) + 9.0 * a.Cin * Cout), (hipStream_t)s);
-        const int rc = conv_first_fwd(srcs[0], w_fwd, dtype, N, (float*)y, stat, (hipStream_t)s);
+        const int rc = conv_first_fwd(srcs[0], w_fwd, dtype, N, y, stat, (hipStream_t)s);
         prof_end((hipStream_t)s);
         return rc;
     }
@@ -119,13 +120,13 @@ extern "C" int ustrun_conv3x3_dgrad(const void* dy, const void* w_dgrad, int N, 
     ustrun_src_t sd = {};
     sd.ptr = dy; sd.C = Cout; sd.H = H; sd.W = W;
     sd.sC = 1; sd.sW = Cout; sd.sH = (int64_t)W * Cout; sd.sN = (int64_t)H * W * Cout;
-    a.nsrc = 1; a.src[0] = make_src(sd); a.Cin = Cout;
+    a.nsrc = 1; a.src[0] = make_src(sd, dtype); a.Cin = Cout;
     a.W = (const float*)w_dgrad; a.Cout = Cin;
     a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
     a.s_in = 1; a.nseg = 9; a.segw = 3; a.d0 = 1; a.dstep = -1;   // da[q] = sum_t dy[q - (t-1)] W[t]^T
     a.nz = 1; a.s_out = 1;
     a.out0 = (float*)da0; a.C0 = C0; a.Ho = H; a.Wo = W;
-    a.out1 = (float*)da1; a.H1 = H1; a.W1 = W1; a.o1y = o1y; a.o1x = o1x;
+    a.out1 = (float*)da1; a.H1 = H1; a.W1 = W1; a.o1y = o1y; a.o1x = o1x; a.out_esz = act_esz(dtype);
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
 
@@ -134,14 +135,14 @@ extern "C" int ustrun_convT2x2_fwd(const ustrun_src_t* src, const void* w_fwd, c
     USTRUN_TRY(check_srcs(src, 1, "convT2x2_fwd"));
     USTRUN_CHECK(w_fwd && u && N > 0 && H > 0 && W > 0 && Cout > 0, "convT2x2_fwd: bad args");
     IgemmArgs a = {};
-    a.nsrc = 1; a.src[0] = make_src(*src); a.Cin = src->C;
+    a.nsrc = 1; a.src[0] = make_src(*src, dtype); a.Cin = src->C;
     USTRUN_CHECK(a.src[0].LH == H && a.src[0].LW == W, "convT2x2_fwd: source extent %dx%d != %dx%d", a.src[0].LH, a.src[0].LW, H, W);
     a.W = (const float*)w_fwd; a.Cout = Cout;
     a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
     a.s_in = 1; a.nseg = 1; a.segw = 1; a.d0 = 0; a.dstep = 0;
     a.nz = 4; a.s_out = 2;                                          // u[2p + (i,j)] = a[p] W[ij] + bias
     a.out0 = (float*)u; a.C0 = Cout; a.Ho = 2 * H; a.Wo = 2 * W;
-    a.bias = bias;
+    a.bias = bias; a.out_esz = act_esz(dtype);
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
 
@@ -152,12 +153,12 @@ extern "C" int ustrun_convT2x2_dgrad(const void* du, const void* w_dgrad, int N,
     ustrun_src_t sd = {};
     sd.ptr = du; sd.C = Cout; sd.H = 2 * H; sd.W = 2 * W;
     sd.sC = 1; sd.sW = Cout; sd.sH = (int64_t)2 * W * Cout; sd.sN = (int64_t)4 * H * W * Cout;
-    a.nsrc = 1; a.src[0] = make_src(sd); a.Cin = Cout;
+    a.nsrc = 1; a.src[0] = make_src(sd, dtype); a.Cin = Cout;
     a.W = (const float*)w_dgrad; a.Cout = Cin;
     a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
     a.s_in = 2; a.nseg = 4; a.segw = 2; a.d0 = 0; a.dstep = 1;     // da[p] = sum_ij du[2p+(i,j)] W[ij]^T
     a.nz = 1; a.s_out = 1;
-    a.out0 = (float*)da; a.C0 = Cin; a.Ho = H; a.Wo = W;
+    a.out0 = (float*)da; a.C0 = Cin; a.Ho = H; a.Wo = W; a.out_esz = act_esz(dtype);
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
 
@@ -181,14 +182,14 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
     USTRUN_CHECK(dy && dw && partials && N > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_wgrad: bad args");
     WgradArgs a = {};
     a.nsrc = nsrc; a.Cin = 0;
-    for (int i = 0; i < nsrc; ++i) { a.src[i] = make_src(srcs[i]); a.Cin += srcs[i].C; }
-    a.dy = (const float*)dy; a.Cout = Cout;
+    for (int i = 0; i < nsrc; ++i) { a.src[i] = make_src(srcs[i], dtype); a.Cin += srcs[i].C; }
+    a.dy = (const float*)dy; a.Cout = Cout; a.dy_esz = act_esz(dtype);
     a.N = N; a.Hb = H; a.Wb = W; a.M = (long)N * H * W;
     a.nseg = 9; a.segw = 3; a.d0 = -1; a.astep = 1; a.dy_s = 1; a.dyH = H; a.dyW = W;
     int slabs;
     a.partials = partials;
-    if (dtype == USTRUN_BF16 && nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W)
-        return conv_first_wgrad(srcs[0], (const float*)dy, N, dw, accumulate, partials, partials_bytes, (hipStream_t)s);
+    if (dtype == USTRUN_BF16 && nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W && srcs[0].f32)
+        return conv_first_wgrad(srcs[0], dy, act_esz(dtype), N, dw, accumulate, partials, partials_bytes, (hipStream_t)s);
     if (dtype == USTRUN_BF16 && wgrad_halo_supported(a)) {
         int per;
         wgrad_halo_plan(a, &slabs, &per);
@@ -208,7 +209,7 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
 namespace ustrun {
 namespace {
 // db[co] = sum over all pixels of du[p][co]: block partials then reduce_rows
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ du, long npix, int C,
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ du, int esz, long npix, int C,
                                                        float* __restrict__ partials) {
     __shared__ float red[256];
     // thread = (channel lane, pixel lane); C <= 256 handled per pass of 256/CL pixel lanes
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
         const int c = cb + cl;
         float s = 0.f;
         if (c < C)
-            for (long p = (long)blockIdx.x * PL + pl; p < npix; p += (long)gridDim.x * PL) s += du[p * C + c];
+            for (long p = (long)blockIdx.x * PL + pl; p < npix; p += (long)gridDim.x * PL)
+                s += esz == 4 ? du[p * C + c] : (float)((const __bf16*)du)[p * C + c];
         red[threadIdx.x] = s;
         __syncthreads();
         if (pl == 0 && c < C) {
@@ -237,8 +239,8 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
     USTRUN_TRY(check_srcs(src, 1, "convT2x2_wgrad"));
     USTRUN_CHECK(du && dw && partials && N > 0 && H > 0 && W > 0 && Cout > 0, "convT2x2_wgrad: bad args");
     WgradArgs a = {};
-    a.nsrc = 1; a.src[0] = make_src(*src); a.Cin = src->C;
-    a.dy = (const float*)du; a.Cout = Cout;
+    a.nsrc = 1; a.src[0] = make_src(*src, dtype); a.Cin = src->C;
+    a.dy = (const float*)du; a.Cout = Cout; a.dy_esz = act_esz(dtype);
     a.N = N; a.Hb = H; a.Wb = W; a.M = (long)N * H * W;
     a.nseg = 4; a.segw = 2; a.d0 = 0; a.astep = 0; a.dy_s = 2; a.dyH = 2 * H; a.dyW = 2 * W;
     int slabs;
@@ -252,7 +254,7 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
         int blocks = cdiv(npix, 512);
         if (blocks > 512) blocks = 512;
         USTRUN_CHECK(partials_bytes >= (int64_t)blocks * Cout * 4, "convT2x2_wgrad: partials too small for bias");
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)du, npix, Cout, partials);
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)du, act_esz(dtype), npix, Cout, partials);
         USTRUN_LAUNCH_CHECK("bias_grad");
         USTRUN_TRY(reduce_rows(partials, blocks, Cout, 0, Cout, db, accumulate, (hipStream_t)s));
     }

@@ -17,7 +17,8 @@ struct Plan {
     int Hs[5], Ws[5];            // extent per level
     int cin[18], cout[18], lvl[18];
     int up_cin[4], up_cout[4];   // convT j: level of its input = 4-j (j = 0..3), output level 3-j
-    // element offsets
+    // BYTE offsets (activations are esz bytes per element, everything else f32)
+    int esz;
     long y_off[18], aff_off[18]; // aff: scale, shift, mean, rstd (4*cout)
     long u_off[4];
     long stat_off, fwd_total;
@@ -52,16 +53,18 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
         p.cin[11 + 2 * j] = ch[l]; p.cout[11 + 2 * j] = ch[l];
         p.lvl[10 + 2 * j] = p.lvl[11 + 2 * j] = l;
     }
+    p.esz = act_esz(d->dtype);
+    const long E = p.esz;
     long o = 0;
     long stat_max = 0;
     for (int i = 0; i < 18; ++i) {
-        p.y_off[i] = o; o = align_up(o + p.y_elems(i), 64);
-        p.aff_off[i] = o; o = align_up(o + 4L * p.cout[i], 64);
+        p.y_off[i] = o; o = align_up(o + p.y_elems(i) * E, 256);
+        p.aff_off[i] = o; o = align_up(o + 16L * p.cout[i], 256);
         const long st = (long)ustrun_conv_mtiles(p.N, p.Hs[p.lvl[i]], p.Ws[p.lvl[i]], p.cout[i]) * 2 * p.cout[i];
         if (st > stat_max) stat_max = st;
     }
-    for (int j = 0; j < 4; ++j) { p.u_off[j] = o; o = align_up(o + p.u_elems(j), 64); }
-    p.stat_off = o; o = align_up(o + stat_max, 64);
+    for (int j = 0; j < 4; ++j) { p.u_off[j] = o; o = align_up(o + p.u_elems(j) * E, 256); }
+    p.stat_off = o; o = align_up(o + stat_max * 4, 256);
     p.fwd_total = o;
 
     o = 0;
@@ -80,7 +83,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     o = 0;
     long part = ustrun_loss_partials_bytes(1, 1, 1);
     for (int i = 0; i < 18; ++i) {
-        p.da_off[i] = o; o = align_up(o + p.y_elems(i), 64);
+        p.da_off[i] = o; o = align_up(o + p.y_elems(i) * E, 256);
         const long npix = (long)p.N * p.Hs[p.lvl[i]] * p.Ws[p.lvl[i]];
         long b1 = ustrun_bn_bwd_partials_bytes(npix, p.cout[i]);
         long b2 = ustrun_wgrad_partials_bytes(9, p.cin[i], p.cout[i], npix);
@@ -88,9 +91,9 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
         if (b2 > part) part = b2;
     }
     for (int j = 0; j < 4; ++j) {
-        p.du_off[j] = o; o = align_up(o + p.u_elems(j), 64);
+        p.du_off[j] = o; o = align_up(o + p.u_elems(j) * E, 256);
         const int l = 3 - j;                                     // pooled grad of the skip at level l
-        p.dp_off[j] = o; o = align_up(o + (long)p.N * p.Hs[l + 1] * p.Ws[l + 1] * ch[l], 64);
+        p.dp_off[j] = o; o = align_up(o + (long)p.N * p.Hs[l + 1] * p.Ws[l + 1] * ch[l] * E, 256);
         const long npix = (long)p.N * p.Hs[l + 1] * p.Ws[l + 1];
         long b2 = ustrun_wgrad_partials_bytes(4, p.up_cin[j], p.up_cout[j], npix);
         if (b2 > part) part = b2;
@@ -99,14 +102,14 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     }
     long bh = 1024L * ((long)p.K * b + p.K) * 4;
     if (bh > part) part = bh;
-    p.coef_off = o; o = align_up(o + 3L * 16 * b, 64);
+    p.coef_off = o; o = align_up(o + 12L * 16 * b, 256);
     p.part_off = o; p.part_bytes = align_up(part, 256);
-    o += p.part_bytes / 4;
+    o += p.part_bytes;
     p.bwd_total = o;
     return 0;
 }
 
-ustrun_src_t nhwc_src(const float* ptr, const float* aff, int C, int H, int W, int relu, int pool) {
+ustrun_src_t nhwc_src(const void* ptr, const float* aff, int C, int H, int W, int relu, int pool) {
     ustrun_src_t s = {};
     s.ptr = ptr; s.scale = aff; s.shift = aff ? aff + C : nullptr;
     s.C = C; s.H = H; s.W = W;
@@ -116,14 +119,15 @@ ustrun_src_t nhwc_src(const float* ptr, const float* aff, int C, int H, int W, i
 }
 
 // sources of conv i (forward input), from the saved workspace
-int conv_sources(const Plan& p, const float* x, const float* ws, int i, ustrun_src_t* srcs) {
+int conv_sources(const Plan& p, const float* x, const char* ws, int i, ustrun_src_t* srcs) {
     auto act = [&](int k, int pool) {
-        return nhwc_src(ws + p.y_off[k], ws + p.aff_off[k], p.cout[k], p.Hs[p.lvl[k]], p.Ws[p.lvl[k]], 1, pool);
+        return nhwc_src(ws + p.y_off[k], (const float*)(ws + p.aff_off[k]), p.cout[k], p.Hs[p.lvl[k]], p.Ws[p.lvl[k]], 1, pool);
     };
     if (i == 0) {   // network input, NCHW
         ustrun_src_t s = {};
         s.ptr = x; s.C = p.C; s.H = p.H; s.W = p.W;
         s.sW = 1; s.sH = p.W; s.sC = (int64_t)p.H * p.W; s.sN = (int64_t)p.C * p.H * p.W;
+        s.f32 = 1;                                  // the network input is f32 whatever the storage dtype
         srcs[0] = s;
         return 1;
     }
@@ -162,11 +166,11 @@ extern "C" int64_t ustrun_unet_packed_bytes(const ustrun_unet_desc_t* d) {
 }
 extern "C" int64_t ustrun_unet_fwd_workspace_bytes(const ustrun_unet_desc_t* d) {
     Plan p; if (make_plan(d, p)) return -1;
-    return p.fwd_total * 4;
+    return p.fwd_total;
 }
 extern "C" int64_t ustrun_unet_bwd_scratch_bytes(const ustrun_unet_desc_t* d) {
     Plan p; if (make_plan(d, p)) return -1;
-    return p.bwd_total * 4;
+    return p.bwd_total;
 }
 
 extern "C" int ustrun_unet_pack(const ustrun_unet_desc_t* d, ustrun_stream_t s) {
@@ -188,14 +192,15 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
                                    void* workspace, ustrun_stream_t s) {
     Plan p; USTRUN_TRY(make_plan(d, p));
     USTRUN_CHECK(x && logits && workspace && d->packed, "unet_forward: null pointer");
-    float* ws = (float*)workspace;
+    char* ws = (char*)workspace;
     const float* pk = (const float*)d->packed;
-    float* stat = ws + p.stat_off;
+    float* stat = (float*)(ws + p.stat_off);
+    auto affp = [&](int k) { return (float*)(ws + p.aff_off[k]); };
     for (int i = 0; i < 18; ++i) {
         if (i >= 10 && i % 2 == 0) {   // Up: ConvTranspose of the previous level's output first
             const int j = (i - 10) / 2, l = 3 - j;
             const int prev = (j == 0) ? 9 : i - 1;
-            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], ws + p.aff_off[prev], p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0);
+            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0);
             USTRUN_TRY(ustrun_convT2x2_fwd(&a, pk + p.uf_off[j], d->up_b[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
                                            ws + p.u_off[j], d->dtype, s));
         }
@@ -204,7 +209,7 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
         const int H = p.Hs[p.lvl[i]], W = p.Ws[p.lvl[i]];
         USTRUN_TRY(ustrun_conv3x3_fwd(srcs, ns, pk + p.wf_off[i], p.N, H, W, p.cout[i], ws + p.y_off[i],
                                       d->train ? stat : nullptr, d->dtype, s));
-        float* aff = ws + p.aff_off[i];
+        float* aff = affp(i);
         const int C = p.cout[i];
         if (d->train) {
             USTRUN_TRY(ustrun_bn_finalize(stat, ustrun_conv_mtiles(p.N, H, W, C), C, (int64_t)p.N * H * W, d->bn_w[i],
@@ -216,10 +221,10 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
     }
     const int C = p.cout[17];
     const long npix = (long)p.N * p.H * p.W;
-    USTRUN_TRY(ustrun_head_fwd(ws + p.y_off[17], ws + p.aff_off[17], ws + p.aff_off[17] + C, npix, p.H * p.W, C, p.K,
+    USTRUN_TRY(ustrun_head_fwd(ws + p.y_off[17], affp(17), affp(17) + C, npix, p.H * p.W, C, p.K,
                                d->head_w, d->head_b, logits, d->dtype, s));
     if (feat)
-        USTRUN_TRY(ustrun_bn_relu_apply(ws + p.y_off[17], ws + p.aff_off[17], ws + p.aff_off[17] + C, npix, C, p.H * p.W,
+        USTRUN_TRY(ustrun_bn_relu_apply(ws + p.y_off[17], affp(17), affp(17) + C, npix, C, p.H * p.W,
                                         feat, 1, d->dtype, s));
     return 0;
 }
@@ -229,28 +234,29 @@ extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x,
     Plan p; USTRUN_TRY(make_plan(d, p));
     USTRUN_CHECK(x && dlogits && workspace && scratch && grads && d->packed, "unet_backward: null pointer");
     USTRUN_CHECK(d->train, "unet_backward: forward must have run in train mode");
-    const float* ws = (const float*)workspace;
-    float* sc = (float*)scratch;
+    const char* ws = (const char*)workspace;
+    char* sc = (char*)scratch;
     const float* pk = (const float*)d->packed;
-    float* coef = sc + p.coef_off;
-    float* part = sc + p.part_off;
+    float* coef = (float*)(sc + p.coef_off);
+    float* part = (float*)(sc + p.part_off);
+    auto affp = [&](int k) { return (const float*)(ws + p.aff_off[k]); };
     const int dt = d->dtype;
 
     {   // head
         const int C = p.cout[17];
-        USTRUN_TRY(ustrun_head_bwd(dlogits, ws + p.y_off[17], ws + p.aff_off[17], ws + p.aff_off[17] + C,
+        USTRUN_TRY(ustrun_head_bwd(dlogits, ws + p.y_off[17], affp(17), affp(17) + C,
                                    (long)p.N * p.H * p.W, p.H * p.W, C, p.K, d->head_w, sc + p.da_off[17], grads[62],
                                    grads[63], accumulate, part, p.part_bytes, dt, s));
     }
     for (int i = 17; i >= 0; --i) {
         if (i == ustrun_debug_stop_layer) return 0;
         const int l = p.lvl[i], H = p.Hs[l], W = p.Ws[l], C = p.cout[i];
-        const float* aff = ws + p.aff_off[i];
+        const float* aff = affp(i);
         const int gi = grad_index_conv(i);
         // the encoder outputs x1..x4 (convs 1,3,5,7) also feed a MaxPool: add the routed pooled grad
         const bool pooled = (i < 8) && (i % 2 == 1);
-        const float* dp = pooled ? sc + p.dp_off[3 - l] : nullptr;
-        float* da = sc + p.da_off[i];
+        const void* dp = pooled ? sc + p.dp_off[3 - l] : nullptr;
+        void* da = sc + p.da_off[i];
         USTRUN_TRY(ustrun_bn_bwd_reduce(da, dp, ws + p.y_off[i], aff, aff + C, aff + 2 * C, aff + 3 * C, d->bn_w[i], p.N, H,
                                         W, C, grads[gi + 1], grads[gi + 2], accumulate, coef, part, p.part_bytes, dt, s));
         USTRUN_TRY(ustrun_bn_bwd_apply(da, dp, ws + p.y_off[i], aff, aff + C, coef, p.N, H, W, C, da, dt, s));
@@ -268,7 +274,7 @@ extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x,
             USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, p.cin[i], sc + p.da_off[skip], p.cout[skip],
                                             sc + p.du_off[j], uh, uw, (H - uh) / 2, (W - uw) / 2, dt, s));
             const int prev = (j == 0) ? 9 : i - 1;
-            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], ws + p.aff_off[prev], p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0);
+            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0);
             const int ub = 30 + j * 8;
             USTRUN_TRY(ustrun_convT2x2_wgrad(&a, sc + p.du_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], grads[ub],
                                              grads[ub + 1], accumulate, part, p.part_bytes, dt, s));

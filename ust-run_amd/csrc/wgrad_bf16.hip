@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, c
     const long kend = (kbeg + a.kchunk < a.M) ? kbeg + a.kchunk : a.M;
     const int hw = a.Hb * a.Wb;
 
-    const bool vecA = sources_vectorizable(a.src[0], a.src[1], a.nsrc);
+    const bool vecA = sources_vectorizable(a.src[0], a.src[1], a.nsrc, 2);
     const bool vecB = (a.Cout & 3) == 0;
     const int a_q = tid % AQ, a_r0 = tid / AQ;
     const int b_q = tid % BQ, b_r0 = tid / BQ;
@@ -90,13 +90,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, c
                     if (cg < a.Cin && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW) {
                         aok |= 1u << i;
                         if (POOL) {
-                            const float* p = S.ptr + n * S.sN + (long)(2 * ly) * S.sH + (long)(2 * lx) * S.sW + cl;
-                            av[i][0] = *(const f32x4*)p;
-                            av[i][1 % NP] = *(const f32x4*)(p + S.sW);
-                            av[i][2 % NP] = *(const f32x4*)(p + S.sH);
-                            av[i][3 % NP] = *(const f32x4*)(p + S.sH + S.sW);
+                            const long p = n * S.sN + (long)(2 * ly) * S.sH + (long)(2 * lx) * S.sW + cl;
+                            av[i][0] = ld4t<2>(S.ptr, p);
+                            av[i][1 % NP] = ld4t<2>(S.ptr, p + S.sW);
+                            av[i][2 % NP] = ld4t<2>(S.ptr, p + S.sH);
+                            av[i][3 % NP] = ld4t<2>(S.ptr, p + S.sH + S.sW);
                         } else {
-                            av[i][0] = *(const f32x4*)(S.ptr + n * S.sN + (long)ly * S.sH + (long)lx * S.sW + cl);
+                            av[i][0] = ld4t<2>(S.ptr, n * S.sN + (long)ly * S.sH + (long)lx * S.sW + cl);
                         }
                     }
                 } else {
@@ -116,11 +116,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, c
                 const int rem = (int)(m - (long)n * hw);
                 const int by = rem / a.Wb, bx = rem - by * a.Wb;
                 const int oy = by * a.dy_s + boy, ox = bx * a.dy_s + box;
-                const float* p = a.dy + (((long)n * a.dyH + oy) * a.dyW + ox) * a.Cout + co;
-                if (vecB) v = *(const f32x4*)p;
+                const long p = (((long)n * a.dyH + oy) * a.dyW + ox) * a.Cout + co;
+                if (vecB) v = ld4t<2>(a.dy, p);
                 else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (co + j < a.Cout) v[j] = p[j];
+                    for (int j = 0; j < 4; ++j) if (co + j < a.Cout) v[j] = ld1(a.dy, p + j, a.dy_esz);
                 }
             }
             bv[i] = v;

@@ -37,8 +37,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lane_base, int k0) {
 template <bool POOL>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs a, const int ntn, const int tiles_x,
                                                                  const int tiles_y, const int tiles_per) {
-    constexpr int AIT = (HP * 16 + 255) / 256;     // 7 float4 per thread for the A patch
-    constexpr int BIT = (TH * TW * 16) / 256;      // 4 float4 per thread for the dY tile
+    constexpr int AIT = (HP * 8 + 255) / 256;      // 16-byte (8-channel) items per thread for the A patch: 4
+    constexpr int BIT = (TH * TW * 8) / 256;       // ... and for the dY tile: 2
     __shared__ __attribute__((aligned(16))) char As[HP * RB];
     __shared__ __attribute__((aligned(16))) char Bs[TH * TW * RB];
 
@@ -50,23 +50,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
     const int tbeg = blockIdx.y * tiles_per;
     const int tend = min(ttotal, tbeg + tiles_per);
 
-    const int c4 = tid & 15;                        // 4-channel group of this thread (same for A and dY)
-    const int cg = ci0 + 4 * c4;
+    const int c8 = tid & 7;                         // 8-channel group of this thread (same for A and dY)
+    const int cg = ci0 + 8 * c8;
     const bool second = (a.nsrc == 2 && cg >= a.src[0].C);
     const SrcDev S = pick_src(a.src[0], a.src[1], second);
     const int cl = cg - (second ? a.src[0].C : 0);
-    f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
-    if (S.scale) { asc = *(const f32x4*)(S.scale + cl); ash = *(const f32x4*)(S.shift + cl); }
+    const bool aff = S.scale != nullptr;
+    f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
+    if (aff) {
+        asc0 = *(const f32x4*)(S.scale + cl); asc1 = *(const f32x4*)(S.scale + cl + 4);
+        ash0 = *(const f32x4*)(S.shift + cl); ash1 = *(const f32x4*)(S.shift + cl + 4);
+    }
+    const __bf16* sp = (const __bf16*)S.ptr;
+    const __bf16* dyp = (const __bf16*)a.dy;
 
-    f32x4 av[AIT], bv[BIT];
+    bf16x8 av[AIT], bv[BIT];
     unsigned aok;
     // patch coordinates of this thread's A items are tile-invariant: (hy << 8) | hx, hp >= HP -> 0xffff
     int hyx[AIT];
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
-        const int hp = (tid + 256 * i) >> 4;
+        const int hp = (tid + 256 * i) >> 3;
         hyx[i] = hp < HP ? (((hp / HW2) << 8) | (hp % HW2)) : 0xffff;
     }
+    auto act8 = [&](bf16x8 r, f32x4& lo, f32x4& hi) {
+        lo = (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * asc0 + ash0;
+        hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
+        if (S.relu) { lo = relu4(lo); hi = relu4(hi); }
+    };
+    auto pack8 = [](f32x4 lo, f32x4 hi) {
+        bf16x8 h;
+        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+        return h;
+    };
+    auto zero8 = []() { bf16x8 h; for (int q = 0; q < 8; ++q) h[q] = (__bf16)0.f; return h; };
 
     auto load_tile = [&](int t) {
         const int img = t / (tiles_y * tiles_x);
@@ -74,58 +92,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
         const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
         aok = 0;
         const int by = y0 - 1 - S.off_y, bx = x0 - 1 - S.off_x;
-        const float* base = S.ptr + img * S.sN + cl;
+        const long base = img * S.sN + cl;
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            av[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            av[i] = zero8();
             const int ly = by + (hyx[i] >> 8), lx = bx + (hyx[i] & 0xff);
             if (hyx[i] != 0xffff && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW) {
                 aok |= 1u << i;
                 if (POOL) {          // 2x2 max of the activated source, evaluated right here (no raw prefetch)
-                    const float* p = base + (long)(2 * ly) * S.sH + (long)(2 * lx) * S.sW;
-                    f32x4 v = relu4(*(const f32x4*)p * asc + ash);
-                    v = max4(v, relu4(*(const f32x4*)(p + S.sW) * asc + ash));
-                    v = max4(v, relu4(*(const f32x4*)(p + S.sH) * asc + ash));
-                    av[i] = max4(v, relu4(*(const f32x4*)(p + S.sH + S.sW) * asc + ash));
+                    const long p = base + (long)(2 * ly) * S.sH + (long)(2 * lx) * S.sW;
+                    f32x4 lo, hi, l2, h2;
+                    act8(*(const bf16x8*)(sp + p), lo, hi);
+                    act8(*(const bf16x8*)(sp + p + S.sW), l2, h2); lo = max4(lo, l2); hi = max4(hi, h2);
+                    act8(*(const bf16x8*)(sp + p + S.sH), l2, h2); lo = max4(lo, l2); hi = max4(hi, h2);
+                    act8(*(const bf16x8*)(sp + p + S.sH + S.sW), l2, h2); lo = max4(lo, l2); hi = max4(hi, h2);
+                    av[i] = pack8(lo, hi);
                 } else {
-                    av[i] = *(const f32x4*)(base + (long)ly * S.sH + (long)lx * S.sW);
+                    av[i] = *(const bf16x8*)(sp + base + (long)ly * S.sH + (long)lx * S.sW);
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
-            const int p = (tid + 256 * i) >> 4;              // 0..63 inside the tile
+            const int p = (tid + 256 * i) >> 3;              // 0..63 inside the tile
             const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
-            bv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            bv[i] = zero8();
             if (oy < a.dyH && ox < a.dyW)
-                bv[i] = *(const f32x4*)(a.dy + (((long)img * a.dyH + oy) * a.dyW + ox) * a.Cout + co0 + 4 * c4);
+                bv[i] = *(const bf16x8*)(dyp + (((long)img * a.dyH + oy) * a.dyW + ox) * a.Cout + co0 + 8 * c8);
         }
-    };
-    auto to_bf16 = [](f32x4 v) {
-        bf16x4 h;
-        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-        return h;
     };
     auto write_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            const int hp = (tid + 256 * i) >> 4;
+            const int hp = (tid + 256 * i) >> 3;
             if (hp < HP) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((aok >> i) & 1u) {
-                    if (POOL) v = av[i];
-                    else {
-                        v = av[i] * asc + ash;
-                        if (S.relu) v = relu4(v);
-                    }
+                bf16x8 h = av[i];
+                if (!POOL && aff && ((aok >> i) & 1u)) {     // (out-of-image items stay zero: padding is applied after the activation)
+                    f32x4 lo, hi;
+                    act8(av[i], lo, hi);
+                    h = pack8(lo, hi);
                 }
-                *(bf16x4*)(As + hp * RB + c4 * 8) = to_bf16(v);
+                *(bf16x8*)(As + hp * RB + c8 * 16) = h;
             }
         }
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
-            const int p = (tid + 256 * i) >> 4;
-            *(bf16x4*)(Bs + p * RB + c4 * 8) = to_bf16(bv[i]);
+            const int p = (tid + 256 * i) >> 3;
+            *(bf16x8*)(Bs + p * RB + c8 * 16) = bv[i];
         }
     };
 
@@ -174,9 +187,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
 }  // namespace
 
 bool wgrad_halo_supported(const WgradArgs& a) {
-    if (a.nseg != 9 || a.segw != 3 || a.dy_s != 1 || a.astep != 1 || a.d0 != -1) return false;
+    if (a.nseg != 9 || a.segw != 3 || a.dy_s != 1 || a.astep != 1 || a.d0 != -1 || a.dy_esz != 2) return false;
     for (int i = 0; i < a.nsrc; ++i)
-        if (a.src[i].sC != 1 || (a.src[i].C % 64) || (a.src[i].pool && (a.nsrc != 1 || !a.src[i].relu))) return false;
+        if (a.src[i].sC != 1 || a.src[i].esz != 2 || (a.src[i].C % 64) || (a.src[i].relu && !a.src[i].scale && !a.src[i].pool) || (a.src[i].pool && (a.nsrc != 1 || !a.src[i].relu))) return false;
     if (a.Cin % 64 || a.Cout % 64) return false;
     if (a.Hb < 4 || a.Wb < 8) return false;
     return true;

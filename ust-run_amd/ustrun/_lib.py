@@ -18,7 +18,7 @@ class Src(C.Structure):
     """ustrun_src_t"""
     _fields_ = [("ptr", vp), ("scale", vp), ("shift", vp), ("C", i32), ("H", i32), ("W", i32),
                 ("sN", i64), ("sH", i64), ("sW", i64), ("sC", i64),
-                ("relu", i32), ("pool", i32), ("off_y", i32), ("off_x", i32)]
+                ("relu", i32), ("pool", i32), ("off_y", i32), ("off_x", i32), ("f32", i32)]
 
 
 class UNetDesc(C.Structure):
@@ -103,9 +103,10 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def nhwc_src(t_ptr, C_, H, W, scale=None, shift=None, relu=0, pool=0, off=(0, 0)):
-    return Src(t_ptr, scale, shift, C_, H, W, H * W * C_, W * C_, C_, 1, relu, pool, off[0], off[1])
+def nhwc_src(t_ptr, C_, H, W, scale=None, shift=None, relu=0, pool=0, off=(0, 0), f32=0):
+    return Src(t_ptr, scale, shift, C_, H, W, H * W * C_, W * C_, C_, 1, relu, pool, off[0], off[1], f32)
 
 
 def nchw_src(t_ptr, C_, H, W):
-    return Src(t_ptr, None, None, C_, H, W, C_ * H * W, W, 1, H * W, 0, 0, 0, 0)
+    """The network input: NCHW, always f32."""
+    return Src(t_ptr, None, None, C_, H, W, C_ * H * W, W, 1, H * W, 0, 0, 0, 0, 1)
