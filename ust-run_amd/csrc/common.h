@@ -88,6 +88,7 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st);
 int igemm_launch_bf16(const IgemmArgs& a, hipStream_t st);
 bool halo_supported(const IgemmArgs& a);
 bool halo_tall_tile(const IgemmArgs& a);
+int halo_stat_rows_used(const IgemmArgs& a);
 int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st);
 int halo_stat_rows(int N, int H, int W);
 int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, void* wf, void* wd, hipStream_t st);

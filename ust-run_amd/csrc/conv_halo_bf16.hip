@@ -21,13 +21,16 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-constexpr int TW = 16, HW2 = TW + 2;
 
-// MI = 32-pixel (2 rows x 16) MFMA sub-tiles per wave along M: the wave tile is (2*MI rows x 16 px) x 64 channels
-template <int TH, int BN, int BK, int MI, bool POOL>
+// MI = 32-pixel MFMA sub-tiles per wave along M.  TW = 16: a sub-tile is 2 rows x 16 px (wave tile 2*MI rows x 16 px);
+// TW = 32: a sub-tile is one row of 32 consecutive pixels (wave tile MI rows x 32 px) -- 32 consecutive patch rows
+// per ds_read_b128 make the swizzled A reads conflict-free (with 16-wide tiles 2 of 16 lanes collide).
+template <int TH, int TW, int BN, int BK, int MI, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
-    constexpr int WM = TH / (2 * MI), WN = 4 / WM;
+    constexpr int HW2 = TW + 2;
+    constexpr int SR = 32 / TW;                 // tile rows per 32-pixel sub-tile (2 or 1)
+    constexpr int WM = TH / (SR * MI), WN = 4 / WM;
     static_assert(WM * WN == 4 && BN == WN * 64, "4 waves, 64 channels per wave");
     constexpr int HP = (TH + 2) * HW2;          // halo pixels
     constexpr int CPR = BK / 8;                 // 8-channel (16-byte) groups per pixel
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
 
     // halo pixel (before the tap shift) of this lane's A rows: subtile i covers tile rows
     // wm*2*MI + 2i + (l31>>4), column l31&15
-    const int hpb0 = (wm * 2 * MI + (l31 >> 4) + 1) * HW2 + (l31 & 15) + 1;
+    const int hpb0 = (wm * SR * MI + (TW == 16 ? (l31 >> 4) : 0) + 1) * HW2 + (l31 & (TW - 1)) + 1;
     const int nstage = nchunk * 9;
 
     dma_B(0, 0);
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                 const bf16x8 b1 = *(const bf16x8*)(Bp + (2 * ks * BN + 32) * 16);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    const int hp = hp0 + 2 * i * HW2;
+                    const int hp = hp0 + SR * i * HW2;
                     const bf16x8 af = *(const bf16x8*)(Acur + hp * ROWB + ((ch ^ swz(hp)) * 16));
                     acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[i][0], 0, 0, 0);
                     acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[i][1], 0, 0, 0);
@@ -230,8 +233,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;          // 0..31 inside the 2x16 subtile
-                const int oy = y0 + wm * 2 * MI + 2 * i + (row >> 4), ox = x0 + (row & 15);
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;          // 0..31 inside the sub-tile
+                const int oy = y0 + wm * SR * MI + SR * i + (TW == 16 ? (row >> 4) : 0), ox = x0 + (row & (TW - 1));
                 if (oy < a.Ho && ox < a.Wo) {
                     const float v = rndt<2>(acc[i][j][r] + bias);   // statistics see the stored value
                     if (col < a.C0) {
@@ -270,12 +273,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     }
 }
 
-template <int TH, int BN, int BK, int MI, bool POOL>
+template <int TH, int TW, int BN, int BK, int MI, bool POOL>
 int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
-    const size_t lds = 2 * (size_t)(((TH + 2) * HW2 * BK * 2 + 15) & ~15) + 2 * (size_t)(BK / 8) * BN * 16;
+    const size_t lds = 2 * (size_t)(((TH + 2) * (TW + 2) * BK * 2 + 15) & ~15) + 2 * (size_t)(BK / 8) * BN * 16;
     dim3 grid(a.N * ty * tx * nt), block(256);
-    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, BN, BK, MI, POOL>), grid, block, lds, st, a, tx, ty, nt);
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;
 }
@@ -307,16 +310,31 @@ bool halo_tall_tile(const IgemmArgs& a) {
     return (long)a.N * cdiv(a.Hb, 16) * cdiv(a.Wb, 16) * (a.Cout / 128) >= 512;
 }
 
+// BatchNorm-statistics rows written by the configuration conv3x3_halo_launch_bf16 picks
+int halo_stat_rows_used(const IgemmArgs& a) {
+    bool pool = false;
+    for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
+    const bool wide = a.Wb >= 32;
+    if (pool) return a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
+    if (a.Cout % 128 == 0) {
+        if (halo_tall_tile(a)) return wide ? a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 32) : a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16);
+        return a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
+    }
+    return wide ? a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 32) : a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16);
+}
+
 int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     bool pool = false;
     for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
-    if (pool) return launch_cfg<8, 128, 32, 2, true>(a, st);
+    const bool wide = a.Wb >= 32;                 // 32-pixel rows: conflict-free A fragment reads
+    if (pool) return launch_cfg<8, 16, 128, 32, 2, true>(a, st);
     if (a.Cout % 128 == 0) {
-        if (halo_tall_tile(a)) return launch_cfg<16, 128, 32, 4, false>(a, st);   // wave tile 128 px x 64 ch
-        if (a.Cin % 64 == 0) return launch_cfg<8, 128, 64, 2, false>(a, st);
-        return launch_cfg<8, 128, 32, 2, false>(a, st);
+        if (halo_tall_tile(a))                    // 256 px x 128 ch per block, wave tile 128 px x 64 ch
+            return wide ? launch_cfg<8, 32, 128, 32, 4, false>(a, st) : launch_cfg<16, 16, 128, 32, 4, false>(a, st);
+        if (a.Cin % 64 == 0) return launch_cfg<8, 16, 128, 64, 2, false>(a, st);
+        return launch_cfg<8, 16, 128, 32, 2, false>(a, st);
     }
-    return launch_cfg<16, 64, 32, 2, false>(a, st);
+    return wide ? launch_cfg<8, 32, 64, 32, 2, false>(a, st) : launch_cfg<16, 16, 64, 32, 2, false>(a, st);
 }
 
 }  // namespace ustrun

@@ -280,12 +280,7 @@ int igemm_mtiles(int64_t M, int Cout) { (void)Cout; return cdiv(M, 128); }
 
 // stat rows actually written by the kernel igemm_launch will pick
 int igemm_stat_rows_used(const IgemmArgs& a, int dtype) {
-    if (dtype == USTRUN_BF16 && halo_supported(a)) {
-        bool pool = false;
-        for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
-        const bool th16 = !pool && (a.Cout % 128 != 0 || halo_tall_tile(a));
-        return th16 ? a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16) : a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
-    }
+    if (dtype == USTRUN_BF16 && halo_supported(a)) return halo_stat_rows_used(a);
     return cdiv(a.M, 128);
 }
 

@@ -1,6 +1,7 @@
 // ops.hip -- C-ABI wrappers that phrase each U-Net operator as one launch of the generic
 // implicit-GEMM / weight-gradient kernels, plus the weight packing kernels.
 #include "common.h"
+#include "loader.h"
 
 namespace ustrun {
 namespace {
@@ -208,24 +209,26 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
 
 namespace ustrun {
 namespace {
-// db[co] = sum over all pixels of du[p][co]: block partials then reduce_rows
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ du, int esz, long npix, int C,
+// db[co] = sum over all pixels of du[p][co]: block partials then reduce_rows.  thread = (4-channel group,
+// pixel lane); fixed-order LDS combine.  C % 4 == 0.
+template <int ESZ>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ du, long npix, int C,
                                                        float* __restrict__ partials) {
-    __shared__ float red[256];
-    // thread = (channel lane, pixel lane); C <= 256 handled per pass of 256/CL pixel lanes
-    int CL = 1; while (CL < C && CL < 256) CL <<= 1;
-    const int PL = 256 / CL, cl = threadIdx.x % CL, pl = threadIdx.x / CL;
-    for (int cb = 0; cb < C; cb += CL) {
-        const int c = cb + cl;
-        float s = 0.f;
-        if (c < C)
-            for (long p = (long)blockIdx.x * PL + pl; p < npix; p += (long)gridDim.x * PL)
-                s += esz == 4 ? du[p * C + c] : (float)((const __bf16*)du)[p * C + c];
+    __shared__ f32x4 red[256];
+    const int C4 = C / 4;
+    int G = 1; while (G < C4 && G < 256) G <<= 1;
+    const int PL = 256 / G, g = threadIdx.x % G, pl = threadIdx.x / G;
+    for (int cb = 0; cb < C4; cb += G) {
+        const int cq = cb + g;
+        const bool active = cq < C4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (active)
+            for (long p = (long)blockIdx.x * PL + pl; p < npix; p += (long)gridDim.x * PL) s += ld4t<ESZ>(du, p * C + cq * 4);
         red[threadIdx.x] = s;
         __syncthreads();
-        if (pl == 0 && c < C) {
-            for (int k = 1; k < PL; ++k) s += red[k * CL + cl];
-            partials[(long)blockIdx.x * C + c] = s;
+        if (pl == 0 && active) {
+            for (int k = 1; k < PL; ++k) s += red[k * G + g];
+            *(f32x4*)(partials + (long)blockIdx.x * C + cq * 4) = s;
         }
         __syncthreads();
     }
@@ -254,7 +257,11 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
         int blocks = cdiv(npix, 512);
         if (blocks > 512) blocks = 512;
         USTRUN_CHECK(partials_bytes >= (int64_t)blocks * Cout * 4, "convT2x2_wgrad: partials too small for bias");
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)du, act_esz(dtype), npix, Cout, partials);
+        USTRUN_CHECK(Cout % 4 == 0, "convT2x2_wgrad: Cout %d must be a multiple of 4", Cout);
+        if (dtype == USTRUN_BF16)
+            hipLaunchKernelGGL(bias_grad_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)du, npix, Cout, partials);
+        else
+            hipLaunchKernelGGL(bias_grad_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)du, npix, Cout, partials);
         USTRUN_LAUNCH_CHECK("bias_grad");
         USTRUN_TRY(reduce_rows(partials, blocks, Cout, 0, Cout, db, accumulate, (hipStream_t)s));
     }
