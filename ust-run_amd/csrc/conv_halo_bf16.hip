@@ -222,35 +222,58 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         }
     }
 
-    // ---- epilogue: f32 outputs (NHWC), optional two-destination split, BN-statistics partials ----
+    // ---- epilogue: bf16 outputs (NHWC), optional two-destination split, BN-statistics partials.
+    // The accumulator layout has lanes along channels and registers along pixels, so a direct store would be
+    // 2 bytes per lane (64 store instructions per 32x64 sub-tile).  Each wave instead transposes one 32-pixel
+    // sub-tile at a time through its own LDS scratch (rows padded to 144 B: the two half-waves hit disjoint
+    // banks) and writes 16 bytes per lane, 128 contiguous bytes per pixel.
     const int C1 = a.Cout - a.C0;
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    constexpr int EPITCH = 144;
+    char* ep = smem + wave * (32 * EPITCH);         // the A patches are dead after the last barrier
+    const float bias0 = a.bias ? a.bias[n0 + wn * 64 + l31] : 0.f, bias1 = a.bias ? a.bias[n0 + wn * 64 + 32 + l31] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-        const float bias = a.bias ? a.bias[col] : 0.f;
+    for (int i = 0; i < MI; ++i) {
+        const int oyb = y0 + wm * SR * MI + SR * i;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;          // 0..31 inside the sub-tile
-                const int oy = y0 + wm * SR * MI + SR * i + (TW == 16 ? (row >> 4) : 0), ox = x0 + (row & (TW - 1));
+                const int oy = oyb + (TW == 16 ? (row >> 4) : 0), ox = x0 + (row & (TW - 1));
+                const __bf16 hv = (__bf16)(acc[i][j][r] + (j ? bias1 : bias0));
+                *(__bf16*)(ep + row * EPITCH + (j * 32 + l31) * 2) = hv;
                 if (oy < a.Ho && ox < a.Wo) {
-                    const float v = rndt<2>(acc[i][j][r] + bias);   // statistics see the stored value
-                    if (col < a.C0) {
-                        st1t<2>(a.out0, (((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col, v);
-                    } else {
-                        const int y1 = oy - a.o1y, x1 = ox - a.o1x;
-                        if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
-                            st1t<2>(a.out1, (((long)img * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0), v);
-                    }
+                    const float v = (float)hv;                             // statistics see the stored value
                     s1[j] += v; s2[j] += v * v;
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = lane + 64 * t, row = idx >> 3, ch = idx & 7;
+            const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
+            const int oy = oyb + (TW == 16 ? (row >> 4) : 0), ox = x0 + (row & (TW - 1));
+            const int col = n0 + wn * 64 + ch * 8;
+            if (oy < a.Ho && ox < a.Wo) {
+                if (col < a.C0) {
+                    *(bf16x8*)((__bf16*)a.out0 + (((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col) = v8;
+                } else {
+                    const int y1 = oy - a.o1y, x1 = ox - a.o1x;
+                    if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
+                        *(bf16x8*)((__bf16*)a.out1 + (((long)img * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0)) = v8;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (a.stat) {
-        float* red = (float*)As;   // [WM][2][BN]; the A patches are dead after the last barrier
+        float* red = (float*)(smem + 4 * 32 * EPITCH);   // [WM][2][BN], behind the waves' transpose scratch
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             s1[j] += __shfl_xor(s1[j], 32);
@@ -292,7 +315,7 @@ int halo_stat_rows(int N, int H, int W) { return N * cdiv(H, 8) * cdiv(W, 16); }
 bool halo_supported(const IgemmArgs& a) {
     if (a.nseg != 9 || a.nz != 1 || a.s_in != 1 || a.s_out != 1 || a.segw != 3) return false;
     bool pool = false;
-    if (a.out_esz != 2) return false;
+    if (a.out_esz != 2 || (a.C0 & 7) || ((a.Cout - a.C0) & 7)) return false;
     for (int i = 0; i < a.nsrc; ++i) {
         if (a.src[i].sC != 1 || (a.src[i].C & 7) || a.src[i].esz != 2) return false;
         pool |= a.src[i].pool != 0;
