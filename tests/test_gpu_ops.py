@@ -290,25 +290,33 @@ def test_conv3x3_bf16_mfma(n, ci, co, h, w, exact):
     assert rel(dw.cpu(), wr.grad) < tol
 
 
-def test_convT2x2_bf16_mfma_exact():
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 128, 64, 5, 7), (3, 256, 128, 12, 10), (1, 64, 64, 3, 50), (4, 256, 128, 128, 128),
+                                         (2, 40, 24, 6, 5)])
+def test_convT2x2_bf16_mfma_exact(n, ci, co, h, w):
+    """Dedicated GEMM kernels (convT_bf16.hip) for 64-multiple channels -- ragged pixel counts, odd widths,
+    the 256-column dgrad tile at the large size -- and the generic fallback for the last shape."""
     l = L()
     lib = l.lib()
-    n, ci, co, h, w = 2, 128, 64, 5, 7
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-3, 4, (n, ci, h, w), generator=g).float()
     wt = torch.randint(-2, 3, (ci, co, 2, 2), generator=g).float()
     b = torch.randint(-2, 3, (co,), generator=g).float()
     du = torch.randint(-3, 4, (n, co, 2 * h, 2 * w), generator=g).float()
-    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    # producer's BatchNorm affine + ReLU on load: power-of-two scales and integer shifts keep everything exact
+    sc = torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (ci,), generator=g)]
+    sh = torch.randint(-1, 2, (ci,), generator=g).float()
+    xa = torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    xr, wr, br = xa.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
     u_ref = F.conv_transpose2d(xr, wr, br, stride=2)
     u_ref.backward(du)
-    nel = 4 * ci * co
+    nel = 4 * ((ci + 7) // 8 * 8) * ((co + 7) // 8 * 8)
     wf = torch.zeros(nel, dtype=torch.bfloat16, device="cuda")
     wd = torch.zeros(nel, dtype=torch.bfloat16, device="cuda")
     wg = wt.cuda()
     l.check(lib.ustrun_pack_convT2x2(wg.data_ptr(), ci, co, wf.data_ptr(), wd.data_ptr(), 1, None))
     xg, bg, dug = nhwc16(x), b.cuda(), nhwc16(du)
-    src = l.nhwc_src(xg.data_ptr(), ci, h, w)
+    scg, shg = sc.cuda(), sh.cuda()
+    src = l.nhwc_src(xg.data_ptr(), ci, h, w, scale=scg.data_ptr(), shift=shg.data_ptr(), relu=1)
     u = torch.empty(n, 2 * h, 2 * w, co, device="cuda", dtype=torch.bfloat16)
     l.check(lib.ustrun_convT2x2_fwd(C.byref(src), wf.data_ptr(), bg.data_ptr(), n, h, w, co, u.data_ptr(), 1, None))
     assert rel(from_nhwc(u.float()), r16(u_ref.detach())) < 1e-6

@@ -91,6 +91,10 @@ bool halo_tall_tile(const IgemmArgs& a);
 int halo_stat_rows_used(const IgemmArgs& a);
 int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st);
 int halo_stat_rows(int N, int H, int W);
+bool convT_fwd_supported(const IgemmArgs& a);
+bool convT_dgrad_supported(const IgemmArgs& a);
+int convT_fwd_launch_bf16(const IgemmArgs& a, hipStream_t st);
+int convT_dgrad_launch_bf16(const IgemmArgs& a, hipStream_t st);
 int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, void* wf, void* wd, hipStream_t st);
 static inline bool dtype_ok(int dtype) { return dtype == USTRUN_F32 || dtype == USTRUN_BF16; }
 

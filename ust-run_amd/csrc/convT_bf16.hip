@@ -1,0 +1,286 @@
+// convT_bf16.hip -- ConvTranspose2d(k=2, s=2) forward and input-gradient on the bf16 matrix cores.
+// Replaces nn.ConvTranspose2d in Up (reference networks/unet_parts.py:50-52) and its autograd backward.
+//
+// With stride == kernel the four taps never overlap, so both directions are plain GEMMs over the
+// LOW-resolution pixel grid m = (n, y, x):
+//   forward   u[n, 2y+dy, 2x+dx, co] = bias[co] + sum_ci act(a[m, ci]) w[ci, co, dy, dx]
+//             -> [M x Cin] x [Cin x 4*Cout], columns ordered (tap, co), scatter epilogue
+//   dgrad     da[m, ci] = sum_{tap, co} du[n, 2y+dy, 2x+dx, co] w[ci, co, dy, dx]
+//             -> [M x 4*Cout] x [4*Cout x Cin], the K axis ordered (tap, co), gather loader
+// A rows are 128 consecutive pixels (no halo, no tile waste at any extent), staged global -> registers ->
+// [BatchNorm affine + ReLU in f32] -> bf16 -> XOR-swizzled LDS one chunk ahead of the MFMAs; weights are
+// [tap][K/8][N][8] bf16 tiles fetched by LDS-DMA.  The epilogue transposes through per-wave LDS scratch and
+// stores 16 bytes per lane (see conv_halo_bf16.hip).  The high-resolution pixel of (m, tap) is
+// 4m - 2x + 2*dy*W + dx, so only x = m mod W is ever needed.
+#include "common.h"
+#include "loader.h"
+
+namespace ustrun {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+__device__ __forceinline__ int fastmod(int v, int d, float inv) {      // v mod d for 0 <= v < 2^22, d < 2^16
+    const int q = (int)(((float)v + 0.5f) * inv);
+    int r = v - q * d;
+    if (r < 0) r += d;
+    if (r >= d) r -= d;
+    return r;
+}
+
+// DG = false: forward (a.src[0] = activation source, a.Cin = Cin, a.Cout = Cout, out0 = u, bias)
+// DG = true : dgrad   (a.src[0] = du [N,2H,2W,Cout] contiguous, a.Cin = Cout, a.Cout = Cin, out0 = da)
+template <int BN, int BK, bool DG>
+__global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, const int mt_total, const int nt_total) {
+    constexpr int BM = 128;
+    constexpr int WN = BN / 64, WM = 4 / WN, MI = BM / (32 * WM);
+    constexpr int CPR = BK / 8;                 // 16-byte groups per pixel per chunk
+    constexpr int AIT = BM * CPR / 256;         // A items per thread per chunk
+    constexpr int ROWB = BK * 2;
+    constexpr int ABYTES = BM * ROWB;
+    constexpr int BCH = CPR * BN;               // 16-byte chunks per B tile
+    constexpr int BIT = BCH / 256;
+    static_assert(BCH % 256 == 0 && 256 % BN == 0, "B tile mapping: a thread keeps one column");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + 2 * ABYTES;
+
+    const int ntiles = mt_total * nt_total;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, j = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int mtile = bid / nt_total, ntile = bid % nt_total;
+    const int n0 = ntile * BN;
+    const long m0 = (long)mtile * BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    auto swz = [](int p) { return BK == 64 ? ((p >> 1) & 7) : ((p >> 2) & 3); };
+
+    const int W = a.Wb, HWb = a.Hb * a.Wb;
+    const float invW = 1.f / (float)W;
+    const int Ktot = DG ? 4 * a.Cin : a.Cin;
+    const int nchunk = Ktot / BK;
+    const __bf16* Wp = (const __bf16*)a.W;
+    const __bf16* Ap = (const __bf16*)a.src[0].ptr;
+    const int x0r = (int)(m0 % W);              // x of the tile's first pixel
+
+    // ---- A items: pixel = (tid + 256 i) / CPR, 8-channel group c8 = tid % CPR ------------------------------
+    const int c8 = tid % CPR;
+    long aoff[AIT];                             // element offset of the pixel (forward) / of its tap-(0,0) pixel (dgrad)
+    unsigned aok = 0;
+#pragma unroll
+    for (int i = 0; i < AIT; ++i) {
+        const int px = (tid + 256 * i) / CPR;
+        const long m = m0 + px;
+        aoff[i] = 0;
+        if (m < a.M) {
+            aok |= 1u << i;
+            const int x = fastmod(x0r + px, W, invW);
+            if (DG) {
+                aoff[i] = (4 * m - 2 * x) * (long)a.Cin;
+            } else {
+                const int n = (int)(m / HWb);
+                const int y = (int)((m - (long)n * HWb - x) / W);
+                aoff[i] = n * a.src[0].sN + (long)y * a.src[0].sH + (long)x * a.src[0].sW;
+            }
+        }
+    }
+    bf16x8 av[AIT];
+    f32x4 asc0, asc1, ash0, ash1;
+    const bool a_aff = !DG && a.src[0].scale != nullptr;
+    const bool a_relu = !DG && a.src[0].relu;
+    auto load_A = [&](int c) {
+        long koff;
+        if (DG) {
+            const int k0 = c * BK, tap = k0 / a.Cin, kk = k0 - tap * a.Cin;
+            koff = ((long)(tap >> 1) * 2 * W + (tap & 1)) * a.Cin + kk + 8 * c8;
+        } else {
+            koff = c * BK + 8 * c8;
+            if (a_aff) {
+                asc0 = *(const f32x4*)(a.src[0].scale + koff); asc1 = *(const f32x4*)(a.src[0].scale + koff + 4);
+                ash0 = *(const f32x4*)(a.src[0].shift + koff); ash1 = *(const f32x4*)(a.src[0].shift + koff + 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AIT; ++i)
+            if ((aok >> i) & 1u) av[i] = *(const bf16x8*)(Ap + aoff[i] + koff);
+    };
+    auto write_A = [&](char* Adst) {
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const int px = (tid + 256 * i) / CPR;
+            bf16x8 h;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h[q] = (__bf16)0.f;
+            if ((aok >> i) & 1u) {
+                if (a_aff) {
+                    const bf16x8 r = av[i];
+                    f32x4 lo = (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * asc0 + ash0;
+                    f32x4 hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
+                    if (a_relu) { lo = relu4(lo); hi = relu4(hi); }
+                    h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+                    h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+                } else {
+                    h = av[i];
+                }
+            }
+            *(bf16x8*)(Adst + px * ROWB + ((c8 ^ swz(px)) * 16)) = h;
+        }
+    };
+    // ---- B tile of chunk c: rows c*CPR .. +CPR of the [K/8][ncols][8] matrix; this thread's column is fixed ----
+    long bcol;                                   // element offset of the thread's column in K-row 0
+    {
+        const int n = n0 + (tid % BN);
+        if (DG) {
+            bcol = (long)n * 8;
+        } else {
+            const int tap = n / a.Cout, co = n - tap * a.Cout;
+            bcol = ((long)tap * (a.Cin / 8) * a.Cout + co) * 8;
+        }
+    }
+    const long brow = (long)a.Cout * 8;          // elements per K/8 row
+    auto dma_B = [&](int c, int buf) {
+        char* dst = Bs + buf * (BCH * 16);
+#pragma unroll
+        for (int i = 0; i < BIT; ++i) {
+            const int o = (tid + 256 * i) / BN;
+            const __bf16* src = Wp + bcol + (long)(c * CPR + o) * brow;
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    dma_B(0, 0);
+    load_A(0);
+    write_A(As);
+    __syncthreads();
+    int buf = 0;
+    const int prow0 = wm * 32 * MI + l31;        // this lane's A row in sub-tile 0
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = c + 1 < nchunk;
+        if (more) { dma_B(c + 1, buf ^ 1); load_A(c + 1); }
+        const char* Acur = As + buf * ABYTES;
+        const char* Bp = Bs + buf * (BCH * 16) + (lh * BN + wn * 64 + l31) * 16;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int ch = 2 * ks + lh;
+            const bf16x8 b0 = *(const bf16x8*)(Bp + (2 * ks * BN) * 16);
+            const bf16x8 b1 = *(const bf16x8*)(Bp + (2 * ks * BN + 32) * 16);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int p = prow0 + 32 * i;
+                const bf16x8 af = *(const bf16x8*)(Acur + p * ROWB + ((ch ^ swz(p)) * 16));
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[i][1], 0, 0, 0);
+            }
+        }
+        if (more) write_A(As + (buf ^ 1) * ABYTES);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue: bias, bf16, per-wave LDS transpose, 16-byte stores of 64 contiguous channels ----
+    constexpr int EPITCH = 144;
+    char* ep = smem + wave * (32 * EPITCH);
+    const int colw = n0 + wn * 64;               // first of this wave's 64 columns
+    int tap = 0, co0 = colw;
+    if (!DG) { tap = colw / a.Cout; co0 = colw - tap * a.Cout; }
+    const float bias0 = (!DG && a.bias) ? a.bias[co0 + l31] : 0.f, bias1 = (!DG && a.bias) ? a.bias[co0 + 32 + l31] : 0.f;
+    __bf16* outp = (__bf16*)a.out0;
+    const long tapoff = (long)(tap >> 1) * 2 * W + (tap & 1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                *(__bf16*)(ep + row * EPITCH + (j * 32 + l31) * 2) = (__bf16)(acc[i][j][r] + (j ? bias1 : bias0));
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = lane + 64 * t, row = idx >> 3, ch = idx & 7;
+            const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
+            const int d = wm * 32 * MI + 32 * i + row;
+            const long m = m0 + d;
+            if (m < a.M) {
+                if (DG) {
+                    *(bf16x8*)(outp + m * a.Cout + colw + ch * 8) = v8;
+                } else {
+                    const int x = fastmod(x0r + d, W, invW);
+                    *(bf16x8*)(outp + (4 * m - 2 * x + tapoff) * a.Cout + co0 + ch * 8) = v8;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+template <int BN, int BK, bool DG>
+int launch_cfg(const IgemmArgs& a, hipStream_t st) {
+    const int ncols = DG ? a.Cout : 4 * a.Cout;
+    const int mt = cdiv(a.M, 128), nt = ncols / BN;
+    const size_t lds = 2 * (size_t)128 * BK * 2 + 2 * (size_t)(BK / 8) * BN * 16;
+    dim3 grid(mt * nt), block(256);
+    hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, DG>), grid, block, lds, st, a, mt, nt);
+    USTRUN_LAUNCH_CHECK("convT_bf16");
+    return 0;
+}
+
+bool common_ok(const IgemmArgs& a) {
+    if (a.nsrc != 1 || a.out_esz != 2 || a.out1) return false;
+    const SrcDev& s = a.src[0];
+    if (s.esz != 2 || s.sC != 1 || s.pool || s.off_y || s.off_x) return false;
+    if (a.M >= (1l << 29) || a.Wb >= 32768) return false;
+    return true;
+}
+
+}  // namespace
+
+// ConvTranspose forward as built by ustrun_convT2x2_fwd (nz = 4 parity classes, one segment)
+bool convT_fwd_supported(const IgemmArgs& a) {
+    if (a.nz != 4 || a.nseg != 1 || a.s_out != 2 || a.s_in != 1 || a.stat) return false;
+    if (!common_ok(a)) return false;
+    const SrcDev& s = a.src[0];
+    if (s.LH != a.Hb || s.LW != a.Wb || (s.sN & 7) || (s.sH & 7) || (s.sW & 7)) return false;
+    return a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.C0 == a.Cout;
+}
+// ConvTranspose input-gradient as built by ustrun_convT2x2_dgrad (4 segments reading du at stride 2)
+bool convT_dgrad_supported(const IgemmArgs& a) {
+    if (a.nz != 1 || a.nseg != 4 || a.segw != 2 || a.s_in != 2 || a.s_out != 1 || a.stat || a.bias) return false;
+    if (!common_ok(a)) return false;
+    const SrcDev& s = a.src[0];
+    if (s.scale || s.relu || s.H != 2 * a.Hb || s.W != 2 * a.Wb) return false;
+    if (s.sW != s.C || s.sH != (long)s.W * s.C || s.sN != (long)s.H * s.W * s.C) return false;
+    return a.Cin % 64 == 0 && a.Cout % 128 == 0 && a.C0 == a.Cout;
+}
+
+int convT_fwd_launch_bf16(const IgemmArgs& a, hipStream_t st) {
+    return launch_cfg<256, 32, false>(a, st);
+}
+int convT_dgrad_launch_bf16(const IgemmArgs& a, hipStream_t st) {
+    if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 512) return launch_cfg<256, 32, true>(a, st);
+    return launch_cfg<128, 64, true>(a, st);
+}
+
+}  // namespace ustrun

@@ -302,7 +302,10 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, 4.0 * (in_elems + out_elems + w_elems), st);
     int rc;
     if (dtype == USTRUN_BF16) {
-        rc = halo_supported(a) ? conv3x3_halo_launch_bf16(a, st) : igemm_launch_bf16(a, st);
+        if (halo_supported(a)) rc = conv3x3_halo_launch_bf16(a, st);
+        else if (convT_fwd_supported(a)) rc = convT_fwd_launch_bf16(a, st);
+        else if (convT_dgrad_supported(a)) rc = convT_dgrad_launch_bf16(a, st);
+        else rc = igemm_launch_bf16(a, st);
     } else if (pick_bm(a.Cout) == 128 || pool) {   // (narrow outputs with a pooled source only occur in tiny test nets)
         rc = pool ? launch_cfg<2, 2, true>(a, st) : launch_cfg<2, 2, false>(a, st);
     } else {
