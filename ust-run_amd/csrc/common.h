@@ -108,8 +108,12 @@ struct WgradArgs {
     int dy_s;                  // dY pixel = base*dy_s + (dy_s == 2 ? (s/2, s%2) : (0,0))
     int dyH, dyW;              // dY extent
     float* partials;           // [ksplit][nseg][Cin][Cout]
+    float* bias_partials;      // wgradT only: [ksplit][Cout] column sums of dY, or null
     int ksplit; long kchunk;   // block-level K splits; pixels per split (multiple of 32)
 };
+bool wgradT_supported(const WgradArgs& a);
+int wgradT_plan(int Cin, int Cout, long M, int* ksplit, long* kchunk);
+int wgradT_launch_bf16(const WgradArgs& a, hipStream_t st);
 // slabs = total partial slabs written (ksplit x in-block K waves)
 int wgrad_plan(int nseg, int Cin, int Cout, int64_t M, int* ksplit, long* kchunk, int* slabs);
 int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);

@@ -171,7 +171,13 @@ extern "C" int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int6
         const int halo = (int)((1024 + pairs - 1) / pairs) + 1;
         if (halo > slabs) slabs = halo;
     }
+    if (nseg == 4 && Cin % 128 == 0 && Cout % 32 == 0) {         // the ConvTranspose all-taps bf16 kernel
+        int kt; long ct;
+        wgradT_plan(Cin, Cout, npix, &kt, &ct);
+        if (kt > slabs) slabs = kt;
+    }
     int64_t b = (int64_t)slabs * nseg * Cin * Cout * sizeof(float);
+    if (nseg == 4) b += (int64_t)slabs * Cout * sizeof(float);    // bias column sums ride behind the slabs
     if (nseg == 9 && Cin <= 4 && Cout == 64 && conv_first_wgrad_partials_bytes() > b) b = conv_first_wgrad_partials_bytes();
     return b;
 }
@@ -247,9 +253,22 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
     a.N = N; a.Hb = H; a.Wb = W; a.M = (long)N * H * W;
     a.nseg = 4; a.segw = 2; a.d0 = 0; a.astep = 0; a.dy_s = 2; a.dyH = 2 * H; a.dyW = 2 * W;
     int slabs;
+    a.partials = partials;
+    if (dtype == USTRUN_BF16 && wgradT_supported(a)) {       // all four taps (and the bias) in one GEMM: wgradT_bf16.hip
+        wgradT_plan(a.Cin, Cout, a.M, &a.ksplit, &a.kchunk);
+        slabs = a.ksplit;
+        const int64_t slab_bytes = (int64_t)slabs * 4 * a.Cin * Cout * 4;
+        USTRUN_CHECK(partials_bytes >= slab_bytes + (db ? (int64_t)slabs * Cout * 4 : 0), "convT2x2_wgrad: partials too small");
+        a.bias_partials = db ? partials + slab_bytes / 4 : nullptr;
+        prof_begin(1, 2.0 * a.M * 4 * a.Cin * Cout, 2.0 * (a.M * (double)a.Cin + 4.0 * a.M * Cout) + 16.0 * a.Cin * Cout, (hipStream_t)s);
+        const int rc = wgradT_launch_bf16(a, (hipStream_t)s);
+        prof_end((hipStream_t)s);
+        USTRUN_TRY(rc);
+        if (db) USTRUN_TRY(reduce_rows(a.bias_partials, slabs, Cout, 0, Cout, db, accumulate, (hipStream_t)s));
+        return reduce_partials(partials, slabs, 4, a.Cin, Cout, dw, 2, accumulate, (hipStream_t)s);
+    }
     wgrad_plan(4, a.Cin, Cout, a.M, &a.ksplit, &a.kchunk, &slabs);
     USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 4 * a.Cin * Cout * 4, "convT2x2_wgrad: partials too small");
-    a.partials = partials;
     USTRUN_TRY(wgrad_launch(a, dtype, (hipStream_t)s));
     USTRUN_TRY(reduce_partials(partials, slabs, 4, a.Cin, Cout, dw, 1, accumulate, (hipStream_t)s));
     if (db) {

@@ -1,0 +1,261 @@
+// wgradT_bf16.hip -- ConvTranspose2d(k=2, s=2) weight gradient on the bf16 matrix cores (the autograd backward
+// of nn.ConvTranspose2d in Up, reference networks/unet_parts.py:50-52):
+//
+//   dW[tap][ci][co] = sum_m act(a[m][ci]) * du[hi(m, tap)][co]        hi(m, tap) = 4m - 2x + 2*dy*W + dx
+//
+// One GEMM over the low-resolution pixels m with the four taps folded into the COLUMN axis: a block owns
+// 128 ci x (4 taps x 32 co) columns and a contiguous range of pixels (split-K over space), 64 pixels per
+// stage, double-buffered.  Both operands stay pixel-major in LDS ([pixel][channel], 64-byte segments XORed by
+// the pixel index) and the fragments come from the transposing LDS read, as in wgrad_bf16.hip.  The activation
+// tile goes global -> registers -> [BatchNorm affine + ReLU, f32] -> bf16 -> LDS; the du tile is a pure copy and
+// is fetched by LDS-DMA (the swizzle is applied on the global side: every lane fetches the 16 bytes that belong
+// at its LDS position).  The du fragments are gathered so that the 32 accumulator lanes are (8 co) x (4 taps):
+// the f32 slab comes out directly in the torch [Cin][Cout][2][2] layout with fully coalesced stores and is summed
+// in fixed order by the streaming reduce.  The bias gradient rides along: blocks of the first ci tile add one
+// MFMA with an all-ones A fragment per du fragment, whose result is the column sum of du.
+#include "common.h"
+#include "loader.h"
+
+namespace ustrun {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+constexpr int TM = 128, TN = 128, KP = 64, RB = 256;   // tile, pixels per stage, LDS row pitch (bytes)
+
+// rows k0 + 8*(l>>5) + {0..3 | 4..7}, columns col0 + 16*((l>>4)&1) + 4*(l&3) .. +3, delivered column-major
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, int lane) {
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int colb = (col0 + 16 * ((lane >> 4) & 1) + 4 * p) * 2;
+    const int r0 = k0 + 8 * (lane >> 5) + q, r1 = r0 + 4;      // r1 & 3 == r0 & 3
+    const int off = colb ^ ((r0 & 3) << 6);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * RB + off));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * RB + off));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+// du fragment of 8-co group t: lane (q, p, g) reads row q, tap p, channels 8t + 4g .. +3 of the [tap][32 co] row,
+// so after the transpose lane 16g + 4*tap + c of the MFMA holds column (co = 8t + 4g + c, tap)
+__device__ __forceinline__ bf16x8 tr_frag_du(const char* tile, int k0, int t, int lane) {
+    const int q = (lane & 15) >> 2, p = lane & 3, g = (lane >> 4) & 1;
+    const int r0 = k0 + 8 * (lane >> 5) + q, r1 = r0 + 4;
+    const int off = ((p ^ (r0 & 3)) << 6) + 16 * t + 8 * g;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * RB + off));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * RB + off));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__device__ __forceinline__ int wrap_add(int x, int inc, int W, float invW) {   // (x + inc) mod W, x < W < 2^15, inc <= 64
+    const int v = x + inc;
+    const int q = (int)(((float)v + 0.5f) * invW);
+    int r = v - q * W;
+    if (r < 0) r += W;
+    if (r >= W) r -= W;
+    return r;
+}
+
+// grid = (ci tiles * column tiles, ksplit)
+__global__ __launch_bounds__(256, 2) void wgradT_bf16_kernel(const WgradArgs a, const int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                      // 2 x [KP][TM] bf16
+    char* Bs = smem + 2 * KP * RB;        // 2 x [KP][TN] bf16
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int mtile = blockIdx.x / ntn, ntile = blockIdx.x % ntn;
+    const int ci0 = mtile * TM, co0 = ntile * 32;
+    const int ks = blockIdx.y;
+    const long kbeg = (long)ks * a.kchunk;
+    const long kend = (kbeg + a.kchunk < a.M) ? kbeg + a.kchunk : a.M;
+    const int W = a.Wb;
+    const float invW = 1.f / (float)W;
+
+    // ---- A items: pixel row (tid >> 4) + 16 i, 8-channel group tid & 15; the source is pixel-linear (m * sW) ----
+    const SrcDev& S = a.src[0];
+    const int c8 = tid & 15;
+    const int cl = ci0 + 8 * c8;
+    const bool aff = S.scale != nullptr;
+    f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
+    if (aff) {
+        asc0 = *(const f32x4*)(S.scale + cl); asc1 = *(const f32x4*)(S.scale + cl + 4);
+        ash0 = *(const f32x4*)(S.shift + cl); ash1 = *(const f32x4*)(S.shift + cl + 4);
+    }
+    const __bf16* sp = (const __bf16*)S.ptr + cl;
+    const int arow = tid >> 4;
+    bf16x8 av[4];
+    auto load_A = [&](long k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = k0 + arow + 16 * i;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) av[i][q] = (__bf16)0.f;
+            if (m < kend) av[i] = *(const bf16x8*)(sp + m * S.sW);
+        }
+    };
+    auto write_A = [&](long k0, char* dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = arow + 16 * i;
+            bf16x8 h = av[i];
+            if (aff && k0 + row < kend) {       // rows past the range stay zero
+                f32x4 lo = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]} * asc0 + ash0;
+                f32x4 hi = (f32x4){(float)h[4], (float)h[5], (float)h[6], (float)h[7]} * asc1 + ash1;
+                if (S.relu) { lo = relu4(lo); hi = relu4(hi); }
+                h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+                h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+            }
+            *(bf16x8*)(dst + row * RB + ((c8 * 16) ^ ((row & 3) << 6))) = h;
+        }
+    };
+    // ---- du tile by LDS-DMA: wave-instruction i fills rows 16 i + 4 wave .. +3 (1 KB, lane-linear).  The lane at
+    // LDS position `pos` of row r fetches logical 16-byte item ((pos >> 2) ^ (r & 3)) << 2 | (pos & 3).
+    const int brl = lane >> 4, pos = lane & 15;
+    const int item = ((((pos >> 2) ^ brl) << 2) | (pos & 3));      // (4 wave + brl) & 3 == brl
+    const int tap = item >> 2, co = co0 + 8 * (item & 3);          // LDS row = [tap][32 co]
+    const long tapoff = (long)(tap >> 1) * 2 * W + (tap & 1);
+    const __bf16* dup = (const __bf16*)a.dy + co;
+    int bx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bx[i] = (int)((kbeg + 16 * i + 4 * wave + brl) % W);
+    auto dma_B = [&](long k0, char* dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = k0 + 16 * i + 4 * wave + brl;
+            // rows past the tensor read pixel 0: any finite value will do, their A rows are zero
+            const long hp = m < a.M ? 4 * m - 2 * bx[i] + tapoff : 0;
+            __builtin_amdgcn_global_load_lds((gptr_t*)(dup + hp * a.Cout), (lptr_t*)(dst + (16 * i + 4 * wave) * RB), 16, 0, 0);
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bx[i] = wrap_add(bx[i], KP, W, invW);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool do_bias = a.bias_partials != nullptr && mtile == 0 && wm == 0;      // wave-uniform
+    f32x16 accb[2];
+    bf16x8 ones;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[j][r] = 0.f;
+
+    if (kbeg < kend) {
+        dma_B(kbeg, Bs);
+        load_A(kbeg);
+        write_A(kbeg, As);
+    }
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (long k0 = kbeg; k0 < kend; k0 += KP) {
+        const bool more = k0 + KP < kend;
+        if (more) {
+            advance();
+            dma_B(k0 + KP, Bs + (buf ^ 1) * (KP * RB));
+            load_A(k0 + KP);
+        }
+        const char* At = As + buf * (KP * RB);
+        const char* Bt = Bs + buf * (KP * RB);
+#pragma unroll
+        for (int kk = 0; kk < KP / 16; ++kk) {
+            const bf16x8 a0 = tr_frag(At, kk * 16, wm * 64, lane);
+            const bf16x8 a1 = tr_frag(At, kk * 16, wm * 64 + 32, lane);
+            const bf16x8 b0 = tr_frag_du(Bt, kk * 16, 2 * wn, lane);
+            const bf16x8 b1 = tr_frag_du(Bt, kk * 16, 2 * wn + 1, lane);
+            if (do_bias) {
+                // this lane's 8 K entries are pixels k0 + 16 kk + 8 (lane >> 5) + 0..7: only those inside the range count
+                const long rem = kend - k0 - 16 * kk - 8 * (lane >> 5);
+                bf16x8 on = ones;
+                if (rem < 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) on[q] = (__bf16)(q < rem ? 1.f : 0.f);
+                }
+                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(on, b0, accb[0], 0, 0, 0);
+                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(on, b1, accb[1], 0, 0, 0);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) write_A(k0 + KP, As + (buf ^ 1) * (KP * RB));
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // slab in the torch layout [Cin][Cout][2][2]: rows of D are ci (registers); lane 16g + 4*tap + c is column
+    // (co = co0 + 8t + 4g + c, tap) -> the 32 lanes of a row write 32 consecutive floats
+    float* slab = a.partials + (long)ks * 4 * a.Cin * a.Cout;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int lg = l31 >> 4, ltap = (l31 >> 2) & 3, lc = l31 & 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = co0 + 8 * (2 * wn + j) + 4 * lg + lc;
+        float* o = slab + (long)co * 4 + ltap;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                o[(long)ci * a.Cout * 4] = acc[i][j][r];
+            }
+        if (do_bias) {      // every row of accb is the column sum; fold the four taps (lane bits 2..3)
+            float v = accb[j][0];
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            if (lh == 0 && ltap == 0) a.bias_partials[(long)ks * a.Cout + co] = v;
+        }
+    }
+}
+
+}  // namespace
+
+bool wgradT_supported(const WgradArgs& a) {
+    if (a.nseg != 4 || a.segw != 2 || a.dy_s != 2 || a.astep != 0 || a.d0 != 0 || a.dy_esz != 2 || a.nsrc != 1) return false;
+    const SrcDev& s = a.src[0];
+    if (s.esz != 2 || s.sC != 1 || s.pool || s.off_y || s.off_x || s.LH != a.Hb || s.LW != a.Wb) return false;
+    if ((s.relu && !s.scale) || (s.sW & 7)) return false;
+    if (s.sH != (long)a.Wb * s.sW || s.sN != (long)a.Hb * s.sH) return false;      // pixel-linear source
+    if (a.dyH != 2 * a.Hb || a.dyW != 2 * a.Wb || a.Wb >= 32768) return false;
+    return a.Cin % 128 == 0 && a.Cout % 32 == 0;
+}
+
+// split-K plan: one resident wave of blocks (2 per CU), at least four 64-pixel stages per block
+int wgradT_plan(int Cin, int Cout, long M, int* ksplit, long* kchunk) {
+    const long tiles = (long)(Cin / TM) * (Cout / 32);
+    long ks = (512 + tiles - 1) / tiles;
+    if (ks > M / (4 * KP)) ks = M / (4 * KP);
+    if (ks < 1) ks = 1;
+    long chunk = (M + ks - 1) / ks;
+    chunk = (chunk + KP - 1) / KP * KP;
+    *kchunk = chunk; *ksplit = (int)((M + chunk - 1) / chunk);
+    return 0;
+}
+
+int wgradT_launch_bf16(const WgradArgs& a, hipStream_t st) {
+    dim3 grid((a.Cin / TM) * (a.Cout / 32), a.ksplit), block(256);
+    hipLaunchKernelGGL(wgradT_bf16_kernel, grid, block, 4 * KP * RB, st, a, a.Cout / 32);
+    USTRUN_LAUNCH_CHECK("wgradT_bf16");
+    return 0;
+}
+
+}  // namespace ustrun
