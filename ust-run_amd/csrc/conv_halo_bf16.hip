@@ -12,6 +12,7 @@
 #include "common.h"
 #include "loader.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace ustrun {
 namespace {
@@ -22,31 +23,53 @@ typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
 
+__device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};   // source of padding pixels
+
+template <int V> using ic = std::integral_constant<int, V>;
+
 // MI = 32-pixel MFMA sub-tiles per wave along M.  TW = 16: a sub-tile is 2 rows x 16 px (wave tile 2*MI rows x 16 px);
-// TW = 32: a sub-tile is one row of 32 consecutive pixels (wave tile MI rows x 32 px) -- 32 consecutive patch rows
-// per ds_read_b128 make the swizzled A reads conflict-free (with 16-wide tiles 2 of 16 lanes collide).
+// TW = 32: a sub-tile is one row of 32 consecutive pixels (wave tile MI rows x 32 px).
+//
+// The kernel is instruction-issue bound, not MFMA- or LDS-bound (SQ counters: at ~210 VALU+SALU instructions per
+// 16 MFMAs the two waves of a SIMD keep its issue port 80 % busy), so the stage body is built to need almost no
+// address arithmetic:
+//   * patch rows are padded to 80 bytes instead of XOR-swizzled (16 consecutive rows still cover all 64 banks once),
+//     so every A fragment of every tap is ONE per-chunk base register plus a compile-time immediate; the nine taps
+//     are unrolled, the input-gradient walks the weight slices backwards instead of mirroring the geometry;
+//   * the patch pixel, bounds test and source offset of every staging item are tile constants computed once per
+//     source, not once per stage.
+// Pipeline (one stage = one tap of one K chunk, 2*MI*BK/16 MFMAs per wave, one barrier):
+//   top    : LDS-DMA of the next stage's weight tile (two tile buffers); LDS-DMA of one item (8 channels of one
+//            patch pixel per thread) of the NEXT chunk's patch -- straight into the other patch buffer when the
+//            source needs no arithmetic (dY, ConvTranspose outputs), else into a private raw slot
+//   middle : all fragment reads, then the MFMAs of this tap
+//   bottom : counted s_waitcnt: the weight tile and the raw item fetched one stage ago have landed; that raw item
+//            gets its BatchNorm affine + ReLU (+2x2 max) in f32 and is written to the other patch buffer; barrier.
 template <int TH, int TW, int BN, int BK, int MI, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
+    static_assert(BK == 32, "80-byte patch rows hold one 32-channel chunk");
     constexpr int HW2 = TW + 2;
     constexpr int SR = 32 / TW;                 // tile rows per 32-pixel sub-tile (2 or 1)
     constexpr int WM = TH / (SR * MI), WN = 4 / WM;
     static_assert(WM * WN == 4 && BN == WN * 64, "4 waves, 64 channels per wave");
     constexpr int HP = (TH + 2) * HW2;          // halo pixels
-    constexpr int CPR = BK / 8;                 // 8-channel (16-byte) groups per pixel
-    constexpr int AIT = (HP * CPR + 255) / 256; // A items per thread per chunk
+    constexpr int PITCH = 80;                   // patch row: 4 x 16 B of channels + 16 B pad
+    constexpr int DSLOTS = (HP * 5 + 63) / 64 * 64;   // direct staging: 16-byte LDS slots incl. the pad slots, whole waves
+    constexpr int XSLOTS = (HP * 4 + 63) / 64 * 64;   // transform staging: (pixel, channel group) items, whole waves
+    constexpr int AIT = (DSLOTS + 255) / 256;   // staging steps per chunk (taps 0 .. AIT-1), one item per thread each
+    static_assert(AIT <= 8, "the next patch must be complete one stage before the chunk ends");
     constexpr int NP = POOL ? 4 : 1;
-    constexpr int ROWB = BK * 2;
+    constexpr int ABYTES = DSLOTS * 16;
     constexpr int BCH = (BK / 8) * BN;          // 16-byte chunks per B tile
     constexpr int BIT = BCH / 256;
     static_assert(BCH % 256 == 0, "B tile must be a whole number of wave-instructions per wave");
-
-    constexpr int BATCH = (AIT + 8) / 9;        // A items staged per tap (the next patch is spread over the 9 taps)
-    constexpr int ABYTES = (HP * ROWB + 15) & ~15;
+    constexpr int RAWB = NP * 4096;             // one raw slot: NP x 16 B per thread
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                            // 2 x [HP][BK] bf16 (current patch / patch being staged)
+    char* As = smem;                            // 2 x patch [HP][80 B] (current / being staged)
     char* Bs = smem + 2 * ABYTES;               // 2 x [BK/8][BN][8] bf16
+    char* Raw = Bs + 2 * (BCH * 16);            // 2 x raw slot
 
     const int mt_total = a.N * tiles_y * tiles_x;
     const int ntiles = mt_total * nt_total;
@@ -65,62 +88,68 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    auto swz = [](int hp) { return BK == 64 ? ((hp >> 1) & 7) : ((hp >> 2) & 3); };
-
     const int nchunk = a.Cin / BK;
     const int K8 = a.Cin / 8;
     const __bf16* Wp = (const __bf16*)a.W;
+    const __bf16* zsrc = (const __bf16*)g_zero16;
+    const bool wflip = a.dstep < 0;             // input-gradient: geometric tap g pairs with weight slice 8 - g
 
-    // ---- A patch staging, BATCH items per call; an item = 8 channels (16 B of bf16) of one patch pixel:
-    // global -> registers (raw bf16) ... -> [affine + ReLU (+ 2x2 max) in f32] -> bf16 -> LDS.  Sources without an
-    // affine (dY in the input-gradient, the ConvTranspose output in a concat) are copied through untouched.
-    bf16x8 av[BATCH][NP];
+    // ---- A patch staging.  Tile constants per SOURCE (recomputed when a concat switches source):
+    //   direct   : item i = LDS slot q = tid + 256 i of the patch image: pixel q / 5, 16-byte group q % 5 (4 = pad)
+    //   transform: item i = (pixel (tid + 256 i) / 4, channel group tid % 4): the thread keeps one group, its
+    //              scale/shift stay in registers
+    // aoff[i] = element offset of the item from the chunk base, bit i of aokm = the item reads the image. ----
+    int aoff[AIT];
+    unsigned aokm = 0;
+    int cur_src = -1, a_xf = 0, a_relu = 0;
+    const __bf16* aptr = nullptr;               // chunk base: source + image + first channel of the chunk
+    long dq1 = 0, dq2 = 0;                      // pooled source: element offsets of the right / lower neighbour
     f32x4 asc0, asc1, ash0, ash1;
-    int a_relu = 0, a_aff = 0;
-    unsigned aok = 0;
-    const int c8 = tid % CPR;                       // constant per thread: 256 % CPR == 0
-    const float* aptr = nullptr;
-    long abase = 0;
-    int aLH = 0, aLW = 0, aby = 0, abx = 0;
-    long asH = 0, asW = 0;
-    auto stage_begin = [&](int c) {                 // per-chunk constants: source, affine, origin
-        const int cg = c * BK + 8 * c8;
-        const bool second = (a.nsrc == 2 && cg >= a.src[0].C);
-        const SrcDev S = pick_src(a.src[0], a.src[1], second);
-        const int cl = cg - (second ? a.src[0].C : 0);
-        a_aff = S.scale != nullptr;
-        asc0 = asc1 = (f32x4){1.f, 1.f, 1.f, 1.f}; ash0 = ash1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (a_aff) {
-            asc0 = *(const f32x4*)(S.scale + cl); asc1 = *(const f32x4*)(S.scale + cl + 4);
-            ash0 = *(const f32x4*)(S.shift + cl); ash1 = *(const f32x4*)(S.shift + cl + 4);
-        }
+    const int p8 = tid & 3;
+    auto src_setup = [&](const SrcDev& S) {
         a_relu = S.relu;
-        aptr = S.ptr; abase = img * S.sN + cl;
-        aLH = S.LH; aLW = S.LW; asH = S.sH; asW = S.sW;
-        aby = y0 - 1 - S.off_y; abx = x0 - 1 - S.off_x;
-    };
-    auto ld8 = [&](long idx) { return *(const bf16x8*)((const __bf16*)aptr + idx); };
-    auto stage_load = [&](int t) {                  // items t*BATCH .. t*BATCH+BATCH-1
-        aok = 0;
+        a_xf = (S.scale != nullptr) || S.relu || POOL;
+        dq1 = S.sW; dq2 = S.sH;
+        const int by = y0 - 1 - S.off_y, bx = x0 - 1 - S.off_x;
+        aokm = 0;
 #pragma unroll
-        for (int b = 0; b < BATCH; ++b) {
-            const int hp = (tid + 256 * (t * BATCH + b)) / CPR;
-            if (t * BATCH + b < AIT && hp < HP) {
-                const int hy = hp / HW2, hx = hp - hy * HW2;
-                const int ly = aby + hy, lx = abx + hx;
-                if (ly >= 0 && ly < aLH && lx >= 0 && lx < aLW) {
-                    aok |= 1u << b;
-                    if (POOL) {
-                        const long p = abase + (long)(2 * ly) * asH + (long)(2 * lx) * asW;
-                        av[b][0] = ld8(p);
-                        av[b][1 % NP] = ld8(p + asW);
-                        av[b][2 % NP] = ld8(p + asH);
-                        av[b][3 % NP] = ld8(p + asH + asW);
-                    } else {
-                        av[b][0] = ld8(abase + (long)ly * asH + (long)lx * asW);
-                    }
-                }
+        for (int i = 0; i < AIT; ++i) {
+            const int q = tid + 256 * i;
+            const int hp = a_xf ? (q >> 2) : q / 5;
+            const int g = a_xf ? p8 : q - 5 * hp;
+            const int hy = hp / HW2, hx = hp - hy * HW2;
+            const int ly = by + hy, lx = bx + hx;
+            const bool ok = hp < HP && g < 4 && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
+            aoff[i] = ok ? (int)((POOL ? 2 : 1) * ((long)ly * S.sH + (long)lx * S.sW)) + 8 * g : 0;
+            aokm |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto stage_begin = [&](int c) {                  // per-chunk state, set one chunk ahead of its use
+        const int cg = c * BK;
+        const int second = (a.nsrc == 2 && cg >= a.src[0].C) ? 1 : 0;
+        const SrcDev S = pick_src(a.src[0], a.src[1], second != 0);
+        const int cl = cg - (second ? a.src[0].C : 0);
+        if (second != cur_src) { src_setup(S); cur_src = second; }
+        aptr = (const __bf16*)S.ptr + (img * S.sN + cl);
+        asc0 = asc1 = (f32x4){1.f, 1.f, 1.f, 1.f}; ash0 = ash1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (S.scale) {
+            asc0 = *(const f32x4*)(S.scale + cl + 8 * p8); asc1 = *(const f32x4*)(S.scale + cl + 8 * p8 + 4);
+            ash0 = *(const f32x4*)(S.shift + cl + 8 * p8); ash1 = *(const f32x4*)(S.shift + cl + 8 * p8 + 4);
+        }
+    };
+    // does this wave own a slot of staging step i?  (wave-uniform: the counted waits depend on it)
+    auto wave_has = [&](int i) { return 256 * i + wave * 64 < (a_xf ? XSLOTS : DSLOTS); };
+    auto issue_A = [&](auto ic_i, char* Adst, char* rawslot) {
+        constexpr int i = decltype(ic_i)::value;
+        const __bf16* src = ((aokm >> i) & 1u) ? aptr + aoff[i] : zsrc;
+        if (a_xf) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const long d = ((aokm >> i) & 1u) ? (q & 1 ? dq1 : 0) + (q & 2 ? dq2 : 0) : 0;
+                __builtin_amdgcn_global_load_lds((gptr_t*)(src + d), (lptr_t*)(rawslot + (q * 256 + wave * 64) * 16), 16, 0, 0);
             }
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Adst + (256 * i + wave * 64) * 16), 16, 0, 0);
         }
     };
     auto act8 = [&](bf16x8 r, f32x4& lo, f32x4& hi) {     // bf16 raw -> activated f32
@@ -128,47 +157,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
         if (a_relu) { lo = relu4(lo); hi = relu4(hi); }
     };
-    auto stage_write = [&](int t, char* Adst) {
+    auto xform8 = [&](const bf16x8* r, bool inimg) {      // NP raw pieces -> one activated (pooled) bf16 group
+        bf16x8 h;
 #pragma unroll
-        for (int b = 0; b < BATCH; ++b) {
-            const int hp = (tid + 256 * (t * BATCH + b)) / CPR;
-            if (t * BATCH + b < AIT && hp < HP) {
-                bf16x8 h;
+        for (int q = 0; q < 8; ++q) h[q] = (__bf16)0.f;
+        if (inimg) {                                      // padding is applied after the activation
+            f32x4 lo, hi;
+            act8(r[0], lo, hi);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) h[q] = (__bf16)0.f;
-                if ((aok >> b) & 1u) {
-                    if (a_aff || POOL) {
-                        f32x4 lo, hi;
-                        act8(av[b][0], lo, hi);
-                        if (POOL) {
-#pragma unroll
-                            for (int q = 1; q < NP; ++q) {
-                                f32x4 l2, h2;
-                                act8(av[b][q], l2, h2);
-                                lo = max4(lo, l2); hi = max4(hi, h2);
-                            }
-                        }
-                        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-                        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
-                    } else {
-                        h = av[b][0];
-                    }
-                }
-                *(bf16x8*)(Adst + hp * ROWB + ((c8 ^ swz(hp)) * 16)) = h;
+            for (int q = 1; q < NP; ++q) {
+                f32x4 l2, h2;
+                act8(r[q], l2, h2);
+                lo = max4(lo, l2); hi = max4(hi, h2);
             }
+            h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+            h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
         }
+        return h;
     };
-    // ---- B tile of stage s = chunk*9 + tap: LDS-DMA, 16 B per lane, lane-linear destination ----
-    auto dma_B = [&](int s, int buf) {
-        const int c = s / 9, tap = s - c * 9;
-        const __bf16* wb = Wp + (((long)tap * K8 + c * (BK / 8)) * a.Cout + n0) * 8;
+    const int xw0 = (tid >> 2) * PITCH + p8 * 16;         // transform item i lands at xw0 + i * 64 * PITCH
+    auto transform_A = [&](auto ic_i, char* Adst, const char* rawslot) {
+        constexpr int i = decltype(ic_i)::value;
+        bf16x8 r[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) r[q] = *(const bf16x8*)(rawslot + (q * 256 + tid) * 16);
+        if ((tid >> 2) + 64 * i < HP) *(bf16x8*)(Adst + xw0 + i * 64 * PITCH) = xform8(r, (aokm >> i) & 1u);
+    };
+    // ---- B tile of (chunk c, geometric tap): LDS-DMA, 16 B per lane, lane-linear destination ----
+    const __bf16* wthr[BIT];
+#pragma unroll
+    for (int i = 0; i < BIT; ++i) {
+        const int idx = tid + 256 * i, o = idx / BN, n = idx % BN;
+        wthr[i] = Wp + ((long)o * a.Cout + n0 + n) * 8;
+    }
+    auto dma_B = [&](int c, int tap, int buf) {
+        const int wt = wflip ? 8 - tap : tap;
+        const long woff = ((long)wt * K8 + c * (BK / 8)) * a.Cout * 8;
         char* dst = Bs + buf * (BCH * 16);
 #pragma unroll
-        for (int i = 0; i < BIT; ++i) {
-            const int idx = tid + 256 * i, o = idx / BN, n = idx % BN;
-            const __bf16* src = wb + ((long)o * a.Cout + n) * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + (wave * 64 + 256 * i) * 16), 16, 0, 0);
-        }
+        for (int i = 0; i < BIT; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(wthr[i] + woff), (lptr_t*)(dst + (wave * 64 + 256 * i) * 16), 16, 0, 0);
     };
 
     f32x16 acc[MI][2];
@@ -179,47 +207,87 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // halo pixel (before the tap shift) of this lane's A rows: subtile i covers tile rows
-    // wm*2*MI + 2i + (l31>>4), column l31&15
-    const int hpb0 = (wm * SR * MI + (TW == 16 ? (l31 >> 4) : 0) + 1) * HW2 + (l31 & (TW - 1)) + 1;
+    // this lane's fragment bases: patch pixel of sub-tile 0 at tap (0,0), K half lh; weight column wn*64 + l31
+    const int afrag0 = ((wm * SR * MI + (TW == 16 ? (l31 >> 4) : 0)) * HW2 + (l31 & (TW - 1))) * PITCH + lh * 16;
+    const int bfrag0 = (lh * BN + wn * 64 + l31) * 16;
     const int nstage = nchunk * 9;
 
-    dma_B(0, 0);
+    // ---- prologue: weight tile 0 and the whole first patch, all transfers in flight together ----
+    dma_B(0, 0, 0);
     stage_begin(0);
-    for (int t = 0; t * BATCH < AIT; ++t) { stage_load(t); stage_write(t, As); }
+    if (a_xf) {
+        bf16x8 pv[AIT][NP];
+#pragma unroll
+        for (int i = 0; i < AIT; ++i) {
+            const bool ok = (aokm >> i) & 1u;
+            const __bf16* src = ok ? aptr + aoff[i] : zsrc;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) pv[i][q] = *(const bf16x8*)(src + (ok ? (q & 1 ? dq1 : 0) + (q & 2 ? dq2 : 0) : 0));
+        }
+#pragma unroll
+        for (int i = 0; i < AIT; ++i)
+            if ((tid >> 2) + 64 * i < HP) *(bf16x8*)(As + xw0 + i * 64 * PITCH) = xform8(pv[i], (aokm >> i) & 1u);
+    } else {
+        auto go = [&](auto ic_i) { if (wave_has(decltype(ic_i)::value)) issue_A(ic_i, As, Raw); };
+        go(ic<0>{}); go(ic<1>{}); go(ic<2>{}); go(ic<3>{});
+        if constexpr (AIT > 4) go(ic<4>{});
+        if constexpr (AIT > 5) go(ic<5>{});
+        if constexpr (AIT > 6) go(ic<6>{});
+        if constexpr (AIT > 7) go(ic<7>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int buf = 0;
+
     for (int c = 0; c < nchunk; ++c) {
-        const char* Acur = As + (c & 1) * ABYTES;
+        const char* Afrag = As + (c & 1) * ABYTES + afrag0;
         char* Anext = As + ((c + 1) & 1) * ABYTES;
         const bool more = c + 1 < nchunk;
         if (more) stage_begin(c + 1);
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
+        auto stage = [&](auto ic_tap) {
+            constexpr int tap = decltype(ic_tap)::value;
             const int s = c * 9 + tap;
-            if (s + 1 < nstage) dma_B(s + 1, buf ^ 1);
-            const bool stg = more && tap * BATCH < AIT;
-            if (stg) stage_load(tap);                      // raw loads of the next patch fly under this tap's MFMAs
-            const int dy = a.d0 + (tap / 3) * a.dstep, dx = a.d0 + (tap % 3) * a.dstep;
-            const int hp0 = hpb0 + dy * HW2 + dx;
-            const char* Bp = Bs + buf * (BCH * 16) + (lh * BN + wn * 64 + l31) * 16;
+            // top: next stage's weights, one item of the next patch
+            if (s + 1 < nstage) {
+                if (tap < 8) dma_B(c, tap + 1, (s + 1) & 1); else dma_B(c + 1, 0, (s + 1) & 1);
+            }
+            bool iA = false;
+            if constexpr (tap < AIT) {
+                iA = more && wave_has(tap);
+                if (iA) issue_A(ic<tap>{}, Anext, Raw + (tap & 1) * RAWB);
+            }
+            // middle: every fragment is base + immediate
+            const char* Bp = Bs + (s & 1) * (BCH * 16) + bfrag0;
+            bf16x8 bf[BK / 16][2], af[BK / 16][MI];
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                const int ch = 2 * ks + lh;
-                const bf16x8 b0 = *(const bf16x8*)(Bp + (2 * ks * BN) * 16);
-                const bf16x8 b1 = *(const bf16x8*)(Bp + (2 * ks * BN + 32) * 16);
+                bf[ks][0] = *(const bf16x8*)(Bp + (2 * ks * BN) * 16);
+                bf[ks][1] = *(const bf16x8*)(Bp + (2 * ks * BN + 32) * 16);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[ks][i] = *(const bf16x8*)(Afrag + ((tap / 3 + SR * i) * HW2 + tap % 3) * PITCH + ks * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    const int hp = hp0 + SR * i * HW2;
-                    const bf16x8 af = *(const bf16x8*)(Acur + hp * ROWB + ((ch ^ swz(hp)) * 16));
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[i][1], 0, 0, 0);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][1], acc[i][1], 0, 0, 0);
                 }
             }
-            if (stg) stage_write(tap, Anext);              // the other patch buffer: no reader until the next chunk
-            __syncthreads();                               // B[buf] is free; DMA of B[buf^1] has landed
-            buf ^= 1;
-        }
+            // bottom: all but this top's patch item has landed (the weight tile was issued before it)
+            if (iA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (tap >= 1 && tap <= AIT) {
+                if (more && a_xf && 256 * (tap - 1) + wave * 64 < XSLOTS)
+                    transform_A(ic<tap - 1>{}, Anext, Raw + ((tap - 1) & 1) * RAWB);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        stage(ic<0>{}); stage(ic<1>{}); stage(ic<2>{}); stage(ic<3>{}); stage(ic<4>{});
+        stage(ic<5>{}); stage(ic<6>{}); stage(ic<7>{}); stage(ic<8>{});
     }
 
     // ---- epilogue: bf16 outputs (NHWC), optional two-destination split, BN-statistics partials.
@@ -299,7 +367,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
 template <int TH, int TW, int BN, int BK, int MI, bool POOL>
 int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
-    const size_t lds = 2 * (size_t)(((TH + 2) * (TW + 2) * BK * 2 + 15) & ~15) + 2 * (size_t)(BK / 8) * BN * 16;
+    constexpr int DSLOTS = ((TH + 2) * (TW + 2) * 5 + 63) / 64 * 64;
+    const size_t lds = 2 * (size_t)DSLOTS * 16 + 2 * (size_t)(BK / 8) * BN * 16 + 2 * (size_t)(POOL ? 4 : 1) * 4096;
     dim3 grid(a.N * ty * tx * nt), block(256);
     hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
@@ -354,7 +423,6 @@ int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     if (a.Cout % 128 == 0) {
         if (halo_tall_tile(a))                    // 256 px x 128 ch per block, wave tile 128 px x 64 ch
             return wide ? launch_cfg<8, 32, 128, 32, 4, false>(a, st) : launch_cfg<16, 16, 128, 32, 4, false>(a, st);
-        if (a.Cin % 64 == 0) return launch_cfg<8, 16, 128, 64, 2, false>(a, st);
         return launch_cfg<8, 16, 128, 32, 2, false>(a, st);
     }
     return wide ? launch_cfg<8, 32, 64, 32, 2, false>(a, st) : launch_cfg<16, 16, 64, 32, 2, false>(a, st);

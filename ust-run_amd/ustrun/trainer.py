@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import math
 import random
+import time
 
 import numpy as np
 import torch
@@ -153,8 +154,13 @@ class SSLTrainer:
         self.choice_th = 0.1
         self.lq_u = self.lq_pl = self.lq_mask = None
         self.last = {}
+        self.timeline = None                             # list of (label, perf_counter) when host timing is on
 
     # ---------------------------------------------------------------------------------------
+    def _mark(self, label):
+        if self.timeline is not None:
+            self.timeline.append((label, time.perf_counter()))
+
     def _pl(self, logits):
         return F.pseudo_label(logits, self.threshold, self.mode)
 
@@ -185,6 +191,7 @@ class SSLTrainer:
         dev = lb_x_w.device
         B = len(ulb_x_s)
         epoch_num = self.iter_num // self.num_eval_iter
+        self._mark("start")
         if epoch_start:
             self.lq_u = self.lq_pl = self.lq_mask = None
         lb_mask = decode_labels(ds, lb_y)
@@ -210,9 +217,11 @@ class SSLTrainer:
 
         # FFT low-frequency amplitude mix (train.py:628-636, Q13)
         move_transx = self._freq_mix(mix_img, ulb_x_w, len(lb_x_w))
+        self._mark("select+freqmix")
 
         with torch.no_grad():
             box = torch.from_numpy(np.stack([cutmix_box(self.patch, p=self.cutmix_prob) for _ in range(B)])).to(dev)
+            self._mark("boxes")
             # teacher: three train-mode forwards (train.py:638-667, Q11)
             pl, mask = self._pl(ema(ulb_x_w))
             pl_w_ul, mask_w_ul = self._pl(ema(F.box_mix(ulb_x_w, mix_img, box)))
@@ -224,11 +233,14 @@ class SSLTrainer:
             x_s_ul = F.box_mix(ulb_x_s, move_transx, box)
             x_s_lu = F.box_mix(move_transx, ulb_x_s, box)
 
+        self._mark("teacher+targets issued")
         # student: four forwards that carry gradient (train.py:699-702)
         lg_lb, lg_ul, lg_lu, lg_s = model(lb_x_w), model(x_s_ul), model(x_s_lu), model(ulb_x_s)
+        self._mark("student fwd issued")
 
         # hardness and the low-quality sample forward (train.py:705-747, Q2, Q7)
         d = self._sample_dice(stu_pl, pl)
+        self._mark("dice on host")
         hardness = 1 - d.sum(0) / self.n_part
         if epoch_num == 0:
             hardness[:] = 1
@@ -271,6 +283,7 @@ class SSLTrainer:
         else:
             self.choice_th = min(self.increase * self.choice_th, 0.1)
 
+        self._mark("lq+bank")
         # losses and backward (train.py:816-848; Q5, Q6): loss = sup + w*(ul + lu + w*s)
         w = self.consistency * ramps.sigmoid_rampup(self.iter_num // (self.max_iterations / self.rampup), self.rampup)
         terms = ((lg_lb, lb_mask, None, 1.0), (lg_ul, pl_ul, mask_ul, w), (lg_lu, pl_lu, mask_lu, w), (lg_s, pl_w, mask_w, w * w))
@@ -281,6 +294,7 @@ class SSLTrainer:
             outs.append(out)
             dl = F.seg_loss_bwd(lg.detach(), tgt, msk, mode, out, gscale=coef)
             lg.backward(dl)
+        self._mark("backward issued")
         if self.grad_allreduce is not None:
             self.grad_allreduce(self.flat_g)
 
@@ -294,6 +308,7 @@ class SSLTrainer:
         self.lr = self.base_lr * (1.0 - self.iter_num / self.max_iterations) ** 0.9
         self.iter_num += 1
         self.last = {"outs": outs, "w": w, "pl": pl, "ulb_mask": ulb_mask, "mask": mask}
+        self._mark("end")
         return self.last
 
     def scalars(self):
