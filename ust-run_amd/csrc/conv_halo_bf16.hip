@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     constexpr int DSLOTS = (HP * 5 + 63) / 64 * 64;   // direct staging: 16-byte LDS slots incl. the pad slots, whole waves
     constexpr int XSLOTS = (HP * 4 + 63) / 64 * 64;   // transform staging: (pixel, channel group) items, whole waves
     constexpr int AIT = (DSLOTS + 255) / 256;   // staging steps per chunk (taps 0 .. AIT-1), one item per thread each
-    static_assert(AIT <= 8, "the next patch must be complete one stage before the chunk ends");
+    static_assert(AIT <= 7, "the next patch must be complete one stage before the chunk ends; tap 7 carries the constants");
     constexpr int NP = POOL ? 4 : 1;
     constexpr int ABYTES = DSLOTS * 16;
     constexpr int BCH = (BK / 8) * BN;          // 16-byte chunks per B tile
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     char* As = smem;                            // 2 x patch [HP][80 B] (current / being staged)
     char* Bs = smem + 2 * ABYTES;               // 2 x [BK/8][BN][8] bf16
     char* Raw = Bs + 2 * (BCH * 16);            // 2 x raw slot
+    char* Cst = Raw + 2 * RAWB;                 // 2 x {32 scales, 32 shifts} f32 of a chunk (kept out of vmcnt's way)
 
     const int mt_total = a.N * tiles_y * tiles_x;
     const int ntiles = mt_total * nt_total;
@@ -132,9 +133,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         if (second != cur_src) { src_setup(S); cur_src = second; }
         aptr = (const __bf16*)S.ptr + (img * S.sN + cl);
         asc0 = asc1 = (f32x4){1.f, 1.f, 1.f, 1.f}; ash0 = ash1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (S.scale) {
-            asc0 = *(const f32x4*)(S.scale + cl + 8 * p8); asc1 = *(const f32x4*)(S.scale + cl + 8 * p8 + 4);
-            ash0 = *(const f32x4*)(S.shift + cl + 8 * p8); ash1 = *(const f32x4*)(S.shift + cl + 8 * p8 + 4);
+        if (S.scale) {                               // staged in LDS two chunks ahead by dma_consts
+            const char* cs = Cst + (c & 1) * 256 + p8 * 32;
+            asc0 = *(const f32x4*)cs; asc1 = *(const f32x4*)(cs + 16);
+            ash0 = *(const f32x4*)(cs + 128); ash1 = *(const f32x4*)(cs + 144);
+        }
+    };
+    // BatchNorm scale/shift of chunk c -> LDS (wave 0, 16 lanes x 16 B): a plain global load here would make the
+    // compiler drain vmcnt(0) -- every DMA in flight -- at each use
+    auto dma_consts = [&](int c) {
+        const int cg = c * BK;
+        const bool second = (a.nsrc == 2 && cg >= a.src[0].C);
+        const SrcDev S = pick_src(a.src[0], a.src[1], second);
+        const int cl = cg - (second ? a.src[0].C : 0);
+        if (S.scale && wave == 0 && lane < 16) {
+            const float* src = (lane < 8 ? S.scale : S.shift) + cl + 4 * (lane & 7);
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Cst + (c & 1) * 256), 16, 0, 0);
         }
     };
     // does this wave own a slot of staging step i?  (wave-uniform: the counted waits depend on it)
@@ -214,6 +228,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
 
     // ---- prologue: weight tile 0 and the whole first patch, all transfers in flight together ----
     dma_B(0, 0, 0);
+    dma_consts(0);
+    if (nchunk > 1) dma_consts(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     stage_begin(0);
     if (a_xf) {
         bf16x8 pv[AIT][NP];
@@ -250,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             if (s + 1 < nstage) {
                 if (tap < 8) dma_B(c, tap + 1, (s + 1) & 1); else dma_B(c + 1, 0, (s + 1) & 1);
             }
+            if constexpr (tap == 7) { if (c + 2 < nchunk) dma_consts(c + 2); }
             bool iA = false;
             if constexpr (tap < AIT) {
                 iA = more && wave_has(tap);
@@ -265,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
                     af[ks][i] = *(const bf16x8*)(Afrag + ((tap / 3 + SR * i) * HW2 + tap % 3) * PITCH + ks * 32);
+                __builtin_amdgcn_sched_barrier(0);      // keep the two K halves in issue order: the first MFMAs wait for theirs only
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
 #pragma unroll
@@ -368,7 +387,7 @@ template <int TH, int TW, int BN, int BK, int MI, bool POOL>
 int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
     constexpr int DSLOTS = ((TH + 2) * (TW + 2) * 5 + 63) / 64 * 64;
-    const size_t lds = 2 * (size_t)DSLOTS * 16 + 2 * (size_t)(BK / 8) * BN * 16 + 2 * (size_t)(POOL ? 4 : 1) * 4096;
+    const size_t lds = 2 * (size_t)DSLOTS * 16 + 2 * (size_t)(BK / 8) * BN * 16 + 2 * (size_t)(POOL ? 4 : 1) * 4096 + 512;
     dim3 grid(a.N * ty * tx * nt), block(256);
     hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
