@@ -1,14 +1,17 @@
 // wgrad_halo_bf16.hip -- 3x3 weight gradient on the bf16 matrix cores with all nine taps per block:
 //
-//   dW[tap][ci][co] = sum_{pixels p} A[p + tap][ci] * dY[p][co]        (64 ci x 64 co per block)
+//   dW[tap][ci][co] = sum_q A[q][ci] * dY[q - (tap - center)][co]        (64 ci x 64 co per block)
 //
-// Per 4x16-pixel tile the block stages ONE 6x18-pixel input patch (BatchNorm affine + ReLU / concat /
-// zero padding applied in f32, rounded to bf16) and ONE dY tile in LDS, both pixel-major; the nine
-// taps are nine shifted views of the same patch.  Each wave owns a 32x32 (ci,co) quadrant with nine
-// accumulators (one per tap): per 16-pixel row it fetches one dY fragment and nine shifted A fragments
-// with the transposing LDS read (ds_read_b64_tr_b16) and issues nine MFMAs.  The block walks a range
-// of tiles (split-K over space) and writes one f32 slab already in the torch [Cout][Cin][3][3] layout,
-// summed in fixed order by a plain streaming reduce.
+// i.e. the taps are nine shifted views of the dY HALO patch, not of the activation: per 4x16-pixel tile the block
+// stages ONE plain activation tile (BatchNorm affine + ReLU / 2x2 max / concat applied in f32, rounded to bf16 --
+// 64 pixels to transform instead of a 108-pixel halo; the kernel is VALU-issue bound on exactly that arithmetic)
+// and ONE 6x18-pixel dY patch, which needs no arithmetic and is fetched by LDS-DMA (padding pixels read a zero
+// page).  Both are pixel-major with 192-byte rows (128 B of channels + 64 B pad: the 4 rows of a transposing
+// read fall on disjoint bank quarters and every fragment address is base + immediate).  Each wave owns a 32x32
+// (ci,co) quadrant with nine accumulators: per 16-pixel row one activation fragment and nine shifted dY fragments
+// (ds_read_b64_tr_b16), nine MFMAs.  Tiles are double-buffered: one barrier per tile.  The block walks a range of
+// tiles (split-K over space) and writes one f32 slab already in the torch [Cout][Cin][3][3] layout, summed in
+// fixed order by a plain streaming reduce.
 #include "common.h"
 #include "loader.h"
 
@@ -18,10 +21,17 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
 
 constexpr int TH = 4, TW = 16, HW2 = TW + 2, HP = (TH + 2) * HW2;   // 108 halo pixels
-constexpr int RB = 192;   // LDS row pitch: 64 channels x bf16 = 128 B + 64 B pad, so that the 4 rows of a
-                          // transposed read fall on disjoint bank quarters and every address is base + immediate
+constexpr int RB = 192;                          // LDS row pitch
+constexpr int SPP = RB / 16;                     // 16-byte slots per patch pixel (8 data + 4 pad)
+constexpr int DSLOTS = (HP * SPP + 63) / 64 * 64;
+constexpr int DIT = (DSLOTS + 255) / 256;        // dY DMA items per thread per tile
+constexpr int ATILE = TH * TW * RB, DTILE = DSLOTS * 16;
+
+__device__ __attribute__((aligned(16))) const unsigned g_zero16w[4] = {0u, 0u, 0u, 0u};
 
 // lane_base = per-lane byte offset ((8*(l>>5) + q) * RB + column bytes), k0 = first pixel row of the fragment
 __device__ __forceinline__ bf16x8 tr_frag(const char* lane_base, int k0) {
@@ -37,10 +47,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lane_base, int k0) {
 template <bool POOL>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs a, const int ntn, const int tiles_x,
                                                                  const int tiles_y, const int tiles_per) {
-    constexpr int AIT = (HP * 8 + 255) / 256;      // 16-byte (8-channel) items per thread for the A patch: 4
-    constexpr int BIT = (TH * TW * 8) / 256;       // ... and for the dY tile: 2
-    __shared__ __attribute__((aligned(16))) char As[HP * RB];
-    __shared__ __attribute__((aligned(16))) char Bs[TH * TW * RB];
+    constexpr int AIT = (TH * TW * 8) / 256;       // activation items (8 channels of one pixel) per thread per tile: 2
+    constexpr int NP = POOL ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                               // 2 x activation tile [64 px][RB]
+    char* Ds = smem + 2 * ATILE;                   // 2 x dY patch [108 px][RB] (+ slack to whole wave-instructions)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
@@ -50,95 +61,106 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
     const int tbeg = blockIdx.y * tiles_per;
     const int tend = min(ttotal, tbeg + tiles_per);
 
-    const int c8 = tid & 7;                         // 8-channel group of this thread (same for A and dY)
+    // ---- activation side: item i = pixel (tid + 256 i) >> 3 of the tile, channel group tid & 7 ----
+    const int c8 = tid & 7;
     const int cg = ci0 + 8 * c8;
     const bool second = (a.nsrc == 2 && cg >= a.src[0].C);
     const SrcDev S = pick_src(a.src[0], a.src[1], second);
     const int cl = cg - (second ? a.src[0].C : 0);
     const bool aff = S.scale != nullptr;
+    const bool xf = aff || S.relu || POOL;
     f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
     if (aff) {
         asc0 = *(const f32x4*)(S.scale + cl); asc1 = *(const f32x4*)(S.scale + cl + 4);
         ash0 = *(const f32x4*)(S.shift + cl); ash1 = *(const f32x4*)(S.shift + cl + 4);
     }
-    const __bf16* sp = (const __bf16*)S.ptr;
-    const __bf16* dyp = (const __bf16*)a.dy;
+    const __bf16* sp = (const __bf16*)S.ptr + cl;
+    const __bf16* zsrc = (const __bf16*)g_zero16w;
 
-    bf16x8 av[AIT], bv[BIT];
-    unsigned aok;
-    // patch coordinates of this thread's A items are tile-invariant: (hy << 8) | hx, hp >= HP -> 0xffff
-    int hyx[AIT];
+    // ---- dY side: DMA item i = LDS slot tid + 256 i of the patch image: pixel slot / 12, group slot % 12 (>= 8: pad).
+    // Tile-invariant: the relative element offset and the patch coordinates (hy << 8 | hx; 0xffff = no data) ----
+    int droff[DIT], dhyx[DIT];
 #pragma unroll
-    for (int i = 0; i < AIT; ++i) {
-        const int hp = (tid + 256 * i) >> 3;
-        hyx[i] = hp < HP ? (((hp / HW2) << 8) | (hp % HW2)) : 0xffff;
+    for (int i = 0; i < DIT; ++i) {
+        const int slot = tid + 256 * i, hp = slot / SPP, g = slot - hp * SPP;
+        const int hy = hp / HW2, hx = hp - hy * HW2;
+        const bool v = hp < HP && g < 8;
+        droff[i] = v ? (hy * a.dyW + hx) * a.Cout + 8 * g : 0;
+        dhyx[i] = v ? ((hy << 8) | hx) : 0xffff;
     }
+    const __bf16* dyp = (const __bf16*)a.dy + co0;
+
+    bf16x8 av[AIT][NP];
+    unsigned aok = 0;
     auto act8 = [&](bf16x8 r, f32x4& lo, f32x4& hi) {
         lo = (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * asc0 + ash0;
         hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
         if (S.relu) { lo = relu4(lo); hi = relu4(hi); }
     };
-    auto pack8 = [](f32x4 lo, f32x4 hi) {
-        bf16x8 h;
-        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
-        return h;
-    };
-    auto zero8 = []() { bf16x8 h; for (int q = 0; q < 8; ++q) h[q] = (__bf16)0.f; return h; };
-
-    auto load_tile = [&](int t) {
-        const int img = t / (tiles_y * tiles_x);
+    auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
+        img = t / (tiles_y * tiles_x);
         const int rem = t - img * tiles_y * tiles_x;
-        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
-        aok = 0;
-        const int by = y0 - 1 - S.off_y, bx = x0 - 1 - S.off_x;
-        const long base = img * S.sN + cl;
+        y0 = (rem / tiles_x) * TH; x0 = (rem % tiles_x) * TW;
+    };
+    // top of a stage: the whole next dY patch by DMA, the next activation items into registers
+    auto fetch_tile = [&](int t, char* Dbuf) {
+        int img, y0, x0;
+        tile_origin(t, img, y0, x0);
+        const __bf16* dbase = dyp + (((long)img * a.dyH + (y0 - 1)) * a.dyW + (x0 - 1)) * a.Cout;
 #pragma unroll
-        for (int i = 0; i < AIT; ++i) {
-            av[i] = zero8();
-            const int ly = by + (hyx[i] >> 8), lx = bx + (hyx[i] & 0xff);
-            if (hyx[i] != 0xffff && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW) {
-                aok |= 1u << i;
-                if (POOL) {          // 2x2 max of the activated source, evaluated right here (no raw prefetch)
-                    const long p = base + (long)(2 * ly) * S.sH + (long)(2 * lx) * S.sW;
-                    f32x4 lo, hi, l2, h2;
-                    act8(*(const bf16x8*)(sp + p), lo, hi);
-                    act8(*(const bf16x8*)(sp + p + S.sW), l2, h2); lo = max4(lo, l2); hi = max4(hi, h2);
-                    act8(*(const bf16x8*)(sp + p + S.sH), l2, h2); lo = max4(lo, l2); hi = max4(hi, h2);
-                    act8(*(const bf16x8*)(sp + p + S.sH + S.sW), l2, h2); lo = max4(lo, l2); hi = max4(hi, h2);
-                    av[i] = pack8(lo, hi);
-                } else {
-                    av[i] = *(const bf16x8*)(sp + base + (long)ly * S.sH + (long)lx * S.sW);
-                }
+        for (int i = 0; i < DIT; ++i) {
+            if (256 * i + wave * 64 < DSLOTS) {                // wave-uniform
+                const int ly = y0 - 1 + (dhyx[i] >> 8), lx = x0 - 1 + (dhyx[i] & 0xff);
+                const bool ok = dhyx[i] != 0xffff && ly >= 0 && ly < a.dyH && lx >= 0 && lx < a.dyW;
+                const __bf16* src = ok ? dbase + droff[i] : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Dbuf + (256 * i + wave * 64) * 16), 16, 0, 0);
             }
         }
+        aok = 0;
+        const long sbase = img * S.sN;
 #pragma unroll
-        for (int i = 0; i < BIT; ++i) {
-            const int p = (tid + 256 * i) >> 3;              // 0..63 inside the tile
-            const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
-            bv[i] = zero8();
-            if (oy < a.dyH && ox < a.dyW)
-                bv[i] = *(const bf16x8*)(dyp + (((long)img * a.dyH + oy) * a.dyW + ox) * a.Cout + co0 + 8 * c8);
+        for (int i = 0; i < AIT; ++i) {
+            const int px = (tid + 256 * i) >> 3;
+            const int ly = y0 + (px >> 4) - S.off_y, lx = x0 + (px & 15) - S.off_x;
+            if (ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW) {
+                aok |= 1u << i;
+                if (POOL) {
+                    const long p = sbase + (long)(2 * ly) * S.sH + (long)(2 * lx) * S.sW;
+                    av[i][0] = *(const bf16x8*)(sp + p);
+                    av[i][1 % NP] = *(const bf16x8*)(sp + p + S.sW);
+                    av[i][2 % NP] = *(const bf16x8*)(sp + p + S.sH);
+                    av[i][3 % NP] = *(const bf16x8*)(sp + p + S.sH + S.sW);
+                } else {
+                    av[i][0] = *(const bf16x8*)(sp + sbase + (long)ly * S.sH + (long)lx * S.sW);
+                }
+            }
         }
     };
-    auto write_tile = [&]() {
+    // bottom of a stage: activate the fetched items and park them in the other tile buffer
+    auto write_tile = [&](char* Abuf) {
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            const int hp = (tid + 256 * i) >> 3;
-            if (hp < HP) {
-                bf16x8 h = av[i];
-                if (!POOL && aff && ((aok >> i) & 1u)) {     // (out-of-image items stay zero: padding is applied after the activation)
-                    f32x4 lo, hi;
-                    act8(av[i], lo, hi);
-                    h = pack8(lo, hi);
-                }
-                *(bf16x8*)(As + hp * RB + c8 * 16) = h;
-            }
-        }
+            const int px = (tid + 256 * i) >> 3;
+            bf16x8 h;
 #pragma unroll
-        for (int i = 0; i < BIT; ++i) {
-            const int p = (tid + 256 * i) >> 3;
-            *(bf16x8*)(Bs + p * RB + c8 * 16) = bv[i];
+            for (int q = 0; q < 8; ++q) h[q] = (__bf16)0.f;
+            if ((aok >> i) & 1u) {                   // outside the source: zero (padding is applied after the activation)
+                if (xf) {
+                    f32x4 lo, hi;
+                    act8(av[i][0], lo, hi);
+#pragma unroll
+                    for (int q = 1; q < NP; ++q) {
+                        f32x4 l2, h2;
+                        act8(av[i][q], l2, h2);
+                        lo = max4(lo, l2); hi = max4(hi, h2);
+                    }
+                    h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+                    h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+                } else {
+                    h = av[i][0];
+                }
+            }
+            *(bf16x8*)(Abuf + px * RB + c8 * 16) = h;
         }
     };
 
@@ -150,24 +172,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
 
     // per-lane fragment bases: rows 8*(l>>5) + q, columns quadrant + 16*((l>>4)&1) + 4p
     const int lrow = 8 * (lane >> 5) + ((lane & 15) >> 2), lcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    const char* Abase = As + lrow * RB + (wi * 32 + lcol) * 2;
-    const char* Bbase = Bs + lrow * RB + (wj * 32 + lcol) * 2;
+    const int afrag = lrow * RB + (wi * 32 + lcol) * 2;
+    const int dfrag = lrow * RB + (wj * 32 + lcol) * 2;
 
-    if (tbeg < tend) load_tile(tbeg);
+    if (tbeg < tend) {
+        fetch_tile(tbeg, Ds);
+        write_tile(As);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
     for (int t = tbeg; t < tend; ++t) {
-        write_tile();
-        __syncthreads();
-        if (t + 1 < tend) load_tile(t + 1);
+        const bool more = t + 1 < tend;
+        if (more) fetch_tile(t + 1, Ds + (buf ^ 1) * DTILE);
+        const char* Ab = As + buf * ATILE + afrag;
+        const char* Db = Ds + buf * DTILE + dfrag;
+        // every dY fragment (patch row pr, column shift kw) feeds up to three taps: load it once, use it at once
+        bf16x8 af[TH];
 #pragma unroll
-        for (int r = 0; r < TH; ++r) {
-            const bf16x8 b = tr_frag(Bbase, r * TW);
+        for (int r = 0; r < TH; ++r) af[r] = tr_frag(Ab, r * TW);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {       // tap (kh,kw) reads the patch at (+kh-1, +kw-1): constant offsets
-                const bf16x8 af = tr_frag(Abase, (r + tap / 3) * HW2 + tap % 3);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, af, acc[tap], 0, 0, 0);   // D[co][ci]
+        for (int pr = 0; pr < TH + 2; ++pr) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const bf16x8 b = tr_frag(Db, pr * HW2 + 2 - kw);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {      // tap (kh,kw) pairs pixel row r with dY row r + 2 - kh of the patch
+                    const int r = pr + kh - 2;
+                    if (r >= 0 && r < TH)
+                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                }
             }
         }
+        if (more) write_tile(As + (buf ^ 1) * ATILE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        buf ^= 1;
     }
 
     // slab in the torch weight layout [Cout][Cin][3][3]: rows of D are co, lanes are ci, and a lane
@@ -199,7 +240,9 @@ bool wgrad_halo_supported(const WgradArgs& a) {
 int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
     const int ttotal = a.N * cdiv(a.Hb, TH) * cdiv(a.Wb, TW);
     const long pairs = (long)(a.Cin / 64) * (a.Cout / 64);
-    long ks = (1024 + pairs - 1) / pairs;          // whole waves of 512 resident blocks (2 per CU)
+    // one resident wave of blocks (2 per CU): every extra block costs a 147 KB f32 slab written and read back --
+    // at 1024 blocks the slab traffic exceeded the layer's own input bytes (measured 527 -> 641 TFLOP/s at 512)
+    long ks = (512 + pairs - 1) / pairs;
     if (ks > ttotal / 4) ks = ttotal / 4;          // at least four tiles per block
     if (ks < 1) ks = 1;
     const int per = cdiv(ttotal, ks);
@@ -210,9 +253,9 @@ int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
 int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t st) {
     dim3 grid((a.Cin / 64) * (a.Cout / 64), ksplit), block(256);
     if (a.src[0].pool)
-        hipLaunchKernelGGL(wgrad_halo_bf16_kernel<true>, grid, block, 0, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
+        hipLaunchKernelGGL(wgrad_halo_bf16_kernel<true>, grid, block, 2 * ATILE + 2 * DTILE, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
     else
-        hipLaunchKernelGGL(wgrad_halo_bf16_kernel<false>, grid, block, 0, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
+        hipLaunchKernelGGL(wgrad_halo_bf16_kernel<false>, grid, block, 2 * ATILE + 2 * DTILE, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
     USTRUN_LAUNCH_CHECK("wgrad_halo_bf16");
     return 0;
 }
