@@ -38,14 +38,14 @@ template <int V> using ic = std::integral_constant<int, V>;
 //     are unrolled, the input-gradient walks the weight slices backwards instead of mirroring the geometry;
 //   * the patch pixel, bounds test and source offset of every staging item are tile constants computed once per
 //     source, not once per stage.
-// Pipeline (one stage = one tap of one K chunk, 2*MI*BK/16 MFMAs per wave, one barrier):
-//   top    : LDS-DMA of the next stage's weight tile (two tile buffers); LDS-DMA of one item (8 channels of one
-//            patch pixel per thread) of the NEXT chunk's patch -- straight into the other patch buffer when the
+// Pipeline (one stage = NT taps of one K chunk, NT*2*MI*BK/16 MFMAs per wave, one barrier):
+//   top    : LDS-DMA of the next stage's NT weight tiles (two buffers of NT tiles); LDS-DMA of BATCH items (8 channels
+//            of one patch pixel per thread) of the NEXT chunk's patch -- straight into the other patch buffer when the
 //            source needs no arithmetic (dY, ConvTranspose outputs), else into a private raw slot
-//   middle : all fragment reads, then the MFMAs of this tap
-//   bottom : counted s_waitcnt: the weight tile and the raw item fetched one stage ago have landed; that raw item
-//            gets its BatchNorm affine + ReLU (+2x2 max) in f32 and is written to the other patch buffer; barrier.
-template <int TH, int TW, int BN, int BK, int MI, bool POOL>
+//   middle : all fragment reads, then the MFMAs of the stage's taps (>= 512 MFMA cycles: longer than an L2-hit DMA)
+//   bottom : s_waitcnt vmcnt(0): this top's transfers have landed; the raw items get their BatchNorm affine + ReLU
+//            (+2x2 max) in f32 and are written to the other patch buffer; barrier.
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
     static_assert(BK == 32, "80-byte patch rows hold one 32-channel chunk");
@@ -58,19 +58,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     constexpr int DSLOTS = (HP * 5 + 63) / 64 * 64;   // direct staging: 16-byte LDS slots incl. the pad slots, whole waves
     constexpr int XSLOTS = (HP * 4 + 63) / 64 * 64;   // transform staging: (pixel, channel group) items, whole waves
     constexpr int AIT = (DSLOTS + 255) / 256;   // staging steps per chunk (taps 0 .. AIT-1), one item per thread each
-    static_assert(AIT <= 7, "the next patch must be complete one stage before the chunk ends; tap 7 carries the constants");
+    constexpr int NSTG = (9 + NT - 1) / NT;     // stages per chunk: NT taps (weight tiles) per barrier
+    constexpr int BATCH = (AIT + NSTG - 2) / (NSTG - 1);   // patch items per stage; the chunk's last stage carries the constants
+    static_assert(BATCH * (NSTG - 1) >= AIT, "staging fits the chunk");
     constexpr int NP = POOL ? 4 : 1;
     constexpr int ABYTES = DSLOTS * 16;
     constexpr int BCH = (BK / 8) * BN;          // 16-byte chunks per B tile
     constexpr int BIT = BCH / 256;
     static_assert(BCH % 256 == 0, "B tile must be a whole number of wave-instructions per wave");
-    constexpr int RAWB = NP * 4096;             // one raw slot: NP x 16 B per thread
+    constexpr int RAWB = BATCH * NP * 4096;     // the raw slot: BATCH x NP x 16 B per thread
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                            // 2 x patch [HP][80 B] (current / being staged)
-    char* Bs = smem + 2 * ABYTES;               // 2 x [BK/8][BN][8] bf16
-    char* Raw = Bs + 2 * (BCH * 16);            // 2 x raw slot
-    char* Cst = Raw + 2 * RAWB;                 // 2 x {32 scales, 32 shifts} f32 of a chunk (kept out of vmcnt's way)
+    char* Bs = smem + 2 * ABYTES;               // 2 x NT x [BK/8][BN][8] bf16
+    char* Raw = Bs + 2 * NT * (BCH * 16);       // raw slot
+    char* Cst = Raw + RAWB;                 // 2 x {32 scales, 32 shifts} f32 of a chunk (kept out of vmcnt's way)
 
     const int mt_total = a.N * tiles_y * tiles_x;
     const int ntiles = mt_total * nt_total;
@@ -153,14 +155,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     };
     // does this wave own a slot of staging step i?  (wave-uniform: the counted waits depend on it)
     auto wave_has = [&](int i) { return 256 * i + wave * 64 < (a_xf ? XSLOTS : DSLOTS); };
-    auto issue_A = [&](auto ic_i, char* Adst, char* rawslot) {
-        constexpr int i = decltype(ic_i)::value;
-        const __bf16* src = ((aokm >> i) & 1u) ? aptr + aoff[i] : zsrc;
+    // item i of the chunk, b-th item of its stage (both fold to constants: the callers are fully unrolled)
+    auto issue_one = [&](int i, int b, char* Adst) {
+        const bool ok = (aokm >> i) & 1u;
+        const __bf16* src = ok ? aptr + aoff[i] : zsrc;
         if (a_xf) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const long d = ((aokm >> i) & 1u) ? (q & 1 ? dq1 : 0) + (q & 2 ? dq2 : 0) : 0;
-                __builtin_amdgcn_global_load_lds((gptr_t*)(src + d), (lptr_t*)(rawslot + (q * 256 + wave * 64) * 16), 16, 0, 0);
+                const long d = ok ? (q & 1 ? dq1 : 0) + (q & 2 ? dq2 : 0) : 0;
+                __builtin_amdgcn_global_load_lds((gptr_t*)(src + d), (lptr_t*)(Raw + ((b * NP + q) * 256 + wave * 64) * 16), 16, 0, 0);
             }
         } else {
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Adst + (256 * i + wave * 64) * 16), 16, 0, 0);
@@ -190,11 +193,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         return h;
     };
     const int xw0 = (tid >> 2) * PITCH + p8 * 16;         // transform item i lands at xw0 + i * 64 * PITCH
-    auto transform_A = [&](auto ic_i, char* Adst, const char* rawslot) {
-        constexpr int i = decltype(ic_i)::value;
+    auto transform_one = [&](int i, int b, char* Adst) {
         bf16x8 r[NP];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) r[q] = *(const bf16x8*)(rawslot + (q * 256 + tid) * 16);
+        for (int q = 0; q < NP; ++q) r[q] = *(const bf16x8*)(Raw + ((b * NP + q) * 256 + tid) * 16);
         if ((tid >> 2) + 64 * i < HP) *(bf16x8*)(Adst + xw0 + i * 64 * PITCH) = xform8(r, (aokm >> i) & 1u);
     };
     // ---- B tile of (chunk c, geometric tap): LDS-DMA, 16 B per lane, lane-linear destination ----
@@ -204,10 +206,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         const int idx = tid + 256 * i, o = idx / BN, n = idx % BN;
         wthr[i] = Wp + ((long)o * a.Cout + n0 + n) * 8;
     }
-    auto dma_B = [&](int c, int tap, int buf) {
+    auto dma_B = [&](int c, int tap, int slot) {      // slot = tile index inside Bs
         const int wt = wflip ? 8 - tap : tap;
         const long woff = ((long)wt * K8 + c * (BK / 8)) * a.Cout * 8;
-        char* dst = Bs + buf * (BCH * 16);
+        char* dst = Bs + slot * (BCH * 16);
 #pragma unroll
         for (int i = 0; i < BIT; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t*)(wthr[i] + woff), (lptr_t*)(dst + (wave * 64 + 256 * i) * 16), 16, 0, 0);
@@ -224,10 +226,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     // this lane's fragment bases: patch pixel of sub-tile 0 at tap (0,0), K half lh; weight column wn*64 + l31
     const int afrag0 = ((wm * SR * MI + (TW == 16 ? (l31 >> 4) : 0)) * HW2 + (l31 & (TW - 1))) * PITCH + lh * 16;
     const int bfrag0 = (lh * BN + wn * 64 + l31) * 16;
-    const int nstage = nchunk * 9;
+    const int nstage = nchunk * NSTG;
 
-    // ---- prologue: weight tile 0 and the whole first patch, all transfers in flight together ----
-    dma_B(0, 0, 0);
+    // ---- prologue: the first stage's weight tiles and the whole first patch, all transfers in flight together ----
+#pragma unroll
+    for (int k = 0; k < NT; ++k) dma_B(0, k, k);
     dma_consts(0);
     if (nchunk > 1) dma_consts(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -246,12 +249,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         for (int i = 0; i < AIT; ++i)
             if ((tid >> 2) + 64 * i < HP) *(bf16x8*)(As + xw0 + i * 64 * PITCH) = xform8(pv[i], (aokm >> i) & 1u);
     } else {
-        auto go = [&](auto ic_i) { if (wave_has(decltype(ic_i)::value)) issue_A(ic_i, As, Raw); };
-        go(ic<0>{}); go(ic<1>{}); go(ic<2>{}); go(ic<3>{});
-        if constexpr (AIT > 4) go(ic<4>{});
-        if constexpr (AIT > 5) go(ic<5>{});
-        if constexpr (AIT > 6) go(ic<6>{});
-        if constexpr (AIT > 7) go(ic<7>{});
+#pragma unroll
+        for (int i = 0; i < AIT; ++i)
+            if (wave_has(i)) issue_one(i, 0, As);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -261,52 +261,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         char* Anext = As + ((c + 1) & 1) * ABYTES;
         const bool more = c + 1 < nchunk;
         if (more) stage_begin(c + 1);
-        auto stage = [&](auto ic_tap) {
-            constexpr int tap = decltype(ic_tap)::value;
-            const int s = c * 9 + tap;
+        auto stage = [&](auto ic_j) {
+            constexpr int j = decltype(ic_j)::value;          // stage of the chunk: taps j*NT .. j*NT + nt - 1
+            constexpr int t0 = j * NT, nt = (9 - t0 < NT) ? 9 - t0 : NT;
+            constexpr int jn = (j + 1) % NSTG, tn0 = jn * NT, nn = (9 - tn0 < NT) ? 9 - tn0 : NT;
+            const int s = c * NSTG + j;
             // top: next stage's weights, one item of the next patch
             if (s + 1 < nstage) {
-                if (tap < 8) dma_B(c, tap + 1, (s + 1) & 1); else dma_B(c + 1, 0, (s + 1) & 1);
+#pragma unroll
+                for (int k = 0; k < nn; ++k) dma_B(jn == 0 ? c + 1 : c, tn0 + k, ((s + 1) & 1) * NT + k);
             }
-            if constexpr (tap == 7) { if (c + 2 < nchunk) dma_consts(c + 2); }
-            bool iA = false;
-            if constexpr (tap < AIT) {
-                iA = more && wave_has(tap);
-                if (iA) issue_A(ic<tap>{}, Anext, Raw + (tap & 1) * RAWB);
-            }
-            // middle: every fragment is base + immediate
-            const char* Bp = Bs + (s & 1) * (BCH * 16) + bfrag0;
-            bf16x8 bf[BK / 16][2], af[BK / 16][MI];
+            if constexpr (j == NSTG - 1) { if (c + 2 < nchunk) dma_consts(c + 2); }
+            if constexpr (j < NSTG - 1) {
+                if (more) {
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                bf[ks][0] = *(const bf16x8*)(Bp + (2 * ks * BN) * 16);
-                bf[ks][1] = *(const bf16x8*)(Bp + (2 * ks * BN + 32) * 16);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    af[ks][i] = *(const bf16x8*)(Afrag + ((tap / 3 + SR * i) * HW2 + tap % 3) * PITCH + ks * 32);
-                __builtin_amdgcn_sched_barrier(0);      // keep the two K halves in issue order: the first MFMAs wait for theirs only
-            }
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][0], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][1], acc[i][1], 0, 0, 0);
+                    for (int b = 0; b < BATCH; ++b) {
+                        constexpr int dummy = 0; (void)dummy;
+                        if (j * BATCH + b < AIT && wave_has(j * BATCH + b)) issue_one(j * BATCH + b, b, Anext);
+                    }
                 }
             }
-            // bottom: all but this top's patch item has landed (the weight tile was issued before it)
-            if (iA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if constexpr (tap >= 1 && tap <= AIT) {
-                if (more && a_xf && 256 * (tap - 1) + wave * 64 < XSLOTS)
-                    transform_A(ic<tap - 1>{}, Anext, Raw + ((tap - 1) & 1) * RAWB);
+            // middle: every fragment is base + immediate
+            const char* Bp = Bs + (s & 1) * NT * (BCH * 16) + bfrag0;
+            bf16x8 bf[NT][BK / 16][2], af[NT][BK / 16][MI];
+#pragma unroll
+            for (int k = 0; k < nt; ++k) {
+                constexpr int dummy = 0; (void)dummy;
+                const int tap = t0 + k;
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks) {
+                    bf[k][ks][0] = *(const bf16x8*)(Bp + k * (BCH * 16) + (2 * ks * BN) * 16);
+                    bf[k][ks][1] = *(const bf16x8*)(Bp + k * (BCH * 16) + (2 * ks * BN + 32) * 16);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        af[k][ks][i] = *(const bf16x8*)(Afrag + ((tap / 3 + SR * i) * HW2 + tap % 3) * PITCH + ks * 32);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < nt; ++k)
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][ks][i], bf[k][ks][0], acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][ks][i], bf[k][ks][1], acc[i][1], 0, 0, 0);
+                    }
+            // bottom: this top's transfers have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (j < NSTG - 1) {
+                if (more && a_xf) {
+#pragma unroll
+                    for (int b = 0; b < BATCH; ++b)
+                        if (j * BATCH + b < AIT && 256 * (j * BATCH + b) + wave * 64 < XSLOTS) transform_one(j * BATCH + b, b, Anext);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };
         stage(ic<0>{}); stage(ic<1>{}); stage(ic<2>{}); stage(ic<3>{}); stage(ic<4>{});
-        stage(ic<5>{}); stage(ic<6>{}); stage(ic<7>{}); stage(ic<8>{});
+        if constexpr (NSTG > 5) { stage(ic<5>{}); stage(ic<6>{}); stage(ic<7>{}); stage(ic<8>{}); }
     }
 
     // ---- epilogue: bf16 outputs (NHWC), optional two-destination split, BN-statistics partials.
@@ -383,13 +398,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     }
 }
 
-template <int TH, int TW, int BN, int BK, int MI, bool POOL>
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT = 1>
 int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
     constexpr int DSLOTS = ((TH + 2) * (TW + 2) * 5 + 63) / 64 * 64;
-    const size_t lds = 2 * (size_t)DSLOTS * 16 + 2 * (size_t)(BK / 8) * BN * 16 + 2 * (size_t)(POOL ? 4 : 1) * 4096 + 512;
+    constexpr int AIT = (DSLOTS + 255) / 256, NSTG = (9 + NT - 1) / NT, BATCH = (AIT + NSTG - 2) / (NSTG - 1);
+    const size_t lds = 2 * (size_t)DSLOTS * 16 + 2 * NT * (size_t)(BK / 8) * BN * 16 + (size_t)BATCH * (POOL ? 4 : 1) * 4096 + 512;
     dim3 grid(a.N * ty * tx * nt), block(256);
-    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL>), grid, block, lds, st, a, tx, ty, nt);
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;
 }
@@ -438,13 +454,17 @@ int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     bool pool = false;
     for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
     const bool wide = a.Wb >= 32;                 // 32-pixel rows: conflict-free A fragment reads
-    if (pool) return launch_cfg<8, 16, 128, 32, 2, true>(a, st);
+    static const int nt_dbg = getenv("USTRUN_HALO_NT") ? atoi(getenv("USTRUN_HALO_NT")) : 0;   // tuning aid: 1 = one tap per stage everywhere
+    const bool pair = nt_dbg != 1;
+    // MI = 2 tiles run two taps per barrier (16 MFMAs per wave and stage, like the MI = 4 tiles)
+    if (pool) return pair ? launch_cfg<8, 16, 128, 32, 2, true, 2>(a, st) : launch_cfg<8, 16, 128, 32, 2, true, 1>(a, st);
     if (a.Cout % 128 == 0) {
         if (halo_tall_tile(a))                    // 256 px x 128 ch per block, wave tile 128 px x 64 ch
             return wide ? launch_cfg<8, 32, 128, 32, 4, false>(a, st) : launch_cfg<16, 16, 128, 32, 4, false>(a, st);
-        return launch_cfg<8, 16, 128, 32, 2, false>(a, st);
+        return pair ? launch_cfg<8, 16, 128, 32, 2, false, 2>(a, st) : launch_cfg<8, 16, 128, 32, 2, false, 1>(a, st);
     }
-    return wide ? launch_cfg<8, 32, 64, 32, 2, false>(a, st) : launch_cfg<16, 16, 64, 32, 2, false>(a, st);
+    if (wide) return pair ? launch_cfg<8, 32, 64, 32, 2, false, 2>(a, st) : launch_cfg<8, 32, 64, 32, 2, false, 1>(a, st);
+    return pair ? launch_cfg<16, 16, 64, 32, 2, false, 2>(a, st) : launch_cfg<16, 16, 64, 32, 2, false, 1>(a, st);
 }
 
 }  // namespace ustrun
