@@ -299,7 +299,8 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     for (int i = 0; i < a.nsrc; ++i) in_elems += (double)a.N * a.src[i].H * a.src[i].W * a.src[i].C;
     const double out_elems = (double)a.M * a.nz * a.Cout;
     const double w_elems = (double)a.nseg * a.nz * a.Cin * a.Cout;
-    prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, 4.0 * (in_elems + out_elems + w_elems), st);
+    const double aesz = dtype == USTRUN_BF16 ? 2.0 : 4.0;     // stored element size of activations and packed weights
+    prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, aesz * (in_elems + out_elems + w_elems), st);
     int rc;
     if (dtype == USTRUN_BF16) {
         if (halo_supported(a)) rc = conv3x3_halo_launch_bf16(a, st);
