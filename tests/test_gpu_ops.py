@@ -290,6 +290,30 @@ def test_conv3x3_bf16_mfma(n, ci, co, h, w, exact):
     assert rel(dw.cpu(), wr.grad) < tol
 
 
+@pytest.mark.parametrize("n,c,h,w", [(2, 3, 16, 32), (1, 1, 19, 37), (2, 4, 9, 70), (3, 3, 40, 33)])
+def test_conv_first_bf16_mfma_exact(n, c, h, w):
+    """First convolution (NCHW f32 network input, C <= 4 -> 64) on the bf16 matrix cores as an im2col GEMM:
+    small-integer data is exact in bf16, so a slip in the k -> (channel, tap) gather or the ragged-tile masks
+    shows as an O(1) error; BatchNorm-statistics partials must be the sums of the stored outputs."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(11 * c + h)
+    x = torch.randint(-3, 4, (n, c, h, w), generator=g).float()
+    wt = torch.randint(-2, 3, (64, c, 3, 3), generator=g).float()
+    y_ref = F.conv2d(x, wt, None, 1, 1)
+    wf, _ = pack_conv_bf16(wt)
+    xg = x.contiguous().cuda()
+    src = l.nchw_src(xg.data_ptr(), c, h, w)
+    y = torch.empty(n, h, w, 64, device="cuda", dtype=torch.bfloat16)
+    rows = lib.ustrun_conv_mtiles(n, h, w, 64)
+    stat = torch.full((rows, 2, 64), 7.0, device="cuda")
+    l.check(lib.ustrun_conv3x3_fwd(C.byref(src), 1, wf.data_ptr(), n, h, w, 64, y.data_ptr(), stat.data_ptr(), 1, None))
+    yc = from_nhwc(y.float())
+    assert rel(yc, r16(y_ref)) < 1e-6
+    np.testing.assert_allclose(stat[:, 0].sum(0).cpu().numpy(), yc.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(stat[:, 1].sum(0).cpu().numpy(), (yc * yc).sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-2)
+
+
 @pytest.mark.parametrize("n,ci,co,h,w", [(2, 128, 64, 5, 7), (3, 256, 128, 12, 10), (1, 64, 64, 3, 50), (4, 256, 128, 128, 128),
                                          (2, 40, 24, 6, 5)])
 def test_convT2x2_bf16_mfma_exact(n, ci, co, h, w):

@@ -133,7 +133,7 @@ void prof_end(hipStream_t st);
 
 // first convolution (C <= 4 input channels, 64 outputs): conv_first.hip
 bool conv_first_supported(const ustrun_src_t& s, int Cout);
-int conv_first_stat_rows(int N, int H, int W);
+int conv_first_stat_rows(int N, int H, int W, int dtype);
 int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, void* y, float* stat, hipStream_t st);
 int64_t conv_first_wgrad_partials_bytes();
 int conv_first_wgrad(const ustrun_src_t& s, const void* dy, int dy_esz, int N, float* dw, int accumulate, float* partials,

@@ -96,6 +96,124 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
     }
 }
 
+// ---- forward on the bf16 matrix cores (dtype = bf16) ---------------------------------------------
+// The f32 stencil above is VALU-bound (27*64 FMAs per pixel: 134 us at N=16, 256^2) while the layer only has to
+// write 134 MB.  As an im2col GEMM [pixels x 9C] x [9C x 64] with K padded to 16*KS it is a handful of MFMAs:
+// 8x32-pixel tile per block, the (10 x 34 x C) f32 patch in LDS, every lane gathers the 8 K-values of its pixel
+// with ds_read_b32 at per-lane constant offsets (k -> (c, tap)) and rounds them to bf16; the weight fragments are
+// block constants kept in registers.  Epilogue as in conv_halo_bf16.hip: per-wave LDS transpose, 16-byte stores,
+// BatchNorm-statistics partials of the stored values (one row per block).
+constexpr int MTH = 8, MTW = 32, MHW = MTW + 2, MHP = (MTH + 2) * MHW;   // 10 x 34 patch
+
+template <int KS>
+__global__ __launch_bounds__(256, 4) void conv_first_fwd_mfma_kernel(const float* __restrict__ x, long sN, long sC, long sH, long sW,
+                                                                    int C, int H, int W, const __bf16* __restrict__ w,
+                                                                    __bf16* __restrict__ y, float* __restrict__ stat,
+                                                                    int tiles_x, int tiles_y) {
+    constexpr int EPITCH = 144;
+    __shared__ float patch[CMAX * MHP + 4];                 // [c][10][34]; the last word stays zero (K padding)
+    __shared__ __attribute__((aligned(16))) __bf16 Bw[KS * 2][64][8];
+    __shared__ __attribute__((aligned(16))) char eps[4 * 32 * EPITCH];
+    __shared__ float red[4][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int img = blockIdx.x / (tiles_y * tiles_x);
+    const int rem = blockIdx.x - img * tiles_y * tiles_x;
+    const int y0 = (rem / tiles_x) * MTH, x0 = (rem % tiles_x) * MTW;
+    const int K = 9 * C;
+    for (int t = tid; t < C * MHP; t += 256) {
+        const int c = t / MHP, hp = t - c * MHP;
+        const int iy = y0 + hp / MHW - 1, ix = x0 + hp % MHW - 1;
+        patch[t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[img * sN + c * sC + iy * sH + ix * sW] : 0.f;
+    }
+    if (tid < 4) patch[CMAX * MHP + tid] = 0.f;
+    for (int t = tid; t < KS * 2 * 64 * 8; t += 256) {       // k = c*9 + tap; packed forward weights are [tap][1][64][8 (c)]
+        const int j = t & 7, co = (t >> 3) & 63, k8 = t >> 9, k = k8 * 8 + j;
+        const int c = k / 9, tap = k - c * 9;
+        Bw[k8][co][j] = k < K ? w[((long)tap * 64 + co) * 8 + c] : (__bf16)0.f;
+    }
+    // this lane's K entries: k = 16 ks + 8 lh + j -> patch offset relative to the pixel's (0,0) tap
+    int koff[KS][8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * lh + j, c = k / 9, tap = k - c * 9;
+            koff[ks][j] = k < K ? c * MHP + (tap / 3) * MHW + tap % 3 : -1;
+        }
+    __syncthreads();
+    bf16x8 bfr[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        bfr[ks][0] = *(const bf16x8*)&Bw[2 * ks + lh][l31][0];
+        bfr[ks][1] = *(const bf16x8*)&Bw[2 * ks + lh][32 + l31][0];
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                            // wave owns tile rows 2*wave + i, 32 pixels each
+        const int base = (2 * wave + i) * MHW + l31;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 af;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) af[j] = (__bf16)patch[koff[ks][j] >= 0 ? base + koff[ks][j] : CMAX * MHP];
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[ks][0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[ks][1], acc[i][1], 0, 0, 0);
+        }
+    }
+    // epilogue
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    char* ep = eps + wave * (32 * EPITCH);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int oy = y0 + 2 * wave + i;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const __bf16 hv = (__bf16)acc[i][n][r];
+                *(__bf16*)(ep + row * EPITCH + (n * 32 + l31) * 2) = hv;
+                if (oy < H && x0 + row < W) {
+                    const float v = (float)hv;                 // statistics see the stored value
+                    s1[n] += v; s2[n] += v * v;
+                }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = lane + 64 * t, row = idx >> 3, ch = idx & 7;
+            const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
+            const int ox = x0 + row;
+            if (oy < H && ox < W) *(bf16x8*)(y + (((long)img * H + oy) * W + ox) * 64 + ch * 8) = v8;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (stat) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            s1[n] += __shfl_xor(s1[n], 32);
+            s2[n] += __shfl_xor(s2[n], 32);
+            if (lh == 0) { red[wave][0][n * 32 + l31] = s1[n]; red[wave][1][n * 32 + l31] = s2[n]; }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int q = tid >> 6, c = tid & 63;
+            stat[((long)blockIdx.x * 2 + q) * 64 + c] = red[0][q][c] + red[1][q][c] + red[2][q][c] + red[3][q][c];
+        }
+    }
+}
+
 // ---- weight gradient -----------------------------------------------------------------------
 // block: a range of 8x16 tiles; wave w owns tile rows {2w, 2w+1}: D[32 im2col rows][64 co] per wave,
 // waves summed through LDS at the end, one slab per block: slab[(c*9 + t)][co] (rows >= 9C unused)
@@ -199,11 +317,23 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const floa
 bool conv_first_supported(const ustrun_src_t& s, int Cout) {
     return s.C <= CMAX && Cout == 64 && !s.pool && !s.scale && !s.relu && s.off_y == 0 && s.off_x == 0;
 }
-int conv_first_stat_rows(int N, int H, int W) { return N * cdiv(H, FTH) * cdiv(W, FTW); }
+int conv_first_stat_rows(int N, int H, int W, int dtype) {
+    return dtype == USTRUN_BF16 ? N * cdiv(H, MTH) * cdiv(W, MTW) : N * cdiv(H, FTH) * cdiv(W, FTW);
+}
 
 int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, void* y, float* stat, hipStream_t st) {
+    if (dtype == USTRUN_BF16) {            // im2col on the matrix cores
+        const int tx = cdiv(s.W, MTW), ty = cdiv(s.H, MTH), ks = cdiv(9 * s.C, 16);
+        dim3 grid(N * ty * tx), block(256);
+#define USTRUN_CF(KS) hipLaunchKernelGGL(conv_first_fwd_mfma_kernel<KS>, grid, block, 0, st, (const float*)s.ptr, (long)s.sN, \
+                                         (long)s.sC, (long)s.sH, (long)s.sW, s.C, s.H, s.W, (const __bf16*)w_fwd, (__bf16*)y, stat, tx, ty)
+        if (ks == 1) USTRUN_CF(1); else if (ks == 2) USTRUN_CF(2); else USTRUN_CF(3);
+#undef USTRUN_CF
+        USTRUN_LAUNCH_CHECK("conv_first_fwd_mfma");
+        return 0;
+    }
     const int tx = cdiv(s.W, FTW), ty = cdiv(s.H, FTH);
-    if (dtype == USTRUN_BF16)
+    if (false)
         hipLaunchKernelGGL(conv_first_fwd_kernel<2>, dim3(N * ty * tx), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
                            (long)s.sH, (long)s.sW, s.C, s.H, s.W, w_fwd, 1, (float*)y, stat, tx, ty);
     else

@@ -98,7 +98,7 @@ extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void
                        (srcs[0].f32 || dtype == USTRUN_F32);
     if (stat) {
         const int rows = ustrun_conv_mtiles(N, H, W, Cout);
-        if ((first ? conv_first_stat_rows(N, H, W) : igemm_stat_rows_used(a, dtype)) < rows) {
+        if ((first ? conv_first_stat_rows(N, H, W, dtype) : igemm_stat_rows_used(a, dtype)) < rows) {
             hipError_t e = hipMemsetAsync(stat, 0, (size_t)rows * 2 * Cout * sizeof(float), (hipStream_t)s);
             USTRUN_CHECK(e == hipSuccess, "conv3x3_fwd: memset failed: %s", hipGetErrorString(e));
         }
