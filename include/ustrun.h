@@ -68,6 +68,10 @@ int ustrun_pack_convT2x2(const float* w, int Cin, int Cout, void* w_fwd, void* w
 int ustrun_conv_mtiles(int N, int H, int W, int Cout);
 int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W,
                        int Cout, void* y, float* stat, int dtype, ustrun_stream_t s);
+/* Same launch, but reports in *stat_rows how many rows of stat it wrote (<= ustrun_conv_mtiles) instead of
+ * zero-filling the rest: pass that count to ustrun_bn_finalize and no memset is enqueued.            */
+int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W,
+                            int Cout, void* y, float* stat, int* stat_rows, int dtype, ustrun_stream_t s);
 
 /* ---- train-mode BatchNorm statistics: replaces nn.BatchNorm2d at unet_parts.py:17,20 -------
  * Reduces stat[mtiles][2][C] (fixed order, f64) to batch mean / biased variance, writes

@@ -53,6 +53,63 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     }
 }
 
+// bf16 feature map, C = 8*G channels with G a power of two: G lanes share a pixel, 16 bytes (8 channels) each, the
+// lane's scale/shift/weights live in registers for the whole launch, four pixels in flight per lane; after the
+// butterfly every lane of the group holds the logits and lane k stores class k.
+template <int K>
+__global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const __bf16* __restrict__ y, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, long npix, int HW, int C, int G,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ logits) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+    const int g = threadIdx.x % G, pl = threadIdx.x / G, PPB = 256 / G;
+    float sc[8], sh[8], wk[K][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = scale ? scale[8 * g + j] : 1.f;
+        sh[j] = scale ? shift[8 * g + j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) wk[k][j] = w[k * C + 8 * g + j];
+    }
+    const bool relu = scale != nullptr;
+    const float bk = g < K ? bias[g] : 0.f;
+    constexpr int U = 4;
+    for (long p0 = (long)blockIdx.x * PPB * U; p0 < npix; p0 += (long)gridDim.x * PPB * U) {
+        bf16x8 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long p = p0 + u * PPB + pl;
+            if (p < npix) v[u] = *(const bf16x8*)(y + p * C + 8 * g);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long p = p0 + u * PPB + pl;
+            float acc[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] = 0.f;
+            if (p < npix) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float a = (float)v[u][j] * sc[j] + sh[j];
+                    if (relu) a = fmaxf(a, 0.f);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) acc[k] += a * wk[k][j];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                for (int o = G >> 1; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+            if (g < K && p < npix) {
+                float out = acc[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) if (g == k) out = acc[k];
+                const long n = p / HW, hw = p - n * HW;
+                logits[(n * K + g) * HW + hw] = out + bk;
+            }
+        }
+    }
+}
+
 // da[p][c] = sum_k dl[k][p] w[k][c];  block partials of dW[k][c] = sum_p dl[k][p] a[p][c], db[k] = sum_p dl[k][p]
 // partials[block][K*C + K]
 template <int ESZ>
@@ -160,6 +217,18 @@ extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* s
     USTRUN_CHECK(y && w && bias && logits, "head_fwd: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_fwd: C=%d K=%d unsupported", C, K);
     USTRUN_CHECK(npix > 0 && HW > 0 && npix % HW == 0, "head_fwd: bad extent");
+    const int G = C / 8;
+    if (dtype == USTRUN_BF16 && C % 8 == 0 && G <= 64 && (G & (G - 1)) == 0 && K >= 1 && K <= 4 && K <= G) {
+        long nb = (npix + (256 / G) * 8 - 1) / ((256 / G) * 8);      // two rounds of four pixels per lane
+        if (nb > 8192) nb = 8192;
+        dim3 grid((int)nb), block(256);
+#define USTRUN_HF(KK) hipLaunchKernelGGL(head_fwd_bf16_kernel<KK>, grid, block, 0, (hipStream_t)s, (const __bf16*)y, scale, shift, \
+                                         (long)npix, HW, C, G, w, bias, logits)
+        if (K == 1) USTRUN_HF(1); else if (K == 2) USTRUN_HF(2); else if (K == 3) USTRUN_HF(3); else USTRUN_HF(4);
+#undef USTRUN_HF
+        USTRUN_LAUNCH_CHECK("head_fwd_bf16");
+        return 0;
+    }
     const int LPP = lanes_per_pixel(C / 4);
     long blocks = (npix + (256 / LPP) * 4 - 1) / ((256 / LPP) * 4);
     if (blocks > 8192) blocks = 8192;

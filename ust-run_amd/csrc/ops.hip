@@ -83,6 +83,11 @@ static int check_srcs(const ustrun_src_t* srcs, int nsrc, const char* who) {
 
 extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W, int Cout,
                                   void* y, float* stat, int dtype, ustrun_stream_t s) {
+    return ustrun_conv3x3_fwd_rows(srcs, nsrc, w_fwd, N, H, W, Cout, y, stat, nullptr, dtype, s);
+}
+
+extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W, int Cout,
+                                       void* y, float* stat, int* stat_rows, int dtype, ustrun_stream_t s) {
     USTRUN_TRY(check_srcs(srcs, nsrc, "conv3x3_fwd"));
     USTRUN_CHECK(w_fwd && y && N > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_fwd: bad args");
     IgemmArgs a = {};
@@ -98,7 +103,9 @@ extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void
                        (srcs[0].f32 || dtype == USTRUN_F32);
     if (stat) {
         const int rows = ustrun_conv_mtiles(N, H, W, Cout);
-        if ((first ? conv_first_stat_rows(N, H, W, dtype) : igemm_stat_rows_used(a, dtype)) < rows) {
+        const int used = first ? conv_first_stat_rows(N, H, W, dtype) : igemm_stat_rows_used(a, dtype);
+        if (stat_rows) *stat_rows = used;                 // the caller finalizes exactly these rows
+        else if (used < rows) {
             hipError_t e = hipMemsetAsync(stat, 0, (size_t)rows * 2 * Cout * sizeof(float), (hipStream_t)s);
             USTRUN_CHECK(e == hipSuccess, "conv3x3_fwd: memset failed: %s", hipGetErrorString(e));
         }

@@ -207,12 +207,13 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
         ustrun_src_t srcs[2];
         const int ns = conv_sources(p, x, ws, i, srcs);
         const int H = p.Hs[p.lvl[i]], W = p.Ws[p.lvl[i]];
-        USTRUN_TRY(ustrun_conv3x3_fwd(srcs, ns, pk + p.wf_off[i], p.N, H, W, p.cout[i], ws + p.y_off[i],
-                                      d->train ? stat : nullptr, d->dtype, s));
+        int stat_rows = 0;
+        USTRUN_TRY(ustrun_conv3x3_fwd_rows(srcs, ns, pk + p.wf_off[i], p.N, H, W, p.cout[i], ws + p.y_off[i],
+                                           d->train ? stat : nullptr, &stat_rows, d->dtype, s));
         float* aff = affp(i);
         const int C = p.cout[i];
         if (d->train) {
-            USTRUN_TRY(ustrun_bn_finalize(stat, ustrun_conv_mtiles(p.N, H, W, C), C, (int64_t)p.N * H * W, d->bn_w[i],
+            USTRUN_TRY(ustrun_bn_finalize(stat, stat_rows, C, (int64_t)p.N * H * W, d->bn_w[i],
                                           d->bn_b[i], d->bn_rm[i], d->bn_rv[i], d->bn_nbt[i], d->momentum, d->eps,
                                           d->update_running, aff, aff + C, aff + 2 * C, aff + 3 * C, s));
         } else {

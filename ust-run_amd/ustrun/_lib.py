@@ -40,6 +40,7 @@ SIGNATURES = {
     "ustrun_pack_convT2x2": (i32, [fp, i32, i32, vp, vp, i32, vp]),
     "ustrun_conv_mtiles": (i32, [i32, i32, i32, i32]),
     "ustrun_conv3x3_fwd": (i32, [PSrc, i32, vp, i32, i32, i32, i32, vp, fp, i32, vp]),
+    "ustrun_conv3x3_fwd_rows": (i32, [PSrc, i32, vp, i32, i32, i32, i32, vp, fp, C.POINTER(C.c_int), i32, vp]),
     "ustrun_bn_finalize": (i32, [fp, i32, i32, i64, fp, fp, fp, fp, vp, f32, f32, i32, fp, fp, fp, fp, vp]),
     "ustrun_bn_eval_affine": (i32, [i32, fp, fp, fp, fp, f32, fp, fp, vp]),
     "ustrun_bn_relu_apply": (i32, [vp, fp, fp, i64, i32, i32, fp, i32, i32, vp]),
