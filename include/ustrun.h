@@ -53,6 +53,9 @@ typedef struct ustrun_src {
     int32_t off_y, off_x;    /* logical (y,x) reads stored (y-off_y, x-off_x)              */
     int32_t f32;             /* 1: this tensor is f32 even when dtype is USTRUN_BF16 (the    */
                              /*    network input); otherwise its element type follows dtype  */
+    int32_t gN;              /* > 0: the batch is several independent forward passes laid end to end, gN images */
+    int64_t gstride;         /*      each, with their own BatchNorm statistics: image n uses scale/shift +      */
+                             /*      (n / gN) * gstride                                                          */
 } ustrun_src_t;
 
 /* ---- weight packing (done once per optimizer step) ---------------------------------------
@@ -197,6 +200,8 @@ typedef struct ustrun_unet_desc {
     int32_t dtype;               /* storage dtype of activations                              */
     int32_t train;               /* batch statistics (1) or running statistics (0)            */
     int32_t update_running;      /* update BN running buffers (train mode)                    */
+    int32_t groups;              /* > 1: N = groups * n images of `groups` independent forward passes batched into one
+                                  * call; BatchNorm statistics (and running-buffer updates, in order) are per pass  */
     float   momentum, eps;
     /* parameters/buffers, torch layouts, in state_dict order:                 */
     const float* conv_w[18];     /* inc.0, inc.3, down1..4 (.0,.3), up1..4.conv (.0,.3)        */

@@ -153,3 +153,31 @@ def test_bf16_compute_tracks_f32(c, k, n, h, w, base):
     ref.square().mean().backward()
     errs = [rel_l2(p.grad.cpu(), ref_sd[key].grad) for (name, p), key in zip(m.named_parameters(), U.param_keys(ref_sd))]
     assert max(errs) < 0.8 and float(np.median(errs)) < 0.4, (max(errs), float(np.median(errs)))
+
+
+@pytest.mark.parametrize("dtype,base,n,hw", [("bf16", 64, 2, 32), ("f32", 16, 2, 32), ("bf16", 16, 3, 48)])
+def test_forward_passes_equals_separate_calls(dtype, base, n, hw):
+    """Three forward passes batched into one call (BatchNorm per pass) == three separate calls: logits bit-identical,
+    running statistics identical (updated pass after pass), parameter gradients equal up to f32 summation order."""
+    import copy
+    from networks.unet_model import UNet
+    torch.manual_seed(3)
+    m1 = UNet(3, 2, base_channels=base, dtype=dtype).cuda().train()
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(n, 3, hw, hw, generator=g).cuda() for _ in range(3)]
+    dls = [torch.randn(n, 2, hw, hw, generator=g).cuda() for _ in range(3)]
+    outs = [m1(x) for x in xs]
+    for o, dl in zip(outs, dls):
+        o.backward(dl)
+    lg = m2.forward_passes(xs)
+    assert lg.shape[0] == 3 * n
+    for o, l in zip(outs, lg.split(n)):
+        assert torch.equal(o.detach(), l.detach())
+    lg.backward(torch.cat(dls, 0))
+    for (k, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        assert torch.equal(b1, b2), k
+    tol = 2e-2 if dtype == "bf16" else 2e-4
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        e = float((p1.grad - p2.grad).norm() / (p1.grad.norm() + 1e-20))
+        assert e < tol, (k, e)

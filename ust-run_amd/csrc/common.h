@@ -47,6 +47,8 @@ struct SrcDev {
     int relu, pool, off_y, off_x;
     int LH, LW;  // logical extent (H/2 when pooled)
     int esz;     // element size of the stored tensor: 4 (f32) or 2 (bf16); strides are in elements
+    int gN;      // > 0: image n takes scale/shift + (n / gN) * gstride (several passes batched, BatchNorm per pass)
+    long gstride;
 };
 
 static inline int act_esz(int dtype) { return dtype == USTRUN_BF16 ? 2 : 4; }
@@ -60,6 +62,7 @@ static inline SrcDev make_src(const ustrun_src_t& s, int dtype) {
     d.relu = s.relu; d.pool = s.pool; d.off_y = s.off_y; d.off_x = s.off_x;
     d.LH = s.pool ? s.H / 2 : s.H;
     d.LW = s.pool ? s.W / 2 : s.W;
+    d.gN = s.scale ? s.gN : 0; d.gstride = s.gstride;
     return d;
 }
 

@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     bf16x8 av[AIT];
     f32x4 asc0, asc1, ash0, ash1;
     const bool a_aff = !DG && a.src[0].scale != nullptr;
+    // batched passes: a tile never straddles two passes (checked on the host), its pass picks the BatchNorm constants
+    const long goff = (!DG && a.src[0].gN > 0) ? (m0 / ((long)a.src[0].gN * HWb)) * a.src[0].gstride : 0;
     const bool a_relu = !DG && a.src[0].relu;
     auto load_A = [&](int c) {
         long koff;
@@ -104,8 +106,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
         } else {
             koff = c * BK + 8 * c8;
             if (a_aff) {
-                asc0 = *(const f32x4*)(a.src[0].scale + koff); asc1 = *(const f32x4*)(a.src[0].scale + koff + 4);
-                ash0 = *(const f32x4*)(a.src[0].shift + koff); ash1 = *(const f32x4*)(a.src[0].shift + koff + 4);
+                asc0 = *(const f32x4*)(a.src[0].scale + goff + koff); asc1 = *(const f32x4*)(a.src[0].scale + goff + koff + 4);
+                ash0 = *(const f32x4*)(a.src[0].shift + goff + koff); ash1 = *(const f32x4*)(a.src[0].shift + goff + koff + 4);
             }
         }
 #pragma unroll
@@ -263,6 +265,7 @@ bool convT_fwd_supported(const IgemmArgs& a) {
     if (!common_ok(a)) return false;
     const SrcDev& s = a.src[0];
     if (s.LH != a.Hb || s.LW != a.Wb || (s.sN & 7) || (s.sH & 7) || (s.sW & 7)) return false;
+    if (s.gN > 0 && ((long)s.gN * a.Hb * a.Wb) % 128) return false;     // 128-pixel tiles must not straddle passes
     return a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.C0 == a.Cout;
 }
 // ConvTranspose input-gradient as built by ustrun_convT2x2_dgrad (4 segments reading du at stride 2)

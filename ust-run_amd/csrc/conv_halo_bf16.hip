@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         const SrcDev S = pick_src(a.src[0], a.src[1], second);
         const int cl = cg - (second ? a.src[0].C : 0);
         if (S.scale && wave == 0 && lane < 16) {
-            const float* src = (lane < 8 ? S.scale : S.shift) + cl + 4 * (lane & 7);
+            const long goff = S.gN > 0 ? (long)(img / S.gN) * S.gstride : 0;        // this image's pass
+            const float* src = (lane < 8 ? S.scale : S.shift) + goff + cl + 4 * (lane & 7);
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Cst + (c & 1) * 256), 16, 0, 0);
         }
     };

@@ -302,10 +302,14 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     const double aesz = dtype == USTRUN_BF16 ? 2.0 : 4.0;     // stored element size of activations and packed weights
     prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, aesz * (in_elems + out_elems + w_elems), st);
     int rc;
+    bool grouped = false;
+    for (int i = 0; i < a.nsrc; ++i) grouped |= a.src[i].gN > 0;
+    USTRUN_CHECK(!grouped || dtype == USTRUN_BF16, "igemm: batched passes reached a kernel without per-pass BatchNorm constants");
     if (dtype == USTRUN_BF16) {
         if (halo_supported(a)) rc = conv3x3_halo_launch_bf16(a, st);
         else if (convT_fwd_supported(a)) rc = convT_fwd_launch_bf16(a, st);
         else if (convT_dgrad_supported(a)) rc = convT_dgrad_launch_bf16(a, st);
+        else if (grouped) { set_error("igemm: batched passes reached a kernel without per-pass BatchNorm constants"); rc = 1; }
         else rc = igemm_launch_bf16(a, st);
     } else if (pick_bm(a.Cout) == 128 || pool) {   // (narrow outputs with a pooled source only occur in tiny test nets)
         rc = pool ? launch_cfg<2, 2, true>(a, st) : launch_cfg<2, 2, false>(a, st);

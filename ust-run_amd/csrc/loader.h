@@ -67,6 +67,7 @@ __device__ __forceinline__ SrcDev pick_src(const SrcDev& s0, const SrcDev& s1, b
     d.off_y = second ? s1.off_y : s0.off_y; d.off_x = second ? s1.off_x : s0.off_x;
     d.LH = second ? s1.LH : s0.LH; d.LW = second ? s1.LW : s0.LW;
     d.esz = second ? s1.esz : s0.esz;
+    d.gN = second ? s1.gN : s0.gN; d.gstride = second ? s1.gstride : s0.gstride;
     return d;
 }
 

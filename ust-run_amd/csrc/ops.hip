@@ -81,6 +81,28 @@ static int check_srcs(const ustrun_src_t* srcs, int nsrc, const char* who) {
     return 0;
 }
 
+// ---- several forward passes batched into one call (ustrun_src_t::gN): the fast bf16 kernels pick the BatchNorm
+// constants per image; every other kernel is run once per pass on the corresponding slices -------------------------
+static int src_groups(const ustrun_src_t* srcs, int nsrc, int N, int* gN) {
+    int g = 0;
+    for (int i = 0; i < nsrc; ++i)
+        if (srcs[i].scale && srcs[i].gN > 0) {
+            if (g && g != srcs[i].gN) return -1;
+            g = srcs[i].gN;
+        }
+    *gN = g;
+    if (g == 0) return 1;
+    return (N % g == 0) ? N / g : -1;
+}
+static ustrun_src_t src_slice(const ustrun_src_t& s, int g, int gN, int dtype) {
+    ustrun_src_t t = s;
+    const int esz = (s.f32 || dtype != USTRUN_BF16) ? 4 : 2;
+    t.ptr = (const char*)s.ptr + (int64_t)g * gN * s.sN * esz;
+    if (s.scale && s.gN > 0) { t.scale = s.scale + (int64_t)g * s.gstride; t.shift = s.shift + (int64_t)g * s.gstride; }
+    t.gN = 0; t.gstride = 0;
+    return t;
+}
+
 extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W, int Cout,
                                   void* y, float* stat, int dtype, ustrun_stream_t s) {
     return ustrun_conv3x3_fwd_rows(srcs, nsrc, w_fwd, N, H, W, Cout, y, stat, nullptr, dtype, s);
@@ -101,6 +123,24 @@ extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const
     a.bias = nullptr; a.stat = stat; a.out_esz = act_esz(dtype);
     const bool first = nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W &&
                        (srcs[0].f32 || dtype == USTRUN_F32);
+    int gN = 0;
+    const int G = src_groups(srcs, nsrc, N, &gN);
+    USTRUN_CHECK(G >= 1, "conv3x3_fwd: inconsistent pass groups");
+    if (G > 1 && !(dtype == USTRUN_BF16 && halo_supported(a))) {      // one launch per pass
+        USTRUN_CHECK(!stat || stat_rows, "conv3x3_fwd: batched passes need ustrun_conv3x3_fwd_rows");
+        int total = 0;
+        for (int g = 0; g < G; ++g) {
+            ustrun_src_t sl[2];
+            for (int i = 0; i < nsrc; ++i) sl[i] = src_slice(srcs[i], g, gN, dtype);
+            int rows = 0;
+            USTRUN_TRY(ustrun_conv3x3_fwd_rows(sl, nsrc, w_fwd, gN, H, W, Cout,
+                                               (char*)y + (int64_t)g * gN * H * W * Cout * act_esz(dtype),
+                                               stat ? stat + (int64_t)total * 2 * Cout : nullptr, &rows, dtype, s));
+            total += rows;
+        }
+        if (stat_rows) *stat_rows = total;
+        return 0;
+    }
     if (stat) {
         const int rows = ustrun_conv_mtiles(N, H, W, Cout);
         const int used = first ? conv_first_stat_rows(N, H, W, dtype) : igemm_stat_rows_used(a, dtype);
@@ -151,6 +191,19 @@ extern "C" int ustrun_convT2x2_fwd(const ustrun_src_t* src, const void* w_fwd, c
     a.nz = 4; a.s_out = 2;                                          // u[2p + (i,j)] = a[p] W[ij] + bias
     a.out0 = (float*)u; a.C0 = Cout; a.Ho = 2 * H; a.Wo = 2 * W;
     a.bias = bias; a.out_esz = act_esz(dtype);
+    {
+        int gN = 0;
+        const int G = src_groups(src, 1, N, &gN);
+        USTRUN_CHECK(G >= 1, "convT2x2_fwd: inconsistent pass groups");
+        if (G > 1 && !(dtype == USTRUN_BF16 && convT_fwd_supported(a))) {
+            for (int g = 0; g < G; ++g) {
+                const ustrun_src_t sl = src_slice(*src, g, gN, dtype);
+                USTRUN_TRY(ustrun_convT2x2_fwd(&sl, w_fwd, bias, gN, H, W, Cout,
+                                               (char*)u + (int64_t)g * gN * 4 * H * W * Cout * act_esz(dtype), dtype, s));
+            }
+            return 0;
+        }
+    }
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
 
@@ -202,6 +255,20 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
     a.nseg = 9; a.segw = 3; a.d0 = -1; a.astep = 1; a.dy_s = 1; a.dyH = H; a.dyW = W;
     int slabs;
     a.partials = partials;
+    {
+        int gN = 0;
+        const int G = src_groups(srcs, nsrc, N, &gN);
+        USTRUN_CHECK(G >= 1, "conv3x3_wgrad: inconsistent pass groups");
+        if (G > 1 && !(dtype == USTRUN_BF16 && wgrad_halo_supported(a))) {
+            for (int g = 0; g < G; ++g) {
+                ustrun_src_t sl[2];
+                for (int i = 0; i < nsrc; ++i) sl[i] = src_slice(srcs[i], g, gN, dtype);
+                USTRUN_TRY(ustrun_conv3x3_wgrad(sl, nsrc, (const char*)dy + (int64_t)g * gN * H * W * Cout * act_esz(dtype), gN, H,
+                                                W, Cout, dw, g == 0 ? accumulate : 1, partials, partials_bytes, dtype, s));
+            }
+            return 0;
+        }
+    }
     if (dtype == USTRUN_BF16 && nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W && srcs[0].f32)
         return conv_first_wgrad(srcs[0], dy, act_esz(dtype), N, dw, accumulate, partials, partials_bytes, (hipStream_t)s);
     if (dtype == USTRUN_BF16 && wgrad_halo_supported(a)) {
@@ -261,6 +328,19 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
     a.nseg = 4; a.segw = 2; a.d0 = 0; a.astep = 0; a.dy_s = 2; a.dyH = 2 * H; a.dyW = 2 * W;
     int slabs;
     a.partials = partials;
+    {
+        int gN = 0;
+        const int G = src_groups(src, 1, N, &gN);
+        USTRUN_CHECK(G >= 1, "convT2x2_wgrad: inconsistent pass groups");
+        if (G > 1 && !(dtype == USTRUN_BF16 && wgradT_supported(a))) {
+            for (int g = 0; g < G; ++g) {
+                const ustrun_src_t sl = src_slice(*src, g, gN, dtype);
+                USTRUN_TRY(ustrun_convT2x2_wgrad(&sl, (const char*)du + (int64_t)g * gN * 4 * H * W * Cout * act_esz(dtype), gN, H, W,
+                                                 Cout, dw, db, g == 0 ? accumulate : 1, partials, partials_bytes, dtype, s));
+            }
+            return 0;
+        }
+    }
     if (dtype == USTRUN_BF16 && wgradT_supported(a)) {       // all four taps (and the bias) in one GEMM: wgradT_bf16.hip
         wgradT_plan(a.Cin, Cout, a.M, &a.ksplit, &a.kchunk);
         slabs = a.ksplit;

@@ -14,6 +14,7 @@ namespace {
 
 struct Plan {
     int N, C, H, W, K, base;
+    int G, gN;                   // forward passes batched into this call, images per pass (BatchNorm is per pass)
     int Hs[5], Ws[5];            // extent per level
     int cin[18], cout[18], lvl[18];
     int up_cin[4], up_cout[4];   // convT j: level of its input = 4-j (j = 0..3), output level 3-j
@@ -37,6 +38,9 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     USTRUN_CHECK(d->H >= 16 && d->W >= 16, "unet: extent %dx%d too small for 4 poolings", d->H, d->W);
     USTRUN_CHECK(dtype_ok(d->dtype), "unet: dtype %d not built", d->dtype);
     p.N = d->N; p.C = d->C; p.H = d->H; p.W = d->W; p.K = d->K; p.base = d->base;
+    p.G = d->groups > 1 ? d->groups : 1;
+    USTRUN_CHECK(d->N % p.G == 0, "unet: N=%d is not a multiple of groups=%d", d->N, p.G);
+    p.gN = d->N / p.G;
     p.Hs[0] = d->H; p.Ws[0] = d->W;
     for (int l = 1; l < 5; ++l) { p.Hs[l] = p.Hs[l - 1] / 2; p.Ws[l] = p.Ws[l - 1] / 2; }
     const int b = d->base;
@@ -59,7 +63,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     long stat_max = 0;
     for (int i = 0; i < 18; ++i) {
         p.y_off[i] = o; o = align_up(o + p.y_elems(i) * E, 256);
-        p.aff_off[i] = o; o = align_up(o + 16L * p.cout[i], 256);
+        p.aff_off[i] = o; o = align_up(o + 16L * p.cout[i] * p.G, 256);       // [G][scale, shift, mean, rstd]
         const long st = (long)ustrun_conv_mtiles(p.N, p.Hs[p.lvl[i]], p.Ws[p.lvl[i]], p.cout[i]) * 2 * p.cout[i];
         if (st > stat_max) stat_max = st;
     }
@@ -109,9 +113,10 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     return 0;
 }
 
-ustrun_src_t nhwc_src(const void* ptr, const float* aff, int C, int H, int W, int relu, int pool) {
+ustrun_src_t nhwc_src(const void* ptr, const float* aff, int C, int H, int W, int relu, int pool, int gN = 0) {
     ustrun_src_t s = {};
     s.ptr = ptr; s.scale = aff; s.shift = aff ? aff + C : nullptr;
+    s.gN = aff ? gN : 0; s.gstride = 4L * C;        // pass g keeps its constants at aff + g * 4C
     s.C = C; s.H = H; s.W = W;
     s.sC = 1; s.sW = C; s.sH = (int64_t)W * C; s.sN = (int64_t)H * W * C;
     s.relu = relu; s.pool = pool;
@@ -121,7 +126,8 @@ ustrun_src_t nhwc_src(const void* ptr, const float* aff, int C, int H, int W, in
 // sources of conv i (forward input), from the saved workspace
 int conv_sources(const Plan& p, const float* x, const char* ws, int i, ustrun_src_t* srcs) {
     auto act = [&](int k, int pool) {
-        return nhwc_src(ws + p.y_off[k], (const float*)(ws + p.aff_off[k]), p.cout[k], p.Hs[p.lvl[k]], p.Ws[p.lvl[k]], 1, pool);
+        return nhwc_src(ws + p.y_off[k], (const float*)(ws + p.aff_off[k]), p.cout[k], p.Hs[p.lvl[k]], p.Ws[p.lvl[k]], 1, pool,
+                        p.G > 1 ? p.gN : 0);
     };
     if (i == 0) {   // network input, NCHW
         ustrun_src_t s = {};
@@ -200,7 +206,8 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
         if (i >= 10 && i % 2 == 0) {   // Up: ConvTranspose of the previous level's output first
             const int j = (i - 10) / 2, l = 3 - j;
             const int prev = (j == 0) ? 9 : i - 1;
-            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0);
+            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0,
+                                      p.G > 1 ? p.gN : 0);
             USTRUN_TRY(ustrun_convT2x2_fwd(&a, pk + p.uf_off[j], d->up_b[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
                                            ws + p.u_off[j], d->dtype, s));
         }
@@ -212,21 +219,32 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
                                            d->train ? stat : nullptr, &stat_rows, d->dtype, s));
         float* aff = affp(i);
         const int C = p.cout[i];
-        if (d->train) {
-            USTRUN_TRY(ustrun_bn_finalize(stat, stat_rows, C, (int64_t)p.N * H * W, d->bn_w[i],
-                                          d->bn_b[i], d->bn_rm[i], d->bn_rv[i], d->bn_nbt[i], d->momentum, d->eps,
-                                          d->update_running, aff, aff + C, aff + 2 * C, aff + 3 * C, s));
+        if (d->train) {     // statistics per pass, running buffers updated pass after pass as separate calls would
+            USTRUN_CHECK(stat_rows % p.G == 0, "unet_forward: %d statistics rows do not split into %d passes", stat_rows, p.G);
+            const int rpg = stat_rows / p.G;
+            for (int g = 0; g < p.G; ++g) {
+                float* ag = aff + 4L * C * g;
+                USTRUN_TRY(ustrun_bn_finalize(stat + (long)g * rpg * 2 * C, rpg, C, (int64_t)p.gN * H * W, d->bn_w[i],
+                                              d->bn_b[i], d->bn_rm[i], d->bn_rv[i], d->bn_nbt[i], d->momentum, d->eps,
+                                              d->update_running, ag, ag + C, ag + 2 * C, ag + 3 * C, s));
+            }
         } else {
-            USTRUN_TRY(ustrun_bn_eval_affine(C, d->bn_w[i], d->bn_b[i], d->bn_rm[i], d->bn_rv[i], d->eps, aff, aff + C, s));
+            for (int g = 0; g < p.G; ++g) {
+                float* ag = aff + 4L * C * g;
+                USTRUN_TRY(ustrun_bn_eval_affine(C, d->bn_w[i], d->bn_b[i], d->bn_rm[i], d->bn_rv[i], d->eps, ag, ag + C, s));
+            }
         }
     }
     const int C = p.cout[17];
-    const long npix = (long)p.N * p.H * p.W;
-    USTRUN_TRY(ustrun_head_fwd(ws + p.y_off[17], affp(17), affp(17) + C, npix, p.H * p.W, C, p.K,
-                               d->head_w, d->head_b, logits, d->dtype, s));
-    if (feat)
-        USTRUN_TRY(ustrun_bn_relu_apply(ws + p.y_off[17], affp(17), affp(17) + C, npix, C, p.H * p.W,
-                                        feat, 1, d->dtype, s));
+    const long gpix = (long)p.gN * p.H * p.W;
+    for (int g = 0; g < p.G; ++g) {
+        const float* ag = affp(17) + 4L * C * g;
+        const char* yg = ws + p.y_off[17] + g * gpix * C * p.esz;
+        USTRUN_TRY(ustrun_head_fwd(yg, ag, ag + C, gpix, p.H * p.W, C, p.K, d->head_w, d->head_b, logits + g * gpix * p.K,
+                                   d->dtype, s));
+        if (feat)
+            USTRUN_TRY(ustrun_bn_relu_apply(yg, ag, ag + C, gpix, C, p.H * p.W, feat + g * gpix * C, 1, d->dtype, s));
+    }
     return 0;
 }
 
@@ -243,11 +261,15 @@ extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x,
     auto affp = [&](int k) { return (const float*)(ws + p.aff_off[k]); };
     const int dt = d->dtype;
 
-    {   // head
+    {   // head, pass by pass (the BatchNorm constants on load are per pass)
         const int C = p.cout[17];
-        USTRUN_TRY(ustrun_head_bwd(dlogits, ws + p.y_off[17], affp(17), affp(17) + C,
-                                   (long)p.N * p.H * p.W, p.H * p.W, C, p.K, d->head_w, sc + p.da_off[17], grads[62],
-                                   grads[63], accumulate, part, p.part_bytes, dt, s));
+        const long gpix = (long)p.gN * p.H * p.W;
+        for (int g = 0; g < p.G; ++g) {
+            const float* ag = affp(17) + 4L * C * g;
+            USTRUN_TRY(ustrun_head_bwd(dlogits + g * gpix * p.K, ws + p.y_off[17] + g * gpix * C * p.esz, ag, ag + C, gpix,
+                                       p.H * p.W, C, p.K, d->head_w, sc + p.da_off[17] + g * gpix * C * p.esz, grads[62],
+                                       grads[63], g == 0 ? accumulate : 1, part, p.part_bytes, dt, s));
+        }
     }
     for (int i = 17; i >= 0; --i) {
         if (i == ustrun_debug_stop_layer) return 0;
@@ -258,9 +280,16 @@ extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x,
         const bool pooled = (i < 8) && (i % 2 == 1);
         const void* dp = pooled ? sc + p.dp_off[3 - l] : nullptr;
         void* da = sc + p.da_off[i];
-        USTRUN_TRY(ustrun_bn_bwd_reduce(da, dp, ws + p.y_off[i], aff, aff + C, aff + 2 * C, aff + 3 * C, d->bn_w[i], p.N, H,
-                                        W, C, grads[gi + 1], grads[gi + 2], accumulate, coef, part, p.part_bytes, dt, s));
-        USTRUN_TRY(ustrun_bn_bwd_apply(da, dp, ws + p.y_off[i], aff, aff + C, coef, p.N, H, W, C, da, dt, s));
+        for (int g = 0; g < p.G; ++g) {        // BatchNorm backward is a per-pass reduction
+            const float* ag = aff + 4L * C * g;
+            const long go = (long)g * p.gN * H * W * C * p.esz;
+            char* dag = (char*)da + go;
+            const char* dpg = dp ? (const char*)dp + (long)g * p.gN * (H / 2) * (W / 2) * C * p.esz : nullptr;
+            USTRUN_TRY(ustrun_bn_bwd_reduce(dag, dpg, ws + p.y_off[i] + go, ag, ag + C, ag + 2 * C, ag + 3 * C, d->bn_w[i], p.gN,
+                                            H, W, C, grads[gi + 1], grads[gi + 2], g == 0 ? accumulate : 1, coef, part,
+                                            p.part_bytes, dt, s));
+            USTRUN_TRY(ustrun_bn_bwd_apply(dag, dpg, ws + p.y_off[i] + go, ag, ag + C, coef, p.gN, H, W, C, dag, dt, s));
+        }
         ustrun_src_t srcs[2];
         const int ns = conv_sources(p, x, ws, i, srcs);
         USTRUN_TRY(ustrun_conv3x3_wgrad(srcs, ns, da, p.N, H, W, C, grads[gi], accumulate, part, p.part_bytes, dt, s));
@@ -275,7 +304,8 @@ extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x,
             USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, p.cin[i], sc + p.da_off[skip], p.cout[skip],
                                             sc + p.du_off[j], uh, uw, (H - uh) / 2, (W - uw) / 2, dt, s));
             const int prev = (j == 0) ? 9 : i - 1;
-            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0);
+            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0,
+                                      p.G > 1 ? p.gN : 0);
             const int ub = 30 + j * 8;
             USTRUN_TRY(ustrun_convT2x2_wgrad(&a, sc + p.du_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], grads[ub],
                                              grads[ub + 1], accumulate, part, p.part_bytes, dt, s));

@@ -282,6 +282,8 @@ int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
     const bool pool = a.src[0].pool != 0;
     USTRUN_CHECK(!pool || a.nsrc == 1, "wgrad: pooled source cannot be concatenated");
     USTRUN_CHECK(a.kchunk % 64 == 0, "wgrad: K chunk must be a multiple of 64");
+    for (int i = 0; i < a.nsrc; ++i)
+        USTRUN_CHECK(a.src[i].gN == 0, "wgrad: batched passes reached a kernel without per-pass BatchNorm constants");
     const bool m128 = a.Cin > 64, n128 = a.Cout > 64;
     double in_elems = 0;
     for (int i = 0; i < a.nsrc; ++i) in_elems += (double)a.N * a.src[i].H * a.src[i].W * a.src[i].C;

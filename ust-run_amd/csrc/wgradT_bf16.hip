@@ -86,14 +86,22 @@ __global__ __launch_bounds__(256, 2) void wgradT_bf16_kernel(const WgradArgs a, 
     const int cl = ci0 + 8 * c8;
     const bool aff = S.scale != nullptr;
     f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
-    if (aff) {
-        asc0 = *(const f32x4*)(S.scale + cl); asc1 = *(const f32x4*)(S.scale + cl + 4);
-        ash0 = *(const f32x4*)(S.shift + cl); ash1 = *(const f32x4*)(S.shift + cl + 4);
-    }
+    int cur_grp = -1;                     // batched passes: a 64-pixel stage never straddles two passes (host check)
+    const long gpix = S.gN > 0 ? (long)S.gN * a.Hb * a.Wb : 0;
+    auto load_consts = [&](long k0) {
+        const int grp = gpix > 0 ? (int)(k0 / gpix) : 0;
+        if (aff && grp != cur_grp) {
+            const long o = (long)grp * (gpix > 0 ? S.gstride : 0) + cl;
+            asc0 = *(const f32x4*)(S.scale + o); asc1 = *(const f32x4*)(S.scale + o + 4);
+            ash0 = *(const f32x4*)(S.shift + o); ash1 = *(const f32x4*)(S.shift + o + 4);
+            cur_grp = grp;
+        }
+    };
     const __bf16* sp = (const __bf16*)S.ptr + cl;
     const int arow = tid >> 4;
     bf16x8 av[4];
     auto load_A = [&](long k0) {
+        load_consts(k0);                  // write_A of this stage runs before the next load_A
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long m = k0 + arow + 16 * i;
@@ -236,6 +244,7 @@ bool wgradT_supported(const WgradArgs& a) {
     if ((s.relu && !s.scale) || (s.sW & 7)) return false;
     if (s.sH != (long)a.Wb * s.sW || s.sN != (long)a.Hb * s.sH) return false;      // pixel-linear source
     if (a.dyH != 2 * a.Hb || a.dyW != 2 * a.Wb || a.Wb >= 32768) return false;
+    if (s.gN > 0 && ((long)s.gN * a.Hb * a.Wb) % KP) return false;        // stages must not straddle passes
     return a.Cin % 128 == 0 && a.Cout % 32 == 0;
 }
 

@@ -70,10 +70,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
     const bool aff = S.scale != nullptr;
     const bool xf = aff || S.relu || POOL;
     f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
-    if (aff) {
-        asc0 = *(const f32x4*)(S.scale + cl); asc1 = *(const f32x4*)(S.scale + cl + 4);
-        ash0 = *(const f32x4*)(S.shift + cl); ash1 = *(const f32x4*)(S.shift + cl + 4);
-    }
+    int cur_grp = -1;                              // batched passes: BatchNorm constants follow the tile's image
+    auto load_consts = [&](int img) {
+        const int grp = S.gN > 0 ? img / S.gN : 0;
+        if (aff && grp != cur_grp) {
+            const long o = (long)grp * (S.gN > 0 ? S.gstride : 0) + cl;
+            asc0 = *(const f32x4*)(S.scale + o); asc1 = *(const f32x4*)(S.scale + o + 4);
+            ash0 = *(const f32x4*)(S.shift + o); ash1 = *(const f32x4*)(S.shift + o + 4);
+            cur_grp = grp;
+        }
+    };
     const __bf16* sp = (const __bf16*)S.ptr + cl;
     const __bf16* zsrc = (const __bf16*)g_zero16w;
 
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
     auto fetch_tile = [&](int t, char* Dbuf) {
         int img, y0, x0;
         tile_origin(t, img, y0, x0);
+        load_consts(img);                          // the items fetched below are transformed at this stage's bottom
         const __bf16* dbase = dyp + (((long)img * a.dyH + (y0 - 1)) * a.dyW + (x0 - 1)) * a.Cout;
 #pragma unroll
         for (int i = 0; i < DIT; ++i) {

@@ -38,3 +38,20 @@ class UNet(nn.Module):
                                       "the ConvTranspose2d default, train.py:499); not built in the HIP path yet")
         from ustrun import engine
         return engine.unet_forward(self, x, feature)
+
+    def forward_passes(self, xs, feature=False):
+        """Additive API (not in the reference): run several forward passes of equal shape as ONE batched call.
+        Equivalent to `[self(x) for x in xs]` -- BatchNorm batch statistics and running-buffer updates stay per
+        pass, in order -- but every kernel sees the concatenated batch (better GPU fill on the deep, small layers,
+        a third of the launches, one weight-gradient reduction for all passes).  Returns the logits of the
+        concatenated batch; split them with `.split(len(xs[0]))`."""
+        import torch
+        xs = list(xs)
+        if len({tuple(x.shape) for x in xs}) != 1:
+            raise RuntimeError("forward_passes: all passes must have the same shape")
+        x = torch.cat(xs, 0) if len(xs) > 1 else xs[0]
+        _hip_only(x)
+        if self.bilinear:
+            raise NotImplementedError("bilinear=True is not built in the HIP path yet")
+        from ustrun import engine
+        return engine.unet_forward(self, x, feature, groups=len(xs))

@@ -18,13 +18,14 @@ class Src(C.Structure):
     """ustrun_src_t"""
     _fields_ = [("ptr", vp), ("scale", vp), ("shift", vp), ("C", i32), ("H", i32), ("W", i32),
                 ("sN", i64), ("sH", i64), ("sW", i64), ("sC", i64),
-                ("relu", i32), ("pool", i32), ("off_y", i32), ("off_x", i32), ("f32", i32)]
+                ("relu", i32), ("pool", i32), ("off_y", i32), ("off_x", i32), ("f32", i32),
+                ("gN", i32), ("gstride", i64)]
 
 
 class UNetDesc(C.Structure):
     """ustrun_unet_desc_t"""
     _fields_ = [("N", i32), ("C", i32), ("H", i32), ("W", i32), ("K", i32), ("base", i32), ("dtype", i32),
-                ("train", i32), ("update_running", i32), ("momentum", f32), ("eps", f32),
+                ("train", i32), ("update_running", i32), ("groups", i32), ("momentum", f32), ("eps", f32),
                 ("conv_w", vp * 18), ("bn_w", vp * 18), ("bn_b", vp * 18), ("bn_rm", vp * 18),
                 ("bn_rv", vp * 18), ("bn_nbt", vp * 18), ("up_w", vp * 4), ("up_b", vp * 4),
                 ("head_w", vp), ("head_b", vp), ("packed", vp)]

@@ -35,10 +35,11 @@ def _check_param(t, name):
         raise RuntimeError(f"{name}: parameters/buffers must be contiguous float32 HIP tensors")
 
 
-def _desc(model, N, H, W, train):
+def _desc(model, N, H, W, train, groups=1):
     pairs, ups, head = conv_bn_list(model)
     d = L.UNetDesc()
     d.N, d.C, d.H, d.W, d.K = N, model.n_channels, H, W, model.n_classes
+    d.groups = groups
     d.base, d.dtype = model.base_channels, _DT[model.compute_dtype]
     d.train, d.update_running = int(train), int(train)
     bn0 = pairs[0][1]
@@ -91,8 +92,8 @@ def model_params(model):
 
 class _UNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, model, feature, *params):
-        logits, feat, ws, d = _run_forward(model, x, feature)
+    def forward(ctx, x, model, feature, groups, *params):
+        logits, feat, ws, d = _run_forward(model, x, feature, groups)
         ctx.model, ctx.ws, ctx.desc, ctx.x = model, ws, d, x
         ctx.nparams = len(params)
         if feature:
@@ -124,10 +125,10 @@ class _UNetFn(torch.autograd.Function):
                                          scratch.data_ptr(), arr, accumulate, stream_ptr()), "ustrun_unet_backward")
         ctx.ws = None
         grads = (None,) * ctx.nparams if sink is not None else tuple(targets)
-        return (None, None, None) + grads
+        return (None, None, None, None) + grads
 
 
-def _run_forward(model, x, feature):
+def _run_forward(model, x, feature, groups=1):
     lib = L.lib()
     if x.dim() != 4 or x.shape[1] != model.n_channels:
         raise RuntimeError(f"UNet: expected input [N,{model.n_channels},H,W], got {tuple(x.shape)}")
@@ -135,7 +136,9 @@ def _run_forward(model, x, feature):
         raise RuntimeError("UNet: input must be float32")
     x = x.contiguous()
     N, _, H, W = x.shape
-    d = _desc(model, N, H, W, model.training)
+    if groups < 1 or N % groups:
+        raise RuntimeError(f"UNet: batch {N} does not split into {groups} passes")
+    d = _desc(model, N, H, W, model.training, groups)
     _ensure_packed(model, d)
     nbytes = lib.ustrun_unet_fwd_workspace_bytes(C.byref(d))
     if nbytes < 0:
@@ -148,12 +151,15 @@ def _run_forward(model, x, feature):
     return logits, feat, ws, d
 
 
-def unet_forward(model, x, feature=False):
+def unet_forward(model, x, feature=False, groups=1):
+    """groups > 1: x holds `groups` independent forward passes laid end to end along the batch axis; they run as one
+    batched call with BatchNorm statistics (and running-buffer updates, in order) kept per pass -- the results are
+    those of `groups` separate calls, at the launch count and GPU fill of one."""
     params = model_params(model)
     needs_grad = torch.is_grad_enabled() and model.training and any(p.requires_grad for p in params)
     if x.requires_grad:
         raise NotImplementedError("gradient w.r.t. the network input is not on the hot path (train.py never needs it)")
     if needs_grad:
-        return _UNetFn.apply(x, model, feature, *params)
-    logits, feat, _, _ = _run_forward(model, x, feature)
+        return _UNetFn.apply(x, model, feature, groups, *params)
+    logits, feat, _, _ = _run_forward(model, x, feature, groups)
     return (logits, feat) if feature else logits
