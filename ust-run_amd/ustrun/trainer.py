@@ -117,7 +117,7 @@ class SSLTrainer:
     def __init__(self, dataset, model, ema_model, base_lr=0.03, max_iterations=None, threshold=0.95,
                  ema_decay=0.99, consistency=1.0, consistency_rampup=200.0, cutmix_prob=1.0, LB=0.01,
                  increase=1.0005, queue_len=10, num_eval_iter=500, momentum=0.9, weight_decay=1e-4,
-                 patch_size=None, grad_allreduce=None, world_size=1, fft="host"):
+                 patch_size=None, grad_allreduce=None, world_size=1, fft="host", batch_passes=True):
         cfg = DATASETS[dataset]
         self.dataset = dataset
         self.n_classes, self.mode, self.n_part = cfg[2], cfg[3], cfg[4]
@@ -145,6 +145,7 @@ class SSLTrainer:
         self.grad_allreduce = grad_allreduce             # callable(flat_g): SUM over ranks (RCCL all-reduce)
         self.world_size = world_size
         self.fft = fft
+        self.batch_passes = batch_passes                 # run the 3 teacher / 4 student passes as one batched call each
         self.iter_num = 0
         self.first_step = True
         # memory bank + low-quality sample state (train.py:554-561,576)
@@ -222,10 +223,15 @@ class SSLTrainer:
         with torch.no_grad():
             box = torch.from_numpy(np.stack([cutmix_box(self.patch, p=self.cutmix_prob) for _ in range(B)])).to(dev)
             self._mark("boxes")
-            # teacher: three train-mode forwards (train.py:638-667, Q11)
-            pl, mask = self._pl(ema(ulb_x_w))
-            pl_w_ul, mask_w_ul = self._pl(ema(F.box_mix(ulb_x_w, mix_img, box)))
-            pl_w_lu, mask_w_lu = self._pl(ema(F.box_mix(mix_img, ulb_x_w, box)))
+            # teacher: three train-mode forwards (train.py:638-667, Q11), batched into one call with BatchNorm per pass
+            t_in = [ulb_x_w, F.box_mix(ulb_x_w, mix_img, box), F.box_mix(mix_img, ulb_x_w, box)]
+            if self.batch_passes:
+                t_out = ema.forward_passes(t_in).split(B)
+            else:
+                t_out = [ema(t) for t in t_in]
+            pl, mask = self._pl(t_out[0])
+            pl_w_ul, mask_w_ul = self._pl(t_out[1])
+            pl_w_lu, mask_w_lu = self._pl(t_out[2])
             # student forward on the weak view: only its pseudo-label is used (Q3)
             stu_pl, _ = self._pl(model(ulb_x_w))
             pl_w, mask_w, pl_ul, mask_ul, pl_lu, mask_lu = F.mix_targets(
@@ -235,7 +241,12 @@ class SSLTrainer:
 
         self._mark("teacher+targets issued")
         # student: four forwards that carry gradient (train.py:699-702)
-        lg_lb, lg_ul, lg_lu, lg_s = model(lb_x_w), model(x_s_ul), model(x_s_lu), model(ulb_x_s)
+        lg_all = None
+        if self.batch_passes and len(lb_x_w) == B:
+            lg_all = model.forward_passes([lb_x_w, x_s_ul, x_s_lu, ulb_x_s])
+            lg_lb, lg_ul, lg_lu, lg_s = lg_all.detach().split(B)
+        else:
+            lg_lb, lg_ul, lg_lu, lg_s = model(lb_x_w), model(x_s_ul), model(x_s_lu), model(ulb_x_s)
         self._mark("student fwd issued")
 
         # hardness and the low-quality sample forward (train.py:705-747, Q2, Q7)
@@ -289,11 +300,17 @@ class SSLTrainer:
         terms = ((lg_lb, lb_mask, None, 1.0), (lg_ul, pl_ul, mask_ul, w), (lg_lu, pl_lu, mask_lu, w), (lg_s, pl_w, mask_w, w * w))
         outs = []
         model._ustrun_sink_fresh = True
+        dls = []
         for lg, tgt, msk, coef in terms:
             out = F.seg_loss_fwd(lg.detach(), tgt, msk, mode)
             outs.append(out)
             dl = F.seg_loss_bwd(lg.detach(), tgt, msk, mode, out, gscale=coef)
-            lg.backward(dl)
+            if lg_all is None:
+                lg.backward(dl)
+            else:
+                dls.append(dl)
+        if lg_all is not None:                    # one backward over the four passes
+            lg_all.backward(torch.cat(dls, 0))
         self._mark("backward issued")
         if self.grad_allreduce is not None:
             self.grad_allreduce(self.flat_g)
