@@ -16,6 +16,7 @@ namespace {
 // and it does so before the barrier that precedes the writes.
 __global__ __launch_bounds__(256) void bn_stat_stage1_kernel(float* stat, int rows, int C, int R) {
     __shared__ double red[2][8][32];
+    stat += (long)blockIdx.z * rows * 2 * C;            // blockIdx.z = forward pass (its own rows)
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl, r0 = blockIdx.y * R, r1 = min(rows, r0 + R);
     double s1 = 0.0, s2 = 0.0;
@@ -35,48 +36,58 @@ __global__ __launch_bounds__(256) void bn_stat_stage1_kernel(float* stat, int ro
     }
 }
 
+// `passes` forward passes batched into one launch: pass g owns rows [g*rows, (g+1)*rows) of stat and the constants at
+// scale/shift/mean/rstd + g*astride; the running buffers receive the passes' updates one after the other, exactly as
+// `passes` separate calls would apply them.
 template <bool PRE>
 __global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int C, double count, int R,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* rm, float* rv, int64_t* nbt, float momentum, float eps, int update,
-                                   float* scale, float* shift, float* mean, float* rstd) {
+                                   float* scale, float* shift, float* mean, float* rstd, int passes, long astride) {
     __shared__ double red[2][32][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 channels x 32 row lanes
     const int c = blockIdx.x * 32 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        if (PRE) {       // stage-1 doubles parked at rows sp*R / sp*R+1, columns of this channel block
-            for (int sp = rg; sp * R < rows; sp += 32) {
-                const long a0 = (long)(sp * R) * 2 * C + c, a1 = (long)(sp * R + 1) * 2 * C + c;
-                s1 += (double)stat[a0] + (double)stat[a0 + C];
-                s2 += (double)stat[a1] + (double)stat[a1 + C];
-            }
-        } else {
-            for (int r = rg; r < rows; r += 32) {
-                s1 += (double)stat[((long)r * 2 + 0) * C + c];
-                s2 += (double)stat[((long)r * 2 + 1) * C + c];
+    double run_m = 0.0, run_v = 0.0;
+    if (update && rg == 0 && c < C) { run_m = (double)rm[c]; run_v = (double)rv[c]; }
+    for (int g = 0; g < passes; ++g) {
+        const float* st = stat + (long)g * rows * 2 * C;
+        double s1 = 0.0, s2 = 0.0;
+        if (c < C) {
+            if (PRE) {       // stage-1 doubles parked at rows sp*R / sp*R+1, columns of this channel block
+                for (int sp = rg; sp * R < rows; sp += 32) {
+                    const long a0 = (long)(sp * R) * 2 * C + c, a1 = (long)(sp * R + 1) * 2 * C + c;
+                    s1 += (double)st[a0] + (double)st[a0 + C];
+                    s2 += (double)st[a1] + (double)st[a1 + C];
+                }
+            } else {
+                for (int r = rg; r < rows; r += 32) {
+                    s1 += (double)st[((long)r * 2 + 0) * C + c];
+                    s2 += (double)st[((long)r * 2 + 1) * C + c];
+                }
             }
         }
-    }
-    red[0][rg][cl] = s1; red[1][rg][cl] = s2;
-    __syncthreads();
-    if (rg == 0 && c < C) {
-        for (int k = 1; k < 32; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
-        const double m = s1 / count;
-        double var = s2 / count - m * m;
-        if (var < 0.0) var = 0.0;
-        const double rs = 1.0 / sqrt(var + (double)eps);
-        const float sc = (float)((double)gamma[c] * rs);
-        scale[c] = sc;
-        shift[c] = (float)((double)beta[c] - m * (double)gamma[c] * rs);
-        mean[c] = (float)m; rstd[c] = (float)rs;
-        if (update) {
-            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            rm[c] = (float)((1.0 - momentum) * (double)rm[c] + momentum * m);
-            rv[c] = (float)((1.0 - momentum) * (double)rv[c] + momentum * unb);
+        red[0][rg][cl] = s1; red[1][rg][cl] = s2;
+        __syncthreads();
+        if (rg == 0 && c < C) {
+            for (int k = 1; k < 32; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+            const double m = s1 / count;
+            double var = s2 / count - m * m;
+            if (var < 0.0) var = 0.0;
+            const double rs = 1.0 / sqrt(var + (double)eps);
+            const long o = (long)g * astride + c;
+            scale[o] = (float)((double)gamma[c] * rs);
+            shift[o] = (float)((double)beta[c] - m * (double)gamma[c] * rs);
+            mean[o] = (float)m; rstd[o] = (float)rs;
+            if (update) {    // through float after every pass, as the stored buffer of separate calls would be
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                run_m = (double)(float)((1.0 - momentum) * run_m + momentum * m);
+                run_v = (double)(float)((1.0 - momentum) * run_v + momentum * unb);
+            }
         }
+        __syncthreads();
     }
-    if (update && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+    if (update && rg == 0 && c < C) { rm[c] = (float)run_m; rv[c] = (float)run_v; }
+    if (update && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += passes;
 }
 
 __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm,
@@ -265,29 +276,38 @@ int reduce_blocks(long nwin, int G) {
 
 using namespace ustrun;
 
+namespace ustrun {
+int bn_finalize_passes(float* stat, int mtiles, int passes, int C, int64_t count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                       int update_running, float* scale, float* shift, float* mean, float* rstd, long astride, hipStream_t s) {
+    USTRUN_CHECK(stat && gamma && beta && scale && shift && mean && rstd, "bn_finalize: null pointer");
+    USTRUN_CHECK(!update_running || (running_mean && running_var), "bn_finalize: running buffers missing");
+    USTRUN_CHECK(mtiles > 0 && passes > 0 && C > 0 && count > 0, "bn_finalize: empty");
+    if (mtiles >= 512 && C % 32 == 0) {     // long table: two stages (the first one rewrites `stat` in place)
+        int R = cdiv(mtiles, 32);
+        while (mtiles % R == 1) ++R;         // every split needs two rows to park its sums in
+        hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(mtiles, R), passes), dim3(256), 0, s, (float*)stat, mtiles,
+                           C, R);
+        USTRUN_LAUNCH_CHECK("bn_stat_stage1");
+        hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3(C / 32), dim3(1024), 0, s, stat, mtiles, C, (double)count, R, gamma,
+                           beta, running_mean, running_var, num_batches_tracked, momentum, eps, update_running, scale, shift,
+                           mean, rstd, passes, astride);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(cdiv(C, 32)), dim3(1024), 0, s, stat, mtiles, C, (double)count, 0,
+                           gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, update_running, scale,
+                           shift, mean, rstd, passes, astride);
+    }
+    USTRUN_LAUNCH_CHECK("bn_finalize");
+    return 0;
+}
+}  // namespace ustrun
+
 extern "C" int ustrun_bn_finalize(float* stat, int mtiles, int C, int64_t count, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var,
                                   int64_t* num_batches_tracked, float momentum, float eps, int update_running,
                                   float* scale, float* shift, float* mean, float* rstd, ustrun_stream_t s) {
-    USTRUN_CHECK(stat && gamma && beta && scale && shift && mean && rstd, "bn_finalize: null pointer");
-    USTRUN_CHECK(!update_running || (running_mean && running_var), "bn_finalize: running buffers missing");
-    USTRUN_CHECK(mtiles > 0 && C > 0 && count > 0, "bn_finalize: empty");
-    if (mtiles >= 512 && C % 32 == 0) {     // long table: two stages (the first one rewrites `stat` in place)
-        int R = cdiv(mtiles, 32);
-        while (mtiles % R == 1) ++R;         // every split needs two rows to park its sums in
-        hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(mtiles, R)), dim3(256), 0, (hipStream_t)s, (float*)stat,
-                           mtiles, C, R);
-        USTRUN_LAUNCH_CHECK("bn_stat_stage1");
-        hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3(C / 32), dim3(1024), 0, (hipStream_t)s, stat, mtiles, C, (double)count,
-                           R, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, update_running,
-                           scale, shift, mean, rstd);
-    } else {
-        hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)s, stat, mtiles, C,
-                           (double)count, 0, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
-                           update_running, scale, shift, mean, rstd);
-    }
-    USTRUN_LAUNCH_CHECK("bn_finalize");
-    return 0;
+    return bn_finalize_passes(stat, mtiles, 1, C, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
+                              eps, update_running, scale, shift, mean, rstd, 0, (hipStream_t)s);
 }
 
 extern "C" int ustrun_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,

@@ -99,6 +99,12 @@ bool convT_dgrad_supported(const IgemmArgs& a);
 int convT_fwd_launch_bf16(const IgemmArgs& a, hipStream_t st);
 int convT_dgrad_launch_bf16(const IgemmArgs& a, hipStream_t st);
 int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, void* wf, void* wd, hipStream_t st);
+int bn_finalize_passes(float* stat, int mtiles, int passes, int C, int64_t count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                       int update_running, float* scale, float* shift, float* mean, float* rstd, long astride, hipStream_t s);
+struct PackJob { const float* w; void* wf; void* wd; int Cout, Cin, taps, transposed_src; };
+struct PackJobs { PackJob j[24]; };
+int pack_bf16_multi(const PackJobs& jobs, int n, hipStream_t st);
 static inline bool dtype_ok(int dtype) { return dtype == USTRUN_F32 || dtype == USTRUN_BF16; }
 
 // ---- generic "TN" weight-gradient GEMM: dW[seg][ci][co] = sum_p A_seg[p][ci] * dY_seg[p][co]

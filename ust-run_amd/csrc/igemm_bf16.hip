@@ -291,6 +291,40 @@ int igemm_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     return launch_cfg<4, 1, false>(a, st);
 }
 
+// all layers of a model in one launch: blockIdx.y = layer
+__global__ void pack_bf16_multi_kernel(const PackJobs jobs) {
+    const PackJob j = jobs.j[blockIdx.y];
+    const float* __restrict__ w = j.w;
+    __bf16* wf = (__bf16*)j.wf;
+    __bf16* wd = (__bf16*)j.wd;
+    const int Cin = j.Cin, Cout = j.Cout, taps = j.taps;
+    const int Ki = (Cin + 7) / 8, Ko = (Cout + 7) / 8;
+    const long nf = (long)taps * Ki * Cout * 8, nd = (long)taps * Ko * Cin * 8;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nf + nd; e += (long)gridDim.x * blockDim.x) {
+        int tap, ci, co;
+        if (e < nf) {
+            const int q = (int)(e & 7); long t = e >> 3;
+            co = (int)(t % Cout); t /= Cout;
+            ci = (int)(t % Ki) * 8 + q; tap = (int)(t / Ki);
+        } else {
+            const long f = e - nf;
+            const int q = (int)(f & 7); long t = f >> 3;
+            ci = (int)(t % Cin); t /= Cin;
+            co = (int)(t % Ko) * 8 + q; tap = (int)(t / Ko);
+        }
+        float v = 0.f;
+        if (ci < Cin && co < Cout)
+            v = j.transposed_src ? w[((long)ci * Cout + co) * taps + tap] : w[((long)co * Cin + ci) * taps + tap];
+        if (e < nf) wf[e] = (__bf16)v; else if (wd) wd[e - nf] = (__bf16)v;
+    }
+}
+
+int pack_bf16_multi(const PackJobs& jobs, int n, hipStream_t st) {
+    hipLaunchKernelGGL(pack_bf16_multi_kernel, dim3(256, n), dim3(256), 0, st, jobs);
+    USTRUN_LAUNCH_CHECK("pack_bf16_multi");
+    return 0;
+}
+
 int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, void* wf, void* wd, hipStream_t st) {
     const long total = (long)taps * (((Cin + 7) / 8) * (long)Cout + ((Cout + 7) / 8) * (long)Cin) * 8;
     long b = (total + 1023) / 1024;

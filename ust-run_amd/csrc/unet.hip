@@ -183,6 +183,18 @@ extern "C" int ustrun_unet_pack(const ustrun_unet_desc_t* d, ustrun_stream_t s) 
     Plan p; USTRUN_TRY(make_plan(d, p));
     USTRUN_CHECK(d->packed, "unet_pack: packed arena missing");
     float* pk = (float*)d->packed;
+    if (d->dtype == USTRUN_BF16) {                 // every layer in one launch
+        PackJobs jobs;
+        for (int i = 0; i < 18; ++i) {
+            USTRUN_CHECK(d->conv_w[i], "unet_pack: conv weight %d missing", i);
+            jobs.j[i] = PackJob{d->conv_w[i], pk + p.wf_off[i], pk + p.wd_off[i], p.cout[i], p.cin[i], 9, 0};
+        }
+        for (int j = 0; j < 4; ++j) {
+            USTRUN_CHECK(d->up_w[j], "unet_pack: up weight %d missing", j);
+            jobs.j[18 + j] = PackJob{d->up_w[j], pk + p.uf_off[j], pk + p.ud_off[j], p.up_cout[j], p.up_cin[j], 4, 1};
+        }
+        return pack_bf16_multi(jobs, 22, (hipStream_t)s);
+    }
     for (int i = 0; i < 18; ++i) {
         USTRUN_CHECK(d->conv_w[i], "unet_pack: conv weight %d missing", i);
         USTRUN_TRY(ustrun_pack_conv3x3(d->conv_w[i], p.cout[i], p.cin[i], pk + p.wf_off[i], pk + p.wd_off[i], d->dtype, s));
@@ -222,12 +234,9 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
         if (d->train) {     // statistics per pass, running buffers updated pass after pass as separate calls would
             USTRUN_CHECK(stat_rows % p.G == 0, "unet_forward: %d statistics rows do not split into %d passes", stat_rows, p.G);
             const int rpg = stat_rows / p.G;
-            for (int g = 0; g < p.G; ++g) {
-                float* ag = aff + 4L * C * g;
-                USTRUN_TRY(ustrun_bn_finalize(stat + (long)g * rpg * 2 * C, rpg, C, (int64_t)p.gN * H * W, d->bn_w[i],
-                                              d->bn_b[i], d->bn_rm[i], d->bn_rv[i], d->bn_nbt[i], d->momentum, d->eps,
-                                              d->update_running, ag, ag + C, ag + 2 * C, ag + 3 * C, s));
-            }
+            USTRUN_TRY(bn_finalize_passes(stat, rpg, p.G, C, (int64_t)p.gN * H * W, d->bn_w[i], d->bn_b[i], d->bn_rm[i],
+                                          d->bn_rv[i], d->bn_nbt[i], d->momentum, d->eps, d->update_running, aff, aff + C,
+                                          aff + 2 * C, aff + 3 * C, 4L * C, (hipStream_t)s));
         } else {
             for (int g = 0; g < p.G; ++g) {
                 float* ag = aff + 4L * C * g;
