@@ -232,6 +232,214 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
     }
 }
 
+// ---- non-pooled sources: everything by LDS-DMA, three tile buffers ------------------------------------------------
+// The operands of a weight gradient stream from HBM with no reuse in flight, so a transfer issued one tile ahead is
+// not there when its tile starts (SQ_WAIT_ANY 44 % of the wave cycles with two buffers).  Here the activation tile and
+// the dY patch of tile t+2 are issued at the top of tile t -- straight into LDS, no registers to carry -- and the
+// bottom of tile t waits with a COUNTED vmcnt for tile t+1 only.  Rows are 128 B with the two 64-byte halves swapped
+// on rows whose bit 1 is set (keeps the four rows of a transposing read on disjoint bank quarters without padding,
+// so a DMA wave-instruction is exactly 8 pixels); a thread's items always hold the same channel group, whose BatchNorm
+// constants it keeps in registers, and the activation is applied IN PLACE at the bottom of the previous tile.
+constexpr int RB3 = 128;
+constexpr int A3SLOTS = TH * TW * 8;                         // 512: two per thread
+constexpr int D3SLOTS = (HP * 8 + 63) / 64 * 64;             // 896
+constexpr int D3IT = (D3SLOTS + 255) / 256;                  // 4 (waves 2,3: 3)
+constexpr int A3TILE = A3SLOTS * 16, D3TILE = D3SLOTS * 16, STAGE3 = A3TILE + D3TILE;
+
+__device__ __forceinline__ bf16x8 tr_frag3(const char* lane_base, int k0) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lane_base + k0 * RB3));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lane_base + (k0 + 4) * RB3));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArgs a, const int ntn, const int tiles_x,
+                                                                  const int tiles_y, const int tiles_per) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x {activation tile [64 px][128 B], dY patch [108 px][128 B]}
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int mtile = blockIdx.x / ntn, ntile = blockIdx.x % ntn;
+    const int ci0 = mtile * 64, co0 = ntile * 64;
+    const int ttotal = a.N * tiles_y * tiles_x;
+    const int tbeg = blockIdx.y * tiles_per;
+    const int tend = min(ttotal, tbeg + tiles_per);
+
+    // ---- activation side: item i = LDS slot tid + 256 i: pixel (tid >> 3) + 32 i, slot tid & 7; bit 1 of the pixel is a
+    // thread constant, so is the channel group the slot holds ----
+    const int apx = tid >> 3;
+    const int agl = (tid & 7) ^ (((apx >> 1) & 1) << 2);
+    const int cg = ci0 + 8 * agl;
+    const bool second = (a.nsrc == 2 && cg >= a.src[0].C);
+    const SrcDev S = pick_src(a.src[0], a.src[1], second);
+    const int cl = cg - (second ? a.src[0].C : 0);
+    const bool aff = S.scale != nullptr;
+    const bool xf = aff || S.relu;
+    f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
+    int cur_grp = -1;
+    auto load_consts = [&](int img) {
+        const int grp = S.gN > 0 ? img / S.gN : 0;
+        if (aff && grp != cur_grp) {
+            const long o = (long)grp * (S.gN > 0 ? S.gstride : 0) + cl;
+            asc0 = *(const f32x4*)(S.scale + o); asc1 = *(const f32x4*)(S.scale + o + 4);
+            ash0 = *(const f32x4*)(S.shift + o); ash1 = *(const f32x4*)(S.shift + o + 4);
+            cur_grp = grp;
+        }
+    };
+    const __bf16* sp = (const __bf16*)S.ptr + cl;
+    const __bf16* zsrc = (const __bf16*)g_zero16w;
+
+    // ---- dY side: item i = LDS slot tid + 256 i of the patch: pixel slot >> 3, logical group (slot & 7) ^ swap ----
+    int droff[D3IT], dhyx[D3IT];
+#pragma unroll
+    for (int i = 0; i < D3IT; ++i) {
+        const int slot = tid + 256 * i, hp = slot >> 3;
+        const int gl = (slot & 7) ^ (((hp >> 1) & 1) << 2);
+        const int hy = hp / HW2, hx = hp - hy * HW2;
+        const bool v = hp < HP;
+        droff[i] = v ? (hy * a.dyW + hx) * a.Cout + 8 * gl : 0;
+        dhyx[i] = v ? ((hy << 8) | hx) : 0xffff;
+    }
+    const __bf16* dyp = (const __bf16*)a.dy + co0;
+    const bool w4 = 256 * (D3IT - 1) + wave * 64 < D3SLOTS;       // does this wave issue the last dY piece?
+
+    auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
+        img = t / (tiles_y * tiles_x);
+        const int rem = t - img * tiles_y * tiles_x;
+        y0 = (rem / tiles_x) * TH; x0 = (rem % tiles_x) * TW;
+    };
+    // all transfers of tile t -> stage buffer; returns the in-source bits of this thread's two activation items
+    auto issue_tile = [&](int t, char* stage) {
+        int img, y0, x0;
+        tile_origin(t, img, y0, x0);
+        const __bf16* dbase = dyp + (((long)img * a.dyH + (y0 - 1)) * a.dyW + (x0 - 1)) * a.Cout;
+#pragma unroll
+        for (int i = 0; i < D3IT; ++i) {
+            if (i < D3IT - 1 || w4) {
+                const int ly = y0 - 1 + (dhyx[i] >> 8), lx = x0 - 1 + (dhyx[i] & 0xff);
+                const bool ok = dhyx[i] != 0xffff && ly >= 0 && ly < a.dyH && lx >= 0 && lx < a.dyW;
+                const __bf16* src = ok ? dbase + droff[i] : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(stage + A3TILE + (256 * i + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+        unsigned ok2 = 0;
+        const long sbase = img * S.sN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int px = apx + 32 * i;
+            const int ly = y0 + (px >> 4) - S.off_y, lx = x0 + (px & 15) - S.off_x;
+            const bool ok = ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
+            ok2 |= (ok ? 1u : 0u) << i;
+            const __bf16* src = ok ? sp + sbase + (long)ly * S.sH + (long)lx * S.sW : zsrc;
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(stage + (256 * i + wave * 64) * 16), 16, 0, 0);
+        }
+        return ok2;
+    };
+    // BatchNorm affine + ReLU of this thread's two items, in place (items outside the source stay zero)
+    auto activate = [&](char* stage, unsigned ok2) {
+        if (!xf) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if ((ok2 >> i) & 1u) {
+                char* p = stage + (tid + 256 * i) * 16;
+                const bf16x8 r = *(const bf16x8*)p;
+                f32x4 lo = (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * asc0 + ash0;
+                f32x4 hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
+                if (S.relu) { lo = relu4(lo); hi = relu4(hi); }
+                bf16x8 h;
+                h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+                h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+                *(bf16x8*)p = h;
+            }
+        }
+    };
+    auto tile_img = [&](int t) { return t / (tiles_y * tiles_x); };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // per-lane fragment bases: rows 8*(l>>5) + q; the half swap of a row depends on bit 1 of (k0 + row), i.e. on k0 & 3
+    const int lrow = 8 * (lane >> 5) + ((lane & 15) >> 2), lcolb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    int abase, dbase4[4];
+    abase = lrow * RB3 + ((wi * 64 + lcolb) ^ (((lrow >> 1) & 1) << 6));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbase4[c] = A3TILE + lrow * RB3 + ((wj * 64 + lcolb) ^ ((((c + lrow) >> 1) & 1) << 6));
+
+    unsigned ok_cur = 0, ok_nxt = 0;                 // in-source bits of the tile being waited for / issued last
+    char* st0 = smem; char* st1 = smem + STAGE3; char* st2 = smem + 2 * STAGE3;   // tile t, t+1, t+2
+    if (tbeg < tend) {
+        load_consts(tile_img(tbeg));
+        ok_cur = issue_tile(tbeg, st0);
+        if (tbeg + 1 < tend) {
+            ok_nxt = issue_tile(tbeg + 1, st1);
+            if (w4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        activate(st0, ok_cur);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = tbeg; t < tend; ++t) {
+        // top: tile t+2 into the buffer tile t-1 used
+        unsigned ok_new = 0;
+        const bool issue = t + 2 < tend;
+        if (issue) ok_new = issue_tile(t + 2, st2);
+        const char* Ab = st0 + abase;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { (void)c; }
+        bf16x8 af[TH];
+#pragma unroll
+        for (int r = 0; r < TH; ++r) af[r] = tr_frag3(Ab, r * TW);
+#pragma unroll
+        for (int pr = 0; pr < TH + 2; ++pr) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int k0 = pr * HW2 + 2 - kw;
+                const bf16x8 b = tr_frag3(st0 + dbase4[k0 & 3], k0);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int r = pr + kh - 2;
+                    if (r >= 0 && r < TH)
+                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                }
+            }
+        }
+        // bottom: tile t+1 (issued one iteration ago) has landed once only this top's transfers are outstanding
+        if (t + 1 < tend) {
+            if (issue) {
+                if (w4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + 2) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + 1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            load_consts(tile_img(t + 1));
+            activate(st1, ok_nxt);
+        }
+        ok_nxt = ok_new;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        char* tmp = st0; st0 = st1; st1 = st2; st2 = tmp;
+    }
+
+    float* slab = a.partials + (long)blockIdx.y * 9 * a.Cin * a.Cout;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ci = ci0 + wi * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float* o = slab + ((long)co * a.Cin + ci) * 9;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) o[tap] = acc[tap][r];
+    }
+}
+
 }  // namespace
 
 bool wgrad_halo_supported(const WgradArgs& a) {
@@ -262,7 +470,7 @@ int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStr
     if (a.src[0].pool)
         hipLaunchKernelGGL(wgrad_halo_bf16_kernel<true>, grid, block, 2 * ATILE + 2 * DTILE, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
     else
-        hipLaunchKernelGGL(wgrad_halo_bf16_kernel<false>, grid, block, 2 * ATILE + 2 * DTILE, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
+        hipLaunchKernelGGL(wgrad_halo3_bf16_kernel, grid, block, 3 * STAGE3, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
     USTRUN_LAUNCH_CHECK("wgrad_halo_bf16");
     return 0;
 }
