@@ -55,7 +55,7 @@ typedef struct ustrun_src {
                              /*    network input); otherwise its element type follows dtype  */
     int32_t gN;              /* > 0: the batch is several independent forward passes laid end to end, gN images */
     int64_t gstride;         /*      each, with their own BatchNorm statistics: image n uses scale/shift +      */
-                             /*      (n / gN) * gstride                                                          */
+                             /*      (n / gN) * gstride; statistics rows of a forward never mix two passes       */
 } ustrun_src_t;
 
 /* ---- weight packing (done once per optimizer step) ---------------------------------------
@@ -91,6 +91,10 @@ int ustrun_bn_eval_affine(int C, const float* gamma, const float* beta, const fl
 /* materialise a = relu(y*scale+shift) as NHWC or NCHW f32 (block-level API and feature=True) */
 int ustrun_bn_relu_apply(const void* y, const float* scale, const float* shift, int64_t npix, int C,
                          int HW, float* out, int out_nchw, int dtype, ustrun_stream_t s);
+/* materialise the Down block's pooled input: out[N,H/2,W/2,C] = MaxPool2d(2)(relu(src*scale+shift)) in the storage
+ * dtype (replaces nn.MaxPool2d at unet_parts.py:34 together with the producer's BatchNorm+ReLU); src is a plain
+ * contiguous NHWC activation, its pass groups are honoured                                                     */
+int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dtype, ustrun_stream_t s);
 
 /* ---- ConvTranspose2d(k=2,s=2,bias): replaces unet_parts.py:53 ------------------------------
  * u[N,2H,2W,Cout] = convT(loader(src)) + bias.                                              */

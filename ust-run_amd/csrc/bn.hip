@@ -113,6 +113,70 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ y, int esz, const
     }
 }
 
+// pooled activation p[n][y][x][c] = max over the 2x2 window of relu(s*y + b): the Down block's MaxPool2d input,
+// materialised once (a quarter of y) so that the Down convolution and its weight gradient read a plain tensor by
+// LDS-DMA instead of pooling four pixels per staged item in an issue-bound kernel.  8 channels (ESZ = 2) or 4
+// (ESZ = 4) per thread; batched passes pick their constants per image.
+template <int ESZ>
+__global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int relu, int gN, long gstride,
+                                                      int N, int H, int W, int C, float* __restrict__ out) {
+    constexpr int V = ESZ == 2 ? 8 : 4;             // channels per thread: one 16-byte load per window pixel
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+    const int Hp = H / 2, Wp = W / 2, CV = C / V;
+    // a thread keeps its channel group (256 % CV == 0 for the power-of-two channel counts; else it re-derives it)
+    const long npix = (long)N * Hp * Wp;
+    const int PPB = 256 / CV > 0 ? 256 / CV : 1;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    if (pl >= PPB) return;
+    float sc[V], sh[V];
+    int cur_grp = -2;
+    for (long p = (long)blockIdx.x * PPB + pl; p < npix; p += (long)gridDim.x * PPB) {
+        const int px = (int)(p % Wp); const long t = p / Wp;
+        const int py = (int)(t % Hp); const int n = (int)(t / Hp);
+        const int grp = gN > 0 ? n / gN : 0;
+        if (grp != cur_grp) {
+            cur_grp = grp;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                sc[j] = scale ? scale[grp * gstride + cv * V + j] : 1.f;
+                sh[j] = scale ? shift[grp * gstride + cv * V + j] : 0.f;
+            }
+        }
+        const long base = (((long)n * H + 2 * py) * W + 2 * px) * C + cv * V;
+        float v[4][V];
+        if (ESZ == 2) {
+            bf16x8v r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = *(const bf16x8v*)((const __bf16*)y + base + ((q >> 1) * (long)W + (q & 1)) * C);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[q][j] = (float)r[q][j % 8];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 r = *(const f32x4*)(y + base + ((q >> 1) * (long)W + (q & 1)) * C);
+#pragma unroll
+                for (int j = 0; j < V; ++j) v[q][j] = r[j % 4];
+            }
+        }
+        float m[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a = v[q][j] * sc[j] + sh[j];
+                if (relu) a = fmaxf(a, 0.f);
+                m[j] = q == 0 ? a : fmaxf(m[j], a);
+            }
+        }
+        const long ob = (((long)n * Hp + py) * Wp + px) * C + cv * V;
+#pragma unroll
+        for (int h = 0; h < V / 4; ++h) st4t<ESZ>(out, ob + 4 * h, (f32x4){m[4 * h], m[4 * h + 1], m[4 * h + 2], m[4 * h + 3]});
+    }
+}
+
 // ---- backward -------------------------------------------------------------------------------
 // One "window" = one pixel (POOL = false) or one 2x2 pooling window (POOL = true).  For each
 // element: a = relu(s*y+b); da_total = da + (dp routed to the window's first arg-max of a);
@@ -329,6 +393,32 @@ extern "C" int ustrun_bn_relu_apply(const void* y, const float* scale, const flo
     hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)y, act_esz(dtype), scale,
                        shift, (long)npix, C, HW, out, out_nchw);
     USTRUN_LAUNCH_CHECK("bn_relu_apply");
+    return 0;
+}
+
+extern "C" int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(dtype_ok(dtype), "pool_act: dtype %d not built", dtype);
+    USTRUN_CHECK(src && src->ptr && out && N > 0, "pool_act: bad args");
+    const int C = src->C, H = src->H, W = src->W, V = dtype == USTRUN_BF16 ? 8 : 4;
+    USTRUN_CHECK(C % V == 0 && H >= 2 && W >= 2, "pool_act: C=%d extent %dx%d unsupported", C, H, W);
+    USTRUN_CHECK(src->sC == 1 && src->sW == C && src->sH == (int64_t)W * C && src->sN == (int64_t)H * W * C && !src->pool &&
+                 !src->off_y && !src->off_x && !src->f32, "pool_act: source must be a plain contiguous NHWC activation");
+    USTRUN_CHECK((src->scale == nullptr) == (src->shift == nullptr), "pool_act: scale/shift must come together");
+    USTRUN_CHECK(C / V <= 256, "pool_act: C=%d too wide", C);
+    const long npix = (long)N * (H / 2) * (W / 2);
+    const int ppb = 256 / (C / V);
+    long nb = (npix + ppb * 4 - 1) / (ppb * 4);             // about four pixels per thread
+    if (nb > 16384) nb = 16384;
+    if (nb < 1) nb = 1;
+    const int blocks = (int)nb;
+    const int gN = src->scale ? src->gN : 0;
+    if (dtype == USTRUN_BF16)
+        hipLaunchKernelGGL(pool_act_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)src->ptr, src->scale,
+                           src->shift, src->relu, gN, (long)src->gstride, N, H, W, C, (float*)out);
+    else
+        hipLaunchKernelGGL(pool_act_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)src->ptr, src->scale,
+                           src->shift, src->relu, gN, (long)src->gstride, N, H, W, C, (float*)out);
+    USTRUN_LAUNCH_CHECK("pool_act");
     return 0;
 }
 

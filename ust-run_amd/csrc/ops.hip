@@ -86,7 +86,7 @@ static int check_srcs(const ustrun_src_t* srcs, int nsrc, const char* who) {
 static int src_groups(const ustrun_src_t* srcs, int nsrc, int N, int* gN) {
     int g = 0;
     for (int i = 0; i < nsrc; ++i)
-        if (srcs[i].scale && srcs[i].gN > 0) {
+        if (srcs[i].gN > 0) {       // (a source without scale/shift still tells where the passes -- the statistics groups -- end)
             if (g && g != srcs[i].gN) return -1;
             g = srcs[i].gN;
         }

@@ -22,6 +22,7 @@ struct Plan {
     int esz;
     long y_off[18], aff_off[18]; // aff: scale, shift, mean, rstd (4*cout)
     long u_off[4];
+    long pool_off[4];            // pooled activation feeding Down l+1 (input of conv 2l+2), kept for its weight gradient
     long stat_off, fwd_total;
     long wf_off[18], wd_off[18], uf_off[4], ud_off[4], pack_total;
     long da_off[18], du_off[4], dp_off[4], coef_off, part_off, bwd_total, part_bytes;
@@ -68,6 +69,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
         if (st > stat_max) stat_max = st;
     }
     for (int j = 0; j < 4; ++j) { p.u_off[j] = o; o = align_up(o + p.u_elems(j) * E, 256); }
+    for (int l = 0; l < 4; ++l) { p.pool_off[l] = o; o = align_up(o + (long)p.N * p.Hs[l + 1] * p.Ws[l + 1] * ch[l] * E, 256); }
     p.stat_off = o; o = align_up(o + stat_max * 4, 256);
     p.fwd_total = o;
 
@@ -116,7 +118,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
 ustrun_src_t nhwc_src(const void* ptr, const float* aff, int C, int H, int W, int relu, int pool, int gN = 0) {
     ustrun_src_t s = {};
     s.ptr = ptr; s.scale = aff; s.shift = aff ? aff + C : nullptr;
-    s.gN = aff ? gN : 0; s.gstride = 4L * C;        // pass g keeps its constants at aff + g * 4C
+    s.gN = gN; s.gstride = 4L * C;                  // pass g keeps its constants at aff + g * 4C
     s.C = C; s.H = H; s.W = W;
     s.sC = 1; s.sW = C; s.sH = (int64_t)W * C; s.sN = (int64_t)H * W * C;
     s.relu = relu; s.pool = pool;
@@ -138,7 +140,9 @@ int conv_sources(const Plan& p, const float* x, const char* ws, int i, ustrun_sr
         return 1;
     }
     if (i < 10) {
-        srcs[0] = (i % 2 == 1) ? act(i - 1, 0) : act(i - 1, 1);
+        if (i % 2 == 1) { srcs[0] = act(i - 1, 0); return 1; }
+        const int l = i / 2;       // Down l: the pooled activation was materialised by ustrun_pool_act (plain tensor)
+        srcs[0] = nhwc_src(ws + p.pool_off[l - 1], nullptr, p.cout[i - 1], p.Hs[l], p.Ws[l], 0, 0, p.G > 1 ? p.gN : 0);
         return 1;
     }
     if (i % 2 == 1) { srcs[0] = act(i - 1, 0); return 1; }
@@ -222,6 +226,12 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
                                       p.G > 1 ? p.gN : 0);
             USTRUN_TRY(ustrun_convT2x2_fwd(&a, pk + p.uf_off[j], d->up_b[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
                                            ws + p.u_off[j], d->dtype, s));
+        }
+        if (i >= 2 && i < 10 && i % 2 == 0) {      // MaxPool2d of the previous level's activated output
+            const int l = i / 2;
+            ustrun_src_t a = nhwc_src(ws + p.y_off[i - 1], affp(i - 1), p.cout[i - 1], p.Hs[l - 1], p.Ws[l - 1], 1, 0,
+                                      p.G > 1 ? p.gN : 0);
+            USTRUN_TRY(ustrun_pool_act(&a, p.N, ws + p.pool_off[l - 1], d->dtype, s));
         }
         ustrun_src_t srcs[2];
         const int ns = conv_sources(p, x, ws, i, srcs);

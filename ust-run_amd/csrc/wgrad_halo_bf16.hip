@@ -246,6 +246,14 @@ constexpr int D3SLOTS = (HP * 8 + 63) / 64 * 64;             // 896
 constexpr int D3IT = (D3SLOTS + 255) / 256;                  // 4 (waves 2,3: 3)
 constexpr int A3TILE = A3SLOTS * 16, D3TILE = D3SLOTS * 16, STAGE3 = A3TILE + D3TILE;
 
+// LDS-DMA issued from inline asm: with the builtin, hipcc puts `s_waitcnt vmcnt(0)` in front of the first transposing
+// LDS read that follows (it cannot prove the read does not alias the transfer in flight), which serialises every tile
+// on its own prefetch.  The kernel orders reads against landed tiles itself (counted vmcnt + barrier).
+__device__ __forceinline__ void dma16(const void* gsrc, const char* lds_wave_base) {
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(m) : "memory", "m0");
+}
+
 __device__ __forceinline__ bf16x8 tr_frag3(const char* lane_base, int k0) {
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lane_base + k0 * RB3));
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lane_base + (k0 + 4) * RB3));
@@ -260,10 +268,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x {activation tile [64 px][128 B], dY patch [108 px][128 B]}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    const int mtile = blockIdx.x / ntn, ntile = blockIdx.x % ntn;
+    // XCD-aware order (1-D grid, workgroups go round-robin over the 8 XCDs): every XCD takes a contiguous range of the
+    // (slice-major, pair-minor) order, so the (ci, co) pairs of one spatial slice run on ONE XCD: the slice's activation
+    // and dY tiles come from HBM once and the other pairs re-read them from that XCD's L2 -- with the natural order the
+    // Cin/64 x Cout/64 re-reads were spread over all eight L2s.
+    const int nblk = gridDim.x, pairs = nblk / a.ksplit;
+    int lin;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int slice = lin / pairs, pair = lin - slice * pairs;
+    const int mtile = pair / ntn, ntile = pair % ntn;
     const int ci0 = mtile * 64, co0 = ntile * 64;
     const int ttotal = a.N * tiles_y * tiles_x;
-    const int tbeg = blockIdx.y * tiles_per;
+    const int tbeg = slice * tiles_per;
     const int tend = min(ttotal, tbeg + tiles_per);
 
     // ---- activation side: item i = LDS slot tid + 256 i: pixel (tid >> 3) + 32 i, slot tid & 7; bit 1 of the pixel is a
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
                 const int ly = y0 - 1 + (dhyx[i] >> 8), lx = x0 - 1 + (dhyx[i] & 0xff);
                 const bool ok = dhyx[i] != 0xffff && ly >= 0 && ly < a.dyH && lx >= 0 && lx < a.dyW;
                 const __bf16* src = ok ? dbase + droff[i] : zsrc;
-                __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(stage + A3TILE + (256 * i + wave * 64) * 16), 16, 0, 0);
+                dma16(src, stage + A3TILE + (256 * i + wave * 64) * 16);
             }
         }
         unsigned ok2 = 0;
@@ -332,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
             const bool ok = ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
             ok2 |= (ok ? 1u : 0u) << i;
             const __bf16* src = ok ? sp + sbase + (long)ly * S.sH + (long)lx * S.sW : zsrc;
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(stage + (256 * i + wave * 64) * 16), 16, 0, 0);
+            dma16(src, stage + (256 * i + wave * 64) * 16);
         }
         return ok2;
     };
@@ -396,19 +415,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
         bf16x8 af[TH];
 #pragma unroll
         for (int r = 0; r < TH; ++r) af[r] = tr_frag3(Ab, r * TW);
+        // the three dY fragments of patch row pr+1 are in flight while row pr's MFMAs run (one LDS round trip per row
+        // instead of one per fragment)
+        bf16x8 bq[2][3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) bq[0][kw] = tr_frag3(st0 + dbase4[(2 - kw) & 3], 2 - kw);
 #pragma unroll
         for (int pr = 0; pr < TH + 2; ++pr) {
+            if (pr + 1 < TH + 2) {
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int k0 = pr * HW2 + 2 - kw;
-                const bf16x8 b = tr_frag3(st0 + dbase4[k0 & 3], k0);
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int r = pr + kh - 2;
-                    if (r >= 0 && r < TH)
-                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int k0 = (pr + 1) * HW2 + 2 - kw;
+                    bq[(pr + 1) & 1][kw] = tr_frag3(st0 + dbase4[k0 & 3], k0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {      // tap (kh,kw) pairs pixel row r with dY row r + 2 - kh of the patch
+                    const int r = pr + kh - 2;
+                    if (r >= 0 && r < TH)
+                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // bottom: tile t+1 (issued one iteration ago) has landed once only this top's transfers are outstanding
         if (t + 1 < tend) {
@@ -428,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
         char* tmp = st0; st0 = st1; st1 = st2; st2 = tmp;
     }
 
-    float* slab = a.partials + (long)blockIdx.y * 9 * a.Cin * a.Cout;
+    float* slab = a.partials + (long)slice * 9 * a.Cin * a.Cout;
     const int l31 = lane & 31, lh = lane >> 5;
     const int ci = ci0 + wi * 32 + l31;
 #pragma unroll
@@ -469,8 +500,12 @@ int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStr
     dim3 grid((a.Cin / 64) * (a.Cout / 64), ksplit), block(256);
     if (a.src[0].pool)
         hipLaunchKernelGGL(wgrad_halo_bf16_kernel<true>, grid, block, 2 * ATILE + 2 * DTILE, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
-    else
-        hipLaunchKernelGGL(wgrad_halo3_bf16_kernel, grid, block, 3 * STAGE3, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
+    else {
+        WgradArgs b = a;
+        b.ksplit = ksplit;
+        hipLaunchKernelGGL(wgrad_halo3_bf16_kernel, dim3(grid.x * ksplit), block, 3 * STAGE3, st, b, a.Cout / 64, cdiv(a.Wb, TW),
+                           cdiv(a.Hb, TH), tiles_per);
+    }
     USTRUN_LAUNCH_CHECK("wgrad_halo_bf16");
     return 0;
 }
