@@ -320,7 +320,7 @@ __global__ void pack_bf16_multi_kernel(const PackJobs jobs) {
 }
 
 int pack_bf16_multi(const PackJobs& jobs, int n, hipStream_t st) {
-    hipLaunchKernelGGL(pack_bf16_multi_kernel, dim3(256, n), dim3(256), 0, st, jobs);
+    hipLaunchKernelGGL(pack_bf16_multi_kernel, dim3(1024, n), dim3(256), 0, st, jobs);   // small layers: most blocks exit at once
     USTRUN_LAUNCH_CHECK("pack_bf16_multi");
     return 0;
 }
