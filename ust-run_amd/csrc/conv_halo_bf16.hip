@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     const int trem = mtile - img * tiles_y * tiles_x;
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA bases and role tests stay scalar
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
 

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256, 2) void wgradT_bf16_kernel(const WgradArgs a, 
     char* As = smem;                      // 2 x [KP][TM] bf16
     char* Bs = smem + 2 * KP * RB;        // 2 x [KP][TN] bf16
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA bases and role tests stay scalar
     const int wm = wave >> 1, wn = wave & 1;
     const int mtile = blockIdx.x / ntn, ntile = blockIdx.x % ntn;
     const int ci0 = mtile * TM, co0 = ntile * 32;

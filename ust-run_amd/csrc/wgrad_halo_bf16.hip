@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
     char* As = smem;                               // 2 x activation tile [64 px][RB]
     char* Ds = smem + 2 * ATILE;                   // 2 x dY patch [108 px][RB] (+ slack to whole wave-instructions)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA bases and role tests stay scalar
     const int wi = wave >> 1, wj = wave & 1;
     const int mtile = blockIdx.x / ntn, ntile = blockIdx.x % ntn;
     const int ci0 = mtile * 64, co0 = ntile * 64;
@@ -266,7 +267,8 @@ __device__ __forceinline__ bf16x8 tr_frag3(const char* lane_base, int k0) {
 __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArgs a, const int ntn, const int tiles_x,
                                                                   const int tiles_y, const int tiles_per) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x {activation tile [64 px][128 B], dY patch [108 px][128 B]}
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA bases and role tests stay scalar
     const int wi = wave >> 1, wj = wave & 1;
     // XCD-aware order (1-D grid, workgroups go round-robin over the 8 XCDs): every XCD takes a contiguous range of the
     // (slice-major, pair-minor) order, so the (ci, co) pairs of one spatial slice run on ONE XCD: the slice's activation
