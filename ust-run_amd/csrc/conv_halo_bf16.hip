@@ -309,7 +309,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][ks][i], bf[k][ks][0], acc[i][0], 0, 0, 0);
                         acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][ks][i], bf[k][ks][1], acc[i][1], 0, 0, 0);
                     }
-            // bottom: this top's transfers have landed
+            // bottom: this top's transfers have landed.  (The scheduling barrier keeps the wait BEHIND the MFMAs: an asm
+            // statement only orders against memory operations, and hipcc otherwise hoists it above fifteen of them.)
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (j < NSTG - 1) {
                 if (more && a_xf) {

@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
             __builtin_amdgcn_sched_barrier(0);
         }
         // bottom: tile t+1 (issued one iteration ago) has landed once only this top's transfers are outstanding
+        __builtin_amdgcn_sched_barrier(0);          // keep the waits behind the MFMAs
         if (t + 1 < tend) {
             if (issue) {
                 if (w4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + 2) : "memory");
