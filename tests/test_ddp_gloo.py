@@ -77,6 +77,44 @@ def test_bucketed_allreduce_world2():
     _run(bucket=4096)
 
 
+def _worker_tail(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "ust-run_amd")]
+    from ustrun import ddp
+    ddp.init("gloo")
+    n, off = 9001, 5432
+    ar = ddp.make_grad_allreduce(world)
+    for step in range(2):
+        grad = torch.randn(n, generator=torch.Generator().manual_seed(ddp.rank_seed(100 * step, rank)))
+        tot = sum(torch.randn(n, generator=torch.Generator().manual_seed(ddp.rank_seed(100 * step, k))) for k in range(world))
+        head_before = grad[:off].clone()
+        ar.start_tail(grad, off)            # decoder gradients (contiguous tail) leave first ...
+        grad[:off] += 0.0                   # ... while the "encoder half" still produces the head
+        assert torch.equal(grad[:off], head_before)
+        ar.finish(grad)                     # head reduced, tail joined
+        assert torch.allclose(grad, tot, rtol=0, atol=1e-6)
+    q.put((rank, float(grad.double().sum())))
+    dist.destroy_process_group()
+
+
+def test_two_piece_reducer_world2():
+    """GradReducer.start_tail / finish (the overlap used by the training step) == one all-reduce of the whole buffer."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tail, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get() for _ in range(2))
+    assert res[0] == res[1]
+
+
 def test_single_process_needs_no_collective():
     from ustrun import ddp
     assert ddp.make_grad_allreduce(1) is None

@@ -181,3 +181,22 @@ def test_forward_passes_equals_separate_calls(dtype, base, n, hw):
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         e = float((p1.grad - p2.grad).norm() / (p1.grad.norm() + 1e-20))
         assert e < tol, (k, e)
+
+
+def test_backward_in_two_parts_equals_one_call():
+    """Head + decoder, then encoder (the split the data-parallel step uses to start the decoder all-reduce early)
+    gives bit-identical gradients to the single backward call, and the hook fires between the halves."""
+    import copy
+    from networks.unet_model import UNet
+    torch.manual_seed(7)
+    m1 = UNet(3, 2, base_channels=16, dtype="bf16").cuda().train()
+    m2 = copy.deepcopy(m1)
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    dl = torch.randn(2, 2, 32, 32, generator=torch.Generator().manual_seed(2)).cuda()
+    m1(x).backward(dl)
+    fired = []
+    m2._ustrun_backward_split_hook = lambda: fired.append(1)
+    m2(x).backward(dl)
+    assert fired == [1]
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p1.grad, p2.grad), k

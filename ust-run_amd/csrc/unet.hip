@@ -269,6 +269,15 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
 
 extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x, const float* dlogits, void* workspace,
                                     void* scratch, float* const* grads, int accumulate, ustrun_stream_t s) {
+    return ustrun_unet_backward_part(d, x, dlogits, workspace, scratch, grads, accumulate, 0, s);
+}
+
+// part 0: everything; part 1: head + decoder (the gradients of up1..up4 and outc, the contiguous tail of the parameter
+// order, are final afterwards); part 2: encoder, continuing from the same scratch.  Lets the caller start the all-reduce
+// of the decoder gradients while the encoder half still runs.
+extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const float* x, const float* dlogits, void* workspace,
+                                         void* scratch, float* const* grads, int accumulate, int which, ustrun_stream_t s) {
+    USTRUN_CHECK(which >= 0 && which <= 2, "unet_backward: part %d", which);
     Plan p; USTRUN_TRY(make_plan(d, p));
     USTRUN_CHECK(x && dlogits && workspace && scratch && grads && d->packed, "unet_backward: null pointer");
     USTRUN_CHECK(d->train, "unet_backward: forward must have run in train mode");
@@ -280,7 +289,7 @@ extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x,
     auto affp = [&](int k) { return (const float*)(ws + p.aff_off[k]); };
     const int dt = d->dtype;
 
-    {   // head, pass by pass (the BatchNorm constants on load are per pass)
+    if (which != 2) {   // head, pass by pass (the BatchNorm constants on load are per pass)
         const int C = p.cout[17];
         const long gpix = (long)p.gN * p.H * p.W;
         for (int g = 0; g < p.G; ++g) {
@@ -290,7 +299,8 @@ extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x,
                                        grads[63], g == 0 ? accumulate : 1, part, p.part_bytes, dt, s));
         }
     }
-    for (int i = 17; i >= 0; --i) {
+    const int i_hi = which == 2 ? 9 : 17, i_lo = which == 1 ? 10 : 0;
+    for (int i = i_hi; i >= i_lo; --i) {
         if (i == ustrun_debug_stop_layer) return 0;
         const int l = p.lvl[i], H = p.Hs[l], W = p.Ws[l], C = p.cout[i];
         const float* aff = affp(i);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "ustrun_unet_pack": (i32, [PDesc, vp]),
     "ustrun_unet_forward": (i32, [PDesc, fp, fp, fp, vp, vp]),
     "ustrun_unet_backward": (i32, [PDesc, fp, fp, vp, vp, C.POINTER(vp), i32, vp]),
+    "ustrun_unet_backward_part": (i32, [PDesc, fp, fp, vp, vp, C.POINTER(vp), i32, i32, vp]),
 }
 
 _lib = None

@@ -31,20 +31,47 @@ def init(backend=None, device=None):
     return rank, local, world
 
 
-def make_grad_allreduce(world, bucket_elems=0):
-    """callable(flat_grad) summing it over ranks in place.  bucket_elems > 0 splits the buffer into
-    buckets launched back to back (async) so that the tail of one overlaps the head of the next."""
-    if world <= 1:
-        return None
+class GradReducer:
+    """SUM of the flat gradient buffer over ranks, in place.
 
-    def allreduce(flat):
-        if bucket_elems <= 0 or flat.numel() <= bucket_elems:
+    Called with the buffer it reduces everything at once (optionally in back-to-back buckets).  The training step
+    uses it in two pieces instead: the decoder gradients are the contiguous TAIL of the buffer (parameter order
+    inc, down1..4, up1..4, outc) and are final once the head + decoder half of the backward has been issued, so
+    `start_tail` launches their all-reduce there (async: RCCL runs it on its own stream behind the backward stream's
+    work so far) and it overlaps the encoder half; `finish` reduces the head and joins."""
+
+    def __init__(self, world, bucket_elems=0):
+        self.world, self.bucket_elems = world, bucket_elems
+        self._work, self._off = None, 0
+
+    def __call__(self, flat):
+        b = self.bucket_elems
+        if b <= 0 or flat.numel() <= b:
             dist.all_reduce(flat)
             return
-        works = [dist.all_reduce(flat[o:o + bucket_elems], async_op=True) for o in range(0, flat.numel(), bucket_elems)]
+        works = [dist.all_reduce(flat[o:o + b], async_op=True) for o in range(0, flat.numel(), b)]
         for w in works:
             w.wait()
-    return allreduce
+
+    def start_tail(self, flat, off):
+        self._off = int(off)
+        self._work = dist.all_reduce(flat[self._off:], async_op=True)
+
+    def finish(self, flat):
+        if self._work is None:
+            self(flat)
+            return
+        if self._off > 0:
+            dist.all_reduce(flat[:self._off])
+        self._work.wait()
+        self._work = None
+
+
+def make_grad_allreduce(world, bucket_elems=0):
+    """GradReducer for world > 1, None for a single process (no collective)."""
+    if world <= 1:
+        return None
+    return GradReducer(world, bucket_elems)
 
 
 def rank_seed(base, rank):

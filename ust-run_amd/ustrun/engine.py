@@ -121,8 +121,17 @@ class _UNetFn(torch.autograd.Function):
                 o += p.numel()
             accumulate = 0
         arr = (C.c_void_p * len(targets))(*[t.data_ptr() for t in targets])
-        L.check(lib.ustrun_unet_backward(C.byref(d), ctx.x.data_ptr(), dlogits.data_ptr(), ctx.ws.data_ptr(),
-                                         scratch.data_ptr(), arr, accumulate, stream_ptr()), "ustrun_unet_backward")
+        split = getattr(model, "_ustrun_backward_split_hook", None)
+        if split is None:
+            L.check(lib.ustrun_unet_backward(C.byref(d), ctx.x.data_ptr(), dlogits.data_ptr(), ctx.ws.data_ptr(),
+                                             scratch.data_ptr(), arr, accumulate, stream_ptr()), "ustrun_unet_backward")
+        else:       # head + decoder, hand the (now final) decoder gradients to the caller, then the encoder
+            for part in (1, 2):
+                L.check(lib.ustrun_unet_backward_part(C.byref(d), ctx.x.data_ptr(), dlogits.data_ptr(), ctx.ws.data_ptr(),
+                                                      scratch.data_ptr(), arr, accumulate, part, stream_ptr()),
+                        "ustrun_unet_backward_part")
+                if part == 1:
+                    split()
         ctx.ws = None
         grads = (None,) * ctx.nparams if sink is not None else tuple(targets)
         return (None, None, None, None) + grads

@@ -132,6 +132,8 @@ class SSLTrainer:
         self.flat_t, _ = flatten_parameters(ema_model)
         params = list(model.parameters())
         self.flat_g, self.grad_views = flat_like(self.flat_p, params)
+        # offset of the first decoder parameter (up1.up.weight, index 30 of 64): the tail [dec_off:] is up1..up4 + outc
+        self.dec_off = sum((p.numel() + 3) // 4 * 4 for p in params[:30]) if len(params) == 64 else 0
         self.flat_v = torch.zeros_like(self.flat_p)
         model._ustrun_grad_sink = self.grad_views        # backward accumulates straight into flat_g
         engine.invalidate_packed(model)
@@ -309,11 +311,20 @@ class SSLTrainer:
                 lg.backward(dl)
             else:
                 dls.append(dl)
+        overlap = self.grad_allreduce is not None and hasattr(self.grad_allreduce, "start_tail")
         if lg_all is not None:                    # one backward over the four passes
-            lg_all.backward(torch.cat(dls, 0))
+            if overlap:                            # decoder gradients go out while the encoder half still runs
+                model._ustrun_backward_split_hook = lambda: self.grad_allreduce.start_tail(self.flat_g, self.dec_off)
+            try:
+                lg_all.backward(torch.cat(dls, 0))
+            finally:
+                model._ustrun_backward_split_hook = None
         self._mark("backward issued")
         if self.grad_allreduce is not None:
-            self.grad_allreduce(self.flat_g)
+            if overlap:
+                self.grad_allreduce.finish(self.flat_g)
+            else:
+                self.grad_allreduce(self.flat_g)
 
         # SGD + EMA (train.py:848-851; alpha from the pre-increment iter_num, Q10), poly LR for the NEXT step
         alpha = min(1 - 1 / (self.iter_num + 1), self.ema_decay)
