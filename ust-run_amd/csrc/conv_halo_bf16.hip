@@ -334,27 +334,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     // sub-tile at a time through its own LDS scratch (rows padded to 144 B: the two half-waves hit disjoint
     // banks) and writes 16 bytes per lane, 128 contiguous bytes per pixel.
     const int C1 = a.Cout - a.C0;
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    f32x2 s1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2v[2] = {{0.f, 0.f}, {0.f, 0.f}};    // two pixel rows at a time (packed f32 math)
     constexpr int EPITCH = 144;
     char* ep = smem + wave * (32 * EPITCH);         // the A patches are dead after the last barrier
-    const float bias0 = a.bias ? a.bias[n0 + wn * 64 + l31] : 0.f, bias1 = a.bias ? a.bias[n0 + wn * 64 + 32 + l31] : 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    const bool full = y0 + TH <= a.Ho && x0 + TW <= a.Wo;     // interior tile: no per-pixel masks
+    // sub-tile i -> LDS scratch (bf16) + statistics; MASK = false on interior tiles (a wave-uniform branch, not selects)
+    auto park = [&](int i, auto mask_c, auto stat_c) {
+        constexpr bool MASK = decltype(mask_c)::value, STAT = decltype(stat_c)::value;
         const int oyb = y0 + wm * SR * MI + SR * i;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;          // 0..31 inside the sub-tile
-                const int oy = oyb + (TW == 16 ? (row >> 4) : 0), ox = x0 + (row & (TW - 1));
-                const __bf16 hv = (__bf16)(acc[i][j][r] + (j ? bias1 : bias0));
-                *(__bf16*)(ep + row * EPITCH + (j * 32 + l31) * 2) = hv;
-                if (oy < a.Ho && ox < a.Wo) {
-                    const float v = (float)hv;                             // statistics see the stored value
-                    s1[j] += v; s2[j] += v * v;
+            for (int r = 0; r < 16; r += 2) {       // registers r, r+1 are pixel rows row, row+1 of the sub-tile
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
+                const bf16x2 h = __builtin_convertvector(v, bf16x2);
+                *(__bf16*)(ep + row * EPITCH + (j * 32 + l31) * 2) = h[0];
+                *(__bf16*)(ep + (row + 1) * EPITCH + (j * 32 + l31) * 2) = h[1];
+                if (!STAT) continue;
+                f32x2 f = __builtin_convertvector(h, f32x2);               // statistics see the stored values
+                if (MASK) {
+                    const int oy0 = oyb + (TW == 16 ? (row >> 4) : 0), ox0 = x0 + (row & (TW - 1));
+                    const int oy1 = oyb + (TW == 16 ? ((row + 1) >> 4) : 0), ox1 = x0 + ((row + 1) & (TW - 1));
+                    if (!(oy0 < a.Ho && ox0 < a.Wo)) f[0] = 0.f;
+                    if (!(oy1 < a.Ho && ox1 < a.Wo)) f[1] = 0.f;
                 }
+                s1v[j] += f;
+                s2v[j] += f * f;
             }
         }
+    };
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int oyb = y0 + wm * SR * MI + SR * i;
+        if (!a.stat) park(i, std::false_type{}, std::false_type{});        // input-gradient: no statistics
+        else if (full) park(i, std::false_type{}, std::true_type{});
+        else park(i, std::true_type{}, std::true_type{});
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -378,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    float s1[2] = {s1v[0][0] + s1v[0][1], s1v[1][0] + s1v[1][1]}, s2[2] = {s2v[0][0] + s2v[0][1], s2v[1][0] + s2v[1][1]};
     if (a.stat) {
         float* red = (float*)(smem + 4 * 32 * EPITCH);   // [WM][2][BN], behind the waves' transpose scratch
 #pragma unroll
@@ -423,7 +441,7 @@ int halo_stat_rows(int N, int H, int W) { return N * cdiv(H, 8) * cdiv(W, 16); }
 bool halo_supported(const IgemmArgs& a) {
     if (a.nseg != 9 || a.nz != 1 || a.s_in != 1 || a.s_out != 1 || a.segw != 3) return false;
     bool pool = false;
-    if (a.out_esz != 2 || (a.C0 & 7) || ((a.Cout - a.C0) & 7)) return false;
+    if (a.out_esz != 2 || (a.C0 & 7) || ((a.Cout - a.C0) & 7) || a.bias) return false;     // (3x3 convs here carry no bias)
     for (int i = 0; i < a.nsrc; ++i) {
         if (a.src[i].sC != 1 || (a.src[i].C & 7) || a.src[i].esz != 2) return false;
         pool |= a.src[i].pool != 0;
