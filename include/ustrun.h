@@ -95,6 +95,10 @@ int ustrun_bn_relu_apply(const void* y, const float* scale, const float* shift, 
  * dtype (replaces nn.MaxPool2d at unet_parts.py:34 together with the producer's BatchNorm+ReLU); src is a plain
  * contiguous NHWC activation, its pass groups are honoured                                                     */
 int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dtype, ustrun_stream_t s);
+/* plain MaxPool2d(2) backward on NHWC tensors (stand-alone Down block): dx[N,H,W,C] from dp[N,H/2,W/2,C] and the
+ * pooled input x; first maximum of the window wins (torch's rule)                                              */
+int ustrun_maxpool_bwd(const void* dp, const void* x, int N, int H, int W, int C, void* dx, int dtype,
+                       ustrun_stream_t s);
 
 /* ---- ConvTranspose2d(k=2,s=2,bias): replaces unet_parts.py:53 ------------------------------
  * u[N,2H,2W,Cout] = convT(loader(src)) + bias.                                              */

@@ -177,6 +177,32 @@ __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__
     }
 }
 
+// plain MaxPool2d(2) backward (stand-alone Down block): dx = dp routed to the first maximum of each window (torch's
+// tie rule: row-major scan, strict >), zero elsewhere, incl. the odd last row/column the pooling drops
+template <int ESZ>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ x, int N, int H,
+                                                         int W, int C, float* __restrict__ dx) {
+    const int Hp = H / 2, Wp = W / 2;
+    const long total = (long)N * H * W * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C); long t = e / C;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H); const int n = (int)(t / H);
+        const int py = iy >> 1, px = ix >> 1;
+        float g = 0.f;
+        if (py < Hp && px < Wp) {
+            const long b = (((long)n * H + 2 * py) * W + 2 * px) * C + c;
+            int best = 0; float bv = ld1(x, b, ESZ);
+            const float v1 = ld1(x, b + C, ESZ), v2 = ld1(x, b + (long)W * C, ESZ), v3 = ld1(x, b + (long)W * C + C, ESZ);
+            if (v1 > bv) { bv = v1; best = 1; }
+            if (v2 > bv) { bv = v2; best = 2; }
+            if (v3 > bv) { bv = v3; best = 3; }
+            if (best == ((iy & 1) * 2 + (ix & 1))) g = ld1(dp, (((long)n * Hp + py) * Wp + px) * C + c, ESZ);
+        }
+        st1(dx, e, g, ESZ);
+    }
+}
+
 // ---- backward -------------------------------------------------------------------------------
 // One "window" = one pixel (POOL = false) or one 2x2 pooling window (POOL = true).  For each
 // element: a = relu(s*y+b); da_total = da + (dp routed to the window's first arg-max of a);
@@ -419,6 +445,23 @@ extern "C" int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dt
         hipLaunchKernelGGL(pool_act_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)src->ptr, src->scale,
                            src->shift, src->relu, gN, (long)src->gstride, N, H, W, C, (float*)out);
     USTRUN_LAUNCH_CHECK("pool_act");
+    return 0;
+}
+
+extern "C" int ustrun_maxpool_bwd(const void* dp, const void* x, int N, int H, int W, int C, void* dx, int dtype,
+                                  ustrun_stream_t s) {
+    USTRUN_CHECK(dtype_ok(dtype), "maxpool_bwd: dtype %d not built", dtype);
+    USTRUN_CHECK(dp && x && dx && N > 0 && H >= 2 && W >= 2 && C > 0, "maxpool_bwd: bad args");
+    const long total = (long)N * H * W * C;
+    long nb = (total + 1023) / 1024;
+    if (nb > 8192) nb = 8192;
+    if (dtype == USTRUN_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<2>, dim3((int)nb), dim3(256), 0, (hipStream_t)s, (const float*)dp, (const float*)x, N, H,
+                           W, C, (float*)dx);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<4>, dim3((int)nb), dim3(256), 0, (hipStream_t)s, (const float*)dp, (const float*)x, N, H,
+                           W, C, (float*)dx);
+    USTRUN_LAUNCH_CHECK("maxpool_bwd");
     return 0;
 }
 
