@@ -242,10 +242,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
 // so a DMA wave-instruction is exactly 8 pixels); a thread's items always hold the same channel group, whose BatchNorm
 // constants it keeps in registers, and the activation is applied IN PLACE at the bottom of the previous tile.
 constexpr int RB3 = 128;
-constexpr int A3SLOTS = TH * TW * 8;                         // 512: two per thread
-constexpr int D3SLOTS = (HP * 8 + 63) / 64 * 64;             // 896
-constexpr int D3IT = (D3SLOTS + 255) / 256;                  // 4 (waves 2,3: 3)
-constexpr int A3TILE = A3SLOTS * 16, D3TILE = D3SLOTS * 16, STAGE3 = A3TILE + D3TILE;
+// tile rows T3 = 4: three buffers, transfers two tiles ahead; T3 = 8: two buffers, one (twice as long) tile ahead --
+// half the per-tile address/bounds/bookkeeping instructions per MFMA of an issue-bound kernel
+template <int T3> struct H3 {
+    static constexpr int HPX = (T3 + 2) * HW2;                       // halo pixels
+    static constexpr int ASLOTS = T3 * TW * 8, AIT = ASLOTS / 256;   // activation items per thread: 2 or 4
+    static constexpr int DSLOTS = (HPX * 8 + 63) / 64 * 64, DIT = (DSLOTS + 255) / 256;
+    static constexpr int ATILE = ASLOTS * 16, DTILE = DSLOTS * 16, STAGE = ATILE + DTILE;
+    static constexpr int NBUF = T3 == 4 ? 3 : 2;
+};
 
 // LDS-DMA issued from inline asm: with the builtin, hipcc puts `s_waitcnt vmcnt(0)` in front of the first transposing
 // LDS read that follows (it cannot prove the read does not alias the transfer in flight), which serialises every tile
@@ -264,9 +269,13 @@ __device__ __forceinline__ bf16x8 tr_frag3(const char* lane_base, int k0) {
     return f;
 }
 
+template <int T3>
 __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArgs a, const int ntn, const int tiles_x,
                                                                   const int tiles_y, const int tiles_per) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x {activation tile [64 px][128 B], dY patch [108 px][128 B]}
+    typedef H3<T3> G;
+    constexpr int A3IT = G::AIT, D3IT = G::DIT, D3SLOTS = G::DSLOTS, A3TILE = G::ATILE, STAGE3 = G::STAGE, NBUF = G::NBUF;
+    constexpr int HPX = G::HPX;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF x {activation tile [T3*16 px][128 B], dY patch [HPX px][128 B]}
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA bases and role tests stay scalar
     const int wi = wave >> 1, wj = wave & 1;
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
         const int slot = tid + 256 * i, hp = slot >> 3;
         const int gl = (slot & 7) ^ (((hp >> 1) & 1) << 2);
         const int hy = hp / HW2, hx = hp - hy * HW2;
-        const bool v = hp < HP;
+        const bool v = hp < HPX;
         droff[i] = v ? (hy * a.dyW + hx) * a.Cout + 8 * gl : 0;
         dhyx[i] = v ? ((hy << 8) | hx) : 0xffff;
     }
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
     auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
         img = t / (tiles_y * tiles_x);
         const int rem = t - img * tiles_y * tiles_x;
-        y0 = (rem / tiles_x) * TH; x0 = (rem % tiles_x) * TW;
+        y0 = (rem / tiles_x) * T3; x0 = (rem % tiles_x) * TW;
     };
     // all transfers of tile t -> stage buffer; returns the in-source bits of this thread's two activation items
     auto issue_tile = [&](int t, char* stage) {
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
         unsigned ok2 = 0;
         const long sbase = img * S.sN;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < A3IT; ++i) {
             const int px = apx + 32 * i;
             const int ly = y0 + (px >> 4) - S.off_y, lx = x0 + (px & 15) - S.off_x;
             const bool ok = ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
     auto activate = [&](char* stage, unsigned ok2) {
         if (!xf) return;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < A3IT; ++i) {
             if ((ok2 >> i) & 1u) {
                 char* p = stage + (tid + 256 * i) * 16;
                 const bf16x8 r = *(const bf16x8*)p;
@@ -390,76 +399,80 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
 #pragma unroll
     for (int c = 0; c < 4; ++c) dbase4[c] = A3TILE + lrow * RB3 + ((wj * 64 + lcolb) ^ ((((c + lrow) >> 1) & 1) << 6));
 
-    unsigned ok_cur = 0, ok_nxt = 0;                 // in-source bits of the tile being waited for / issued last
-    char* st0 = smem; char* st1 = smem + STAGE3; char* st2 = smem + 2 * STAGE3;   // tile t, t+1, t+2
+    // transfers of one tile, per wave: D3IT (- 1 on the waves without a last dY piece) + A3IT
+    auto wait_all_but_one_tile = [&]() {
+        if (w4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + A3IT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT - 1 + A3IT) : "memory");
+    };
+    unsigned ok_q[3] = {0, 0, 0};                    // in-source bits of the tiles in flight (tile t + k at index k)
+    char* st[3] = {smem, smem + STAGE3, smem + (NBUF - 1) * STAGE3};     // buffers of tile t, t+1, (t+2)
+    constexpr int PD = NBUF - 1;                     // tiles issued ahead
     if (tbeg < tend) {
         load_consts(tile_img(tbeg));
-        ok_cur = issue_tile(tbeg, st0);
-        if (tbeg + 1 < tend) {
-            ok_nxt = issue_tile(tbeg + 1, st1);
-            if (w4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + 2) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + 1) : "memory");
+        ok_q[0] = issue_tile(tbeg, st[0]);
+        if (PD == 2 && tbeg + 1 < tend) {
+            ok_q[1] = issue_tile(tbeg + 1, st[1]);
+            wait_all_but_one_tile();
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        activate(st0, ok_cur);
+        activate(st[0], ok_q[0]);
     }
     __syncthreads();
 #pragma unroll 1
     for (int t = tbeg; t < tend; ++t) {
-        // top: tile t+2 into the buffer tile t-1 used
-        unsigned ok_new = 0;
-        const bool issue = t + 2 < tend;
-        if (issue) ok_new = issue_tile(t + 2, st2);
-        const char* Ab = st0 + abase;
+        // top: tile t+PD into the buffer tile t-1 used
+        const bool issue = t + PD < tend;
+        if (issue) ok_q[PD] = issue_tile(t + PD, st[PD]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { (void)c; }
-        bf16x8 af[TH];
+        for (int h = 0; h < T3 / 4; ++h) {           // four tile rows at a time: their dY fragments are patch rows 4h .. 4h+5
+            const char* Ab = st[0] + abase;
+            bf16x8 af[4];
 #pragma unroll
-        for (int r = 0; r < TH; ++r) af[r] = tr_frag3(Ab, r * TW);
-        // the three dY fragments of patch row pr+1 are in flight while row pr's MFMAs run (one LDS round trip per row
-        // instead of one per fragment)
-        bf16x8 bq[2][3];
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) bq[0][kw] = tr_frag3(st0 + dbase4[(2 - kw) & 3], 2 - kw);
-#pragma unroll
-        for (int pr = 0; pr < TH + 2; ++pr) {
-            if (pr + 1 < TH + 2) {
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int k0 = (pr + 1) * HW2 + 2 - kw;
-                    bq[(pr + 1) & 1][kw] = tr_frag3(st0 + dbase4[k0 & 3], k0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < 4; ++r) af[r] = tr_frag3(Ab, (4 * h + r) * TW);
+            // the three dY fragments of the next patch row are in flight while this row's MFMAs run (one LDS round trip
+            // per row instead of one per fragment)
+            bf16x8 bq[2][3];
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {      // tap (kh,kw) pairs pixel row r with dY row r + 2 - kh of the patch
-                    const int r = pr + kh - 2;
-                    if (r >= 0 && r < TH)
-                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
-                }
+                const int k0 = 4 * h * HW2 + 2 - kw;
+                bq[0][kw] = tr_frag3(st[0] + dbase4[k0 & 3], k0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                if (pr + 1 < 6) {
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int k0 = (4 * h + pr + 1) * HW2 + 2 - kw;
+                        bq[(pr + 1) & 1][kw] = tr_frag3(st[0] + dbase4[k0 & 3], k0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {      // tap (kh,kw) pairs tile row r with dY row r + 2 - kh of the patch
+                        const int r = pr + kh - 2;
+                        if (r >= 0 && r < 4)
+                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        // bottom: tile t+1 (issued one iteration ago) has landed once only this top's transfers are outstanding
+        // bottom: tile t+1 has landed once only the transfers of later tiles are outstanding
         __builtin_amdgcn_sched_barrier(0);          // keep the waits behind the MFMAs
         if (t + 1 < tend) {
-            if (issue) {
-                if (w4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + 2) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + 1) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (PD == 2 && issue) wait_all_but_one_tile();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             load_consts(tile_img(t + 1));
-            activate(st1, ok_nxt);
+            activate(st[1], ok_q[1]);
         }
-        ok_nxt = ok_new;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        char* tmp = st0; st0 = st1; st1 = st2; st2 = tmp;
+        if (NBUF == 3) { char* tmp = st[0]; st[0] = st[1]; st[1] = st[2]; st[2] = tmp; ok_q[0] = ok_q[1]; ok_q[1] = ok_q[2]; }
+        else { char* tmp = st[0]; st[0] = st[1]; st[1] = tmp; st[2] = st[1]; ok_q[0] = ok_q[1]; }
     }
 
     float* slab = a.partials + (long)slice * 9 * a.Cin * a.Cout;
@@ -485,9 +498,12 @@ bool wgrad_halo_supported(const WgradArgs& a) {
     return true;
 }
 
+// tile rows of the non-pooled kernel: 8 (two buffers) once the extent has eight rows, else 4 (three buffers)
+static int halo3_rows(const WgradArgs& a) { return (!a.src[0].pool && a.Hb >= 8) ? 8 : 4; }
+
 // split-K plan of the halo kernel: slabs == ksplit
 int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
-    const int ttotal = a.N * cdiv(a.Hb, TH) * cdiv(a.Wb, TW);
+    const int ttotal = a.N * cdiv(a.Hb, halo3_rows(a)) * cdiv(a.Wb, TW);
     const long pairs = (long)(a.Cin / 64) * (a.Cout / 64);
     // one resident wave of blocks (2 per CU): every extra block costs a 147 KB f32 slab written and read back --
     // at 1024 blocks the slab traffic exceeded the layer's own input bytes (measured 527 -> 641 TFLOP/s at 512)
@@ -501,13 +517,17 @@ int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
 
 int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t st) {
     dim3 grid((a.Cin / 64) * (a.Cout / 64), ksplit), block(256);
-    if (a.src[0].pool)
+    if (a.src[0].pool) {
         hipLaunchKernelGGL(wgrad_halo_bf16_kernel<true>, grid, block, 2 * ATILE + 2 * DTILE, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
-    else {
+    } else {
         WgradArgs b = a;
         b.ksplit = ksplit;
-        hipLaunchKernelGGL(wgrad_halo3_bf16_kernel, dim3(grid.x * ksplit), block, 3 * STAGE3, st, b, a.Cout / 64, cdiv(a.Wb, TW),
-                           cdiv(a.Hb, TH), tiles_per);
+        if (halo3_rows(a) == 8)
+            hipLaunchKernelGGL(wgrad_halo3_bf16_kernel<8>, dim3(grid.x * ksplit), block, H3<8>::NBUF * H3<8>::STAGE, st, b, a.Cout / 64,
+                               cdiv(a.Wb, TW), cdiv(a.Hb, 8), tiles_per);
+        else
+            hipLaunchKernelGGL(wgrad_halo3_bf16_kernel<4>, dim3(grid.x * ksplit), block, H3<4>::NBUF * H3<4>::STAGE, st, b, a.Cout / 64,
+                               cdiv(a.Wb, TW), cdiv(a.Hb, 4), tiles_per);
     }
     USTRUN_LAUNCH_CHECK("wgrad_halo_bf16");
     return 0;
