@@ -158,11 +158,17 @@ class SSLTrainer:
         self.lq_u = self.lq_pl = self.lq_mask = None
         self.last = {}
         self.timeline = None                             # list of (label, perf_counter) when host timing is on
+        self._side, self._side_busy = None, False        # side stream of the batch-1 low-quality-sample forward
 
     # ---------------------------------------------------------------------------------------
     def _mark(self, label):
         if self.timeline is not None:
             self.timeline.append((label, time.perf_counter()))
+
+    def _side_stream(self, dev):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     def _pl(self, logits):
         return F.pseudo_label(logits, self.threshold, self.mode)
@@ -269,8 +275,17 @@ class SSLTrainer:
                 region = self.lq_pl[0].clone()
                 region[lb_mask[new_choice].long() > 0] = 1
             ib_lq = torch.from_numpy(all_cover_box(region.cpu().numpy()))[None].to(dev)
-            with torch.no_grad():                 # result unused (Q2); student BN running stats still move
-                model(F.box_mix(self.lq_u, lb_x_w[[new_choice]], ib_lq))
+            # result unused (Q2); student BN running stats still move.  A batch-1 forward fills 16-256 workgroups per
+            # launch, so it runs on a side stream underneath the losses and the backward that follow (ordered after
+            # the student passes issued so far; joined before the weights are repacked for the next step).
+            side = self._side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            lb_pick = lb_x_w[[new_choice]]
+            for t_ in (self.lq_u, lb_pick, ib_lq):
+                t_.record_stream(side)
+            with torch.cuda.stream(side), torch.no_grad():
+                model(F.box_mix(self.lq_u, lb_pick, ib_lq))
+            self._side_busy = True
         self.lq_u = ulb_x_w[[lq_idx]].clone()
         self.lq_pl = pl[[lq_idx]].clone()
         self.lq_mask = mask[[lq_idx]].clone()
@@ -331,6 +346,9 @@ class SSLTrainer:
         F.sgd_ema(self.flat_p, self.flat_g, self.flat_v, self.flat_t, self.lr, self.momentum, self.wd,
                   self.first_step, alpha, grad_scale=1.0 / self.world_size)
         self.first_step = False
+        if self._side_busy:                              # the low-quality-sample forward reads the packed weights
+            torch.cuda.current_stream(dev).wait_stream(self._side)
+            self._side_busy = False
         engine.invalidate_packed(model)
         engine.invalidate_packed(ema)
         self.lr = self.base_lr * (1.0 - self.iter_num / self.max_iterations) ** 0.9
