@@ -291,7 +291,10 @@ int igemm_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     return launch_cfg<4, 1, false>(a, st);
 }
 
-// all layers of a model in one launch: blockIdx.y = layer
+// all layers of a model in one launch: blockIdx.y = layer.  A thread owns one (co, ci) pair of the K/N-padded grid:
+// it reads the pair's `taps` consecutive source floats (threads run along the source's inner index: coalesced) and
+// scatters them to the tap planes of both packed layouts.  (One thread per OUTPUT element re-fetched every source line
+// once per tap: 1.3 GB moved for 250 MB.)
 __global__ void pack_bf16_multi_kernel(const PackJobs jobs) {
     const PackJob j = jobs.j[blockIdx.y];
     const float* __restrict__ w = j.w;
@@ -299,23 +302,19 @@ __global__ void pack_bf16_multi_kernel(const PackJobs jobs) {
     __bf16* wd = (__bf16*)j.wd;
     const int Cin = j.Cin, Cout = j.Cout, taps = j.taps;
     const int Ki = (Cin + 7) / 8, Ko = (Cout + 7) / 8;
-    const long nf = (long)taps * Ki * Cout * 8, nd = (long)taps * Ko * Cin * 8;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nf + nd; e += (long)gridDim.x * blockDim.x) {
-        int tap, ci, co;
-        if (e < nf) {
-            const int q = (int)(e & 7); long t = e >> 3;
-            co = (int)(t % Cout); t /= Cout;
-            ci = (int)(t % Ki) * 8 + q; tap = (int)(t / Ki);
-        } else {
-            const long f = e - nf;
-            const int q = (int)(f & 7); long t = f >> 3;
-            ci = (int)(t % Cin); t /= Cin;
-            co = (int)(t % Ko) * 8 + q; tap = (int)(t / Ko);
+    const int Pi = Ki * 8, Po = Ko * 8;
+    const long total = (long)Pi * Po;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        int ci, co;
+        if (j.transposed_src) { co = (int)(e % Po); ci = (int)(e / Po); }       // source [Cin][Cout][taps]
+        else { ci = (int)(e % Pi); co = (int)(e / Pi); }                        // source [Cout][Cin][taps]
+        const bool in = ci < Cin && co < Cout;
+        const float* src = w + (j.transposed_src ? ((long)ci * Cout + co) : ((long)co * Cin + ci)) * taps;
+        for (int tap = 0; tap < taps; ++tap) {
+            const __bf16 v = (__bf16)(in ? src[tap] : 0.f);
+            if (co < Cout) wf[(((long)tap * Ki + ci / 8) * Cout + co) * 8 + (ci & 7)] = v;
+            if (wd && ci < Cin) wd[(((long)tap * Ko + co / 8) * Cin + ci) * 8 + (co & 7)] = v;
         }
-        float v = 0.f;
-        if (ci < Cin && co < Cout)
-            v = j.transposed_src ? w[((long)ci * Cout + co) * taps + tap] : w[((long)co * Cin + ci) * taps + tap];
-        if (e < nf) wf[e] = (__bf16)v; else if (wd) wd[e - nf] = (__bf16)v;
     }
 }
 
