@@ -253,12 +253,22 @@ __device__ __forceinline__ void window_dz(const float* da, const float* __restri
 }
 
 // grid-stride over windows; thread = (channel quad, window lane).  partials[block][2][C]
+// blockIdx.y = forward pass (batched passes: each has its own slice of every tensor, constants and partial rows)
+struct PassOff { long act, pool, aff, part, coef; };   // element strides between passes (bytes are esz * act for tensors)
+
 template <bool POOL, int ESZ>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ dp,
                                                            const float* __restrict__ y, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int N, int H, int W, int C,
-                                                           int G, float* __restrict__ partials) {
+                                                           int G, float* __restrict__ partials, const PassOff po) {
     constexpr int NPX = Win<POOL>::NPX;
+    {
+        const long g = blockIdx.y;
+        if (da) da = (const float*)((const char*)da + g * po.act * ESZ);
+        if (dp) dp = (const float*)((const char*)dp + g * po.pool * ESZ);
+        y = (const float*)((const char*)y + g * po.act * ESZ);
+        scale += g * po.aff; shift += g * po.aff; partials += g * po.part;
+    }
     __shared__ f32x4 red[2][256];
     const int C4 = C / 4, PL = 256 / G;
     const int cq0 = threadIdx.x % G, pl = threadIdx.x / G;
@@ -291,42 +301,57 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-// partials[rows][2][C] -> dgamma, dbeta, coef[3][C]
+// partials[pass][rows][2][C] -> dgamma, dbeta (the passes' contributions added one after the other, as separate calls
+// would), coef[pass][3][C]
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int rows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, float* dgamma, float* dbeta, int accumulate,
-                                       float* coef) {
+                                       float* coef, int passes, const PassOff po) {
     __shared__ double red[2][32][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 channels x 32 row lanes
     const int c = blockIdx.x * 32 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int r = rg; r < rows; r += 32) {
-            s1 += (double)partials[((long)r * 2 + 0) * C + c];
-            s2 += (double)partials[((long)r * 2 + 1) * C + c];
+    float dg_run = 0.f, db_run = 0.f;
+    if (rg == 0 && c < C && dgamma && accumulate) { dg_run = dgamma[c]; db_run = dbeta[c]; }
+    for (int g = 0; g < passes; ++g) {
+        const float* pt = partials + (long)g * po.part;
+        double s1 = 0.0, s2 = 0.0;
+        if (c < C)
+            for (int r = rg; r < rows; r += 32) {
+                s1 += (double)pt[((long)r * 2 + 0) * C + c];
+                s2 += (double)pt[((long)r * 2 + 1) * C + c];
+            }
+        red[0][rg][cl] = s1; red[1][rg][cl] = s2;
+        __syncthreads();
+        if (rg == 0 && c < C) {
+            for (int k = 1; k < 32; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+            const double mu = mean[(long)g * po.aff + c], rs = rstd[(long)g * po.aff + c], gm = gamma[c];
+            const double dbe = s1, dga = rs * (s2 - mu * s1);
+            const double c0 = gm * rs, m1 = dbe / count, m2 = dga / count;
+            const double c1 = -c0 * m2 * rs, c2 = -c0 * m1 - c1 * mu;
+            float* cf = coef + (long)g * po.coef;
+            cf[c] = (float)c0; cf[C + c] = (float)c1; cf[2 * C + c] = (float)c2;
+            if (g == 0 && !accumulate) { dg_run = (float)dga; db_run = (float)dbe; }
+            else { dg_run = dg_run + (float)dga; db_run = db_run + (float)dbe; }
         }
-    red[0][rg][cl] = s1; red[1][rg][cl] = s2;
-    __syncthreads();
-    if (rg == 0 && c < C) {
-        for (int k = 1; k < 32; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
-        const double mu = mean[c], rs = rstd[c], g = gamma[c];
-        const double dbe = s1, dga = rs * (s2 - mu * s1);
-        const double c0 = g * rs, m1 = dbe / count, m2 = dga / count;
-        const double c1 = -c0 * m2 * rs, c2 = -c0 * m1 - c1 * mu;
-        coef[c] = (float)c0; coef[C + c] = (float)c1; coef[2 * C + c] = (float)c2;
-        if (dgamma) {
-            dgamma[c] = accumulate ? dgamma[c] + (float)dga : (float)dga;
-            dbeta[c] = accumulate ? dbeta[c] + (float)dbe : (float)dbe;
-        }
+        __syncthreads();
     }
+    if (rg == 0 && c < C && dgamma) { dgamma[c] = dg_run; dbeta[c] = db_run; }
 }
 
 template <bool POOL, int ESZ>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* da, const float* __restrict__ dp,
                                                           const float* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ coef,
-                                                          int N, int H, int W, int C, int G, float* dy) {
+                                                          int N, int H, int W, int C, int G, float* dy, const PassOff po) {
     constexpr int NPX = Win<POOL>::NPX;
+    {
+        const long g = blockIdx.y;
+        if (da) da = (const float*)((const char*)da + g * po.act * ESZ);
+        if (dp) dp = (const float*)((const char*)dp + g * po.pool * ESZ);
+        y = (const float*)((const char*)y + g * po.act * ESZ);
+        dy = (float*)((char*)dy + g * po.act * ESZ);
+        scale += g * po.aff; shift += g * po.aff; coef += g * po.coef;
+    }
     const int C4 = C / 4, PL = 256 / G;
     const int cq0 = threadIdx.x % G, pl = threadIdx.x / G;
     const int WH = POOL ? (H + 1) / 2 : H, WW = POOL ? (W + 1) / 2 : W;
@@ -470,35 +495,40 @@ extern "C" int64_t ustrun_bn_bwd_partials_bytes(int64_t npix, int C) {
     return (int64_t)1024 * 2 * C * sizeof(float);
 }
 
-extern "C" int ustrun_bn_bwd_reduce(const void* da, const void* dp, const void* y, const float* scale,
-                                    const float* shift, const float* mean, const float* rstd, const float* gamma,
-                                    int N, int H, int W, int C, float* dgamma, float* dbeta, int accumulate,
-                                    float* coef, float* partials, int64_t partials_bytes, int dtype,
-                                    ustrun_stream_t s) {
+namespace ustrun {
+// `passes` forward passes in one launch each: tensors of pass g start g*act_elems (g*pool_elems for dp) elements
+// further, its constants g*aff_stride floats further (scale/shift/mean/rstd), its coefficients at coef + g*3C.
+// dgamma/dbeta receive the passes' contributions in order.
+int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, const float* gamma, int N, int H, int W, int C, float* dgamma,
+                         float* dbeta, int accumulate, float* coef, float* partials, int64_t partials_bytes, int dtype,
+                         int passes, long act_elems, long pool_elems, long aff_stride, hipStream_t s) {
     USTRUN_CHECK(dtype_ok(dtype), "bn_bwd_reduce: dtype %d not built", dtype);
     USTRUN_CHECK((da || dp) && y && scale && shift && mean && rstd && gamma && coef && partials, "bn_bwd_reduce: null pointer");
-    USTRUN_CHECK(C % 4 == 0 && C > 0, "bn_bwd_reduce: C=%d must be a multiple of 4", C);
+    USTRUN_CHECK(C % 4 == 0 && C > 0 && passes >= 1 && passes <= 64, "bn_bwd_reduce: C=%d must be a multiple of 4", C);
     USTRUN_CHECK(partials_bytes >= ustrun_bn_bwd_partials_bytes((int64_t)N * H * W, C), "bn_bwd_reduce: partials too small");
     const int G = group_size(C / 4);
     const bool pool = dp != nullptr;
     const long nwin = pool ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long)N * H * W;
-    const int blocks = reduce_blocks(nwin, G);
+    int blocks = reduce_blocks(nwin, G);
+    if (blocks > 1024 / passes) blocks = 1024 / passes;          // all passes' rows share the 1024-row table
+    const PassOff po = {act_elems, pool_elems, aff_stride, (long)blocks * 2 * C, 3L * C};
 #define USTRUN_BN_REDUCE(P, E)                                                                                         \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<P, E>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)da, \
-                       (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<P, E>), dim3(blocks, passes), dim3(256), 0, s, (const float*)da,         \
+                       (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials, po)
     if (dtype == USTRUN_BF16) { if (pool) USTRUN_BN_REDUCE(true, 2); else USTRUN_BN_REDUCE(false, 2); }
     else { if (pool) USTRUN_BN_REDUCE(true, 4); else USTRUN_BN_REDUCE(false, 4); }
 #undef USTRUN_BN_REDUCE
     USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)s, partials, blocks, C,
-                       (double)N * H * W, gamma, mean, rstd, dgamma, dbeta, accumulate, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, blocks, C, (double)N * H * W, gamma,
+                       mean, rstd, dgamma, dbeta, accumulate, coef, passes, po);
     USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
     return 0;
 }
 
-extern "C" int ustrun_bn_bwd_apply(const void* da, const void* dp, const void* y, const float* scale,
-                                   const float* shift, const float* coef, int N, int H, int W, int C, void* dy,
-                                   int dtype, ustrun_stream_t s) {
+int bn_bwd_apply_passes(const void* da, const void* dp, const void* y, const float* scale, const float* shift,
+                        const float* coef, int N, int H, int W, int C, void* dy, int dtype, int passes, long act_elems,
+                        long pool_elems, long aff_stride, hipStream_t s) {
     USTRUN_CHECK(dtype_ok(dtype), "bn_bwd_apply: dtype %d not built", dtype);
     USTRUN_CHECK((da || dp) && y && scale && shift && coef && dy, "bn_bwd_apply: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0, "bn_bwd_apply: C=%d must be a multiple of 4", C);
@@ -508,12 +538,29 @@ extern "C" int ustrun_bn_bwd_apply(const void* da, const void* dp, const void* y
     const int PL = 256 / G;
     long blocks = (nwin + (long)PL * 4 - 1) / ((long)PL * 4);
     if (blocks > 4096) blocks = 4096;
+    const PassOff po = {act_elems, pool_elems, aff_stride, 0, 3L * C};
 #define USTRUN_BN_APPLY(P, E)                                                                                               \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<P, E>), dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)da, \
-                       (const float*)dp, (const float*)y, scale, shift, coef, N, H, W, C, G, (float*)dy)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<P, E>), dim3((int)blocks, passes), dim3(256), 0, s, (const float*)da,          \
+                       (const float*)dp, (const float*)y, scale, shift, coef, N, H, W, C, G, (float*)dy, po)
     if (dtype == USTRUN_BF16) { if (pool) USTRUN_BN_APPLY(true, 2); else USTRUN_BN_APPLY(false, 2); }
     else { if (pool) USTRUN_BN_APPLY(true, 4); else USTRUN_BN_APPLY(false, 4); }
 #undef USTRUN_BN_APPLY
     USTRUN_LAUNCH_CHECK("bn_bwd_apply");
     return 0;
+}
+}  // namespace ustrun
+
+extern "C" int ustrun_bn_bwd_reduce(const void* da, const void* dp, const void* y, const float* scale,
+                                    const float* shift, const float* mean, const float* rstd, const float* gamma,
+                                    int N, int H, int W, int C, float* dgamma, float* dbeta, int accumulate,
+                                    float* coef, float* partials, int64_t partials_bytes, int dtype,
+                                    ustrun_stream_t s) {
+    return bn_bwd_reduce_passes(da, dp, y, scale, shift, mean, rstd, gamma, N, H, W, C, dgamma, dbeta, accumulate, coef,
+                                partials, partials_bytes, dtype, 1, 0, 0, 0, (hipStream_t)s);
+}
+
+extern "C" int ustrun_bn_bwd_apply(const void* da, const void* dp, const void* y, const float* scale,
+                                   const float* shift, const float* coef, int N, int H, int W, int C, void* dy,
+                                   int dtype, ustrun_stream_t s) {
+    return bn_bwd_apply_passes(da, dp, y, scale, shift, coef, N, H, W, C, dy, dtype, 1, 0, 0, 0, (hipStream_t)s);
 }

@@ -102,6 +102,13 @@ int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, v
 int bn_finalize_passes(float* stat, int mtiles, int passes, int C, int64_t count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                        int update_running, float* scale, float* shift, float* mean, float* rstd, long astride, hipStream_t s);
+int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, const float* gamma, int N, int H, int W, int C, float* dgamma,
+                         float* dbeta, int accumulate, float* coef, float* partials, int64_t partials_bytes, int dtype,
+                         int passes, long act_elems, long pool_elems, long aff_stride, hipStream_t s);
+int bn_bwd_apply_passes(const void* da, const void* dp, const void* y, const float* scale, const float* shift,
+                        const float* coef, int N, int H, int W, int C, void* dy, int dtype, int passes, long act_elems,
+                        long pool_elems, long aff_stride, hipStream_t s);
 struct PackJob { const float* w; void* wf; void* wd; int Cout, Cin, taps, transposed_src; };
 struct PackJobs { PackJob j[24]; };
 int pack_bf16_multi(const PackJobs& jobs, int n, hipStream_t st);

@@ -108,7 +108,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     }
     long bh = 1024L * ((long)p.K * b + p.K) * 4;
     if (bh > part) part = bh;
-    p.coef_off = o; o = align_up(o + 12L * 16 * b, 256);
+    p.coef_off = o; o = align_up(o + 12L * 16 * b * p.G, 256);      // [pass][3][C]
     p.part_off = o; p.part_bytes = align_up(part, 256);
     o += p.part_bytes;
     p.bwd_total = o;
@@ -309,15 +309,13 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
         const bool pooled = (i < 8) && (i % 2 == 1);
         const void* dp = pooled ? sc + p.dp_off[3 - l] : nullptr;
         void* da = sc + p.da_off[i];
-        for (int g = 0; g < p.G; ++g) {        // BatchNorm backward is a per-pass reduction
-            const float* ag = aff + 4L * C * g;
-            const long go = (long)g * p.gN * H * W * C * p.esz;
-            char* dag = (char*)da + go;
-            const char* dpg = dp ? (const char*)dp + (long)g * p.gN * (H / 2) * (W / 2) * C * p.esz : nullptr;
-            USTRUN_TRY(ustrun_bn_bwd_reduce(dag, dpg, ws + p.y_off[i] + go, ag, ag + C, ag + 2 * C, ag + 3 * C, d->bn_w[i], p.gN,
-                                            H, W, C, grads[gi + 1], grads[gi + 2], g == 0 ? accumulate : 1, coef, part,
-                                            p.part_bytes, dt, s));
-            USTRUN_TRY(ustrun_bn_bwd_apply(dag, dpg, ws + p.y_off[i] + go, ag, ag + C, coef, p.gN, H, W, C, dag, dt, s));
+        {   // BatchNorm backward is a per-pass reduction: all passes in one launch per kernel (blockIdx.y = pass)
+            const long act = (long)p.gN * H * W * C, pl = (long)p.gN * (H / 2) * (W / 2) * C;
+            USTRUN_TRY(bn_bwd_reduce_passes(da, dp, ws + p.y_off[i], aff, aff + C, aff + 2 * C, aff + 3 * C, d->bn_w[i], p.gN, H, W,
+                                            C, grads[gi + 1], grads[gi + 2], accumulate, coef, part, p.part_bytes, dt, p.G, act,
+                                            pl, 4L * C, (hipStream_t)s));
+            USTRUN_TRY(bn_bwd_apply_passes(da, dp, ws + p.y_off[i], aff, aff + C, coef, p.gN, H, W, C, da, dt, p.G, act, pl,
+                                           4L * C, (hipStream_t)s));
         }
         ustrun_src_t srcs[2];
         const int ns = conv_sources(p, x, ws, i, srcs);
