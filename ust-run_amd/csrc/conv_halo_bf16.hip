@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             aokm |= (ok ? 1u : 0u) << i;
         }
     };
-    auto stage_begin = [&](int c) {                  // per-chunk state, set one chunk ahead of its use
+    auto stage_begin = [&](int c, bool from_lds = true) {   // per-chunk state, set one chunk ahead of its use
         const int cg = c * BK;
         const int second = (a.nsrc == 2 && cg >= a.src[0].C) ? 1 : 0;
         const SrcDev S = pick_src(a.src[0], a.src[1], second != 0);
@@ -136,7 +136,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         if (second != cur_src) { src_setup(S); cur_src = second; }
         aptr = (const __bf16*)S.ptr + (img * S.sN + cl);
         asc0 = asc1 = (f32x4){1.f, 1.f, 1.f, 1.f}; ash0 = ash1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (S.scale) {                               // staged in LDS two chunks ahead by dma_consts
+        if (S.scale && !from_lds) {                  // prologue: straight from memory, in flight with the patch loads
+            const long goff = S.gN > 0 ? (long)(img / S.gN) * S.gstride : 0;
+            const float* sc = S.scale + goff + cl + 8 * p8;
+            const float* sh = S.shift + goff + cl + 8 * p8;
+            asc0 = *(const f32x4*)sc; asc1 = *(const f32x4*)(sc + 4);
+            ash0 = *(const f32x4*)sh; ash1 = *(const f32x4*)(sh + 4);
+        } else if (S.scale) {                        // staged in LDS two chunks ahead by dma_consts
             const char* cs = Cst + (c & 1) * 256 + p8 * 32;
             asc0 = *(const f32x4*)cs; asc1 = *(const f32x4*)(cs + 16);
             ash0 = *(const f32x4*)(cs + 128); ash1 = *(const f32x4*)(cs + 144);
@@ -233,11 +239,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     // ---- prologue: the first stage's weight tiles and the whole first patch, all transfers in flight together ----
 #pragma unroll
     for (int k = 0; k < NT; ++k) dma_B(0, k, k);
-    dma_consts(0);
     if (nchunk > 1) dma_consts(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    stage_begin(0);
+    stage_begin(0, false);                        // one memory round trip for constants, patch and weights together
     if (a_xf) {
         bf16x8 pv[AIT][NP];
 #pragma unroll

@@ -71,8 +71,10 @@ __device__ __forceinline__ SrcDev pick_src(const SrcDev& s0, const SrcDev& s1, b
     return d;
 }
 
+// max(v, 0) as ONE v_med3_f32 (fmaxf costs a canonicalising v_max plus the max itself)
+__device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
-    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    v[0] = relu1(v[0]); v[1] = relu1(v[1]); v[2] = relu1(v[2]); v[3] = relu1(v[3]);
     return v;
 }
 __device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
