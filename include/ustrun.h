@@ -160,6 +160,15 @@ int ustrun_mix_targets(int mode, int N, int K, int HW, const float* box, const v
                        const void* pl_w_lu, const float* mask_w_lu, const void* cut_label,
                        const float* cut_mask, void* pl_w, float* mask_w, void* pl_ul, float* mask_ul,
                        void* pl_lu, float* mask_lu, ustrun_stream_t s);
+/* CutMix rectangles -> {0,1} maps on the device: box[n,y,x] = (y0<=y<y1 && x0<=x<x1).  Replaces the host-built
+ * maps of train.py:222-251 (cutmix_box, all_cover_box) that the reference uploads with .cuda(): only the N x 4 corner
+ * ints {y0,y1,x0,x1} (HOST pointer) travel, inside the launch's argument block.                 */
+#define USTRUN_MAX_RECTS 64
+int ustrun_rect_masks(const int32_t* rects_host, int N, int H, int W, float* box, ustrun_stream_t s);
+/* Stream-ordered upload of a few host bytes (indices, ratios) through the launch's argument block; replaces the
+ * small torch.tensor(...).cuda() uploads of train.py:612-636,749-782.                          */
+#define USTRUN_UPLOAD_MAX 2048
+int ustrun_upload_small(void* dst, const void* src_host, int nbytes, ustrun_stream_t s);
 /* CutMix image compositing out = a*(1-box) + b*box on NCHW images: train.py:644-646,688,691   */
 int ustrun_box_mix(const float* a, const float* b, const float* box, int N, int C, int HW,
                    float* out, ustrun_stream_t s);

@@ -101,6 +101,38 @@ def test_mix_targets_and_box_mix_exact(mode):
     assert torch.equal(F().box_mix(a.cuda(), b.cuda(), box.cuda()).cpu(), a * (1 - ib) + b * ib)
 
 
+def test_rect_masks_equal_oracle_cutmix_and_cover_maps():
+    """The device-built CutMix maps equal the oracle's host maps under the same RNG streams (train.py:222-251)."""
+    import random
+    from ustrun import trainer as T
+    for seed in (0, 1, 2):
+        random.seed(seed); np.random.seed(seed)
+        ref = np.stack([H.cutmix_box(64, p=0.7) for _ in range(9)])
+        random.seed(seed); np.random.seed(seed)
+        rects = [T.cutmix_rect(64, p=0.7) for _ in range(9)]
+        got = F().rect_masks(rects, 64, 64, "cuda")
+        assert got.shape == (9, 64, 64) and np.array_equal(got.cpu().numpy(), ref)
+    region = np.zeros((48, 48), dtype=np.float32)
+    region[7, 30] = 1; region[20, 4] = 1; region[33, 11] = 2
+    assert np.array_equal(F().rect_masks([T.all_cover_rect(region)], 48, 48, "cuda")[0].cpu().numpy(), H.all_cover_box(region))
+    random.seed(5); np.random.seed(5)
+    ref = H.all_cover_box(np.zeros((48, 48), dtype=np.float32))          # empty region: falls back to a random box
+    random.seed(5); np.random.seed(5)
+    got = F().rect_masks([T.all_cover_rect(np.zeros((48, 48), dtype=np.float32))], 48, 48, "cuda")[0]
+    assert np.array_equal(got.cpu().numpy(), ref)
+    with pytest.raises(RuntimeError, match="rect_masks"):
+        F().rect_masks(np.zeros((65, 4)), 8, 8, "cuda")
+
+
+def test_upload_small_round_trip():
+    for arr, dt in ((np.arange(16)[::-1].copy(), torch.long), (np.linspace(0, 1, 7, dtype=np.float32), torch.float32),
+                    (np.zeros(0, dtype=np.int64), torch.long), (np.arange(256), torch.long)):
+        got = F().upload_small(arr, "cuda", dt)
+        assert got.dtype == dt and np.array_equal(got.cpu().numpy(), arr)
+    with pytest.raises(RuntimeError, match="upload_small"):
+        F().upload_small(np.arange(257), "cuda", torch.long)
+
+
 def test_dice_counts_match_numpy_dice():
     from utils import metrics
     g = load_golden("g6_metrics")

@@ -3,6 +3,7 @@
 // K logit planes (NCHW: coalesced per plane), reductions go wavefront shuffle -> LDS -> one
 // partial row per block -> single-block f64 finalize (fixed order: reproducible).
 #include "common.h"
+#include <cstring>
 
 namespace ustrun {
 namespace {
@@ -383,6 +384,46 @@ extern "C" int ustrun_box_mix(const float* a, const float* b, const float* box, 
     hipLaunchKernelGGL(box_mix_kernel, dim3(stream_blocks((long)N * C * HW)), dim3(256), 0, (hipStream_t)s, a, b, box, N,
                        C, HW, out);
     USTRUN_LAUNCH_CHECK("box_mix");
+    return 0;
+}
+
+/* Small host values reach the device inside the kernel-argument block: no copy engine, no host wait, ordered on the
+ * stream like any launch.  (A pinned hipMemcpyAsync on a busy stream cost the step 20 ms here; a pageable copy drains
+ * the queue.) */
+struct RectArgs { int r[USTRUN_MAX_RECTS][4]; };
+__global__ void rect_masks_kernel(RectArgs a, int N, int H, int W, float* __restrict__ box) {
+    const long total = (long)N * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / ((long)H * W));
+        const int rem = (int)(i - (long)n * H * W);
+        const int y = rem / W, x = rem - y * W;
+        box[i] = (y >= a.r[n][0] && y < a.r[n][1] && x >= a.r[n][2] && x < a.r[n][3]) ? 1.f : 0.f;
+    }
+}
+extern "C" int ustrun_rect_masks(const int32_t* rects_host, int N, int H, int W, float* box, ustrun_stream_t s) {
+    USTRUN_CHECK(rects_host && box && H > 0 && W > 0, "rect_masks: bad args");
+    USTRUN_CHECK(N > 0 && N <= USTRUN_MAX_RECTS, "rect_masks: 1..USTRUN_MAX_RECTS rectangles per call");
+    RectArgs a;
+    memset(&a, 0, sizeof a);
+    memcpy(a.r, rects_host, sizeof(int) * 4 * N);
+    hipLaunchKernelGGL(rect_masks_kernel, dim3(stream_blocks((long)N * H * W)), dim3(256), 0, (hipStream_t)s, a, N, H, W,
+                       box);
+    USTRUN_LAUNCH_CHECK("rect_masks");
+    return 0;
+}
+
+struct SmallArgs { uint32_t w[USTRUN_UPLOAD_MAX / 4]; };
+__global__ void upload_small_kernel(SmallArgs a, int words, uint32_t* __restrict__ dst) {
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = a.w[i];
+}
+extern "C" int ustrun_upload_small(void* dst, const void* src_host, int nbytes, ustrun_stream_t s) {
+    USTRUN_CHECK(dst && src_host, "upload_small: null pointer");
+    USTRUN_CHECK(nbytes > 0 && nbytes <= USTRUN_UPLOAD_MAX && nbytes % 4 == 0 && ((uintptr_t)dst & 3) == 0,
+                 "upload_small: 4..USTRUN_UPLOAD_MAX bytes, a multiple of 4, to a 4-byte aligned address");
+    SmallArgs a;
+    memcpy(a.w, src_host, nbytes);
+    hipLaunchKernelGGL(upload_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, a, nbytes / 4, (uint32_t*)dst);
+    USTRUN_LAUNCH_CHECK("upload_small");
     return 0;
 }
 

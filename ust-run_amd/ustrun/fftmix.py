@@ -7,13 +7,16 @@ from . import _lib as L
 from .engine import stream_ptr
 
 
-def freq_mix_device(src, trg, LB, ratios):
+def freq_mix_device(src, trg, LB, ratios, h2d=None):
     """src/trg: normalised [n,C,H,W] HIP tensors; ratios: n python floats drawn by the caller."""
     lib = L.lib()
     src, trg = src.contiguous(), trg.contiguous()
     n, C, H, W = src.shape
     b = int(math.floor(min(H, W) * LB))
-    r = torch.tensor(ratios, dtype=torch.float32).to(src.device, non_blocking=True)
+    if h2d is not None:
+        r = h2d(ratios)
+    else:
+        r = torch.tensor(ratios, dtype=torch.float32).to(src.device, non_blocking=True)
     nb = lib.ustrun_freq_mix_work_bytes(n, C, b)
     work = torch.empty(nb, dtype=torch.uint8, device=src.device)
     out = torch.empty_like(src)

@@ -139,6 +139,35 @@ def box_mix(a, b, box):
     return out
 
 
+def rect_masks(rects, H, W, device):
+    """{0,1} maps [N,H,W] on the device from N host rectangles {y0,y1,x0,x1} (train.py:222-251's maps, built where
+    they are used; the corners ride in the launch's arguments, so nothing waits on a copy)."""
+    import numpy as np
+    lib = L.lib()
+    r = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1, 4)
+    out = torch.empty((len(r), H, W), dtype=torch.float32, device=device)
+    L.check(lib.ustrun_rect_masks(r.ctypes.data, len(r), H, W, out.data_ptr(), stream_ptr()), "ustrun_rect_masks")
+    return out
+
+
+UPLOAD_MAX = 2048
+
+
+def upload_small(arr, device, dtype):
+    """A few host values -> a device tensor, stream-ordered, without a copy-engine transfer or a host wait."""
+    import numpy as np
+    lib = L.lib()
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(dtype).contiguous()
+    out = torch.empty(t.shape, dtype=dtype, device=device)
+    nb = t.numel() * t.element_size()
+    if nb == 0:
+        return out
+    if nb % 4 or nb > UPLOAD_MAX:
+        raise RuntimeError(f"upload_small: {nb} bytes (needs a multiple of 4, at most {UPLOAD_MAX})")
+    L.check(lib.ustrun_upload_small(out.data_ptr(), t.data_ptr(), nb, stream_ptr()), "ustrun_upload_small")
+    return out
+
+
 def dice_counts(pred, gt, by_class=False, n_classes=1):
     """Per-sample {|pred|, |gt|, |pred&gt|} as int32 [N,K,3] (inputs of utils/metrics.py:114-146)."""
     lib = L.lib()

@@ -45,11 +45,11 @@ def decode_labels(dataset, y):
     return m.long()
 
 
-def cutmix_box(img_size, p=0.5, size_min=0.02, size_max=0.4, ratio_1=0.3, ratio_2=1 / 0.3):
-    """train.py:222-240 on the host (numpy {0,1} map); same RNG streams and draw order."""
-    box = np.zeros((img_size, img_size), dtype=np.float32)
+def cutmix_rect(img_size, p=0.5, size_min=0.02, size_max=0.4, ratio_1=0.3, ratio_2=1 / 0.3):
+    """train.py:222-240 on the host, as the rectangle {y0,y1,x0,x1} of the map's ones (empty = all zeros); same RNG
+    streams and draw order as the reference."""
     if random.random() > p:
-        return box
+        return (0, 0, 0, 0)
     size = np.random.uniform(size_min, size_max) * img_size * img_size
     while True:
         ratio = np.random.uniform(ratio_1, ratio_2)
@@ -59,18 +59,30 @@ def cutmix_box(img_size, p=0.5, size_min=0.02, size_max=0.4, ratio_1=0.3, ratio_
         y = np.random.randint(0, img_size)
         if x + w <= img_size and y + h <= img_size:
             break
-    box[y:y + h, x:x + w] = 1
+    return (y, y + h, x, x + w)
+
+
+def rect_map(rect, img_size):
+    box = np.zeros((img_size, img_size), dtype=np.float32)
+    box[rect[0]:rect[1], rect[2]:rect[3]] = 1
     return box
+
+
+def cutmix_box(img_size, **kw):
+    """The {0,1} map of train.py:222-240 (numpy)."""
+    return rect_map(cutmix_rect(img_size, **kw), img_size)
+
+
+def all_cover_rect(region):
+    """train.py:242-251: bounding rectangle of the nonzero pixels (rows from scan order, cols min/max)."""
+    loc = np.argwhere(region != 0)
+    if len(loc) == 0:
+        return cutmix_rect(region.shape[0], p=1.0)
+    return (int(loc[0, 0]), int(loc[-1, 0]) + 1, int(loc[:, 1].min()), int(loc[:, 1].max()) + 1)
 
 
 def all_cover_box(region):
-    """train.py:242-251: bounding box of the nonzero pixels (rows from scan order, cols min/max)."""
-    loc = np.argwhere(region != 0)
-    if len(loc) == 0:
-        return cutmix_box(region.shape[0], p=1.0)
-    box = np.zeros(region.shape, dtype=np.float32)
-    box[loc[0, 0]:loc[-1, 0] + 1, loc[:, 1].min():loc[:, 1].max() + 1] = 1
-    return box
+    return rect_map(all_cover_rect(region), region.shape[0])
 
 
 def freq_mix_host(src_img, trg_img, L, ratio):
@@ -165,6 +177,13 @@ class SSLTrainer:
         if self.timeline is not None:
             self.timeline.append((label, time.perf_counter()))
 
+    @staticmethod
+    def _h2d(arr, dev, dtype):
+        """A few host values -> device inside a launch's arguments (ustrun_upload_small): ordered on the stream,
+        no host wait.  (A pageable .to(dev) drains the queue; a pinned non-blocking copy on a busy stream measured
+        20 ms/step slower on this ROCm.)"""
+        return F.upload_small(arr, dev, dtype)
+
     def _side_stream(self, dev):
         if self._side is None:
             self._side = torch.cuda.Stream(device=dev)
@@ -172,6 +191,21 @@ class SSLTrainer:
 
     def _pl(self, logits):
         return F.pseudo_label(logits, self.threshold, self.mode)
+
+    def _sample_dice_async(self, pred, gt):
+        """Device overlap counts -> pinned host buffer (non-blocking); pair with an event before reading."""
+        if self.dataset == "MNMS":
+            cnt = F.dice_counts(pred, gt, by_class=True, n_classes=3)
+        else:
+            cnt = F.dice_counts(pred, gt)
+        host = torch.empty(cnt.shape, dtype=cnt.dtype, pin_memory=True)
+        host.copy_(cnt, non_blocking=True)
+        return host, None
+
+    @staticmethod
+    def _dice_from_host(host):
+        c = host.numpy().astype(np.float64)               # [B, parts, 3]
+        return metrics.dice_from_counts(c[..., 0], c[..., 1], c[..., 2]).T
 
     def _sample_dice(self, pred, gt):
         """Per-sample Dice (numpy array [n_part, B]) from device overlap counts: one small D2H copy."""
@@ -191,7 +225,8 @@ class SSLTrainer:
             out = [np.clip(freq_mix_host(src[i], trg[i], self.LB, ratios[i]), 0, 255).astype(np.float32) for i in range(n)]
             return (torch.tensor(np.array(out), dtype=torch.float32) / 127.5 - 1).to(mix_img.device)
         from . import fftmix
-        return fftmix.freq_mix_device(mix_img[:n], ulb_x_w[:n], self.LB, ratios)
+        return fftmix.freq_mix_device(mix_img[:n], ulb_x_w[:n], self.LB, ratios,
+                                      h2d=lambda r: self._h2d(np.asarray(r, dtype=np.float32), mix_img.device, torch.float32))
 
     # ---------------------------------------------------------------------------------------
     def step(self, lb_x_w, lb_y, ulb_x_w, ulb_x_s, ulb_y, epoch_start=False):
@@ -220,7 +255,7 @@ class SSLTrainer:
             c_lb = np.random.randint(0, len(lb_x_w), B - n_s)
             c_s = np.random.randint(len(lb_x_w), len(lb_x_w) + len(self.simple_ulb), n_s)
             choice = np.random.permutation(np.concatenate((c_lb, c_s)))
-        idx = torch.as_tensor(choice, device=dev, dtype=torch.long)
+        idx = self._h2d(np.asarray(choice), dev, torch.long)
         mix_img = cut_img.index_select(0, idx)
         cut_label_c, cut_mask_c = cut_label.index_select(0, idx), cut_mask.index_select(0, idx)
 
@@ -229,7 +264,7 @@ class SSLTrainer:
         self._mark("select+freqmix")
 
         with torch.no_grad():
-            box = torch.from_numpy(np.stack([cutmix_box(self.patch, p=self.cutmix_prob) for _ in range(B)])).to(dev)
+            box = F.rect_masks([cutmix_rect(self.patch, p=self.cutmix_prob) for _ in range(B)], self.patch, self.patch, dev)
             self._mark("boxes")
             # teacher: three train-mode forwards (train.py:638-667, Q11), batched into one call with BatchNorm per pass
             t_in = [ulb_x_w, F.box_mix(ulb_x_w, mix_img, box), F.box_mix(mix_img, ulb_x_w, box)]
@@ -247,6 +282,28 @@ class SSLTrainer:
             x_s_ul = F.box_mix(ulb_x_s, move_transx, box)
             x_s_lu = F.box_mix(move_transx, ulb_x_s, box)
 
+        # Everything the host decides from device data this step -- the per-sample Dice behind the hardness ranking and
+        # the low-quality sample's region -- is computed and copied to pinned host memory NOW, in front of the student's
+        # gradient passes in stream order: the host reads it while those passes run instead of draining the queue
+        # after them (the GPU sat idle for the 1.5 ms of host work that followed).  The np.random draw keeps its place
+        # in the stream of draws (nothing else consumes it in between).
+        dice_host, dice_ev = self._sample_dice_async(stu_pl, pl)
+        region_host = new_choice = None
+        if self.lq_u is not None:
+            new_choice = np.random.randint(0, len(lb_x_w))
+            if ds == "fundus":
+                region = self.lq_pl[0, 1].clone()
+                region[self.lq_pl[0, 0].long() == 1] = 1
+                region[lb_mask[new_choice, 0].long() == 1] = 1
+                region[lb_mask[new_choice, 1].long() == 1] = 1
+            else:
+                region = self.lq_pl[0].clone()
+                region[lb_mask[new_choice].long() > 0] = 1
+            region_host = torch.empty(region.shape, dtype=region.dtype, pin_memory=True)
+            region_host.copy_(region, non_blocking=True)
+        host_ev = torch.cuda.Event()
+        host_ev.record()
+
         self._mark("teacher+targets issued")
         # student: four forwards that carry gradient (train.py:699-702)
         lg_all = None
@@ -258,54 +315,49 @@ class SSLTrainer:
         self._mark("student fwd issued")
 
         # hardness and the low-quality sample forward (train.py:705-747, Q2, Q7)
-        d = self._sample_dice(stu_pl, pl)
+        host_ev.synchronize()                     # the copies were queued in front of the student passes
+        d = self._dice_from_host(dice_host)
         self._mark("dice on host")
         hardness = 1 - d.sum(0) / self.n_part
         if epoch_num == 0:
             hardness[:] = 1
         lq_idx = int(np.argmax(hardness))
-        if self.lq_u is not None:
-            new_choice = np.random.randint(0, len(lb_x_w))
-            if ds == "fundus":
-                region = self.lq_pl[0, 1].clone()
-                region[self.lq_pl[0, 0].long() == 1] = 1
-                region[lb_mask[new_choice, 0].long() == 1] = 1
-                region[lb_mask[new_choice, 1].long() == 1] = 1
-            else:
-                region = self.lq_pl[0].clone()
-                region[lb_mask[new_choice].long() > 0] = 1
-            ib_lq = torch.from_numpy(all_cover_box(region.cpu().numpy()))[None].to(dev)
+        if region_host is not None:
+            ib_lq = F.rect_masks([all_cover_rect(region_host.numpy())], self.patch, self.patch, dev)
             # result unused (Q2); student BN running stats still move.  A batch-1 forward fills 16-256 workgroups per
             # launch, so it runs on a side stream underneath the losses and the backward that follow (ordered after
             # the student passes issued so far; joined before the weights are repacked for the next step).
             side = self._side_stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            lb_pick = lb_x_w[[new_choice]]
+            lb_pick = lb_x_w[new_choice:new_choice + 1]
             for t_ in (self.lq_u, lb_pick, ib_lq):
                 t_.record_stream(side)
             with torch.cuda.stream(side), torch.no_grad():
                 model(F.box_mix(self.lq_u, lb_pick, ib_lq))
             self._side_busy = True
-        self.lq_u = ulb_x_w[[lq_idx]].clone()
-        self.lq_pl = pl[[lq_idx]].clone()
-        self.lq_mask = mask[[lq_idx]].clone()
+        self.lq_u = ulb_x_w[lq_idx:lq_idx + 1].clone()
+        self.lq_pl = pl[lq_idx:lq_idx + 1].clone()
+        self.lq_mask = mask[lq_idx:lq_idx + 1].clone()
 
         # memory bank of easy unlabelled samples (train.py:749-782)
         simple = hardness < self.choice_th
         n_cur = int(simple.sum())
-        sel = torch.from_numpy(simple).to(dev)
+        sel = self._h2d(np.nonzero(simple)[0], dev, torch.long)        # indices from the host: no device-side nonzero, no sync
+
+        def pick(t):
+            return t.index_select(0, sel)
         if self.simple_ulb is None or len(self.simple_ulb) == 0:
-            self.simple_ulb, self.cor_pl = ulb_x_w[sel].clone(), pl[sel].clone()
-            self.cor_gt, self.cor_mask = ulb_mask[sel].clone(), mask[sel].clone()
+            self.simple_ulb, self.cor_pl = pick(ulb_x_w), pick(pl)
+            self.cor_gt, self.cor_mask = pick(ulb_mask), pick(mask)
             self.cor_hardness = hardness[simple].copy()
             if len(self.simple_ulb) > 0:
                 self.choice_th = min(self.choice_th, self.cor_hardness.max())
         elif n_cur > 0:
             keep = self.queue_len - n_cur if len(self.simple_ulb) + n_cur > self.queue_len else len(self.simple_ulb)
-            self.simple_ulb = torch.cat((ulb_x_w[sel], self.simple_ulb[:keep]), 0)
-            self.cor_pl = torch.cat((pl[sel], self.cor_pl[:keep]), 0)
-            self.cor_gt = torch.cat((ulb_mask[sel], self.cor_gt[:keep]), 0)
-            self.cor_mask = torch.cat((mask[sel], self.cor_mask[:keep]), 0)
+            self.simple_ulb = torch.cat((pick(ulb_x_w), self.simple_ulb[:keep]), 0)
+            self.cor_pl = torch.cat((pick(pl), self.cor_pl[:keep]), 0)
+            self.cor_gt = torch.cat((pick(ulb_mask), self.cor_gt[:keep]), 0)
+            self.cor_mask = torch.cat((pick(mask), self.cor_mask[:keep]), 0)
             self.cor_hardness = np.concatenate((hardness[simple], self.cor_hardness[:keep]))
             self.choice_th = min(self.choice_th, self.cor_hardness.max())
         else:
