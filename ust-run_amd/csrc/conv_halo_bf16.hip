@@ -42,10 +42,14 @@ template <int V> using ic = std::integral_constant<int, V>;
 //   top    : LDS-DMA of the next stage's NT weight tiles (two buffers of NT tiles); LDS-DMA of BATCH items (8 channels
 //            of one patch pixel per thread) of the NEXT chunk's patch -- straight into the other patch buffer when the
 //            source needs no arithmetic (dY, ConvTranspose outputs), else into a private raw slot
-//   middle : all fragment reads, then the MFMAs of the stage's taps (>= 512 MFMA cycles: longer than an L2-hit DMA)
-//   bottom : s_waitcnt vmcnt(0): this top's transfers have landed; the raw items get their BatchNorm affine + ReLU
-//            (+2x2 max) in f32 and are written to the other patch buffer; barrier.
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT>
+//            (XF: BatchNorm affine / ReLU / pooling on load), one stage ahead of their transform
+//   middle : all fragment reads, the raw items the PREVIOUS stage fetched, then the MFMAs of the stage's taps with the
+//            items' BatchNorm affine + ReLU (+2x2 max) in f32 in their shadow (one basic block: branch-free transform,
+//            out-of-patch items land in a trash slot), written to the other patch buffer
+//   bottom : s_waitcnt vmcnt(0): this top's transfers have landed; barrier.
+// A wave's stage used to be DMA issue -> fragment reads -> 16 MFMAs -> wait -> transform -> barrier in sequence, ~700
+// cycles outside the 512 MFMA cycles, more than the SIMD's other wave can cover.
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
     static_assert(BK == 32, "80-byte patch rows hold one 32-channel chunk");
@@ -66,13 +70,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     constexpr int BCH = (BK / 8) * BN;          // 16-byte chunks per B tile
     constexpr int BIT = BCH / 256;
     static_assert(BCH % 256 == 0, "B tile must be a whole number of wave-instructions per wave");
-    constexpr int RAWB = BATCH * NP * 4096;     // the raw slot: BATCH x NP x 16 B per thread
+    constexpr int RAWB = XF ? BATCH * NP * 4096 : 0;   // a raw slot: BATCH x NP x 16 B per thread
+    // SKEW: the items a stage fetches are transformed under the NEXT stage's MFMAs (two raw slots, by stage parity) --
+    // where a second slot still leaves room for two blocks per CU; otherwise after the stage's own MFMAs
+    constexpr bool SKEW = XF && 2 * ABYTES + 2 * NT * BCH * 16 + 2 * RAWB + 512 <= 81920;
+    constexpr int NRAW = SKEW ? 2 : 1;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                            // 2 x patch [HP][80 B] (current / being staged)
     char* Bs = smem + 2 * ABYTES;               // 2 x NT x [BK/8][BN][8] bf16
-    char* Raw = Bs + 2 * NT * (BCH * 16);       // raw slot
-    char* Cst = Raw + RAWB;                 // 2 x {32 scales, 32 shifts} f32 of a chunk (kept out of vmcnt's way)
+    char* Raw = Bs + 2 * NT * (BCH * 16);       // NRAW x raw slot
+    char* Cst = Raw + NRAW * RAWB;              // 2 x {32 scales, 32 shifts} f32 of a chunk (kept out of vmcnt's way)
 
     const int mt_total = a.N * tiles_y * tiles_x;
     const int ntiles = mt_total * nt_total;
@@ -105,22 +113,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     // aoff[i] = element offset of the item from the chunk base, bit i of aokm = the item reads the image. ----
     int aoff[AIT];
     unsigned aokm = 0;
-    int cur_src = -1, a_xf = 0, a_relu = 0;
+    int cur_src = -1;
+    float a_floor = 0.f;                        // ReLU as max(x, floor): 0, or -inf for a source without ReLU
     const __bf16* aptr = nullptr;               // chunk base: source + image + first channel of the chunk
     long dq1 = 0, dq2 = 0;                      // pooled source: element offsets of the right / lower neighbour
     f32x4 asc0, asc1, ash0, ash1;
     const int p8 = tid & 3;
     auto src_setup = [&](const SrcDev& S) {
-        a_relu = S.relu;
-        a_xf = (S.scale != nullptr) || S.relu || POOL;
+        a_floor = S.relu ? 0.f : -__builtin_inff();
         dq1 = S.sW; dq2 = S.sH;
         const int by = y0 - 1 - S.off_y, bx = x0 - 1 - S.off_x;
         aokm = 0;
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             const int q = tid + 256 * i;
-            const int hp = a_xf ? (q >> 2) : q / 5;
-            const int g = a_xf ? p8 : q - 5 * hp;
+            const int hp = XF ? (q >> 2) : q / 5;
+            const int g = XF ? p8 : q - 5 * hp;
             const int hy = hp / HW2, hx = hp - hy * HW2;
             const int ly = by + hy, lx = bx + hx;
             const bool ok = hp < HP && g < 4 && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
@@ -162,16 +170,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         }
     };
     // does this wave own a slot of staging step i?  (wave-uniform: the counted waits depend on it)
-    auto wave_has = [&](int i) { return 256 * i + wave * 64 < (a_xf ? XSLOTS : DSLOTS); };
+    auto wave_has = [&](int i) { return 256 * i + wave * 64 < (XF ? XSLOTS : DSLOTS); };
     // item i of the chunk, b-th item of its stage (both fold to constants: the callers are fully unrolled)
-    auto issue_one = [&](int i, int b, char* Adst) {
+    auto issue_one = [&](int i, int b, char* Adst, char* raw) {
         const bool ok = (aokm >> i) & 1u;
         const __bf16* src = ok ? aptr + aoff[i] : zsrc;
-        if (a_xf) {
+        if constexpr (XF) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 const long d = ok ? (q & 1 ? dq1 : 0) + (q & 2 ? dq2 : 0) : 0;
-                __builtin_amdgcn_global_load_lds((gptr_t*)(src + d), (lptr_t*)(Raw + ((b * NP + q) * 256 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t*)(src + d), (lptr_t*)(raw + ((b * NP + q) * 256 + wave * 64) * 16), 16, 0, 0);
             }
         } else {
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Adst + (256 * i + wave * 64) * 16), 16, 0, 0);
@@ -180,32 +188,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     auto act8 = [&](bf16x8 r, f32x4& lo, f32x4& hi) {     // bf16 raw -> activated f32
         lo = (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * asc0 + ash0;
         hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
-        if (a_relu) { lo = relu4(lo); hi = relu4(hi); }
-    };
-    auto xform8 = [&](const bf16x8* r, bool inimg) {      // NP raw pieces -> one activated (pooled) bf16 group
-        bf16x8 h;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) h[q] = (__bf16)0.f;
-        if (inimg) {                                      // padding is applied after the activation
-            f32x4 lo, hi;
-            act8(r[0], lo, hi);
-#pragma unroll
-            for (int q = 1; q < NP; ++q) {
-                f32x4 l2, h2;
-                act8(r[q], l2, h2);
-                lo = max4(lo, l2); hi = max4(hi, h2);
-            }
-            h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-            h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+        for (int q = 0; q < 4; ++q) {
+            lo[q] = __builtin_amdgcn_fmed3f(lo[q], a_floor, __builtin_inff());
+            hi[q] = __builtin_amdgcn_fmed3f(hi[q], a_floor, __builtin_inff());
         }
-        return h;
+    };
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    auto xform8 = [&](const bf16x8* r, bool inimg) {      // NP raw pieces -> one activated (pooled) bf16 group; no branches
+        f32x4 lo, hi;
+        act8(r[0], lo, hi);
+#pragma unroll
+        for (int q = 1; q < NP; ++q) {
+            f32x4 l2, h2;
+            act8(r[q], l2, h2);
+            lo = max4(lo, l2); hi = max4(hi, h2);
+        }
+        bf16x8 h;
+        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+        u32x4 u = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q] = inimg ? u[q] : 0u;      // padding is applied after the activation
+        return __builtin_bit_cast(bf16x8, u);
     };
     const int xw0 = (tid >> 2) * PITCH + p8 * 16;         // transform item i lands at xw0 + i * 64 * PITCH
-    auto transform_one = [&](int i, int b, char* Adst) {
-        bf16x8 r[NP];
+    auto raw_read = [&](int b, const char* raw, bf16x8* r) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) r[q] = *(const bf16x8*)(Raw + ((b * NP + q) * 256 + tid) * 16);
-        if ((tid >> 2) + 64 * i < HP) *(bf16x8*)(Adst + xw0 + i * 64 * PITCH) = xform8(r, (aokm >> i) & 1u);
+        for (int q = 0; q < NP; ++q) r[q] = *(const bf16x8*)(raw + ((b * NP + q) * 256 + tid) * 16);
+    };
+    // item i -> patch buffer; items past the patch (the rounded-up tail) and a chunk without successor are written back
+    // over the thread's own raw slot, which is dead once read
+    auto xform_store = [&](int i, const bf16x8* r, char* Adst, bool live, const char* raw) {
+        const bool in_patch = live && (tid >> 2) + 64 * i < HP;
+        char* dst = in_patch ? Adst + xw0 + i * 64 * PITCH : (char*)raw + tid * 16;
+        *(bf16x8*)dst = xform8(r, (aokm >> i) & 1u);
     };
     // ---- B tile of (chunk c, geometric tap): LDS-DMA, 16 B per lane, lane-linear destination ----
     const __bf16* wthr[BIT];
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     for (int k = 0; k < NT; ++k) dma_B(0, k, k);
     if (nchunk > 1) dma_consts(1);
     stage_begin(0, false);                        // one memory round trip for constants, patch and weights together
-    if (a_xf) {
+    if constexpr (XF) {
         bf16x8 pv[AIT][NP];
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     } else {
 #pragma unroll
         for (int i = 0; i < AIT; ++i)
-            if (wave_has(i)) issue_one(i, 0, As);
+            if (wave_has(i)) issue_one(i, 0, As, nullptr);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -277,15 +294,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                 for (int k = 0; k < nn; ++k) dma_B(jn == 0 ? c + 1 : c, tn0 + k, ((s + 1) & 1) * NT + k);
             }
             if constexpr (j == NSTG - 1) { if (c + 2 < nchunk) dma_consts(c + 2); }
+            char* rawW = Raw + (SKEW ? (s & 1) * RAWB : 0);
+            const char* rawR = Raw + (SKEW ? ((s & 1) ^ 1) * RAWB : 0);
             if constexpr (j < NSTG - 1) {
                 if (more) {
 #pragma unroll
                     for (int b = 0; b < BATCH; ++b) {
                         constexpr int dummy = 0; (void)dummy;
-                        if (j * BATCH + b < AIT && wave_has(j * BATCH + b)) issue_one(j * BATCH + b, b, Anext);
+                        if (j * BATCH + b < AIT && wave_has(j * BATCH + b)) issue_one(j * BATCH + b, b, Anext, rawW);
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
             // middle: every fragment is base + immediate
             const char* Bp = Bs + (s & 1) * NT * (BCH * 16) + bfrag0;
             bf16x8 bf[NT][BK / 16][2], af[NT][BK / 16][MI];
@@ -302,7 +322,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                         af[k][ks][i] = *(const bf16x8*)(Afrag + ((tap / 3 + SR * i) * HW2 + tap % 3) * PITCH + ks * 32);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            // SKEW: the items the previous stage fetched (landed: that stage ended on vmcnt(0)), transformed under the MFMAs
+            constexpr int jx = SKEW ? j - 1 : j;              // the stage whose items are transformed here
+            constexpr bool XNOW = XF && jx >= 0 && jx < NSTG - 1;
+            constexpr int nitem = !XNOW ? 0 : (jx * BATCH + BATCH <= AIT ? BATCH : (AIT > jx * BATCH ? AIT - jx * BATCH : 0));
+            bf16x8 rr[BATCH][NP];
+            if constexpr (SKEW && nitem > 0) {
+#pragma unroll
+                for (int b = 0; b < nitem; ++b) raw_read(b, rawR, rr[b]);
+            }
+            if constexpr (!SKEW) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < nt; ++k)
 #pragma unroll
@@ -312,15 +341,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][ks][i], bf[k][ks][0], acc[i][0], 0, 0, 0);
                         acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][ks][i], bf[k][ks][1], acc[i][1], 0, 0, 0);
                     }
+            if constexpr (SKEW) {
+#pragma unroll
+                for (int b = 0; b < nitem; ++b) xform_store(jx * BATCH + b, rr[b], Anext, more, rawR);
+                // scheduling: every LDS read up front (the compiler otherwise fetches fragments pair by pair, each behind
+                // a full wait), then the MFMAs with the transform's VALU work in their shadow, the writes last
+                constexpr int nread = nt * (BK / 16) * (2 + MI) + nitem * NP;
+                constexpr int nmfma = nt * (BK / 16) * MI * 2;
+                constexpr int vpm = (nitem * (NP * 26 + 14) + nmfma - 1) / nmfma;
+                __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);
+#pragma unroll
+                for (int m = 0; m < nmfma; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if constexpr (vpm > 0) __builtin_amdgcn_sched_group_barrier(0x002, vpm, 0);
+                }
+                if constexpr (nitem > 0) __builtin_amdgcn_sched_group_barrier(0x200, nitem, 0);
+            }
             // bottom: this top's transfers have landed.  (The scheduling barrier keeps the wait BEHIND the MFMAs: an asm
             // statement only orders against memory operations, and hipcc otherwise hoists it above fifteen of them.)
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if constexpr (j < NSTG - 1) {
-                if (more && a_xf) {
+            if constexpr (!SKEW && nitem > 0) {
+                if (more) {
 #pragma unroll
-                    for (int b = 0; b < BATCH; ++b)
-                        if (j * BATCH + b < AIT && 256 * (j * BATCH + b) + wave * 64 < XSLOTS) transform_one(j * BATCH + b, b, Anext);
+                    for (int b = 0; b < nitem; ++b) {
+                        if (256 * (jx * BATCH + b) + wave * 64 < XSLOTS) {
+                            raw_read(b, rawR, rr[b]);
+                            xform_store(jx * BATCH + b, rr[b], Anext, true, rawR);
+                        }
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -423,16 +472,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     }
 }
 
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT = 1>
-int launch_cfg(const IgemmArgs& a, hipStream_t st) {
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF>
+int launch_xf(const IgemmArgs& a, hipStream_t st) {
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
     constexpr int DSLOTS = ((TH + 2) * (TW + 2) * 5 + 63) / 64 * 64;
     constexpr int AIT = (DSLOTS + 255) / 256, NSTG = (9 + NT - 1) / NT, BATCH = (AIT + NSTG - 2) / (NSTG - 1);
-    const size_t lds = 2 * (size_t)DSLOTS * 16 + 2 * NT * (size_t)(BK / 8) * BN * 16 + (size_t)BATCH * (POOL ? 4 : 1) * 4096 + 512;
+    const size_t rawb = XF ? (size_t)BATCH * (POOL ? 4 : 1) * 4096 : 0;
+    const size_t fixed = 2 * (size_t)DSLOTS * 16 + 2 * NT * (size_t)(BK / 8) * BN * 16 + 512;
+    const size_t lds = fixed + (XF && fixed + 2 * rawb <= 81920 ? 2 : 1) * rawb;
     dim3 grid(a.N * ty * tx * nt), block(256);
-    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT>), grid, block, lds, st, a, tx, ty, nt);
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;
+}
+
+// XF: some source needs arithmetic on load (BatchNorm affine, ReLU, pooling); plain sources (dY, ConvTranspose outputs)
+// then pass through the same path with scale 1, shift 0, floor -inf
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT = 1>
+int launch_cfg(const IgemmArgs& a, hipStream_t st) {
+    bool xf = POOL;
+    for (int i = 0; i < a.nsrc; ++i) xf |= a.src[i].scale != nullptr || a.src[i].relu != 0;
+    if constexpr (POOL) return launch_xf<TH, TW, BN, BK, MI, POOL, NT, true>(a, st);
+    else return xf ? launch_xf<TH, TW, BN, BK, MI, POOL, NT, true>(a, st) : launch_xf<TH, TW, BN, BK, MI, POOL, NT, false>(a, st);
 }
 
 }  // namespace
@@ -479,17 +540,15 @@ int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     bool pool = false;
     for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
     const bool wide = a.Wb >= 32;                 // 32-pixel rows: conflict-free A fragment reads
-    static const int nt_dbg = getenv("USTRUN_HALO_NT") ? atoi(getenv("USTRUN_HALO_NT")) : 0;   // tuning aid: 1 = one tap per stage everywhere
-    const bool pair = nt_dbg != 1;
     // MI = 2 tiles run two taps per barrier (16 MFMAs per wave and stage, like the MI = 4 tiles)
-    if (pool) return pair ? launch_cfg<8, 16, 128, 32, 2, true, 2>(a, st) : launch_cfg<8, 16, 128, 32, 2, true, 1>(a, st);
+    if (pool) return launch_cfg<8, 16, 128, 32, 2, true, 2>(a, st);
     if (a.Cout % 128 == 0) {
         if (halo_tall_tile(a))                    // 256 px x 128 ch per block, wave tile 128 px x 64 ch
             return wide ? launch_cfg<8, 32, 128, 32, 4, false>(a, st) : launch_cfg<16, 16, 128, 32, 4, false>(a, st);
-        return pair ? launch_cfg<8, 16, 128, 32, 2, false, 2>(a, st) : launch_cfg<8, 16, 128, 32, 2, false, 1>(a, st);
+        return launch_cfg<8, 16, 128, 32, 2, false, 2>(a, st);
     }
-    if (wide) return pair ? launch_cfg<8, 32, 64, 32, 2, false, 2>(a, st) : launch_cfg<8, 32, 64, 32, 2, false, 1>(a, st);
-    return pair ? launch_cfg<16, 16, 64, 32, 2, false, 2>(a, st) : launch_cfg<16, 16, 64, 32, 2, false, 1>(a, st);
+    if (wide) return launch_cfg<8, 32, 64, 32, 2, false, 2>(a, st);
+    return launch_cfg<16, 16, 64, 32, 2, false, 2>(a, st);
 }
 
 }  // namespace ustrun
