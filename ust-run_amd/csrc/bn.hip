@@ -214,19 +214,28 @@ struct Win {
 
 template <bool POOL, int ESZ>
 __device__ __forceinline__ void window_dz(const float* da, const float* __restrict__ dp,
-                                          const float* __restrict__ y, f32x4 sc, f32x4 sh, int n, int wy, int wx,
+                                          const float* __restrict__ y, f32x4 sc, f32x4 sh, long w, int WH, int WW,
                                           int H, int W, int C, int c, f32x4 (&yv)[Win<POOL>::NPX],
                                           f32x4 (&dz)[Win<POOL>::NPX], bool (&ok)[Win<POOL>::NPX]) {
     constexpr int NPX = Win<POOL>::NPX;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 av[NPX];
+    // plain: the window IS the pixel, its offset is linear (no division: these kernels were instruction bound on the
+    // 64-bit divides, not memory bound); pooled: 32-bit divides (windows per pass < 2^31)
+    int n = 0, wy = 0, wx = 0;
+    if (POOL) {
+        const unsigned uw = (unsigned)w, per = (unsigned)(WH * WW);
+        n = (int)(uw / per);
+        const unsigned rem = uw - (unsigned)n * per;
+        wy = (int)(rem / (unsigned)WW); wx = (int)(rem - (unsigned)wy * (unsigned)WW);
+    }
 #pragma unroll
     for (int q = 0; q < NPX; ++q) {
-        const int py = POOL ? 2 * wy + (q >> 1) : wy, px = POOL ? 2 * wx + (q & 1) : wx;
-        ok[q] = py < H && px < W;
+        const int py = 2 * wy + (q >> 1), px = 2 * wx + (q & 1);
+        ok[q] = !POOL || (py < H && px < W);
         yv[q] = zero; dz[q] = zero; av[q] = zero;
         if (ok[q]) {
-            const long off = (((long)n * H + py) * W + px) * C + c;
+            const long off = POOL ? (((long)n * H + py) * W + px) * C + c : w * C + c;
             yv[q] = ld4t<ESZ>(y, off);
             av[q] = yv[q] * sc + sh;
             if (da) dz[q] = ld4t<ESZ>(da, off);
@@ -282,11 +291,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         if (active)
             for (long w = (long)blockIdx.x * PL + pl; w < nwin; w += (long)gridDim.x * PL) {
-                const int n = (int)(w / (WH * WW));
-                const int rem = (int)(w - (long)n * WH * WW);
-                const int wy = rem / WW, wx = rem - wy * WW;
                 f32x4 yv[NPX], dz[NPX]; bool ok[NPX];
-                window_dz<POOL, ESZ>(da, dp, y, sc, sh, n, wy, wx, H, W, C, c, yv, dz, ok);
+                window_dz<POOL, ESZ>(da, dp, y, sc, sh, w, WH, WW, H, W, C, c, yv, dz, ok);
 #pragma unroll
                 for (int q = 0; q < NPX; ++q) { s1 += dz[q]; s2 += dz[q] * yv[q]; }
             }
@@ -361,16 +367,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* da, cons
         const f32x4 sc = *(const f32x4*)(scale + c), sh = *(const f32x4*)(shift + c);
         const f32x4 k0 = *(const f32x4*)(coef + c), k1 = *(const f32x4*)(coef + C + c), k2 = *(const f32x4*)(coef + 2 * C + c);
         for (long w = (long)blockIdx.x * PL + pl; w < nwin; w += (long)gridDim.x * PL) {
-            const int n = (int)(w / (WH * WW));
-            const int rem = (int)(w - (long)n * WH * WW);
-            const int wy = rem / WW, wx = rem - wy * WW;
             f32x4 yv[NPX], dz[NPX]; bool ok[NPX];
-            window_dz<POOL, ESZ>(da, dp, y, sc, sh, n, wy, wx, H, W, C, c, yv, dz, ok);
+            window_dz<POOL, ESZ>(da, dp, y, sc, sh, w, WH, WW, H, W, C, c, yv, dz, ok);
+            long base = w * C + c;                       // plain: the pixel itself
+            if (POOL) {
+                const unsigned uw = (unsigned)w, per = (unsigned)(WH * WW);
+                const unsigned n = uw / per, rem = uw - n * per, wy = rem / (unsigned)WW, wx = rem - wy * (unsigned)WW;
+                base = (((long)n * H + 2 * wy) * W + 2 * wx) * C + c;
+            }
 #pragma unroll
             for (int q = 0; q < NPX; ++q) {
                 if (!ok[q]) continue;
-                const int py = POOL ? 2 * wy + (q >> 1) : wy, px = POOL ? 2 * wx + (q & 1) : wx;
-                st4t<ESZ>(dy, (((long)n * H + py) * W + px) * C + c, k0 * dz[q] + k1 * yv[q] + k2);
+                st4t<ESZ>(dy, base + ((long)(q >> 1) * W + (q & 1)) * C, k0 * dz[q] + k1 * yv[q] + k2);
             }
         }
     }
@@ -510,6 +518,7 @@ int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const fl
     const int G = group_size(C / 4);
     const bool pool = dp != nullptr;
     const long nwin = pool ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long)N * H * W;
+    USTRUN_CHECK(nwin < (1L << 31), "bn_bwd_reduce: %ld windows per pass", nwin);
     int blocks = reduce_blocks(nwin, G);
     if (blocks > 1024 / passes) blocks = 1024 / passes;          // all passes' rows share the 1024-row table
     const PassOff po = {act_elems, pool_elems, aff_stride, (long)blocks * 2 * C, 3L * C};
@@ -535,6 +544,7 @@ int bn_bwd_apply_passes(const void* da, const void* dp, const void* y, const flo
     const int G = group_size(C / 4);
     const bool pool = dp != nullptr;
     const long nwin = pool ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long)N * H * W;
+    USTRUN_CHECK(nwin < (1L << 31), "bn_bwd_apply: %ld windows per pass", nwin);
     const int PL = 256 / G;
     long blocks = (nwin + (long)PL * 4 - 1) / ((long)PL * 4);
     if (blocks > 4096) blocks = 4096;
