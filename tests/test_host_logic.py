@@ -35,3 +35,28 @@ def test_all_cover_rectangle():
     ref = H.all_cover_box(np.zeros((40, 40), dtype=np.float32))
     random.seed(1); np.random.seed(1)
     assert np.array_equal(T.all_cover_box(np.zeros((40, 40), dtype=np.float32)), ref)
+
+
+def test_oracle_validation_averages_like_the_reference():
+    """eval_ref.validate: batch Dice -> mean per domain loader -> mean over domains (train.py:318-372)."""
+    import torch
+    from oracle import eval_ref as E
+    from oracle import step_ref as S
+    from oracle import unet_ref as U
+    from ustrun import synthetic
+    torch.manual_seed(2)
+    sd = U.make_state_dict(1, 2, base=4)
+    loaders = synthetic.test_loaders("prostate", 2, 2, 2, 1, 32, seed=9)
+    val, dom = E.validate("prostate", sd, loaders)
+    manual = []
+    for loader in loaders:
+        ds = []
+        for image, label in loader:
+            with torch.no_grad():
+                out = U.unet_forward(image, sd, train=False)
+            pred = out.argmax(1)                              # softmax is monotone: same first-index arg-max
+            ds.append(S.sample_dice("prostate", np.asarray(pred), S.decode_labels("prostate", label))[0])
+        manual.append(sum(ds) / len(ds))
+    assert np.allclose([d[0] for d in dom], manual) and np.isclose(val[0], sum(manual) / 2)
+    lg = torch.zeros(1, 3, 2, 2); lg[0, 1] = 1; lg[0, 2] = 1
+    assert torch.equal(E.predict("MNMS", lg), torch.ones(1, 2, 2, dtype=torch.long))      # first index on ties

@@ -4,7 +4,8 @@
 Keeps the reference's command line (train.py:38-79: same flag names and defaults); new flags are
 additive (--synthetic, --backend_dtype, --data_root, --fft, --log_every).  The step itself is
 ustrun.trainer.SSLTrainer (HIP kernels through libustrun.so).  Data loading, augmentation,
-validation with medpy and tensorboard logging are outside this build's scope: batches
+the medpy metrics and tensorboard logging are outside this build's scope; the Dice
+validation at every epoch end is ustrun.evaluate.validate: batches
 come from the seeded synthetic generator unless a loader is plugged in through `make_loaders`.
 
 Single GPU:   python train.py --dataset fundus --save_name run0 --synthetic 1
@@ -107,6 +108,10 @@ def train(args, snapshot_path):
                          increase=args.increase, queue_len=args.queue_len, num_eval_iter=args.num_eval_iter,
                          grad_allreduce=ddp.make_grad_allreduce(world), world_size=world, fft=args.fft)
     loader = make_loaders(args, C, H)
+    from ustrun import synthetic
+    from ustrun.evaluate import validate
+    test_loaders = synthetic.test_loaders(args.dataset, min(args.domain_num, 2), 4, args.test_bs, C, H, args.seed + 17)
+    best = {"avg": 0.0, "iter": 0, "stu_avg": 0.0, "stu_iter": 0}
     max_epoch = args.max_iterations // args.num_eval_iter
     logging.info("%d iterations per epoch, %d epochs", args.num_eval_iter, max_epoch)
     t0 = time.time()
@@ -121,9 +126,25 @@ def train(args, snapshot_path):
                 logging.info("iteration %d: loss:%.4f sup:%.4f ul:%.4f lu:%.4f s:%.4f cons_w:%.4f mask:%.4f ulb_dice:%s  %.1f img/s",
                              trainer.iter_num, s["loss"], s["sup"], s["ul"], s["lu"], s["s"], s["w"], s["mask_ratio"],
                              ["%.4f" % v for v in s["ulb_dice"]], ips)
+        # epoch end (train.py:913-957): validate teacher then student, keep the student with the best mean Dice
+        # (`unet_avg_dice_best_model.pth`, the file test.py loads), write the checkpoint
         if rank == 0:
-            torch.save({"epoch": epoch + 1, "ema_state_dict": ema_model.state_dict(), "state_dict": model.state_dict()},
-                       os.path.join(snapshot_path, "checkpoint.pth"))
+            logging.info('test ema model')
+            val_dice, _ = validate(args.dataset, ema_model, test_loaders, epoch + 1)
+            if sum(val_dice) / len(val_dice) > best["avg"]:
+                best["avg"], best["iter"] = sum(val_dice) / len(val_dice), trainer.iter_num
+            logging.info('val_best_avg_dice: %f at %d iter', best["avg"], best["iter"])
+            logging.info('test stu model')
+            stu_dice, _ = validate(args.dataset, model, test_loaders, epoch + 1)
+            if sum(stu_dice) / len(stu_dice) > best["stu_avg"]:
+                best["stu_avg"], best["stu_iter"] = sum(stu_dice) / len(stu_dice), trainer.iter_num
+                save_best = os.path.join(snapshot_path, "{}_avg_dice_best_model.pth".format(args.model))
+                logging.info('save cur best avg model to {}'.format(save_best))
+                torch.save(model.state_dict(), save_best)
+            logging.info('val_best_avg_dice: %f at %d iter', best["stu_avg"], best["stu_iter"])
+            torch.save({"epoch": epoch + 1, "ema_state_dict": ema_model.state_dict(), "state_dict": model.state_dict(),
+                        "best_dice": best["avg"], "best_iter": best["iter"], "stu_best_dice": best["stu_avg"],
+                        "stu_best_iter": best["stu_iter"]}, os.path.join(snapshot_path, "checkpoint.pth"))
 
 
 if __name__ == "__main__":

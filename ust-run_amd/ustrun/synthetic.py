@@ -62,3 +62,17 @@ def batch(dataset, B, C, H, seed):
     lb_y, ulb_y = labels(dataset, B, H, g), labels(dataset, B, H, g)
     f_lb, f_ulb = foreground(dataset, lb_y), foreground(dataset, ulb_y)
     return images(B, C, H, g, f_lb), lb_y, images(B, C, H, g, f_ulb), images(B, C, H, g, f_ulb), ulb_y
+
+
+def test_loaders(dataset, domain_num, batches, test_bs, C, H, seed):
+    """One list of (image, raw label) CPU batches per domain, seeded: stands in for the reference's per-domain test
+    DataLoaders (test.py:222-230) when no dataset is on disk."""
+    out = []
+    for d in range(domain_num):
+        dom = []
+        for b in range(batches):
+            g = torch.Generator().manual_seed(seed + 7919 * d + b)
+            y = labels(dataset, test_bs, H, g)
+            dom.append((images(test_bs, C, H, g, foreground(dataset, y)), y))
+        out.append(dom)
+    return out
