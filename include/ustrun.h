@@ -147,6 +147,11 @@ int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, int N, int H,
                           float* dw, float* db, int accumulate, float* partials, int64_t partials_bytes,
                           int dtype, ustrun_stream_t s);
 
+/* ---- bilinear Up block: nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True), unet_parts.py:48-50 ----
+ * x[N,H,W,C] -> y[N,2H,2W,C] (NHWC f32, C % 4 == 0); _bwd is its exact adjoint (dy -> dx), fixed summation order. */
+int ustrun_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, ustrun_stream_t s);
+int ustrun_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, ustrun_stream_t s);
+
 /* ---- pseudo-labels: replaces train.py:648-667 (teacher) and :669-674 (student) ---------------
  * softmax: conf,label = max(softmax(logits,1),1); mask = conf > th   (label int64, mask f32)
  * sigmoid: label = (p >= .5); mask = (p >= th) + (p <= 1-th)          (both f32 [N,K,H,W])   */

@@ -21,6 +21,8 @@ def _build(name):
         return Down(8, 16)
     if name.startswith("g1_up_16_8_convT"):
         return Up(16, 8, bilinear=False)
+    if name == "g1_up_16_8_bilinear":
+        return Up(16, 8, bilinear=True)
     if name == "g1_outconv_8_2":
         return OutConv(8, 2)
     raise KeyError(name)
@@ -31,7 +33,7 @@ def close(a, b, rtol=2e-4, atol=2e-5):
 
 
 NAMES = ["g1_doubleconv_3_8", "g1_doubleconv_8_8_mid4", "g1_down_8_16", "g1_down_8_16_odd", "g1_up_16_8_convT",
-         "g1_up_16_8_convT_odd", "g1_outconv_8_2"]
+         "g1_up_16_8_convT_odd", "g1_up_16_8_bilinear", "g1_outconv_8_2"]
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -64,8 +66,43 @@ def test_block_module_matches_reference_golden(name):
         close(m(*[x.detach() for x in ins]), g["out_eval"])
 
 
-def test_bilinear_up_refuses_loudly():
-    from networks.unet_parts import Up
-    m = Up(16, 8, bilinear=True).cuda()
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 16, 4, 4).cuda(), torch.zeros(1, 8, 8, 8).cuda())
+def test_bilinear_upsample_is_the_adjoint_pair():
+    """ustrun_upsample2x_fwd == F.interpolate(align_corners=True); _bwd == its autograd, odd and 1-pixel extents too."""
+    import torch.nn.functional as TF
+    from ustrun.blocks import _BilinearFn
+    g = torch.Generator().manual_seed(4)
+    for n, c, h, w in ((2, 8, 5, 7), (1, 4, 1, 3), (3, 12, 16, 16)):
+        x = torch.randn(n, c, h, w, generator=g)
+        xr = x.clone().requires_grad_(True)
+        yr = TF.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        xg = x.cuda().requires_grad_(True)
+        yg = _BilinearFn.apply(xg)                            # NHWC
+        close(yg.permute(0, 3, 1, 2), yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+        yg.backward(dy.permute(0, 2, 3, 1).contiguous().cuda())
+        close(xg.grad, xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_unet_bilinear_matches_oracle():
+    """UNet(bilinear=True) (unet_model.py:17-22 channel plan) composed from the block modules vs the CPU oracle."""
+    from networks.unet_model import UNet
+    from oracle import unet_ref as U
+    torch.manual_seed(11)
+    sd = U.make_state_dict(3, 2, bilinear=True, base=8)
+    x = torch.randn(2, 3, 32, 32)
+    ref_sd = U.clone_sd(sd, requires_grad=True)
+    ref = U.unet_forward(x, ref_sd, train=True, bilinear=True)
+    ref.square().mean().backward()
+    m = UNet(3, 2, bilinear=True, base_channels=8)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: v.detach().clone() for k, v in sd.items()})
+    m = m.cuda().train()
+    out = m(x.cuda())
+    close(out, ref.detach().numpy(), rtol=1e-3, atol=1e-5)
+    out.square().mean().backward()
+    for k, p in m.named_parameters():
+        a, b = p.grad.double().cpu().flatten(), ref_sd[k].grad.double().flatten()
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 2e-3, k
+    with pytest.raises(RuntimeError, match="f32"):
+        UNet(3, 2, bilinear=True, base_channels=8, dtype="bf16").cuda()(x.cuda())

@@ -34,10 +34,27 @@ class UNet(nn.Module):
     def forward(self, x, feature=False):
         _hip_only(x)
         if self.bilinear:
-            raise NotImplementedError("bilinear=True is not on the reference's hot path (every call site uses "
-                                      "the ConvTranspose2d default, train.py:499); not built in the HIP path yet")
+            return self._forward_blocks(x, feature)
         from ustrun import engine
         return engine.unet_forward(self, x, feature)
+
+    def _forward_blocks(self, x, feature=False):
+        """unet_model.py:25-39 composed from the block modules (each one HIP kernels through the operator-level ABI,
+        f32).  The bilinear variant runs this way: no reference call site uses it (train.py:499 takes the
+        ConvTranspose2d default), so it has no fused whole-network plan."""
+        if self.compute_dtype != "f32":
+            raise RuntimeError("UNet(bilinear=True) runs through the f32 block modules; construct it with dtype='f32'")
+        x1 = self.inc(x)
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        y = self.up1(x5, x4)
+        y = self.up2(y, x3)
+        y = self.up3(y, x2)
+        y = self.up4(y, x1)
+        logits = self.outc(y)
+        return (logits, y) if feature else logits
 
     def forward_passes(self, xs, feature=False):
         """Additive API (not in the reference): run several forward passes of equal shape as ONE batched call.
@@ -51,7 +68,8 @@ class UNet(nn.Module):
             raise RuntimeError("forward_passes: all passes must have the same shape")
         x = torch.cat(xs, 0) if len(xs) > 1 else xs[0]
         _hip_only(x)
-        if self.bilinear:
-            raise NotImplementedError("bilinear=True is not built in the HIP path yet")
+        if self.bilinear:                                   # no batched plan: pass by pass, in order
+            outs = [self._forward_blocks(t, feature) for t in xs]
+            return tuple(torch.cat(o, 0) for o in zip(*outs)) if feature else torch.cat(outs, 0)
         from ustrun import engine
         return engine.unet_forward(self, x, feature, groups=len(xs))

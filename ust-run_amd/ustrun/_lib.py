@@ -61,6 +61,8 @@ SIGNATURES = {
     "ustrun_pseudo_label": (i32, [fp, i32, i32, i32, f32, i32, vp, fp, vp]),
     "ustrun_mix_targets": (i32, [i32, i32, i32, i32, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp]),
     "ustrun_box_mix": (i32, [fp, fp, fp, i32, i32, i32, fp, vp]),
+    "ustrun_upsample2x_fwd": (i32, [fp, i32, i32, i32, i32, fp, vp]),
+    "ustrun_upsample2x_bwd": (i32, [fp, i32, i32, i32, i32, fp, vp]),
     "ustrun_rect_masks": (i32, [vp, i32, i32, i32, fp, vp]),
     "ustrun_upload_small": (i32, [vp, vp, i32, vp]),
     "ustrun_freq_mix_work_bytes": (i64, [i32, i32, i32]),

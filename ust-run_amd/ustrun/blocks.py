@@ -5,7 +5,7 @@ The reference's scripts never call the blocks directly -- only `UNet.forward` do
 `UNet.forward` runs the whole network as one fused call (engine.py).  A stand-alone block has to materialise the
 activated tensor at its edges, so this module is the convenience / parity surface, not the hot path: it works in
 f32 (the exact path), NCHW in and out like the reference modules; layout changes at the block edge (NCHW <-> the
-kernels' NHWC) are tensor plumbing, every FLOP runs in libustrun.so.  `Up(bilinear=True)` is not built.
+kernels' NHWC) are tensor plumbing, every FLOP runs in libustrun.so.
 """
 from __future__ import annotations
 
@@ -226,11 +226,36 @@ class _ConvTFn(torch.autograd.Function):
         return _nchw(da), dw, db
 
 
+class _BilinearFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (unet_parts.py:48-50): NCHW in, NHWC out."""
+
+    @staticmethod
+    def forward(ctx, x1):
+        lib = L.lib()
+        xh = _nhwc(_f32c(x1, "Up input"))
+        N, H, W, Ci = xh.shape
+        if Ci % 4:
+            raise RuntimeError(f"Up(bilinear): {Ci} channels (needs a multiple of 4)")
+        u = torch.empty(N, 2 * H, 2 * W, Ci, device=x1.device)
+        L.check(lib.ustrun_upsample2x_fwd(xh.data_ptr(), N, H, W, Ci, u.data_ptr(), stream_ptr()), "upsample2x_fwd")
+        ctx.shape = (N, H, W, Ci)
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        lib = L.lib()
+        N, H, W, Ci = ctx.shape
+        du = du.contiguous()
+        dx = torch.empty(N, H, W, Ci, device=du.device)
+        L.check(lib.ustrun_upsample2x_bwd(du.data_ptr(), N, H, W, Ci, dx.data_ptr(), stream_ptr()), "upsample2x_bwd")
+        return _nchw(dx)
+
+
 def up(module, x1, x2):
-    if not isinstance(module.up, torch.nn.ConvTranspose2d):
-        raise NotImplementedError("Up(bilinear=True) is not built in the HIP path (every reference call site uses the "
-                                  "ConvTranspose2d default, train.py:499)")
-    u = _ConvTFn.apply(x1, module.up.weight, module.up.bias)          # NHWC
+    if isinstance(module.up, torch.nn.ConvTranspose2d):
+        u = _ConvTFn.apply(x1, module.up.weight, module.up.bias)      # NHWC
+    else:
+        u = _BilinearFn.apply(x1)                                     # NHWC, channels unchanged
     return _DoubleConvFn.apply(module.conv, False, x2, u, *_dc_params(module.conv))
 
 
