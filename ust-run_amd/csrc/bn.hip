@@ -99,6 +99,22 @@ __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* be
     }
 }
 
+// eval mode: the 18 layers' constants in ONE launch (blockIdx.y = layer x pass), instead of 18 five-microsecond ones
+struct EvalAffineJobs {
+    const float *gamma[18], *beta[18], *rm[18], *rv[18];
+    float* aff[18];          // layer's table: pass g at aff + g * 4C: {scale[C], shift[C], ...}
+    int C[18];
+};
+__global__ void bn_eval_affine_multi_kernel(const EvalAffineJobs j, float eps, int passes) {
+    const int l = blockIdx.y / passes, g = blockIdx.y % passes, C = j.C[l];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = j.gamma[l][c] * (1.0f / sqrtf(j.rv[l][c] + eps));
+        float* a = j.aff[l] + 4L * C * g;
+        a[c] = sc; a[C + c] = j.beta[l][c] - j.rm[l][c] * sc;
+    }
+}
+
 // a = relu(y*scale+shift) materialised (NHWC -> NHWC or NCHW)
 __global__ void bn_relu_apply_kernel(const float* __restrict__ y, int esz, const float* __restrict__ scale,
                                      const float* __restrict__ shift, long npix, int C, int HW,
@@ -442,6 +458,25 @@ extern "C" int ustrun_bn_eval_affine(int C, const float* gamma, const float* bet
     USTRUN_LAUNCH_CHECK("bn_eval_affine");
     return 0;
 }
+
+namespace ustrun {
+// used by the U-Net forward in eval mode
+int bn_eval_affine_layers(int nlayers, const int* C, const float* const* gamma, const float* const* beta,
+                          const float* const* rm, const float* const* rv, float* const* aff, float eps, int passes,
+                          hipStream_t s) {
+    USTRUN_CHECK(nlayers > 0 && nlayers <= 18 && passes >= 1, "bn_eval_affine_layers: %d layers", nlayers);
+    EvalAffineJobs j;
+    int cmax = 0;
+    for (int l = 0; l < nlayers; ++l) {
+        USTRUN_CHECK(gamma[l] && beta[l] && rm[l] && rv[l] && aff[l] && C[l] > 0, "bn_eval_affine_layers: null pointer");
+        j.gamma[l] = gamma[l]; j.beta[l] = beta[l]; j.rm[l] = rm[l]; j.rv[l] = rv[l]; j.aff[l] = aff[l]; j.C[l] = C[l];
+        cmax = C[l] > cmax ? C[l] : cmax;
+    }
+    hipLaunchKernelGGL(bn_eval_affine_multi_kernel, dim3(cdiv(cmax, 256), nlayers * passes), dim3(256), 0, s, j, eps, passes);
+    USTRUN_LAUNCH_CHECK("bn_eval_affine_layers");
+    return 0;
+}
+}  // namespace ustrun
 
 extern "C" int ustrun_bn_relu_apply(const void* y, const float* scale, const float* shift, int64_t npix, int C,
                                     int HW, float* out, int out_nchw, int dtype, ustrun_stream_t s) {

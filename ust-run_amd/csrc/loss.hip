@@ -254,14 +254,14 @@ __global__ __launch_bounds__(256) void box_mix_kernel(const float* __restrict__ 
     }
 }
 
-// one block per (sample, class): exact integer counts {|pred|, |gt|, |pred & gt|}
+// blockIdx.x = (sample, class), blockIdx.y = slice of the pixels: exact integer counts {|pred|, |gt|, |pred & gt|}
 __global__ __launch_bounds__(256) void dice_counts_kernel(const void* pred, const void* gt, int pi64, int gi64, int K,
                                                          int HW, int by_class, int* __restrict__ counts) {
     __shared__ int red[4][3];
     const int n = blockIdx.x / K, c = blockIdx.x % K;
     const long base = by_class ? (long)n * HW : ((long)n * K + c) * HW;
     int s = 0, g = 0, i = 0;
-    for (int e = threadIdx.x; e < HW; e += 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < HW; e += 256 * gridDim.y) {
         bool pb, gb;
         if (by_class) {
             const long long pv = pi64 ? ((const long long*)pred)[base + e] : (long long)((const float*)pred)[base + e];
@@ -278,8 +278,11 @@ __global__ __launch_bounds__(256) void dice_counts_kernel(const void* pred, cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { red[wave][0] = s; red[wave][1] = g; red[wave][2] = i; }
     __syncthreads();
-    if (threadIdx.x < 3)
-        counts[(long)blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 3) {      // integer sums: the order of the blocks' contributions does not matter
+        const int v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (gridDim.y == 1) counts[(long)blockIdx.x * 3 + threadIdx.x] = v;
+        else if (v) atomicAdd(&counts[(long)blockIdx.x * 3 + threadIdx.x], v);
+    }
 }
 
 // SGD(momentum, wd) + EMA over flat f32 buffers, 16 B per lane
@@ -430,7 +433,14 @@ extern "C" int ustrun_upload_small(void* dst, const void* src_host, int nbytes, 
 extern "C" int ustrun_dice_counts(const void* pred, const void* gt, int pred_is_i64, int gt_is_i64, int N, int K,
                                   int HW, int by_class, int32_t* counts, ustrun_stream_t s) {
     USTRUN_CHECK(pred && gt && counts && N > 0 && K > 0 && HW > 0, "dice_counts: bad args");
-    hipLaunchKernelGGL(dice_counts_kernel, dim3(N * K), dim3(256), 0, (hipStream_t)s, pred, gt, pred_is_i64, gt_is_i64, K,
+    // one block per (sample, class) left a 16+16 batch on 32 of 256 CUs (0.2 ms): split the pixels over enough blocks
+    int split = 1;
+    while ((long)N * K * split < 512 && HW / (split * 2) >= 2048) split *= 2;
+    if (split > 1) {
+        const hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * 3 * (size_t)N * K, (hipStream_t)s);
+        USTRUN_CHECK(e == hipSuccess, "dice_counts: memset failed: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(dice_counts_kernel, dim3(N * K, split), dim3(256), 0, (hipStream_t)s, pred, gt, pred_is_i64, gt_is_i64, K,
                        HW, by_class, counts);
     USTRUN_LAUNCH_CHECK("dice_counts");
     return 0;

@@ -218,6 +218,12 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
     const float* pk = (const float*)d->packed;
     float* stat = (float*)(ws + p.stat_off);
     auto affp = [&](int k) { return (float*)(ws + p.aff_off[k]); };
+    if (!d->train) {     // eval: every layer's scale/shift from the running statistics, one launch for all 18 layers
+        float* affs[18];
+        for (int i = 0; i < 18; ++i) affs[i] = affp(i);
+        USTRUN_TRY(bn_eval_affine_layers(18, p.cout, d->bn_w, d->bn_b, (const float* const*)d->bn_rm, (const float* const*)d->bn_rv, affs,
+                                         d->eps, p.G, (hipStream_t)s));
+    }
     for (int i = 0; i < 18; ++i) {
         if (i >= 10 && i % 2 == 0) {   // Up: ConvTranspose of the previous level's output first
             const int j = (i - 10) / 2, l = 3 - j;
@@ -247,11 +253,6 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
             USTRUN_TRY(bn_finalize_passes(stat, rpg, p.G, C, (int64_t)p.gN * H * W, d->bn_w[i], d->bn_b[i], d->bn_rm[i],
                                           d->bn_rv[i], d->bn_nbt[i], d->momentum, d->eps, d->update_running, aff, aff + C,
                                           aff + 2 * C, aff + 3 * C, 4L * C, (hipStream_t)s));
-        } else {
-            for (int g = 0; g < p.G; ++g) {
-                float* ag = aff + 4L * C * g;
-                USTRUN_TRY(ustrun_bn_eval_affine(C, d->bn_w[i], d->bn_b[i], d->bn_rm[i], d->bn_rv[i], d->eps, ag, ag + C, s));
-            }
         }
     }
     const int C = p.cout[17];
