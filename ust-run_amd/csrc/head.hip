@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
             if (k < K)
                 for (int o = LPP >> 1; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
         if (cq0 == 0 && p < npix) {
-            const long n = p / HW, hw = p - n * HW;
+            const long n = (unsigned)p / (unsigned)HW, hw = p - n * HW;   // 32-bit divide: p < 2^32 (checked on the host)
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
                 if (k < K) logits[(n * K + k) * HW + hw] = acc[k] + bias[k];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const __bf16* __rest
                 float out = acc[0];
 #pragma unroll
                 for (int k = 1; k < K; ++k) if (g == k) out = acc[k];
-                const long n = p / HW, hw = p - n * HW;
+                const long n = (unsigned)p / (unsigned)HW, hw = p - n * HW;   // 32-bit divide: p < 2^32 (checked on the host)
                 logits[(n * K + g) * HW + hw] = out + bk;
             }
         }
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         for (int k = 0; k < KMAX; ++k) wk[k] = (k < K) ? *(const f32x4*)(w + k * C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
         if (active)
             for (long p = (long)blockIdx.x * PPB + pl; p < npix; p += (long)gridDim.x * PPB) {
-                const long n = p / HW, hw = p - n * HW;
+                const long n = (unsigned)p / (unsigned)HW, hw = p - n * HW;   // 32-bit divide: p < 2^32 (checked on the host)
                 const f32x4 a = act4(ld4t<ESZ>(y, p * C + c), scale, shift, c);
                 f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -216,7 +216,7 @@ extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* s
     USTRUN_CHECK(dtype_ok(dtype), "head_fwd: dtype %d not built", dtype);
     USTRUN_CHECK(y && w && bias && logits, "head_fwd: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_fwd: C=%d K=%d unsupported", C, K);
-    USTRUN_CHECK(npix > 0 && HW > 0 && npix % HW == 0, "head_fwd: bad extent");
+    USTRUN_CHECK(npix > 0 && HW > 0 && npix % HW == 0 && npix < (1LL << 32), "head_fwd: bad extent");
     const int G = C / 8;
     if (dtype == USTRUN_BF16 && C % 8 == 0 && G <= 64 && (G & (G - 1)) == 0 && K >= 1 && K <= 4 && K <= G) {
         long nb = (npix + (256 / G) * 8 - 1) / ((256 / G) * 8);      // two rounds of four pixels per lane
@@ -248,6 +248,7 @@ extern "C" int ustrun_head_bwd(const float* dlogits, const void* y, const float*
     USTRUN_CHECK(dtype_ok(dtype), "head_bwd: dtype %d not built", dtype);
     USTRUN_CHECK(dlogits && y && w && da && dw && db && partials, "head_bwd: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_bwd: C=%d K=%d unsupported", C, K);
+    USTRUN_CHECK(npix > 0 && HW > 0 && npix < (1LL << 32), "head_bwd: bad extent");
     const int LPP = lanes_per_pixel(C / 4);
     const int blocks = head_blocks(npix, LPP);
     const long row = (long)K * C + K;

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
     if (mode == USTRUN_LOSS_SOFTMAX) {
         const long long* tgt = (const long long*)target;
         for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
-            const long n = p / HW, hw = p - n * HW;
+            const long n = (unsigned)p / (unsigned)HW, hw = p - n * HW;   // 32-bit divide: p < 2^32 (checked on the host)
             float l[KMAX], mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (k < K) { l[k] = logits[(n * K + k) * HW + hw]; mx = fmaxf(mx, l[k]); }
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
             }
         const float cen = cw / (float)npix;
         for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
-            const long n = p / HW, hw = p - n * HW;
+            const long n = (unsigned)p / (unsigned)HW, hw = p - n * HW;   // 32-bit divide: p < 2^32 (checked on the host)
             float l[KMAX], mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (k < K) { l[k] = logits[(n * K + k) * HW + hw]; mx = fmaxf(mx, l[k]); }
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restri
     if (mode == USTRUN_LOSS_SOFTMAX) {
         long long* lab = (long long*)label;
         for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
-            const long n = p / HW, hw = p - n * HW;
+            const long n = (unsigned)p / (unsigned)HW, hw = p - n * HW;   // 32-bit divide: p < 2^32 (checked on the host)
             float l[KMAX], mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (k < K) { l[k] = logits[(n * K + k) * HW + hw]; mx = fmaxf(mx, l[k]); }
@@ -329,7 +329,7 @@ extern "C" int64_t ustrun_loss_partials_bytes(int N, int K, int HW) {
 extern "C" int ustrun_seg_loss_fwd(const float* logits, const void* target, const float* mask, int N, int K, int HW,
                                    int mode, float* out, float* partials, int64_t partials_bytes, ustrun_stream_t s) {
     USTRUN_CHECK(logits && target && out && partials, "seg_loss_fwd: null pointer");
-    USTRUN_CHECK(K >= 1 && K <= KMAX && N > 0 && HW > 0, "seg_loss_fwd: bad shape N=%d K=%d HW=%d", N, K, HW);
+    USTRUN_CHECK(K >= 1 && K <= KMAX && N > 0 && HW > 0 && (long)N * HW < (1L << 32), "seg_loss_fwd: bad shape N=%d K=%d HW=%d", N, K, HW);
     USTRUN_CHECK(mode == USTRUN_LOSS_SOFTMAX || mode == USTRUN_LOSS_SIGMOID, "seg_loss_fwd: bad mode %d", mode);
     USTRUN_CHECK(partials_bytes >= ustrun_loss_partials_bytes(N, K, HW), "seg_loss_fwd: partials too small");
     const long items = mode == USTRUN_LOSS_SOFTMAX ? (long)N * HW : (long)N * K * HW;
@@ -346,7 +346,7 @@ extern "C" int ustrun_seg_loss_bwd(const float* logits, const void* target, cons
                                    int mode, const float* sums, const float* gscale_dev, float gscale, float ce_weight,
                                    float dice_weight, float* dlogits, ustrun_stream_t s) {
     USTRUN_CHECK(logits && target && sums && dlogits, "seg_loss_bwd: null pointer");
-    USTRUN_CHECK(K >= 1 && K <= KMAX && N > 0 && HW > 0, "seg_loss_bwd: bad shape");
+    USTRUN_CHECK(K >= 1 && K <= KMAX && N > 0 && HW > 0 && (long)N * HW < (1L << 32), "seg_loss_bwd: bad shape");
     USTRUN_CHECK(mode == USTRUN_LOSS_SOFTMAX || mode == USTRUN_LOSS_SIGMOID, "seg_loss_bwd: bad mode %d", mode);
     const long items = mode == USTRUN_LOSS_SOFTMAX ? (long)N * HW : (long)N * K * HW;
     hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3(stream_blocks(items)), dim3(256), 0, (hipStream_t)s, logits, target,
@@ -358,7 +358,7 @@ extern "C" int ustrun_seg_loss_bwd(const float* logits, const void* target, cons
 extern "C" int ustrun_pseudo_label(const float* logits, int N, int K, int HW, float threshold, int mode, void* label,
                                    float* mask, ustrun_stream_t s) {
     USTRUN_CHECK(logits && label && mask, "pseudo_label: null pointer");
-    USTRUN_CHECK(K >= 1 && K <= KMAX && N > 0 && HW > 0, "pseudo_label: bad shape");
+    USTRUN_CHECK(K >= 1 && K <= KMAX && N > 0 && HW > 0 && (long)N * HW < (1L << 32), "pseudo_label: bad shape");
     const long items = mode == USTRUN_LOSS_SOFTMAX ? (long)N * HW : (long)N * K * HW;
     hipLaunchKernelGGL(pseudo_label_kernel, dim3(stream_blocks(items)), dim3(256), 0, (hipStream_t)s, logits, N, K, HW,
                        threshold, mode, label, mask);
