@@ -241,26 +241,61 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
     const int lrow = 8 * lh + ((lane & 15) >> 2), lcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
     const int tbeg = blockIdx.x * tiles_per, tend = min(ttotal, tbeg + tiles_per);
-    for (int t = tbeg; t < tend; ++t) {
+    // Register-staged software pipeline: the next tile's dY (16 B per item) and x elements are loaded while the current
+    // tile's MFMAs run (the synchronous load -> barrier -> compute loop spent 16 us per 16 KB tile).  The decomposition
+    // of this thread's x elements into (channel, kw, patch row, pixel) does not depend on the tile.
+    constexpr int XIT = (CMAX * 3 * (FTH + 2) * FTW + 255) / 256;
+    constexpr int DIT = FTH * FTW * (ESZ == 2 ? 8 : 16) / 256;       // 16-byte items: 8 bf16 or 4 f32 channels
+    int xdec[XIT];
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+        const int e = tid + 256 * i;
+        const int px = e % FTW, hy = (e / FTW) % (FTH + 2), kw = (e / (FTW * (FTH + 2))) % 3, c = e / (FTW * (FTH + 2) * 3);
+        xdec[i] = e < C * 3 * (FTH + 2) * FTW ? (c << 16) | (kw << 12) | (hy << 6) | px : -1;
+    }
+    float xr[XIT];
+    f32x4 dr[DIT];
+    auto prefetch = [&](int t) {
         const int img = t / (tiles_y * tiles_x);
         const int rem = t - img * tiles_y * tiles_x;
         const int y0 = (rem / tiles_x) * FTH, x0 = (rem % tiles_x) * FTW;
-        __syncthreads();
-        for (int e = tid; e < C * 3 * (FTH + 2) * FTW; e += 256) {
-            const int px = e % FTW, hy = (e / FTW) % (FTH + 2), kw = (e / (FTW * (FTH + 2))) % 3, c = e / (FTW * (FTH + 2) * 3);
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+            const int d = xdec[i];
+            const int c = d >> 16, kw = (d >> 12) & 3, hy = (d >> 6) & 63, px = d & 63;
             const int iy = y0 + hy - 1, ix = x0 + px + kw - 1;
-            const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[img * sN + c * sC + iy * sH + ix * sW] : 0.f;
-            xs[c][kw][hy][px] = (__bf16)v;
+            xr[i] = (d >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[img * sN + c * sC + iy * sH + ix * sW] : 0.f;
         }
-        for (int e = tid; e < FTH * FTW * 16; e += 256) {
-            const int p = e >> 4, c4 = e & 15;
+#pragma unroll
+        for (int i = 0; i < DIT; ++i) {
+            const int e = tid + 256 * i;
+            const int p = ESZ == 2 ? e >> 3 : e >> 4, g = ESZ == 2 ? e & 7 : e & 15;
             const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < H && ox < W) v = ld4t<ESZ>(dy, (((long)img * H + oy) * W + ox) * 64 + 4 * c4);
-            bf16x4 h;
-            h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-            *(bf16x4*)(dys + p * WRB + c4 * 8) = h;
+            dr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (oy < H && ox < W)
+                dr[i] = *(const f32x4*)((const char*)dy + ((((long)img * H + oy) * W + ox) * 64 + (ESZ == 2 ? 8 : 4) * g) * ESZ);
         }
+    };
+    if (tbeg < tend) prefetch(tbeg);
+    for (int t = tbeg; t < tend; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+            const int d = xdec[i];
+            if (d >= 0) xs[d >> 16][(d >> 12) & 3][(d >> 6) & 63][d & 63] = (__bf16)xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < DIT; ++i) {
+            const int e = tid + 256 * i;
+            if (ESZ == 2) {
+                *(f32x4*)(dys + (e >> 3) * WRB + (e & 7) * 16) = dr[i];          // 8 bf16, as stored
+            } else {
+                bf16x4 h;
+                h[0] = (__bf16)dr[i][0]; h[1] = (__bf16)dr[i][1]; h[2] = (__bf16)dr[i][2]; h[3] = (__bf16)dr[i][3];
+                *(bf16x4*)(dys + (e >> 4) * WRB + (e & 15) * 8) = h;
+            }
+        }
+        if (t + 1 < tend) prefetch(t + 1);
         __syncthreads();
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
