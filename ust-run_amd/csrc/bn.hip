@@ -245,22 +245,32 @@ __device__ __forceinline__ void window_dz(const float* da, const float* __restri
         const unsigned rem = uw - (unsigned)n * per;
         wy = (int)(rem / (unsigned)WW); wx = (int)(rem - (unsigned)wy * (unsigned)WW);
     }
+    // every load of the window is issued unconditionally (out-of-range pixels read the window's first pixel, always
+    // inside, and are zeroed afterwards): nine independent loads in flight instead of one masked region after another
+    const long off0 = POOL ? (((long)n * H + 2 * wy) * W + 2 * wx) * C + c : w * C + c;
 #pragma unroll
     for (int q = 0; q < NPX; ++q) {
         const int py = 2 * wy + (q >> 1), px = 2 * wx + (q & 1);
         ok[q] = !POOL || (py < H && px < W);
-        yv[q] = zero; dz[q] = zero; av[q] = zero;
-        if (ok[q]) {
-            const long off = POOL ? (((long)n * H + py) * W + px) * C + c : w * C + c;
-            yv[q] = ld4t<ESZ>(y, off);
-            av[q] = yv[q] * sc + sh;
-            if (da) dz[q] = ld4t<ESZ>(da, off);
-        }
+        const long off = ok[q] ? off0 + ((long)(q >> 1) * W + (q & 1)) * C : off0;
+        yv[q] = ld4t<ESZ>(y, off);
+        dz[q] = da ? ld4t<ESZ>(da, off) : zero;
+    }
+    f32x4 gpool = zero;
+    bool gok = false;
+    if (POOL && dp) {
+        const int PH = H / 2, PW = W / 2;
+        gok = wy < PH && wx < PW;
+        gpool = ld4t<ESZ>(dp, (((long)n * PH + (gok ? wy : 0)) * PW + (gok ? wx : 0)) * C + c);
+    }
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) {
+        if (!ok[q]) { yv[q] = zero; dz[q] = zero; }
+        av[q] = ok[q] ? yv[q] * sc + sh : zero;
     }
     if (POOL) {
-        const int PH = H / 2, PW = W / 2;
-        if (dp && wy < PH && wx < PW) {
-            const f32x4 g = ld4t<ESZ>(dp, (((long)n * PH + wy) * PW + wx) * C + c);
+        if (gok) {
+            const f32x4 g = gpool;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int best = 0; float bv = fmaxf(av[0][j], 0.f);
