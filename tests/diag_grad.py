@@ -1,3 +1,6 @@
+"""Diagnostic (run by hand, not collected by pytest): where a BatchNorm beta gradient of the deep layers differs between
+the HIP path and the CPU oracle -- conditioning of the problem, not a kernel error.  Lives under tests/ because it uses
+the oracle."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ust-run_amd"), os.path.join(ROOT, "tests")]

@@ -46,7 +46,7 @@ def run_pair(c, k, n, h, w, base, seed, train=True, want64=False):
 
 
 # A pre-activation that lands within rounding of the ReLU kink flips its mask between any two f32
-# evaluation orders (CPU vs CPU included) and moves every upstream gradient by ~1e-3 (tools/diag_grad.py
+# evaluation orders (CPU vs CPU included) and moves every upstream gradient by ~1e-3 (tests/diag_grad.py
 # shows one such case: a single element of a 2x4x4 map).  The small nets are checked against the tight
 # bound (as accurate as the CPU f32 oracle, measured against its f64 evaluation); the full-width nets,
 # whose bottleneck BatchNorms see only 8-24 values per channel, against a flip-tolerant 1e-2.  The
