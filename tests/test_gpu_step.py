@@ -65,3 +65,21 @@ def test_ssl_step_matches_oracle(dataset, C, K):
         for k in sd_ref:
             if k.endswith("num_batches_tracked"):
                 assert int(msd[k]) == int(sd_ref[k]), k
+
+
+def test_memory_bank_stays_bounded_when_the_batch_exceeds_the_queue():
+    """unlabel_bs > queue_len: the reference's `newlen = max_len - cur_simple_num` would go negative and the bank would
+    grow by unlabel_bs - queue_len entries per step; the clamp keeps it at the current batch's easy samples."""
+    from networks.unet_model import UNet
+    from ustrun.trainer import SSLTrainer
+    B, H, base = 12, 32, 8
+    torch.manual_seed(3)
+    stu, tea = UNet(1, 2, base_channels=base).cuda(), UNet(1, 2, base_channels=base).cuda()
+    trn = SSLTrainer("prostate", stu, tea, max_iterations=300, threshold=0.52, patch_size=H, num_eval_iter=1, queue_len=10)
+    trn.choice_th = 2.0                      # every sample counts as easy (hardness <= 1)
+    random.seed(1); np.random.seed(1)
+    for s in range(6):
+        trn.step(*[t.cuda() for t in synth("prostate", B, 1, H, 50 + s)], epoch_start=False)
+        trn.choice_th = 2.0
+        assert trn.simple_ulb is None or len(trn.simple_ulb) <= B, (s, len(trn.simple_ulb))
+    assert len(trn.simple_ulb) == B == len(trn.cor_pl) == len(trn.cor_gt) == len(trn.cor_mask) == len(trn.cor_hardness)

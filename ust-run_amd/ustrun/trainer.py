@@ -353,7 +353,11 @@ class SSLTrainer:
             if len(self.simple_ulb) > 0:
                 self.choice_th = min(self.choice_th, self.cor_hardness.max())
         elif n_cur > 0:
-            keep = self.queue_len - n_cur if len(self.simple_ulb) + n_cur > self.queue_len else len(self.simple_ulb)
+            # train.py:768-771.  The reference's `newlen = max_len - cur_simple_num` goes NEGATIVE once a batch holds more
+            # easy samples than the queue is long (possible only with unlabel_bs > queue_len = 10; the reference runs 4),
+            # and `bank[:negative]` then lets the bank grow by up to unlabel_bs - queue_len entries per step without bound
+            # (29 GB after 1000 steps at B = 16).  Clamped at 0: identical whenever unlabel_bs <= queue_len.
+            keep = max(0, self.queue_len - n_cur) if len(self.simple_ulb) + n_cur > self.queue_len else len(self.simple_ulb)
             self.simple_ulb = torch.cat((pick(ulb_x_w), self.simple_ulb[:keep]), 0)
             self.cor_pl = torch.cat((pick(pl), self.cor_pl[:keep]), 0)
             self.cor_gt = torch.cat((pick(ulb_mask), self.cor_gt[:keep]), 0)
