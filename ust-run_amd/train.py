@@ -65,9 +65,10 @@ parser.add_argument('--backend_dtype', default='f32', choices=['f32', 'bf16'])
 parser.add_argument('--fft', default='device', choices=['host', 'device'])
 parser.add_argument('--data_root', type=str, default='../../data')
 parser.add_argument('--log_every', type=int, default=50)
+parser.add_argument('--synthetic_pool', type=int, default=8, help='distinct synthetic batches kept resident and cycled (0: a fresh batch every step)')
 
 
-def make_loaders(args, C, H):
+def make_loaders(args, C, H, dev=None):
     """-> iterator of (lb_x_w, lb_y, ulb_x_w, ulb_x_s, ulb_y) CPU tensors."""
     if not args.synthetic:
         raise SystemExit("the PIL/scipy dataset pipeline of the reference (dataloaders/) is outside this build's scope; "
@@ -76,6 +77,14 @@ def make_loaders(args, C, H):
     from ustrun.ddp import env_world
     rank = env_world()[0]
     step = 0
+    if args.synthetic_pool > 0:       # a pool of distinct seeded batches, generated once and cycled: the host generator
+        pool = [synthetic.batch(args.dataset, args.label_bs, C, H, args.seed + 100003 * rank + i)   # (0.2 s per batch)
+                for i in range(args.synthetic_pool)]                                                # would cap the step rate
+        if dev is not None:
+            pool = [[t.to(dev) for t in b] for b in pool]
+        while True:
+            yield pool[step % len(pool)]
+            step += 1
     while True:
         yield synthetic.batch(args.dataset, args.label_bs, C, H, args.seed + 100003 * rank + step)
         step += 1
@@ -107,7 +116,7 @@ def train(args, snapshot_path):
                          consistency_rampup=args.consistency_rampup, cutmix_prob=args.cutmix_prob, LB=args.LB,
                          increase=args.increase, queue_len=args.queue_len, num_eval_iter=args.num_eval_iter,
                          grad_allreduce=ddp.make_grad_allreduce(world), world_size=world, fft=args.fft)
-    loader = make_loaders(args, C, H)
+    loader = make_loaders(args, C, H, dev)
     from ustrun import synthetic
     from ustrun.evaluate import validate
     test_loaders = synthetic.test_loaders(args.dataset, min(args.domain_num, 2), 4, args.test_bs, C, H, args.seed + 17)
