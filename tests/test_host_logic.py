@@ -60,3 +60,38 @@ def test_oracle_validation_averages_like_the_reference():
     assert np.allclose([d[0] for d in dom], manual) and np.isclose(val[0], sum(manual) / 2)
     lg = torch.zeros(1, 3, 2, 2); lg[0, 1] = 1; lg[0, 2] = 1
     assert torch.equal(E.predict("MNMS", lg), torch.ones(1, 2, 2, dtype=torch.long))      # first index on ties
+
+
+def _load_driver(name):
+    import importlib.util
+    import os
+    import sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ust-run_amd")
+    for m in ("train", name):
+        sys.modules.pop(m, None)
+    spec = importlib.util.spec_from_file_location(name, os.path.join(root, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.path.insert(0, root)
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.remove(root)
+    return mod
+
+
+def test_driver_command_lines_keep_the_reference_flags_and_defaults():
+    """train.py:38-79, train_mnms.py:38-77, test.py:19-32 -- flag names and defaults (new flags are additive)."""
+    tr = _load_driver("train").parser.parse_args([])
+    want = dict(dataset="BUSI", save_name="debug", model="unet", max_iterations=60000, num_eval_iter=500, deterministic=1,
+                base_lr=0.03, seed=1337, gpu="0", threshold=0.95, amp=1, label_bs=4, unlabel_bs=4, test_bs=1, domain_num=6,
+                lb_domain=1, lb_num=40, lb_ratio=0, ema_decay=0.99, consistency_type="mse", consistency=1.0,
+                consistency_rampup=200.0, depth=28, widen_factor=2, leaky_slope=0.1, bn_momentum=0.1, dropout=0.0,
+                cutmix_prob=1.0, LB=0.01, increase=1.0005, queue_len=10, load=False, eval=False, overwrite=False)
+    for k, v in want.items():
+        assert getattr(tr, k) == v, k
+    mn = _load_driver("train_mnms").parser.parse_args([])
+    assert (mn.dataset, mn.domain_num, mn.lb_num, mn.load_path) == ("MNMS", 4, 20, "../model/lb1_ratio0.2/iter_6000.pth")
+    assert (mn.label_bs, mn.unlabel_bs, mn.queue_len, mn.threshold) == (4, 4, 10, 0.95)
+    te = _load_driver("test").parser.parse_args([])
+    assert (te.dataset, te.save_name, te.model, te.gpu, te.eval, te.test_bs, te.domain_num, te.lb_domain, te.save_img) == \
+        ("prostate", "debug", "unet", "0", True, 1, 6, 1, False)
