@@ -83,3 +83,48 @@ def test_memory_bank_stays_bounded_when_the_batch_exceeds_the_queue():
         trn.choice_th = 2.0
         assert trn.simple_ulb is None or len(trn.simple_ulb) <= B, (s, len(trn.simple_ulb))
     assert len(trn.simple_ulb) == B == len(trn.cor_pl) == len(trn.cor_gt) == len(trn.cor_mask) == len(trn.cor_hardness)
+
+
+def test_checkpoint_interchanges_with_torch_sgd(tmp_path):
+    """util.save_osmancheckpoint / load_osmancheckpoint (util.py:259-297) with the trainer's optimizer facade: the file
+    loads into a plain torch.optim.SGD over the same parameters (the reference's optimizer, train.py:512) and back, and a
+    resumed trainer continues with the same momentum, learning rate and weights."""
+    from networks.unet_model import UNet
+    from ustrun.trainer import SSLTrainer
+    from utils import util
+    B, H, base = 2, 32, 8
+    kw = dict(max_iterations=300, threshold=0.52, patch_size=H, num_eval_iter=2)
+    torch.manual_seed(5)
+    stu, tea = UNet(1, 2, base_channels=base).cuda(), UNet(1, 2, base_channels=base).cuda()
+    trn = SSLTrainer("prostate", stu, tea, **kw)
+    assert trn.optimizer.state_dict()["state"] == {}                       # before the first step: no momentum yet
+    random.seed(2); np.random.seed(2)
+    for s in range(2):
+        trn.step(*[t.cuda() for t in synth("prostate", B, 1, H, 70 + s)], epoch_start=(s == 0))
+    path = str(tmp_path / "checkpoint.pth")
+    util.save_osmancheckpoint(1, tea, stu, trn.optimizer, 0.5, 2, 0.6, 2, path)
+    # the reference side: plain modules' parameters under torch.optim.SGD
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in stu.parameters()]
+    opt = torch.optim.SGD(ref_params, lr=0.03, momentum=0.9, weight_decay=1e-4)
+    ck = torch.load(path, map_location="cuda")
+    opt.load_state_dict(ck["optimizer_state_dict"])
+    assert abs(opt.param_groups[0]["lr"] - trn.lr) < 1e-15 and opt.param_groups[0]["momentum"] == 0.9
+    for p, v in zip(ref_params, trn.optimizer._views()):
+        assert torch.equal(opt.state[p]["momentum_buffer"], v)
+    # a fresh trainer resumed from the file
+    stu2, tea2 = UNet(1, 2, base_channels=base).cuda(), UNet(1, 2, base_channels=base).cuda()
+    trn2 = SSLTrainer("prostate", stu2, tea2, **kw)
+    epoch, _, _, _, bd, bi, sbd, sbi = util.load_osmancheckpoint(path, tea2, stu2, trn2.optimizer)
+    trn2.iter_num = epoch * kw["num_eval_iter"]
+    assert (epoch, bd, bi, sbd, sbi) == (1, 0.5, 2, 0.6, 2)
+    for a, b in ((stu2, stu), (tea2, tea)):                 # (the flat buffers carry uninitialised padding: compare tensors)
+        for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert torch.equal(v, w), k
+    for v, w in zip(trn2.optimizer._views(), trn.optimizer._views()):
+        assert torch.equal(v, w)
+    assert trn2.lr == trn.lr and trn2.iter_num == trn.iter_num and not trn2.first_step
+    # ... and torch's own state_dict loads into the facade
+    trn2.flat_v.zero_()
+    trn2.optimizer.load_state_dict(opt.state_dict())
+    for v, w in zip(trn2.optimizer._views(), trn.optimizer._views()):
+        assert torch.equal(v, w)

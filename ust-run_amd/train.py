@@ -121,10 +121,20 @@ def train(args, snapshot_path):
     from ustrun.evaluate import validate
     test_loaders = synthetic.test_loaders(args.dataset, min(args.domain_num, 2), 4, args.test_bs, C, H, args.seed + 17)
     best = {"avg": 0.0, "iter": 0, "stu_avg": 0.0, "stu_iter": 0}
+    start_epoch = 0
+    if args.load:                                          # train.py:542-548: resume from a checkpoint.pth
+        from ustrun import engine
+        from utils import util
+        (start_epoch, _, _, _, best["avg"], best["iter"], best["stu_avg"], best["stu_iter"]) = util.load_osmancheckpoint(
+            args.load_path, ema_model, model, trainer.optimizer)
+        trainer.iter_num = start_epoch * args.num_eval_iter
+        engine.invalidate_packed(model)
+        engine.invalidate_packed(ema_model)
+        logging.info('Models restored from epoch {}'.format(start_epoch))
     max_epoch = args.max_iterations // args.num_eval_iter
     logging.info("%d iterations per epoch, %d epochs", args.num_eval_iter, max_epoch)
     t0 = time.time()
-    for epoch in range(max_epoch):
+    for epoch in range(start_epoch, max_epoch):
         for i in range(args.num_eval_iter):
             batch = [t.to(dev, non_blocking=True) for t in next(loader)]
             trainer.step(*batch, epoch_start=(i == 0))
@@ -151,9 +161,10 @@ def train(args, snapshot_path):
                 logging.info('save cur best avg model to {}'.format(save_best))
                 torch.save(model.state_dict(), save_best)
             logging.info('val_best_avg_dice: %f at %d iter', best["stu_avg"], best["stu_iter"])
-            torch.save({"epoch": epoch + 1, "ema_state_dict": ema_model.state_dict(), "state_dict": model.state_dict(),
-                        "best_dice": best["avg"], "best_iter": best["iter"], "stu_best_dice": best["stu_avg"],
-                        "stu_best_iter": best["stu_iter"]}, os.path.join(snapshot_path, "checkpoint.pth"))
+            from utils import util
+            util.save_osmancheckpoint(epoch + 1, ema_model, model, trainer.optimizer, best["avg"], best["iter"], best["stu_avg"],
+                                      best["stu_iter"], os.path.join(snapshot_path, "checkpoint.pth"))
+            logging.info('save checkpoint to {}'.format(os.path.join(snapshot_path, "checkpoint.pth")))
 
 
 if __name__ == "__main__":

@@ -125,6 +125,47 @@ def flat_like(flat, params):
     return buf, views
 
 
+class SGDState:
+    """The fused SGD's state behind torch.optim.SGD's `state_dict()` / `load_state_dict()` (the object the reference
+    hands to util.save_osmancheckpoint / load_osmancheckpoint, train.py:512,544,957): per-parameter `momentum_buffer`
+    views of the flat momentum buffer and one param group carrying the current learning rate, so checkpoints
+    interchange with a `torch.optim.SGD(model.parameters(), lr, momentum=0.9, weight_decay=1e-4)`."""
+
+    def __init__(self, trainer):
+        self.t = trainer
+
+    def _views(self):
+        views, o = [], 0
+        for p in self.t.model.parameters():
+            views.append(self.t.flat_v[o:o + p.numel()].view_as(p))
+            o += (p.numel() + 3) // 4 * 4
+        return views
+
+    def state_dict(self):
+        views = self._views()
+        state = {} if self.t.first_step else {i: {"momentum_buffer": v.clone()} for i, v in enumerate(views)}
+        group = {"lr": self.t.lr, "momentum": self.t.momentum, "dampening": 0, "weight_decay": self.t.wd, "nesterov": False,
+                 "maximize": False, "foreach": None, "differentiable": False, "fused": None, "params": list(range(len(views)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        views = self._views()
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(views):
+            raise ValueError("optimizer state_dict: expected one param group over %d parameters" % len(views))
+        g = groups[0]
+        if g.get("nesterov") or g.get("dampening", 0) != 0:
+            raise ValueError("optimizer state_dict: nesterov / dampening are not what the reference trains with")
+        self.t.lr, self.t.momentum, self.t.wd = float(g["lr"]), float(g["momentum"]), float(g["weight_decay"])
+        state = sd["state"]
+        self.t.first_step = len(state) == 0              # torch semantics: the first step sets v = g
+        self.t.flat_v.zero_()
+        for i, v in enumerate(views):
+            buf = state.get(g["params"][i], state.get(str(g["params"][i]), {})).get("momentum_buffer")
+            if buf is not None:
+                v.copy_(buf.to(v.device))
+
+
 class SSLTrainer:
     def __init__(self, dataset, model, ema_model, base_lr=0.03, max_iterations=None, threshold=0.95,
                  ema_decay=0.99, consistency=1.0, consistency_rampup=200.0, cutmix_prob=1.0, LB=0.01,
@@ -162,6 +203,7 @@ class SSLTrainer:
         self.batch_passes = batch_passes                 # run the 3 teacher / 4 student passes as one batched call each
         self.iter_num = 0
         self.first_step = True
+        self.optimizer = SGDState(self)                  # what the reference's checkpoint helpers call `optimizer`
         # memory bank + low-quality sample state (train.py:554-561,576)
         self.simple_ulb = None
         self.cor_pl = self.cor_gt = self.cor_mask = None
