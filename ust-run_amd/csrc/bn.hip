@@ -49,18 +49,25 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int
     const int c = blockIdx.x * 32 + cl;
     double run_m = 0.0, run_v = 0.0;
     if (update && rg == 0 && c < C) { run_m = (double)rm[c]; run_v = (double)rv[c]; }
-    for (int g = 0; g < passes; ++g) {
-        const float* st = stat + (long)g * rows * 2 * C;
+    // The 32 row lanes work on up to four passes at once, eight lanes per pass (the passes' row sums are independent;
+    // only the running-buffer update is sequential): one round of loads instead of one per pass.  A pass always gets
+    // eight lanes, so its sums are formed in the same order whether it comes alone or batched with others.
+    constexpr int LPP = 8, PPR = 32 / LPP;                        // lanes per pass, passes per round
+    const int gl = rg / LPP, lane = rg % LPP;
+    for (int g0 = 0; g0 < passes; g0 += PPR) {
+        const int g = g0 + gl;
         double s1 = 0.0, s2 = 0.0;
-        if (c < C) {
+        if (c < C && g < passes) {
+            const float* st = stat + (long)g * rows * 2 * C;
             if (PRE) {       // stage-1 doubles parked at rows sp*R / sp*R+1, columns of this channel block
-                for (int sp = rg; sp * R < rows; sp += 32) {
+                for (int sp = lane; sp * R < rows; sp += LPP) {
                     const long a0 = (long)(sp * R) * 2 * C + c, a1 = (long)(sp * R + 1) * 2 * C + c;
                     s1 += (double)st[a0] + (double)st[a0 + C];
                     s2 += (double)st[a1] + (double)st[a1 + C];
                 }
             } else {
-                for (int r = rg; r < rows; r += 32) {
+#pragma unroll 8
+                for (int r = lane; r < rows; r += LPP) {        // (unrolled: the loads of eight rows in flight together)
                     s1 += (double)st[((long)r * 2 + 0) * C + c];
                     s2 += (double)st[((long)r * 2 + 1) * C + c];
                 }
@@ -69,19 +76,22 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int
         red[0][rg][cl] = s1; red[1][rg][cl] = s2;
         __syncthreads();
         if (rg == 0 && c < C) {
-            for (int k = 1; k < 32; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
-            const double m = s1 / count;
-            double var = s2 / count - m * m;
-            if (var < 0.0) var = 0.0;
-            const double rs = 1.0 / sqrt(var + (double)eps);
-            const long o = (long)g * astride + c;
-            scale[o] = (float)((double)gamma[c] * rs);
-            shift[o] = (float)((double)beta[c] - m * (double)gamma[c] * rs);
-            mean[o] = (float)m; rstd[o] = (float)rs;
-            if (update) {    // through float after every pass, as the stored buffer of separate calls would be
-                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-                run_m = (double)(float)((1.0 - momentum) * run_m + momentum * m);
-                run_v = (double)(float)((1.0 - momentum) * run_v + momentum * unb);
+            for (int q = 0; q < PPR && g0 + q < passes; ++q) {     // the round's passes, in order
+                double t1 = 0.0, t2 = 0.0;
+                for (int k = 0; k < LPP; ++k) { t1 += red[0][q * LPP + k][cl]; t2 += red[1][q * LPP + k][cl]; }
+                const double m = t1 / count;
+                double var = t2 / count - m * m;
+                if (var < 0.0) var = 0.0;
+                const double rs = 1.0 / sqrt(var + (double)eps);
+                const long o = (long)(g0 + q) * astride + c;
+                scale[o] = (float)((double)gamma[c] * rs);
+                shift[o] = (float)((double)beta[c] - m * (double)gamma[c] * rs);
+                mean[o] = (float)m; rstd[o] = (float)rs;
+                if (update) {    // through float after every pass, as the stored buffer of separate calls would be
+                    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                    run_m = (double)(float)((1.0 - momentum) * run_m + momentum * m);
+                    run_v = (double)(float)((1.0 - momentum) * run_v + momentum * unb);
+                }
             }
         }
         __syncthreads();
