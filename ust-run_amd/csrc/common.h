@@ -102,6 +102,9 @@ int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, v
 int bn_finalize_passes(float* stat, int mtiles, int passes, int C, int64_t count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                        int update_running, float* scale, float* shift, float* mean, float* rstd, long astride, hipStream_t s);
+int head_bwd_passes(const float* dlogits, const void* y, const float* scale, const float* shift, int64_t npix, int HW, int C,
+                    int K, const float* w, void* da, float* dw, float* db, int accumulate, float* partials,
+                    int64_t partials_bytes, int dtype, int passes, long pass_aff, hipStream_t s);
 int bn_eval_affine_layers(int nlayers, const int* C, const float* const* gamma, const float* const* beta,
                           const float* const* rm, const float* const* rv, float* const* aff, float eps, int passes,
                           hipStream_t s);

@@ -117,7 +117,17 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       long npix, int HW, int C, int K, int LPP,
                                                       const float* __restrict__ w, float* __restrict__ da,
-                                                      float* __restrict__ partials) {
+                                                      float* __restrict__ partials, long pass_aff) {
+    // blockIdx.y = forward pass of a batched call: its own slice of dl / y / da (npix pixels each), its own BatchNorm
+    // constants (pass_aff floats apart) and its own partial rows
+    {
+        const long g = blockIdx.y;
+        dl += g * npix * K;
+        y = (const float*)((const char*)y + g * npix * C * ESZ);
+        da = (float*)((char*)da + g * npix * C * ESZ);
+        if (scale) { scale += g * pass_aff; shift += g * pass_aff; }
+        partials += g * (long)gridDim.x * (K * C + K);
+    }
     extern __shared__ float red[];   // [PPB][K*C + K] would be large; reduce per k instead (below)
     const int C4 = C / 4, PPB = 256 / LPP;
     const int cq0 = threadIdx.x % LPP, pl = threadIdx.x / LPP;
@@ -242,26 +252,37 @@ extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* s
     return 0;
 }
 
-extern "C" int ustrun_head_bwd(const float* dlogits, const void* y, const float* scale, const float* shift,
-                               int64_t npix, int HW, int C, int K, const float* w, void* da, float* dw, float* db,
-                               int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s) {
+namespace ustrun {
+// `passes` forward passes (npix pixels each) in one launch: four times the blocks in flight of a per-pass call; the
+// passes' partial rows are summed together in one fixed order
+int head_bwd_passes(const float* dlogits, const void* y, const float* scale, const float* shift, int64_t npix, int HW, int C,
+                    int K, const float* w, void* da, float* dw, float* db, int accumulate, float* partials,
+                    int64_t partials_bytes, int dtype, int passes, long pass_aff, hipStream_t s) {
     USTRUN_CHECK(dtype_ok(dtype), "head_bwd: dtype %d not built", dtype);
     USTRUN_CHECK(dlogits && y && w && da && dw && db && partials, "head_bwd: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_bwd: C=%d K=%d unsupported", C, K);
-    USTRUN_CHECK(npix > 0 && HW > 0 && npix < (1LL << 32), "head_bwd: bad extent");
+    USTRUN_CHECK(npix > 0 && HW > 0 && npix < (1LL << 32) && passes >= 1, "head_bwd: bad extent");
     const int LPP = lanes_per_pixel(C / 4);
     const int blocks = head_blocks(npix, LPP);
     const long row = (long)K * C + K;
-    USTRUN_CHECK(partials_bytes >= (int64_t)(1024 * row * 4), "head_bwd: partials too small (%lld < %lld)",
-                 (long long)partials_bytes, (long long)(1024 * row * 4));
+    USTRUN_CHECK(partials_bytes >= (int64_t)((long)(passes > 1 ? passes * blocks : 1024) * row * 4),
+                 "head_bwd: partials too small (%lld bytes for %d passes)", (long long)partials_bytes, passes);
     if (dtype == USTRUN_BF16)
-        hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(blocks), dim3(256), (1024 + 256) * sizeof(float), (hipStream_t)s, dlogits,
-                           (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials);
+        hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(blocks, passes), dim3(256), (1024 + 256) * sizeof(float), s, dlogits,
+                           (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials, pass_aff);
     else
-        hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(blocks), dim3(256), (1024 + 256) * sizeof(float), (hipStream_t)s, dlogits,
-                           (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials);
+        hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(blocks, passes), dim3(256), (1024 + 256) * sizeof(float), s, dlogits,
+                           (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials, pass_aff);
     USTRUN_LAUNCH_CHECK("head_bwd");
-    USTRUN_TRY(reduce_rows(partials, blocks, row, 0, K * C, dw, accumulate, (hipStream_t)s));
-    USTRUN_TRY(reduce_rows(partials, blocks, row, (long)K * C, K, db, accumulate, (hipStream_t)s));
+    USTRUN_TRY(reduce_rows(partials, blocks * passes, row, 0, K * C, dw, accumulate, s));
+    USTRUN_TRY(reduce_rows(partials, blocks * passes, row, (long)K * C, K, db, accumulate, s));
     return 0;
+}
+}  // namespace ustrun
+
+extern "C" int ustrun_head_bwd(const float* dlogits, const void* y, const float* scale, const float* shift,
+                               int64_t npix, int HW, int C, int K, const float* w, void* da, float* dw, float* db,
+                               int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s) {
+    return head_bwd_passes(dlogits, y, scale, shift, npix, HW, C, K, w, da, dw, db, accumulate, partials, partials_bytes, dtype, 1,
+                           0, (hipStream_t)s);
 }

@@ -290,15 +290,12 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
     auto affp = [&](int k) { return (const float*)(ws + p.aff_off[k]); };
     const int dt = d->dtype;
 
-    if (which != 2) {   // head, pass by pass (the BatchNorm constants on load are per pass)
+    if (which != 2) {   // head: all passes in one launch (blockIdx.y = pass: its BatchNorm constants on load)
         const int C = p.cout[17];
         const long gpix = (long)p.gN * p.H * p.W;
-        for (int g = 0; g < p.G; ++g) {
-            const float* ag = affp(17) + 4L * C * g;
-            USTRUN_TRY(ustrun_head_bwd(dlogits + g * gpix * p.K, ws + p.y_off[17] + g * gpix * C * p.esz, ag, ag + C, gpix,
-                                       p.H * p.W, C, p.K, d->head_w, sc + p.da_off[17] + g * gpix * C * p.esz, grads[62],
-                                       grads[63], g == 0 ? accumulate : 1, part, p.part_bytes, dt, s));
-        }
+        USTRUN_TRY(head_bwd_passes(dlogits, ws + p.y_off[17], affp(17), affp(17) + C, gpix, p.H * p.W, C, p.K, d->head_w,
+                                   sc + p.da_off[17], grads[62], grads[63], accumulate, part, p.part_bytes, dt, p.G, 4L * C,
+                                   (hipStream_t)s));
     }
     const int i_hi = which == 2 ? 9 : 17, i_lo = which == 1 ? 10 : 0;
     for (int i = i_hi; i >= i_lo; --i) {
