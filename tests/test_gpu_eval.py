@@ -37,6 +37,8 @@ def test_validate_matches_oracle(dataset, c, k):
     model.load_state_dict({kk: v.detach().clone() for kk, v in sd.items()})
     model = model.cuda()
     got, got_dom = validate(dataset, model, loaders, epoch=3, log=None)
+    one, one_dom = validate(dataset, model, loaders, epoch=3, log=None, coalesce=1)     # a forward per loader batch
+    assert one == got and one_dom == got_dom                # coalescing batches does not change a bit
     assert model.training                                   # left in train mode, as the reference does
     # predictions are thresholded logits: a pixel within rounding of the boundary may flip between summation orders
     np.testing.assert_allclose(got, want, atol=2e-3)

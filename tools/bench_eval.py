@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--bs", type=int, nargs="+", default=[1, 16, 64])
     ap.add_argument("--batches", type=int, default=20)
     ap.add_argument("--dataset", default="fundus")
+    ap.add_argument("--coalesce", type=int, default=64)
     a = ap.parse_args()
     from networks.unet_model import UNet
     from ustrun import synthetic
@@ -28,10 +29,10 @@ def main():
     model = UNet(n_channels=C, n_classes=K, dtype=a.dtype).cuda()
     for bs in a.bs:
         loaders = [[(x.cuda(), y.cuda()) for x, y in dom] for dom in synthetic.test_loaders(a.dataset, 1, a.batches, bs, C, H, 3)]
-        validate(a.dataset, model, loaders, log=None)
+        validate(a.dataset, model, loaders, log=None, coalesce=a.coalesce)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        validate(a.dataset, model, loaders, log=None)
+        validate(a.dataset, model, loaders, log=None, coalesce=a.coalesce)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"{a.dataset} {a.dtype} test_bs={bs:3d}: {bs * a.batches / dt:9.1f} images/s  ({dt / a.batches * 1e3:.2f} ms per batch)", flush=True)
