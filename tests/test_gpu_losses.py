@@ -120,8 +120,11 @@ def test_rect_masks_equal_oracle_cutmix_and_cover_maps():
     random.seed(5); np.random.seed(5)
     got = F().rect_masks([T.all_cover_rect(np.zeros((48, 48), dtype=np.float32))], 48, 48, "cuda")[0]
     assert np.array_equal(got.cpu().numpy(), ref)
+    many = np.array([[i % 5, 5 + i % 3, i % 7, 4 + i % 4] for i in range(130)])        # more than one launch's 64
+    got = F().rect_masks(many, 8, 8, "cuda").cpu().numpy()
+    assert np.array_equal(got, np.stack([T.rect_map(r, 8) for r in many]))
     with pytest.raises(RuntimeError, match="rect_masks"):
-        F().rect_masks(np.zeros((65, 4)), 8, 8, "cuda")
+        F().rect_masks(np.zeros((0, 4)), 8, 8, "cuda")
 
 
 def test_upload_small_round_trip():
@@ -129,8 +132,10 @@ def test_upload_small_round_trip():
                     (np.zeros(0, dtype=np.int64), torch.long), (np.arange(256), torch.long)):
         got = F().upload_small(arr, "cuda", dt)
         assert got.dtype == dt and np.array_equal(got.cpu().numpy(), arr)
+    big = np.arange(1000)                                   # 8000 bytes: four launches
+    assert np.array_equal(F().upload_small(big, "cuda", torch.long).cpu().numpy(), big)
     with pytest.raises(RuntimeError, match="upload_small"):
-        F().upload_small(np.arange(257), "cuda", torch.long)
+        F().upload_small(np.zeros(20000), "cuda", torch.float64)
 
 
 def test_dice_counts_match_numpy_dice():

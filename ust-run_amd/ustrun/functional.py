@@ -145,12 +145,18 @@ def rect_masks(rects, H, W, device):
     import numpy as np
     lib = L.lib()
     r = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1, 4)
+    if len(r) == 0:
+        raise RuntimeError("rect_masks: no rectangles")
     out = torch.empty((len(r), H, W), dtype=torch.float32, device=device)
-    L.check(lib.ustrun_rect_masks(r.ctypes.data, len(r), H, W, out.data_ptr(), stream_ptr()), "ustrun_rect_masks")
+    for o in range(0, len(r), MAX_RECTS):                 # the launch's argument block holds 64 rectangles
+        part = np.ascontiguousarray(r[o:o + MAX_RECTS])
+        L.check(lib.ustrun_rect_masks(part.ctypes.data, len(part), H, W, out[o:o + len(part)].data_ptr(), stream_ptr()),
+                "ustrun_rect_masks")
     return out
 
 
 UPLOAD_MAX = 2048
+MAX_RECTS = 64
 
 
 def upload_small(arr, device, dtype):
@@ -162,9 +168,11 @@ def upload_small(arr, device, dtype):
     nb = t.numel() * t.element_size()
     if nb == 0:
         return out
-    if nb % 4 or nb > UPLOAD_MAX:
-        raise RuntimeError(f"upload_small: {nb} bytes (needs a multiple of 4, at most {UPLOAD_MAX})")
-    L.check(lib.ustrun_upload_small(out.data_ptr(), t.data_ptr(), nb, stream_ptr()), "ustrun_upload_small")
+    if nb % 4 or nb > 64 * UPLOAD_MAX:
+        raise RuntimeError(f"upload_small: {nb} bytes (needs a multiple of 4, at most {64 * UPLOAD_MAX}: it is meant for a few values)")
+    for o in range(0, nb, UPLOAD_MAX):                    # 2 KB per launch's argument block
+        n = min(UPLOAD_MAX, nb - o)
+        L.check(lib.ustrun_upload_small(out.data_ptr() + o, t.data_ptr() + o, n, stream_ptr()), "ustrun_upload_small")
     return out
 
 
