@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__
     float sc[V], sh[V];
     int cur_grp = -2;
     for (long p = (long)blockIdx.x * PPB + pl; p < npix; p += (long)gridDim.x * PPB) {
-        const int px = (int)(p % Wp); const long t = p / Wp;
-        const int py = (int)(t % Hp); const int n = (int)(t / Hp);
+        const unsigned up = (unsigned)p, t = up / (unsigned)Wp;      // 32-bit divides (pooled pixels < 2^32: host check)
+        const int px = (int)(up - t * (unsigned)Wp), n = (int)(t / (unsigned)Hp), py = (int)(t - (unsigned)n * (unsigned)Hp);
         const int grp = gN > 0 ? n / gN : 0;
         if (grp != cur_grp) {
             cur_grp = grp;
@@ -520,6 +520,7 @@ extern "C" int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dt
     USTRUN_CHECK((src->scale == nullptr) == (src->shift == nullptr), "pool_act: scale/shift must come together");
     USTRUN_CHECK(C / V <= 256, "pool_act: C=%d too wide", C);
     const long npix = (long)N * (H / 2) * (W / 2);
+    USTRUN_CHECK(npix < (1L << 32), "pool_act: %ld pooled pixels", npix);
     const int ppb = 256 / (C / V);
     long nb = (npix + ppb * 4 - 1) / (ppb * 4);             // about four pixels per thread
     if (nb > 16384) nb = 16384;
