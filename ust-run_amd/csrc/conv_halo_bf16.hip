@@ -1,14 +1,14 @@
-// conv_halo_bf16.hip -- 3x3 convolution (forward and input-gradient) on the bf16 matrix cores with
-// LDS-staged input HALO tiles: for every 64-channel (32 when pooling) slice of K the block loads its
-// (TH+2)x18-pixel input patch ONCE -- BatchNorm affine + ReLU (+2x2 max-pool, concat, zero padding)
-// applied in f32 on the way in, rounded to bf16, K-contiguous rows with the 16-byte chunks
-// XOR-swizzled by pixel -- and all nine taps read their shifted A fragments from that one patch.
-// Weights stream tap by tap as pure copies: bf16 [tap][K/8][N][8] tiles fetched by LDS-DMA
-// (global_load_lds_dwordx4, no VGPRs) into a double buffer, one tap ahead of the MFMAs.
+// conv_halo_bf16.hip -- 3x3 convolution (forward and input-gradient; unet_parts.py:16,19 and their autograd) on the
+// bf16 matrix cores with LDS-staged input HALO tiles: for every 32-channel chunk of K the block loads its
+// (TH+2) x (TW+2)-pixel input patch ONCE -- BatchNorm affine + ReLU (+2x2 max-pool, concat, zero padding) applied in f32
+// on the way in, rounded to bf16, one 80-byte row per pixel (64 B of channels + 16 B pad: conflict-free fragment reads
+// with compile-time offsets) -- and all nine taps read their shifted A fragments from that one patch.
+// Weights stream tap by tap as pure copies: bf16 [tap][K/8][N][8] tiles fetched by LDS-DMA (global_load_lds_dwordx4,
+// no VGPRs) into a double buffer, one stage ahead of the MFMAs.
 //
-// Tile: TH x 16 output pixels x BN channels per 256-thread block; every wave owns 4 rows x 16 pixels
-// x 64 channels = 2x2 v_mfma_f32_32x32x16_bf16 accumulators (MI = 2), or 8 rows x 16 pixels x 64 channels
-// = 4x2 accumulators (MI = 4: 0.75 LDS fragment reads per MFMA instead of 1, half the weight traffic per flop).
+// Tile: TH x TW output pixels x BN channels per 256-thread block (8x32 or 16x16 pixels x 128 channels with 4x2
+// v_mfma_f32_32x32x16_bf16 accumulators per wave, MI = 4: 0.75 LDS fragment reads per MFMA; 8x16 x 128 or 8x32 / 16x16 x
+// 64 with 2x2 accumulators, MI = 2, for small grids and 64-channel outputs).  Two blocks per CU.
 #include "common.h"
 #include "loader.h"
 #include <stdlib.h>
