@@ -1,11 +1,13 @@
 // unet.hip -- whole-network forward/backward sequencing (host code): the counterpart of
 // UNet.forward (reference networks/unet_model.py:25-39) and of autograd's backward through it.
 //
-// Nothing is materialised between operators except the raw (pre-BatchNorm) conv outputs y_i and
-// the ConvTranspose outputs u_j, which are also exactly what backward needs:
+// Materialised between operators: the raw (pre-BatchNorm) conv outputs y_i and the ConvTranspose outputs u_j -- exactly
+// what backward needs -- and the four pooled activations that feed the Down blocks (a quarter of their producers):
 //   activated tensor  = loader(y_i, scale_i, shift_i, relu)         (BatchNorm + ReLU on load)
-//   Down input        = loader(..., pool)                           (MaxPool2d on load)
+//   Down input        = pool_act(y_i, scale_i, shift_i)             (MaxPool2d of the activation, one streaming pass:
+//                                                                     pooling on load cost the conv kernels more)
 //   Up input          = loader(skip y_s) ++ loader(u_j, offset)     (pad + cat on load)
+// A call may carry several forward passes of equal shape (desc.groups): BatchNorm statistics and constants per pass.
 #include "common.h"
 #include <string.h>
 

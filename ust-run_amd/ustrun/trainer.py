@@ -6,7 +6,8 @@ target mixing, CutMix compositing, losses, SGD+EMA); this module only sequences 
 the reference's random numbers in the reference's order, and keeps the reference's cross-iteration
 state (memory bank, low-quality sample, choice threshold).  Quirks reproduced: Q2-Q7, Q10, Q11, Q13,
 Q16, Q17.  Deliberate deviations: batch sizes are honoured (Q1); precision is the
-model's compute dtype rather than fp16 autocast (Q12).
+model's compute dtype rather than fp16 autocast (Q12); the memory bank's truncation length is clamped at 0
+(it goes negative in the reference once unlabel_bs exceeds queue_len and the bank then grows without bound).
 """
 from __future__ import annotations
 
