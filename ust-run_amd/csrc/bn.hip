@@ -273,28 +273,36 @@ __device__ __forceinline__ void window_dz(const float* da, const float* __restri
         gok = wy < PH && wx < PW;
         gpool = ld4t<ESZ>(dp, (((long)n * PH + (gok ? wy : 0)) * PW + (gok ? wx : 0)) * C + c);
     }
+    // everything below is selects, not branches (the compiler turned the arg-max routing into ~40 exec-mask regions)
 #pragma unroll
     for (int q = 0; q < NPX; ++q) {
-        if (!ok[q]) { yv[q] = zero; dz[q] = zero; }
-        av[q] = ok[q] ? yv[q] * sc + sh : zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            yv[q][j] = ok[q] ? yv[q][j] : 0.f;
+            dz[q][j] = ok[q] ? dz[q][j] : 0.f;
+            av[q][j] = ok[q] ? yv[q][j] * sc[j] + sh[j] : 0.f;
+        }
     }
     if (POOL) {
-        if (gok) {
-            const f32x4 g = gpool;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int best = 0; float bv = fmaxf(av[0][j], 0.f);
+        for (int j = 0; j < 4; ++j) {
+            const float g = gok ? gpool[j] : 0.f;
+            // first arg-max of relu(a) over the window, in the order (0,0) (0,1) (1,0) (1,1): strict > keeps the first
+            const float a0 = fmaxf(av[0][j], 0.f), a1 = fmaxf(av[1][j], 0.f), a2 = fmaxf(av[2][j], 0.f), a3 = fmaxf(av[3][j], 0.f);
+            const bool m1 = a1 > a0;
+            const float b1 = m1 ? a1 : a0;
+            const bool m2 = a2 > b1;
+            const float b2 = m2 ? a2 : b1;
+            const bool m3 = a3 > b2;
+            const int best = m3 ? 3 : (m2 ? 2 : (m1 ? 1 : 0));
 #pragma unroll
-                for (int q = 1; q < NPX; ++q) { const float t = fmaxf(av[q][j], 0.f); if (t > bv) { bv = t; best = q; } }
-#pragma unroll
-                for (int q = 0; q < NPX; ++q) if (q == best) dz[q][j] += g[j];
-            }
+            for (int q = 0; q < NPX; ++q) dz[q][j] += (q == best) ? g : 0.f;
         }
     }
 #pragma unroll
     for (int q = 0; q < NPX; ++q)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (!(av[q][j] > 0.f)) dz[q][j] = 0.f;
+        for (int j = 0; j < 4; ++j) dz[q][j] = (av[q][j] > 0.f) ? dz[q][j] : 0.f;
 }
 
 // grid-stride over windows; thread = (channel quad, window lane).  partials[block][2][C]
