@@ -112,12 +112,17 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const __bf16* __rest
 
 // da[p][c] = sum_k dl[k][p] w[k][c];  block partials of dW[k][c] = sum_p dl[k][p] a[p][c], db[k] = sum_p dl[k][p]
 // partials[block][K*C + K]
-template <int ESZ>
+// KT > 0: the class count is a compile-time constant (no per-class branches: every dl load of a pixel is issued before
+// the first use -- with the runtime K the loads sat one behind the other, each inside its own `k < K` branch);
+// KT == 0: any K <= KMAX.
+template <int ESZ, int KT>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ y,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      long npix, int HW, int C, int K, int LPP,
+                                                      long npix, int HW, int C, int Krt, int LPP,
                                                       const float* __restrict__ w, float* __restrict__ da,
                                                       float* __restrict__ partials, long pass_aff) {
+    constexpr int KN = KT > 0 ? KT : KMAX;           // accumulators kept
+    const int K = KT > 0 ? KT : Krt;
     // blockIdx.y = forward pass of a batched call: its own slice of dl / y / da (npix pixels each), its own BatchNorm
     // constants (pass_aff floats apart) and its own partial rows
     {
@@ -137,24 +142,32 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         const int cq = cb + cq0;
         const bool active = cq < C4;
         const int c = active ? cq * 4 : 0;
-        f32x4 dwp[KMAX]; float dbp[KMAX];
+        f32x4 dwp[KN]; float dbp[KN];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) { dwp[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; dbp[k] = 0.f; }
-        f32x4 wk[KMAX];
+        for (int k = 0; k < KN; ++k) { dwp[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; dbp[k] = 0.f; }
+        f32x4 wk[KN];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) wk[k] = (k < K) ? *(const f32x4*)(w + k * C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < KN; ++k) wk[k] = (k < K) ? *(const f32x4*)(w + k * C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 scv = {1.f, 1.f, 1.f, 1.f}, shv = {0.f, 0.f, 0.f, 0.f};
+        if (scale && active) { scv = *(const f32x4*)(scale + c); shv = *(const f32x4*)(shift + c); }
         if (active)
             for (long p = (long)blockIdx.x * PPB + pl; p < npix; p += (long)gridDim.x * PPB) {
                 const long n = (unsigned)p / (unsigned)HW, hw = p - n * HW;   // 32-bit divide: p < 2^32 (checked on the host)
-                const f32x4 a = act4(ld4t<ESZ>(y, p * C + c), scale, shift, c);
+                f32x4 a = ld4t<ESZ>(y, p * C + c);
+                float d[KN];
+#pragma unroll
+                for (int k = 0; k < KN; ++k) d[k] = (KT > 0 || k < K) ? dl[(n * K + k) * HW + hw] : 0.f;
+                if (scale) {
+                    a = a * scv + shv;
+                    a[0] = fmaxf(a[0], 0.f); a[1] = fmaxf(a[1], 0.f); a[2] = fmaxf(a[2], 0.f); a[3] = fmaxf(a[3], 0.f);
+                }
                 f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k)
-                    if (k < K) {
-                        const float d = dl[(n * K + k) * HW + hw];
-                        g += d * wk[k];
-                        dwp[k] += d * a;
-                        dbp[k] += d;
+                for (int k = 0; k < KN; ++k)
+                    if (KT > 0 || k < K) {
+                        g += d[k] * wk[k];
+                        dwp[k] += d[k] * a;
+                        dbp[k] += d[k];
                     }
                 st4t<ESZ>(da, p * C + c, g);
             }
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         for (int k = 0; k < K; ++k) {
             f32x4 v = dwp[0]; float b = dbp[0];
 #pragma unroll
-            for (int kk = 1; kk < KMAX; ++kk) if (kk == k) { v = dwp[kk]; b = dbp[kk]; }
+            for (int kk = 1; kk < KN; ++kk) if (kk == k) { v = dwp[kk]; b = dbp[kk]; }
             ((f32x4*)red)[threadIdx.x] = v;
             red[1024 + threadIdx.x] = b;
             __syncthreads();
@@ -267,12 +280,12 @@ int head_bwd_passes(const float* dlogits, const void* y, const float* scale, con
     const long row = (long)K * C + K;
     USTRUN_CHECK(partials_bytes >= (int64_t)((long)(passes > 1 ? passes * blocks : 1024) * row * 4),
                  "head_bwd: partials too small (%lld bytes for %d passes)", (long long)partials_bytes, passes);
-    if (dtype == USTRUN_BF16)
-        hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(blocks, passes), dim3(256), (1024 + 256) * sizeof(float), s, dlogits,
-                           (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials, pass_aff);
-    else
-        hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(blocks, passes), dim3(256), (1024 + 256) * sizeof(float), s, dlogits,
-                           (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials, pass_aff);
+#define USTRUN_HB(E, KT)                                                                                                     \
+    hipLaunchKernelGGL((head_bwd_kernel<E, KT>), dim3(blocks, passes), dim3(256), (1024 + 256) * sizeof(float), s, dlogits,    \
+                       (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials, pass_aff)
+    if (dtype == USTRUN_BF16) { if (K == 2) USTRUN_HB(2, 2); else if (K == 4) USTRUN_HB(2, 4); else USTRUN_HB(2, 0); }
+    else { if (K == 2) USTRUN_HB(4, 2); else if (K == 4) USTRUN_HB(4, 4); else USTRUN_HB(4, 0); }
+#undef USTRUN_HB
     USTRUN_LAUNCH_CHECK("head_bwd");
     USTRUN_TRY(reduce_rows(partials, blocks * passes, row, 0, K * C, dw, accumulate, s));
     USTRUN_TRY(reduce_rows(partials, blocks * passes, row, (long)K * C, K, db, accumulate, s));
