@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const __bf16* __rest
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long p = p0 + u * PPB + pl;
-            if (p < npix) v[u] = *(const bf16x8*)(y + p * C + 8 * g);
+            v[u] = *(const bf16x8*)(y + (p < npix ? p : npix - 1) * C + 8 * g);   // unconditional: four loads in flight
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -87,14 +87,12 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const __bf16* __rest
             float acc[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) acc[k] = 0.f;
-            if (p < npix) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float a = (float)v[u][j] * sc[j] + sh[j];
-                    if (relu) a = fmaxf(a, 0.f);
+            for (int j = 0; j < 8; ++j) {                   // (out-of-range lanes compute on the clamped pixel, never store)
+                float a = (float)v[u][j] * sc[j] + sh[j];
+                a = relu ? fmaxf(a, 0.f) : a;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) acc[k] += a * wk[k][j];
-                }
+                for (int k = 0; k < K; ++k) acc[k] += a * wk[k][j];
             }
 #pragma unroll
             for (int k = 0; k < K; ++k)
