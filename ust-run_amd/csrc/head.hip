@@ -190,19 +190,26 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
 }
 
-// block = 32 outputs x 8 slab lanes, fixed-order f64 combine
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int nslab, long stride, long offset,
-                                                         int count, float* __restrict__ out, int accumulate) {
-    __shared__ double red[8][32];
+// block = 32 outputs x 32 slab lanes (1024 threads), four rows in flight per lane, fixed-order f64 combine
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ part, int nslab, long stride, long offset,
+                                                          int count, float* __restrict__ out, int accumulate) {
+    __shared__ double red[32][32];
     const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + el;
     double v = 0.0;
-    if (e < count)
-        for (int k = sl; k < nslab; k += 8) v += (double)part[(long)k * stride + offset + e];
+    if (e < count) {
+        int k = sl;
+        for (; k + 96 < nslab; k += 128) {            // rows k, k+32, k+64, k+96: loads issued together, summed in order
+            const float a0 = part[(long)k * stride + offset + e], a1 = part[(long)(k + 32) * stride + offset + e];
+            const float a2 = part[(long)(k + 64) * stride + offset + e], a3 = part[(long)(k + 96) * stride + offset + e];
+            v += (double)a0; v += (double)a1; v += (double)a2; v += (double)a3;
+        }
+        for (; k < nslab; k += 32) v += (double)part[(long)k * stride + offset + e];
+    }
     red[sl][el] = v;
     __syncthreads();
     if (sl == 0 && e < count) {
-        for (int k = 1; k < 8; ++k) v += red[k][el];
+        for (int q = 1; q < 32; ++q) v += red[q][el];
         out[e] = accumulate ? out[e] + (float)v : (float)v;
     }
 }
@@ -213,7 +220,7 @@ int lanes_per_pixel(int C4) { int g = 1; while (g < C4 && g < 64) g <<= 1; retur
 
 int reduce_rows(const float* part, int nslab, long stride, long offset, int count, float* out, int accumulate,
                 hipStream_t st) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(count, 32)), dim3(256), 0, st, part, nslab, stride, offset, count,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(count, 32)), dim3(1024), 0, st, part, nslab, stride, offset, count,
                        out, accumulate);
     USTRUN_LAUNCH_CHECK("reduce_rows");
     return 0;
