@@ -362,26 +362,37 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int r
     const int c = blockIdx.x * 32 + cl;
     float dg_run = 0.f, db_run = 0.f;
     if (rg == 0 && c < C && dgamma && accumulate) { dg_run = dgamma[c]; db_run = dbeta[c]; }
-    for (int g = 0; g < passes; ++g) {
-        const float* pt = partials + (long)g * po.part;
+    // up to four passes per round, eight row lanes each (as bn_finalize_kernel: the passes' sums are independent, only the
+    // dgamma/dbeta accumulation is sequential; a pass's sums are formed in the same order alone or batched)
+    constexpr int LPP = 8, PPR = 32 / LPP;
+    const int gl = rg / LPP, lane = rg % LPP;
+    for (int g0 = 0; g0 < passes; g0 += PPR) {
+        const int g = g0 + gl;
         double s1 = 0.0, s2 = 0.0;
-        if (c < C)
-            for (int r = rg; r < rows; r += 32) {
+        if (c < C && g < passes) {
+            const float* pt = partials + (long)g * po.part;
+#pragma unroll 8
+            for (int r = lane; r < rows; r += LPP) {
                 s1 += (double)pt[((long)r * 2 + 0) * C + c];
                 s2 += (double)pt[((long)r * 2 + 1) * C + c];
             }
+        }
         red[0][rg][cl] = s1; red[1][rg][cl] = s2;
         __syncthreads();
         if (rg == 0 && c < C) {
-            for (int k = 1; k < 32; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
-            const double mu = mean[(long)g * po.aff + c], rs = rstd[(long)g * po.aff + c], gm = gamma[c];
-            const double dbe = s1, dga = rs * (s2 - mu * s1);
-            const double c0 = gm * rs, m1 = dbe / count, m2 = dga / count;
-            const double c1 = -c0 * m2 * rs, c2 = -c0 * m1 - c1 * mu;
-            float* cf = coef + (long)g * po.coef;
-            cf[c] = (float)c0; cf[C + c] = (float)c1; cf[2 * C + c] = (float)c2;
-            if (g == 0 && !accumulate) { dg_run = (float)dga; db_run = (float)dbe; }
-            else { dg_run = dg_run + (float)dga; db_run = db_run + (float)dbe; }
+            for (int q = 0; q < PPR && g0 + q < passes; ++q) {
+                double t1 = 0.0, t2 = 0.0;
+                for (int k = 0; k < LPP; ++k) { t1 += red[0][q * LPP + k][cl]; t2 += red[1][q * LPP + k][cl]; }
+                const int gq = g0 + q;
+                const double mu = mean[(long)gq * po.aff + c], rs = rstd[(long)gq * po.aff + c], gm = gamma[c];
+                const double dbe = t1, dga = rs * (t2 - mu * t1);
+                const double c0 = gm * rs, m1 = dbe / count, m2 = dga / count;
+                const double c1 = -c0 * m2 * rs, c2 = -c0 * m1 - c1 * mu;
+                float* cf = coef + (long)gq * po.coef;
+                cf[c] = (float)c0; cf[C + c] = (float)c1; cf[2 * C + c] = (float)c2;
+                if (gq == 0 && !accumulate) { dg_run = (float)dga; db_run = (float)dbe; }
+                else { dg_run = dg_run + (float)dga; db_run = db_run + (float)dbe; }
+            }
         }
         __syncthreads();
     }

@@ -81,16 +81,23 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
 __global__ void seg_loss_finalize_kernel(const float* __restrict__ partials, int rows, int N, int K, int HW, int mode,
                                          float* __restrict__ out) {
     __shared__ double tot[NS];
-    __shared__ double red[8][32];
-    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 columns (NS used) x 8 row lanes
+    __shared__ double red[32][32];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 columns (NS used) x 32 row lanes (1024 threads)
     double v = 0.0;
-    if (col < NS)
-        for (int r = rg; r < rows; r += 8) v += (double)partials[(long)r * NS + col];
+    if (col < NS) {
+        int r = rg;
+        for (; r + 96 < rows; r += 128) {                         // four rows in flight, summed in order
+            const float a0 = partials[(long)r * NS + col], a1 = partials[(long)(r + 32) * NS + col];
+            const float a2 = partials[(long)(r + 64) * NS + col], a3 = partials[(long)(r + 96) * NS + col];
+            v += (double)a0; v += (double)a1; v += (double)a2; v += (double)a3;
+        }
+        for (; r < rows; r += 32) v += (double)partials[(long)r * NS + col];
+    }
     red[rg][col] = v;
     __syncthreads();
     if (threadIdx.x < NS) {
         double t = 0.0;
-        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
         tot[threadIdx.x] = t;
     }
     __syncthreads();
@@ -337,7 +344,7 @@ extern "C" int ustrun_seg_loss_fwd(const float* logits, const void* target, cons
     hipLaunchKernelGGL(seg_loss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, logits, target, mask, N, K, HW,
                        mode, partials);
     USTRUN_LAUNCH_CHECK("seg_loss_fwd");
-    hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, partials, blocks, N, K, HW, mode, out);
+    hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, partials, blocks, N, K, HW, mode, out);
     USTRUN_LAUNCH_CHECK("seg_loss_finalize");
     return 0;
 }
