@@ -329,20 +329,27 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
 }
 
 // dw[co][c][t] (+)= sum_k partials[k][c*9+t][co]
-__global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const float* __restrict__ partials, int nslab, int C,
+__global__ __launch_bounds__(1024) void conv_first_wgrad_reduce_kernel(const float* __restrict__ partials, int nslab, int C,
                                                                      float* __restrict__ dw, int accumulate) {
-    __shared__ double red[8][32];
-    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;         // 32 outputs x 8 slab lanes
+    __shared__ double red[32][32];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;         // 32 outputs x 32 slab lanes (1024 threads)
     const int e = blockIdx.x * 32 + el;
     double v = 0.0;
     if (e < 64 * C * 9) {
         const int co = e / (C * 9), i = e % (C * 9);
-        for (int k = sl; k < nslab; k += 8) v += (double)partials[((long)k * 32 + i) * 64 + co];
+        const float* p0 = partials + (long)i * 64 + co;
+        int k = sl;
+        for (; k + 96 < nslab; k += 128) {                            // four slabs in flight, summed in order
+            const float a0 = p0[(long)k * 2048], a1 = p0[(long)(k + 32) * 2048], a2 = p0[(long)(k + 64) * 2048],
+                        a3 = p0[(long)(k + 96) * 2048];
+            v += (double)a0; v += (double)a1; v += (double)a2; v += (double)a3;
+        }
+        for (; k < nslab; k += 32) v += (double)p0[(long)k * 2048];
     }
     red[sl][el] = v;
     __syncthreads();
     if (sl == 0 && e < 64 * C * 9) {
-        for (int k = 1; k < 8; ++k) v += red[k][el];
+        for (int k = 1; k < 32; ++k) v += red[k][el];
         dw[e] = accumulate ? dw[e] + (float)v : (float)v;
     }
 }
@@ -394,7 +401,7 @@ int conv_first_wgrad(const ustrun_src_t& s, const void* dy, int dy_esz, int N, f
         hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(blocks), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
                            (long)s.sH, (long)s.sW, s.C, s.H, s.W, (const float*)dy, partials, tx, ty, ttotal, per);
     USTRUN_LAUNCH_CHECK("conv_first_wgrad");
-    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(cdiv(64 * s.C * 9, 32)), dim3(256), 0, st, partials, blocks, s.C, dw,
+    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(cdiv(64 * s.C * 9, 32)), dim3(1024), 0, st, partials, blocks, s.C, dw,
                        accumulate);
     USTRUN_LAUNCH_CHECK("conv_first_wgrad_reduce");
     return 0;
