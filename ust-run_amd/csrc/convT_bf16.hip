@@ -112,29 +112,27 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
             }
         }
 #pragma unroll
-        for (int i = 0; i < AIT; ++i)
-            if ((aok >> i) & 1u) av[i] = *(const bf16x8*)(Ap + aoff[i] + koff);
-    };
+        for (int i = 0; i < AIT; ++i) av[i] = *(const bf16x8*)(Ap + aoff[i] + koff);   // unconditional (rows past M read pixel 0
+    };                                                                                 // and are zeroed in write_A)
     auto write_A = [&](char* Adst) {
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             const int px = (tid + 256 * i) / CPR;
-            bf16x8 h;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) h[q] = (__bf16)0.f;
-            if ((aok >> i) & 1u) {
-                if (a_aff) {
-                    const bf16x8 r = av[i];
-                    f32x4 lo = (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * asc0 + ash0;
-                    f32x4 hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
-                    if (a_relu) { lo = relu4(lo); hi = relu4(hi); }
-                    h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-                    h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
-                } else {
-                    h = av[i];
-                }
+            bf16x8 h = av[i];
+            if (a_aff) {                                  // wave-uniform
+                const bf16x8 r = av[i];
+                f32x4 lo = (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * asc0 + ash0;
+                f32x4 hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
+                if (a_relu) { lo = relu4(lo); hi = relu4(hi); }
+                h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+                h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
             }
-            *(bf16x8*)(Adst + px * ROWB + ((c8 ^ swz(px)) * 16)) = h;
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            u32x4 u = __builtin_bit_cast(u32x4, h);
+            const bool ok = (aok >> i) & 1u;              // a select, not a branch
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[q] = ok ? u[q] : 0u;
+            *(bf16x8*)(Adst + px * ROWB + ((c8 ^ swz(px)) * 16)) = __builtin_bit_cast(bf16x8, u);
         }
     };
     // ---- B tile of chunk c: rows c*CPR .. +CPR of the [K/8][ncols][8] matrix; this thread's column is fixed ----
