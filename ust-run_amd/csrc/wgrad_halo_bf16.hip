@@ -369,19 +369,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
     // BatchNorm affine + ReLU of this thread's two items, in place (items outside the source stay zero)
     auto activate = [&](char* stage, unsigned ok2) {
         if (!xf) return;
+        // all items read first (one LDS round trip), selects instead of per-item branches (items outside the source
+        // hold zeros and must stay zero: relu(shift) is not)
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const float floor_ = S.relu ? 0.f : -__builtin_inff();
 #pragma unroll
-        for (int i = 0; i < A3IT; ++i) {
-            if ((ok2 >> i) & 1u) {
-                char* p = stage + (tid + 256 * i) * 16;
-                const bf16x8 r = *(const bf16x8*)p;
-                f32x4 lo = (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * asc0 + ash0;
-                f32x4 hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
-                if (S.relu) { lo = relu4(lo); hi = relu4(hi); }
-                bf16x8 h;
-                h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-                h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
-                *(bf16x8*)p = h;
+        for (int i0 = 0; i0 < A3IT; i0 += 2) {              // two items per LDS round trip (four would spill)
+        bf16x8 r[A3IT];
+#pragma unroll
+        for (int i = i0; i < i0 + 2 && i < A3IT; ++i) r[i] = *(const bf16x8*)(stage + (tid + 256 * i) * 16);
+#pragma unroll
+        for (int i = i0; i < i0 + 2 && i < A3IT; ++i) {
+            f32x4 lo = (f32x4){(float)r[i][0], (float)r[i][1], (float)r[i][2], (float)r[i][3]} * asc0 + ash0;
+            f32x4 hi = (f32x4){(float)r[i][4], (float)r[i][5], (float)r[i][6], (float)r[i][7]} * asc1 + ash1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lo[q] = __builtin_amdgcn_fmed3f(lo[q], floor_, __builtin_inff());
+                hi[q] = __builtin_amdgcn_fmed3f(hi[q], floor_, __builtin_inff());
             }
+            bf16x8 h;
+            h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+            h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+            u32x4 u = __builtin_bit_cast(u32x4, h);
+            const bool ok = (ok2 >> i) & 1u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[q] = ok ? u[q] : 0u;
+            *(u32x4*)(stage + (tid + 256 * i) * 16) = u;
+        }
         }
     };
     auto tile_img = [&](int t) { return t / (tiles_y * tiles_x); };
