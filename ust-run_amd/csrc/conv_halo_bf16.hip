@@ -427,6 +427,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (full && n0 + wn * 64 + 64 <= a.C0) {
+            // interior tile, one destination (wave-uniform): four plain stores off one base -- the general path below costs
+            // three nested exec-mask regions and a 64-bit address chain per store
+            const int r0 = lane >> 3, ch = lane & 7;
+            __bf16* base = (__bf16*)a.out0 + (((long)img * a.Ho + oyb) * a.Wo + x0) * a.C0 + n0 + wn * 64 + ch * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = r0 + 8 * t;
+                const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
+                const long off = TW == 16 ? ((long)(row >> 4) * a.Wo + (row & 15)) * a.C0 : (long)row * a.C0;
+                *(bf16x8*)(base + off) = v8;
+            }
+        } else
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int idx = lane + 64 * t, row = idx >> 3, ch = idx & 7;
