@@ -269,7 +269,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         }
 #pragma unroll
         for (int i = 0; i < AIT; ++i)
-            if ((tid >> 2) + 64 * i < HP) *(bf16x8*)(As + xw0 + i * 64 * PITCH) = xform8(pv[i], (aokm >> i) & 1u);
+        {   // no branch per item: items past the patch (the rounded-up tail) land in the raw slot, unused until the loop
+            const bool in_patch = (tid >> 2) + 64 * i < HP;
+            *(bf16x8*)(in_patch ? As + xw0 + i * 64 * PITCH : Raw + tid * 16) = xform8(pv[i], (aokm >> i) & 1u);
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < AIT; ++i)
