@@ -64,14 +64,22 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     const long E = p.esz;
     long o = 0;
     long stat_max = 0;
+    // Tensor sizes here are powers of two (64 images x 256^2 x 64 channels x 2 B = 512 MB): two tensors a power of two apart
+    // that one kernel streams in lockstep -- the two halves of a concat, dY in and dA out of an input gradient -- walk the
+    // same HBM channels together (measured: 0.98 ms instead of 0.80 ms for the 128->64 concat conv).  Every tensor is
+    // therefore followed by a gap that is a different odd multiple of 68 KB.
+    int nplaced = 0;
+    auto gap = [&]() { return (long)(2 * (nplaced++ % 8) + 1) * 69632; };
     for (int i = 0; i < 18; ++i) {
-        p.y_off[i] = o; o = align_up(o + p.y_elems(i) * E, 256);
+        p.y_off[i] = o; o = align_up(o + p.y_elems(i) * E, 256) + gap();
         p.aff_off[i] = o; o = align_up(o + 16L * p.cout[i] * p.G, 256);       // [G][scale, shift, mean, rstd]
         const long st = (long)ustrun_conv_mtiles(p.N, p.Hs[p.lvl[i]], p.Ws[p.lvl[i]], p.cout[i]) * 2 * p.cout[i];
         if (st > stat_max) stat_max = st;
     }
-    for (int j = 0; j < 4; ++j) { p.u_off[j] = o; o = align_up(o + p.u_elems(j) * E, 256); }
-    for (int l = 0; l < 4; ++l) { p.pool_off[l] = o; o = align_up(o + (long)p.N * p.Hs[l + 1] * p.Ws[l + 1] * ch[l] * E, 256); }
+    for (int j = 0; j < 4; ++j) { p.u_off[j] = o; o = align_up(o + p.u_elems(j) * E, 256) + gap(); }
+    for (int l = 0; l < 4; ++l) {
+        p.pool_off[l] = o; o = align_up(o + (long)p.N * p.Hs[l + 1] * p.Ws[l + 1] * ch[l] * E, 256) + gap();
+    }
     p.stat_off = o; o = align_up(o + stat_max * 4, 256);
     p.fwd_total = o;
 
@@ -88,10 +96,11 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     }
     p.pack_total = o;
 
-    o = 0;
+    o = 34816;                                   // (the scratch starts off the workspace's phase as well)
+    nplaced = 3;
     long part = ustrun_loss_partials_bytes(1, 1, 1);
     for (int i = 0; i < 18; ++i) {
-        p.da_off[i] = o; o = align_up(o + p.y_elems(i) * E, 256);
+        p.da_off[i] = o; o = align_up(o + p.y_elems(i) * E, 256) + gap();
         const long npix = (long)p.N * p.Hs[p.lvl[i]] * p.Ws[p.lvl[i]];
         long b1 = ustrun_bn_bwd_partials_bytes(npix, p.cout[i]);
         long b2 = ustrun_wgrad_partials_bytes(9, p.cin[i], p.cout[i], npix);
@@ -99,9 +108,9 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
         if (b2 > part) part = b2;
     }
     for (int j = 0; j < 4; ++j) {
-        p.du_off[j] = o; o = align_up(o + p.u_elems(j) * E, 256);
+        p.du_off[j] = o; o = align_up(o + p.u_elems(j) * E, 256) + gap();
         const int l = 3 - j;                                     // pooled grad of the skip at level l
-        p.dp_off[j] = o; o = align_up(o + (long)p.N * p.Hs[l + 1] * p.Ws[l + 1] * ch[l] * E, 256);
+        p.dp_off[j] = o; o = align_up(o + (long)p.N * p.Hs[l + 1] * p.Ws[l + 1] * ch[l] * E, 256) + gap();
         const long npix = (long)p.N * p.Hs[l + 1] * p.Ws[l + 1];
         long b2 = ustrun_wgrad_partials_bytes(4, p.up_cin[j], p.up_cout[j], npix);
         if (b2 > part) part = b2;
