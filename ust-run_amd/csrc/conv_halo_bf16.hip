@@ -299,12 +299,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             if constexpr (j == NSTG - 1) { if (c + 2 < nchunk) dma_consts(c + 2); }
             char* rawW = Raw + (SKEW ? (s & 1) * RAWB : 0);
             const char* rawR = Raw + (SKEW ? ((s & 1) ^ 1) * RAWB : 0);
+            int ni = 0;                                       // patch transfers this wave issues in this stage (wave-uniform)
             if constexpr (j < NSTG - 1) {
                 if (more) {
 #pragma unroll
                     for (int b = 0; b < BATCH; ++b) {
                         constexpr int dummy = 0; (void)dummy;
-                        if (j * BATCH + b < AIT && wave_has(j * BATCH + b)) issue_one(j * BATCH + b, b, Anext, rawW);
+                        if (j * BATCH + b < AIT && wave_has(j * BATCH + b)) { issue_one(j * BATCH + b, b, Anext, rawW); ni += NP; }
                     }
                 }
             }
@@ -363,7 +364,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             // bottom: this top's transfers have landed.  (The scheduling barrier keeps the wait BEHIND the MFMAs: an asm
             // statement only orders against memory operations, and hipcc otherwise hoists it above fifteen of them.)
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (!XF && j < NSTG - 1) {
+                // plain source: the patch items go straight into the next chunk's buffer, which nobody reads before the
+                // chunk's last stage -- and they come from HBM, not L2 like the weights.  They were issued after the
+                // weights, so "all but the newest ni" = the weights of the next stage and every earlier item: an item
+                // gets two stages to land instead of one (the full wait cost the input-gradient kernels ~8 %).
+                if (ni == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (ni == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             if constexpr (!SKEW && nitem > 0) {
                 if (more) {
 #pragma unroll
