@@ -109,9 +109,9 @@ def main():
     lib = _lib.lib()
     sync()
     prof = not a.no_profile
-    # the HIP-event pairs around every conv launch cost ~5 % of a step, so they sample the LAST min(3, K) steps of the
+    # the HIP-event pairs around every conv launch cost ~5 % of a step, so they sample the LAST min(2, K) steps of the
     # timed region rather than all of it (the whole region is still what `value` is computed from)
-    nprof = min(3, a.steps) if prof else 0
+    nprof = min(2, a.steps) if prof else 0
     t0 = time.perf_counter()
     for s in range(a.steps):
         if s == a.steps - nprof:
