@@ -246,8 +246,9 @@ int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, float* logi
 int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x, const float* dlogits,
                          void* workspace, void* scratch, float* const* grads, int accumulate,
                          ustrun_stream_t s);
-/* the same in two halves sharing one scratch: part 1 = head + decoder (afterwards the gradients of up1..up4 and outc,
- * the contiguous tail of the parameter order, are final: their all-reduce can start), part 2 = encoder; part 0 = all */
+/* the same in pieces sharing one scratch: part 1 = head + decoder (afterwards the gradients of up1..up4 and outc,
+ * the contiguous tail of the parameter order, are final: their all-reduce can start), part 2 = encoder -- or part 3 =
+ * down4 (parameters 24..29 final afterwards) followed by part 4 = down3..inc; part 0 = all */
 int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const float* x, const float* dlogits,
                               void* workspace, void* scratch, float* const* grads, int accumulate, int part,
                               ustrun_stream_t s);

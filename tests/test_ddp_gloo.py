@@ -96,6 +96,14 @@ def _worker_tail(rank, world, port, q):
         assert torch.equal(grad[:off], head_before)
         ar.finish(grad)                     # head reduced, tail joined
         assert torch.allclose(grad, tot, rtol=0, atol=1e-6)
+        # three pieces: tail, then the middle block (down4's gradients) once the encoder half has produced it, then the head
+        grad = torch.randn(n, generator=torch.Generator().manual_seed(ddp.rank_seed(100 * step, rank)))
+        mid = 2100
+        ar.start_tail(grad, off)
+        ar.start_mid(grad, mid)
+        assert torch.equal(grad[:mid], head_before[:mid])
+        ar.finish(grad)
+        assert torch.allclose(grad, tot, rtol=0, atol=1e-6)
     q.put((rank, float(grad.double().sum())))
     dist.destroy_process_group()
 

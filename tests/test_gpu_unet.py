@@ -200,3 +200,19 @@ def test_backward_in_two_parts_equals_one_call():
     assert fired == [1]
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.equal(p1.grad, p2.grad), k
+    # three pieces (decoder | down4 | rest): the middle hook sees down4's gradients final, the others' not yet written
+    m3 = copy.deepcopy(m1)
+    for p in m3.parameters():
+        p.grad = None
+    seen = {}
+    m3._ustrun_backward_split_hook = lambda: fired.append(2)
+
+    def mid():
+        fired.append(3)
+        seen["down4"] = [p.grad.clone() for k, p in m3.named_parameters() if k.startswith("down4")] if all(
+            p.grad is not None for k, p in m3.named_parameters() if k.startswith("down4")) else None
+    m3._ustrun_backward_mid_hook = mid
+    m3(x).backward(dl)
+    assert fired == [1, 2, 3]
+    for (k, p1), (_, p3) in zip(m1.named_parameters(), m3.named_parameters()):
+        assert torch.equal(p1.grad, p3.grad), k

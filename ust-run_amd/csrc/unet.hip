@@ -285,11 +285,12 @@ extern "C" int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x,
 }
 
 // part 0: everything; part 1: head + decoder (the gradients of up1..up4 and outc, the contiguous tail of the parameter
-// order, are final afterwards); part 2: encoder, continuing from the same scratch.  Lets the caller start the all-reduce
-// of the decoder gradients while the encoder half still runs.
+// order, are final afterwards); part 2: encoder, continuing from the same scratch -- or, finer, part 3: down4 (its
+// gradients are final afterwards) then part 4: down3..inc.  Lets the caller start the all-reduce of the decoder gradients
+// while the encoder half still runs, and that of down4's while the high-resolution encoder layers run.
 extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const float* x, const float* dlogits, void* workspace,
                                          void* scratch, float* const* grads, int accumulate, int which, ustrun_stream_t s) {
-    USTRUN_CHECK(which >= 0 && which <= 2, "unet_backward: part %d", which);
+    USTRUN_CHECK(which >= 0 && which <= 4, "unet_backward: part %d", which);
     Plan p; USTRUN_TRY(make_plan(d, p));
     USTRUN_CHECK(x && dlogits && workspace && scratch && grads && d->packed, "unet_backward: null pointer");
     USTRUN_CHECK(d->train, "unet_backward: forward must have run in train mode");
@@ -301,14 +302,16 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
     auto affp = [&](int k) { return (const float*)(ws + p.aff_off[k]); };
     const int dt = d->dtype;
 
-    if (which != 2) {   // head: all passes in one launch (blockIdx.y = pass: its BatchNorm constants on load)
+    if (which <= 1) {   // head: all passes in one launch (blockIdx.y = pass: its BatchNorm constants on load)
         const int C = p.cout[17];
         const long gpix = (long)p.gN * p.H * p.W;
         USTRUN_TRY(head_bwd_passes(dlogits, ws + p.y_off[17], affp(17), affp(17) + C, gpix, p.H * p.W, C, p.K, d->head_w,
                                    sc + p.da_off[17], grads[62], grads[63], accumulate, part, p.part_bytes, dt, p.G, 4L * C,
                                    (hipStream_t)s));
     }
-    const int i_hi = which == 2 ? 9 : 17, i_lo = which == 1 ? 10 : 0;
+    // layers 17..10 = decoder, 9..8 = down4 (57 of the encoder's 75 MB of gradients, and the first to finish), 7..0 = the rest
+    const int i_hi = which <= 1 ? 17 : (which == 4 ? 7 : 9);
+    const int i_lo = which == 1 ? 10 : (which == 3 ? 8 : 0);
     for (int i = i_hi; i >= i_lo; --i) {
         if (i == ustrun_debug_stop_layer) return 0;
         const int l = p.lvl[i], H = p.Hs[l], W = p.Ws[l], C = p.cout[i];

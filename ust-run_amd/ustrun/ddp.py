@@ -38,11 +38,13 @@ class GradReducer:
     uses it in two pieces instead: the decoder gradients are the contiguous TAIL of the buffer (parameter order
     inc, down1..4, up1..4, outc) and are final once the head + decoder half of the backward has been issued, so
     `start_tail` launches their all-reduce there (async: RCCL runs it on its own stream behind the backward stream's
-    work so far) and it overlaps the encoder half; `finish` reduces the head and joins."""
+    work so far) and it overlaps the encoder half; `start_mid` does the same for down4's gradients once the encoder half
+    has produced them; `finish` reduces the remaining head and joins."""
 
     def __init__(self, world, bucket_elems=0):
         self.world, self.bucket_elems = world, bucket_elems
         self._work, self._off = None, 0
+        self._mid, self._mid_lo = None, 0
 
     def __call__(self, flat):
         b = self.bucket_elems
@@ -57,12 +59,24 @@ class GradReducer:
         self._off = int(off)
         self._work = dist.all_reduce(flat[self._off:], async_op=True)
 
+    def start_mid(self, flat, lo):
+        """After `start_tail`: [lo, tail offset) is final too (down4's gradients, 57 of the encoder's 75 MB, are the first
+        the encoder half finishes) -- their all-reduce runs under the high-resolution encoder layers."""
+        if self._work is None or not (0 <= lo < self._off):
+            raise RuntimeError("start_mid: call start_tail first, with a larger offset")
+        self._mid_lo = int(lo)
+        self._mid = dist.all_reduce(flat[self._mid_lo:self._off], async_op=True)
+
     def finish(self, flat):
         if self._work is None:
             self(flat)
             return
-        if self._off > 0:
-            dist.all_reduce(flat[:self._off])
+        head = self._mid_lo if self._mid is not None else self._off
+        if head > 0:
+            dist.all_reduce(flat[:head])
+        if self._mid is not None:
+            self._mid.wait()
+            self._mid = None
         self._work.wait()
         self._work = None
 

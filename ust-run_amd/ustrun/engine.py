@@ -125,13 +125,16 @@ class _UNetFn(torch.autograd.Function):
         if split is None:
             L.check(lib.ustrun_unet_backward(C.byref(d), ctx.x.data_ptr(), dlogits.data_ptr(), ctx.ws.data_ptr(),
                                              scratch.data_ptr(), arr, accumulate, stream_ptr()), "ustrun_unet_backward")
-        else:       # head + decoder, hand the (now final) decoder gradients to the caller, then the encoder
-            for part in (1, 2):
+        else:       # head + decoder, hand the (now final) decoder gradients to the caller, then the encoder -- down4
+            mid = getattr(model, "_ustrun_backward_mid_hook", None)        # first when the caller wants its gradients early
+            for part in ((1, 3, 4) if mid is not None else (1, 2)):
                 L.check(lib.ustrun_unet_backward_part(C.byref(d), ctx.x.data_ptr(), dlogits.data_ptr(), ctx.ws.data_ptr(),
                                                       scratch.data_ptr(), arr, accumulate, part, stream_ptr()),
                         "ustrun_unet_backward_part")
                 if part == 1:
                     split()
+                elif part == 3:
+                    mid()
         ctx.ws = None
         grads = (None,) * ctx.nparams if sink is not None else tuple(targets)
         return (None, None, None, None) + grads

@@ -188,6 +188,8 @@ class SSLTrainer:
         self.flat_g, self.grad_views = flat_like(self.flat_p, params)
         # offset of the first decoder parameter (up1.up.weight, index 30 of 64): the tail [dec_off:] is up1..up4 + outc
         self.dec_off = sum((p.numel() + 3) // 4 * 4 for p in params[:30]) if len(params) == 64 else 0
+        # offset of down4's first parameter (index 24): [mid_off, dec_off) is final after the first encoder block's backward
+        self.mid_off = sum((p.numel() + 3) // 4 * 4 for p in params[:24]) if len(params) == 64 else 0
         self.flat_v = torch.zeros_like(self.flat_p)
         model._ustrun_grad_sink = self.grad_views        # backward accumulates straight into flat_g
         engine.invalidate_packed(model)
@@ -429,10 +431,13 @@ class SSLTrainer:
         if lg_all is not None:                    # one backward over the four passes
             if overlap:                            # decoder gradients go out while the encoder half still runs
                 model._ustrun_backward_split_hook = lambda: self.grad_allreduce.start_tail(self.flat_g, self.dec_off)
+                if hasattr(self.grad_allreduce, "start_mid") and 0 < self.mid_off < self.dec_off:
+                    model._ustrun_backward_mid_hook = lambda: self.grad_allreduce.start_mid(self.flat_g, self.mid_off)
             try:
                 lg_all.backward(torch.cat(dls, 0))
             finally:
                 model._ustrun_backward_split_hook = None
+                model._ustrun_backward_mid_hook = None
         self._mark("backward issued")
         if self.grad_allreduce is not None:
             if overlap:
