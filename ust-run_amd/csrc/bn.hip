@@ -156,18 +156,19 @@ __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
     if (pl >= PPB) return;
     float sc[V], sh[V];
-    int cur_grp = -2;
+    // the constants are (re)loaded every pixel, unconditionally (L1 hits): a "reload when the pass changes" branch kept the
+    // compiler from overlapping one pixel's loads with the next one's
+#pragma unroll 2
     for (long p = (long)blockIdx.x * PPB + pl; p < npix; p += (long)gridDim.x * PPB) {
         const unsigned up = (unsigned)p, t = up / (unsigned)Wp;      // 32-bit divides (pooled pixels < 2^32: host check)
         const int px = (int)(up - t * (unsigned)Wp), n = (int)(t / (unsigned)Hp), py = (int)(t - (unsigned)n * (unsigned)Hp);
         const int grp = gN > 0 ? n / gN : 0;
-        if (grp != cur_grp) {
-            cur_grp = grp;
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                sc[j] = scale ? scale[grp * gstride + cv * V + j] : 1.f;
-                sh[j] = scale ? shift[grp * gstride + cv * V + j] : 0.f;
-            }
+        for (int h = 0; h < V / 4; ++h) {
+            const f32x4 s4 = scale ? *(const f32x4*)(scale + grp * gstride + cv * V + 4 * h) : (f32x4){1.f, 1.f, 1.f, 1.f};
+            const f32x4 b4 = scale ? *(const f32x4*)(shift + grp * gstride + cv * V + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sc[4 * h + k] = s4[k]; sh[4 * h + k] = b4[k]; }
         }
         const long base = (((long)n * H + 2 * py) * W + 2 * px) * C + cv * V;
         float v[4][V];
@@ -193,13 +194,20 @@ __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float a = v[q][j] * sc[j] + sh[j];
-                if (relu) a = fmaxf(a, 0.f);
+                a = relu ? fmaxf(a, 0.f) : a;
                 m[j] = q == 0 ? a : fmaxf(m[j], a);
             }
         }
         const long ob = (((long)n * Hp + py) * Wp + px) * C + cv * V;
+        if (ESZ == 2) {                                     // one 16-byte store
+            bf16x8v o8;
 #pragma unroll
-        for (int h = 0; h < V / 4; ++h) st4t<ESZ>(out, ob + 4 * h, (f32x4){m[4 * h], m[4 * h + 1], m[4 * h + 2], m[4 * h + 3]});
+            for (int j = 0; j < 8; ++j) o8[j] = (__bf16)m[j % V];
+            *(bf16x8v*)((__bf16*)out + ob) = o8;
+        } else {
+#pragma unroll
+            for (int h = 0; h < V / 4; ++h) st4t<ESZ>(out, ob + 4 * h, (f32x4){m[4 * h], m[4 * h + 1], m[4 * h + 2], m[4 * h + 3]});
+        }
     }
 }
 
