@@ -259,6 +259,19 @@ int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const float* x, const
 int ustrun_profile_enable(int on);
 int ustrun_profile_collect(int kind, double* host_ms, double* host_flops, double* host_bytes,
                            int64_t* host_launches);
+/* only != 0: time only the launches issued on stream s (a launch on a side stream overlaps the profiled stream's
+ * kernels, its event pair would measure contention); only == 0: every stream (the default)      */
+int ustrun_profile_stream(ustrun_stream_t s, int only);
+/* one record per timed launch, in launch order, WITHOUT resetting (call before ustrun_profile_collect).  tag: the
+ * whole-network calls label their launches -- 3x3 conv i (0..17, network order) forward = i, ConvTranspose j (0..3)
+ * forward = 20 + j, the input gradients of the same layers + 100, the weight gradients + 200; -1 for operator-level
+ * calls.  n = images in the launch.  flops / bytes = the launch's ALGORITHMIC cost (every stored input, output and
+ * weight element touched once at its stored size).  Returns the number of records written, -1 on error.        */
+typedef struct ustrun_prof_rec {
+    int32_t kind, tag, n, pad;
+    double  ms, flops, bytes;
+} ustrun_prof_rec_t;
+int64_t ustrun_profile_records(ustrun_prof_rec_t* host_out, int64_t max_records);
 
 #ifdef __cplusplus
 }

@@ -86,7 +86,8 @@ def test_driver_command_lines_keep_the_reference_flags_and_defaults():
                 base_lr=0.03, seed=1337, gpu="0", threshold=0.95, amp=1, label_bs=4, unlabel_bs=4, test_bs=1, domain_num=6,
                 lb_domain=1, lb_num=40, lb_ratio=0, ema_decay=0.99, consistency_type="mse", consistency=1.0,
                 consistency_rampup=200.0, depth=28, widen_factor=2, leaky_slope=0.1, bn_momentum=0.1, dropout=0.0,
-                cutmix_prob=1.0, LB=0.01, increase=1.0005, queue_len=10, load=False, eval=False, overwrite=False)
+                cutmix_prob=1.0, LB=0.01, increase=1.0005, queue_len=10, load=False, eval=False, overwrite=False,
+                load_path="../model/lb1_ratio0.2/iter_6000.pth")        # train.py:51
     for k, v in want.items():
         assert getattr(tr, k) == v, k
     mn = _load_driver("train_mnms").parser.parse_args([])
@@ -95,3 +96,15 @@ def test_driver_command_lines_keep_the_reference_flags_and_defaults():
     te = _load_driver("test").parser.parse_args([])
     assert (te.dataset, te.save_name, te.model, te.gpu, te.eval, te.test_bs, te.domain_num, te.lb_domain, te.save_img) == \
         ("prostate", "debug", "unet", "0", True, 1, 6, 1, False)
+
+
+def test_load_resumes_from_the_runs_own_checkpoint_like_the_reference():
+    """train.py:542-546: `--load` restores '../model/{dataset}/{save_name}/checkpoint.pth'; `--load_path` is parsed and never
+    read.  The build's train() must form the same path (checked on the source: train() needs a GPU to run)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "ust-run_amd", "train.py")).read()
+    body = src[src.index("    if args.load:"):]
+    body = body[:body.index("max_epoch =")]
+    assert "'../model/{}/{}/checkpoint.pth'.format(args.dataset, args.save_name)" in body
+    assert "args.load_path" not in body

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""GPU box: run the trajectory experiment of tools/traj_common.py with the HIP trainers (f32 and bf16) on several
+synthetic task difficulties and print, per task, the validation Dice after 200 steps and the f32-vs-bf16 spread --
+used once to pick a task that does not saturate before the CPU oracle spends an hour on it.
+
+    python tools/calib_task.py [--tasks default,hard,...] [--steps 200]
+"""
+import argparse
+import json
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+import traj_common as T
+
+
+def run(dtype, task, steps, C, H, K, perturb=0.0):
+    from networks.unet_model import UNet
+    from oracle import unet_ref as U
+    from ustrun import evaluate
+    from ustrun.trainer import SSLTrainer
+    torch.manual_seed(T.MODEL_SEED)
+    sd_s, sd_t = U.make_state_dict(C, K), U.make_state_dict(C, K)
+    if perturb:
+        for k in U.param_keys(sd_s):
+            sd_s[k] = sd_s[k] * (1 + perturb)
+    model, ema = UNet(C, K, dtype=dtype), UNet(C, K, dtype=dtype)
+    model.load_state_dict({k: v.clone() for k, v in sd_s.items()})
+    ema.load_state_dict({k: v.clone() for k, v in sd_t.items()})
+    tr = SSLTrainer(T.DATASET, model.cuda(), ema.cuda(), fft="device", max_iterations=T.MAX_ITER, num_eval_iter=T.NUM_EVAL_ITER)
+    random.seed(T.PY_SEED); np.random.seed(T.NP_SEED)
+    hist = []
+    for s in range(steps):
+        b = T.batch(s, task, C, H)
+        tr.step(*[t.cuda() for t in b], epoch_start=(s % T.NUM_EVAL_ITER == 0))
+        if s % T.LOG_EVERY == T.LOG_EVERY - 1:
+            sc = tr.scalars()
+            hist.append((s + 1, sc["loss"], float(np.mean(sc["ulb_dice"])), sc["mask_ratio"]))
+    loaders = [[(x.cuda(), y.cuda()) for x, y in dom] for dom in T.val_loaders(task, C, H)]
+    vs, _ = evaluate.validate(T.DATASET, model, loaders, log=None)
+    vt, _ = evaluate.validate(T.DATASET, ema, loaders, log=None)
+    return hist, vs, vt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tasks", default="default,hard")
+    ap.add_argument("--steps", type=int, default=T.STEPS)
+    a = ap.parse_args()
+    from ustrun import synthetic
+    from ustrun.trainer import DATASETS
+    C, H, K = DATASETS[T.DATASET][:3]
+    for name in a.tasks.split(","):
+        if name in synthetic.TASKS:
+            task = synthetic.TASKS[name]
+        else:                      # contrast:noise:rmin:rspan
+            c, n, r0, rs = (float(v) for v in name.split(":"))
+            task = dict(contrast=c, noise=n, rmin=r0, rspan=rs)
+        t0 = time.time()
+        res = {}
+        for tag, dt, pert in (("f32", "f32", 0.0), ("f32p", "f32", 1e-6), ("bf16", "bf16", 0.0)):
+            hist, vs, vt = run(dt, task, a.steps, C, H, K, pert)
+            res[tag] = {"val_student": vs, "val_teacher": vt, "loss_end": hist[-1][1], "pl_dice_tail": [h[2] for h in hist[-3:]],
+                        "loss_curve": [round(h[1], 4) for h in hist]}
+        print("CALIB " + json.dumps({"task": name, "cfg": task, "secs": round(time.time() - t0, 1), **res}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

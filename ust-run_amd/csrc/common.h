@@ -152,6 +152,9 @@ int reduce_partials(const float* partials, int ksplit, int nseg, int Cin, int Co
 // kind 0: implicit-GEMM (conv3x3 fwd/dgrad, convT fwd/dgrad), kind 1: weight-gradient GEMM
 void prof_begin(int kind, double flops, double bytes, hipStream_t st);
 void prof_end(hipStream_t st);
+// layer tag of the launches that follow (unet.hip): conv i forward = i, ConvTranspose j forward = 20 + j, input
+// gradients + 100, weight gradients + 200; n = images in the launch; -1 = untagged (operator-level calls)
+void prof_set_tag(int tag, int n);
 
 // first convolution (C <= 4 input channels, 64 outputs): conv_first.hip
 bool conv_first_supported(const ustrun_src_t& s, int Cout);

@@ -14,8 +14,12 @@ extern "C" const char* ustrun_last_error(void) { return ustrun::get_error(); }
 #include <vector>
 namespace ustrun {
 namespace {
-struct Slot { hipEvent_t a, b; double flops, bytes; int kind; };
+struct Slot { hipEvent_t a, b; double flops, bytes; int kind, tag, n; };
 bool g_prof_on = false;
+bool g_prof_any_stream = true;          // false: only launches on g_prof_stream are timed
+hipStream_t g_prof_stream = nullptr;
+bool g_open = false;                    // the last prof_begin recorded (its prof_end must too)
+int g_tag = -1, g_tag_n = 0;
 std::vector<Slot> g_slots;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event() {
@@ -24,19 +28,44 @@ hipEvent_t get_event() {
     hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e;
 }
 }  // namespace
+void prof_set_tag(int tag, int n) { g_tag = tag; g_tag_n = n; }
 void prof_begin(int kind, double flops, double bytes, hipStream_t st) {
-    if (!g_prof_on) return;
-    Slot s; s.a = get_event(); s.b = get_event(); s.flops = flops; s.bytes = bytes; s.kind = kind;
+    g_open = false;
+    // a launch on another stream (the batch-1 forward on its side stream) overlaps the profiled stream's kernels: its
+    // event pair would measure contention, not the kernel
+    if (!g_prof_on || (!g_prof_any_stream && st != g_prof_stream)) return;
+    Slot s; s.a = get_event(); s.b = get_event(); s.flops = flops; s.bytes = bytes; s.kind = kind; s.tag = g_tag; s.n = g_tag_n;
     (void)hipEventRecord(s.a, st);
     g_slots.push_back(s);
+    g_open = true;
 }
 void prof_end(hipStream_t st) {
-    if (!g_prof_on || g_slots.empty()) return;
+    if (!g_open || g_slots.empty()) return;
     (void)hipEventRecord(g_slots.back().b, st);
+    g_open = false;
 }
 }  // namespace ustrun
 
 extern "C" int ustrun_profile_enable(int on) { ustrun::g_prof_on = on != 0; return 0; }
+
+extern "C" int ustrun_profile_stream(ustrun_stream_t s, int only) {
+    ustrun::g_prof_stream = (hipStream_t)s; ustrun::g_prof_any_stream = only == 0;
+    return 0;
+}
+
+extern "C" int64_t ustrun_profile_records(ustrun_prof_rec_t* out, int64_t max) {
+    using namespace ustrun;
+    int64_t n = 0;
+    for (auto& s : g_slots) {
+        if (n >= max) break;
+        if (hipEventSynchronize(s.b) != hipSuccess) { set_error("profile_records: event sync failed"); return -1; }
+        float e = 0.f; (void)hipEventElapsedTime(&e, s.a, s.b);
+        out[n].kind = s.kind; out[n].tag = s.tag; out[n].n = s.n; out[n].pad = 0;
+        out[n].ms = e; out[n].flops = s.flops; out[n].bytes = s.bytes;
+        ++n;
+    }
+    return n;
+}
 
 extern "C" int ustrun_profile_collect(int kind, double* ms, double* flops, double* bytes, int64_t* launches) {
     using namespace ustrun;

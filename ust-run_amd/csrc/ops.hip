@@ -275,7 +275,7 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
         int per;
         wgrad_halo_plan(a, &slabs, &per);
         USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 9 * a.Cin * Cout * 4, "conv3x3_wgrad: partials too small");
-        prof_begin(1, 2.0 * a.M * 9 * a.Cin * Cout, 0.0, (hipStream_t)s);
+        prof_begin(1, 2.0 * a.M * 9 * a.Cin * Cout, 2.0 * ((double)a.M * a.Cin + (double)a.M * Cout) + 36.0 * a.Cin * Cout, (hipStream_t)s);
         const int rc = wgrad_halo_launch_bf16(a, slabs, per, (hipStream_t)s);
         prof_end((hipStream_t)s);
         USTRUN_TRY(rc);

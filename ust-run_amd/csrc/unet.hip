@@ -241,6 +241,7 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
             const int prev = (j == 0) ? 9 : i - 1;
             ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0,
                                       p.G > 1 ? p.gN : 0);
+            prof_set_tag(20 + j, p.N);
             USTRUN_TRY(ustrun_convT2x2_fwd(&a, pk + p.uf_off[j], d->up_b[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
                                            ws + p.u_off[j], d->dtype, s));
         }
@@ -254,6 +255,7 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
         const int ns = conv_sources(p, x, ws, i, srcs);
         const int H = p.Hs[p.lvl[i]], W = p.Ws[p.lvl[i]];
         int stat_rows = 0;
+        prof_set_tag(i, p.N);
         USTRUN_TRY(ustrun_conv3x3_fwd_rows(srcs, ns, pk + p.wf_off[i], p.N, H, W, p.cout[i], ws + p.y_off[i],
                                            d->train ? stat : nullptr, &stat_rows, d->dtype, s));
         float* aff = affp(i);
@@ -266,6 +268,7 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
                                           aff + 2 * C, aff + 3 * C, 4L * C, (hipStream_t)s));
         }
     }
+    prof_set_tag(-1, 0);
     const int C = p.cout[17];
     const long gpix = (long)p.gN * p.H * p.W;
     for (int g = 0; g < p.G; ++g) {
@@ -331,9 +334,13 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
         }
         ustrun_src_t srcs[2];
         const int ns = conv_sources(p, x, ws, i, srcs);
+        prof_set_tag(200 + i, p.N);
         USTRUN_TRY(ustrun_conv3x3_wgrad(srcs, ns, da, p.N, H, W, C, grads[gi], accumulate, part, p.part_bytes, dt, s));
+        prof_set_tag(-1, 0);
         if (i == 0) break;
         const float* wd = pk + p.wd_off[i];
+        struct Untag { ~Untag() { prof_set_tag(-1, 0); } } untag_;
+        prof_set_tag(100 + i, p.N);
         if (i < 10 && i % 2 == 0) {            // Down conv: grad wrt the pooled activation of conv i-1
             USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, p.cin[i], sc + p.dp_off[3 - (l - 1)], p.cin[i], nullptr, 0,
                                             0, 0, 0, dt, s));
@@ -346,8 +353,10 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0,
                                       p.G > 1 ? p.gN : 0);
             const int ub = 30 + j * 8;
+            prof_set_tag(220 + j, p.N);
             USTRUN_TRY(ustrun_convT2x2_wgrad(&a, sc + p.du_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], grads[ub],
                                              grads[ub + 1], accumulate, part, p.part_bytes, dt, s));
+            prof_set_tag(120 + j, p.N);
             USTRUN_TRY(ustrun_convT2x2_dgrad(sc + p.du_off[j], pk + p.ud_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
                                              p.up_cin[j], sc + p.da_off[prev], dt, s));
         } else {                               // second conv of a DoubleConv

@@ -36,7 +36,7 @@ parser.add_argument("--seed", type=int, default=1337, help="random seed")
 parser.add_argument("--gpu", type=str, default='0')
 parser.add_argument('--load', action='store_true')
 parser.add_argument('--eval', action='store_true')
-parser.add_argument('--load_path', type=str, default='../checkpoints/label_0.2/Prostate/ours_v0_d1/checkpoint.pth')
+parser.add_argument('--load_path', type=str, default='../model/lb1_ratio0.2/iter_6000.pth')
 parser.add_argument("--threshold", type=float, default=0.95, help="confidence threshold for using pseudo-labels")
 parser.add_argument('--amp', type=int, default=1, help='use mixed precision training or not')
 parser.add_argument("--label_bs", type=int, default=4, help="labeled_batch_size per gpu")
@@ -122,11 +122,12 @@ def train(args, snapshot_path):
     test_loaders = synthetic.test_loaders(args.dataset, min(args.domain_num, 2), 4, args.test_bs, C, H, args.seed + 17)
     best = {"avg": 0.0, "iter": 0, "stu_avg": 0.0, "stu_iter": 0}
     start_epoch = 0
-    if args.load:                                          # train.py:542-548: resume from a checkpoint.pth
+    if args.load:      # train.py:542-548: resume from the run's own checkpoint.pth (--load_path is parsed but unused there too)
         from ustrun import engine
         from utils import util
+        path_str = '../model/{}/{}/checkpoint.pth'.format(args.dataset, args.save_name)
         (start_epoch, _, _, _, best["avg"], best["iter"], best["stu_avg"], best["stu_iter"]) = util.load_osmancheckpoint(
-            args.load_path, ema_model, model, trainer.optimizer)
+            path_str, ema_model, model, trainer.optimizer)
         trainer.iter_num = start_epoch * args.num_eval_iter
         engine.invalidate_packed(model)
         engine.invalidate_packed(ema_model)
@@ -165,6 +166,9 @@ def train(args, snapshot_path):
             util.save_osmancheckpoint(epoch + 1, ema_model, model, trainer.optimizer, best["avg"], best["iter"], best["stu_avg"],
                                       best["stu_iter"], os.path.join(snapshot_path, "checkpoint.pth"))
             logging.info('save checkpoint to {}'.format(os.path.join(snapshot_path, "checkpoint.pth")))
+        if world > 1:      # the other ranks wait here, not inside the next step's all-reduce (RCCL watchdog) while rank 0 validates
+            import torch.distributed as dist
+            dist.barrier()
 
 
 if __name__ == "__main__":
@@ -174,7 +178,7 @@ if __name__ == "__main__":
         os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)
     from ustrun.ddp import env_world
     rank = env_world()[0]
-    random.seed(args.seed)
+    random.seed(args.seed + rank)                      # CutMix p-draws and FFT-mix ratios: a stream per rank, like the boxes
     np.random.seed(args.seed + rank)
     torch.manual_seed(args.seed)                       # same initial weights on every rank
     if rank == 0:

@@ -33,7 +33,7 @@ if __name__ == "__main__":
         os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)
     from ustrun.ddp import env_world
     rank = env_world()[0]
-    random.seed(args.seed)
+    random.seed(args.seed + rank)
     np.random.seed(args.seed + rank)
     torch.manual_seed(args.seed)
     if rank == 0:

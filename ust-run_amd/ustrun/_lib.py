@@ -31,6 +31,12 @@ class UNetDesc(C.Structure):
                 ("head_w", vp), ("head_b", vp), ("packed", vp)]
 
 
+class ProfRec(C.Structure):
+    """ustrun_prof_rec_t"""
+    _fields_ = [("kind", i32), ("tag", i32), ("n", i32), ("pad", i32), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 PSrc, PDesc = C.POINTER(Src), C.POINTER(UNetDesc)
 
 # name: (restype, argtypes) -- must list every symbol include/ustrun.h declares
@@ -74,6 +80,8 @@ SIGNATURES = {
     "ustrun_sgd_ema": (i32, [fp, fp, fp, fp, i64, f32, f32, f32, i32, f32, f32, vp]),
     "ustrun_profile_enable": (i32, [i32]),
     "ustrun_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
+    "ustrun_profile_stream": (i32, [vp, i32]),
+    "ustrun_profile_records": (i64, [C.POINTER(ProfRec), i64]),
     "ustrun_unet_packed_bytes": (i64, [PDesc]),
     "ustrun_unet_fwd_workspace_bytes": (i64, [PDesc]),
     "ustrun_unet_bwd_scratch_bytes": (i64, [PDesc]),
@@ -112,8 +120,9 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def nhwc_src(t_ptr, C_, H, W, scale=None, shift=None, relu=0, pool=0, off=(0, 0), f32=0):
-    return Src(t_ptr, scale, shift, C_, H, W, H * W * C_, W * C_, C_, 1, relu, pool, off[0], off[1], f32)
+def nhwc_src(t_ptr, C_, H, W, scale=None, shift=None, relu=0, pool=0, off=(0, 0), f32=0, gN=0, gstride=0):
+    """gN > 0: image n takes scale/shift + (n // gN) * gstride floats (several forward passes batched into one call)."""
+    return Src(t_ptr, scale, shift, C_, H, W, H * W * C_, W * C_, C_, 1, relu, pool, off[0], off[1], f32, gN, gstride)
 
 
 def nchw_src(t_ptr, C_, H, W):

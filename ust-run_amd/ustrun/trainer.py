@@ -106,7 +106,7 @@ def flatten_parameters(model):
     """Re-home all parameters in one contiguous f32 buffer (views keep their names/shapes)."""
     params = list(model.parameters())
     total = sum((p.numel() + 3) // 4 * 4 for p in params)
-    flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
+    flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)   # (the 4-element alignment gaps stay 0)
     views, o = [], 0
     for p in params:
         v = flat[o:o + p.numel()].view_as(p)
@@ -371,7 +371,7 @@ class SSLTrainer:
             ib_lq = F.rect_masks([all_cover_rect(region_host.numpy())], self.patch, self.patch, dev)
             # result unused (Q2); student BN running stats still move.  A batch-1 forward fills 16-256 workgroups per
             # launch, so it runs on a side stream underneath the losses and the backward that follow (ordered after
-            # the student passes issued so far; joined before the weights are repacked for the next step).
+            # the student passes issued so far; joined before the optimizer update touches the parameters).
             side = self._side_stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             lb_pick = lb_x_w[new_choice:new_choice + 1]
@@ -445,14 +445,16 @@ class SSLTrainer:
             else:
                 self.grad_allreduce(self.flat_g)
 
+        # The low-quality-sample forward on the side stream reads BatchNorm gamma/beta, the ConvTranspose biases and the
+        # head straight from flat_p (only the conv weights are packed copies): join it BEFORE the update rewrites flat_p.
+        if self._side_busy:
+            torch.cuda.current_stream(dev).wait_stream(self._side)
+            self._side_busy = False
         # SGD + EMA (train.py:848-851; alpha from the pre-increment iter_num, Q10), poly LR for the NEXT step
         alpha = min(1 - 1 / (self.iter_num + 1), self.ema_decay)
         F.sgd_ema(self.flat_p, self.flat_g, self.flat_v, self.flat_t, self.lr, self.momentum, self.wd,
                   self.first_step, alpha, grad_scale=1.0 / self.world_size)
         self.first_step = False
-        if self._side_busy:                              # the low-quality-sample forward reads the packed weights
-            torch.cuda.current_stream(dev).wait_stream(self._side)
-            self._side_busy = False
         engine.invalidate_packed(model)
         engine.invalidate_packed(ema)
         self.lr = self.base_lr * (1.0 - self.iter_num / self.max_iterations) ** 0.9
