@@ -6,9 +6,10 @@
 One "step" = one semi-supervised iteration (reference train.py:578-858 minus data loading and
 logging: 3 teacher + 5 student forwards (+1 low-quality-sample forward), 4 backwards, losses,
 SGD + EMA) on a synthetic batch resident in HBM.  Metric: train images/sec =
-(label_bs + unlabel_bs) * world / step time.  For N > 1 launch with torch.distributed.run; every
-rank trains its own shard (weak scaling) and gradients are summed with one RCCL all-reduce.
-Prints ONE JSON line on rank 0.
+(label_bs + unlabel_bs) * world / step time.  For N > 1 either launch under torch.distributed.run
+(one rank per GPU) or run `python bench.py --gpus N` plainly: it then starts the N ranks itself before
+touching the GPU.  Every rank trains its own shard (weak scaling) and gradients are summed with one RCCL
+all-reduce.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
@@ -43,9 +44,21 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(dataset):
-    """The oracle's step (CPU restatement of the reference) timed on this host: config[0]
-    (B = 4+4, fp32) -- a reported baseline, not the target."""
+    """The oracle's step (CPU restatement of the reference, oracle/step_ref.py) timed on this host's cores: config[0]
+    (B = 4+4, fp32), 1 warm-up + 3 timed steps at all cores of the GPU's CPU share, plus a 1-thread
+    figure from a bounded sample (one image forward + backward = 3 of the step's 65 image-forward units).  A reported
+    baseline, not the target."""
     from oracle import unet_ref as U
     from oracle.step_ref import DATASETS, RefTrainer
     from ustrun import synthetic
@@ -56,13 +69,85 @@ def cpu_baseline(dataset):
     sd = U.make_state_dict(C, K)
     tr = RefTrainer(dataset, sd)
     random.seed(1212); np.random.seed(1337)
-    b = synthetic.batch(dataset, 4, C, H, 1337)
-    print(f"[bench] cpu_baseline: timing one oracle step on {cores} threads ...", file=sys.stderr, flush=True)
+    batches = [synthetic.batch(dataset, 4, C, H, 1337 + i) for i in range(4)]
+    print(f"[bench] cpu_baseline: 1 warm-up + 3 timed oracle steps on {cores} threads ...", file=sys.stderr, flush=True)
+    tr.step(*batches[0], epoch_start=True)
+    times = []
+    for i in range(1, 4):
+        t0 = time.time()
+        tr.step(*batches[i])
+        times.append(time.time() - t0)
+        print(f"[bench] cpu_baseline: step {i}: {times[-1]:.1f} s", file=sys.stderr, flush=True)
+    dt = sum(times) / len(times)
+    # 1 thread: one image forward + backward of the same network (3 F of a step's (16 B + 1) F = 65 F at B = 4)
+    torch.set_num_threads(1)
+    sd1 = U.clone_sd(sd, requires_grad=True)
+    x1 = batches[0][0][:1]
+    U.unet_forward(x1, sd1, train=True).square().mean().backward()          # warm-up
     t0 = time.time()
-    tr.step(*b, epoch_start=True)
-    dt = time.time() - t0
-    return {"value": round(8 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 step of config[0]: {dataset} {H}x{H}, label_bs=unlabel_bs=4, fp32, oracle/step_ref.py on torch-CPU ({dt:.1f} s)"}
+    U.unet_forward(x1, sd1, train=True).square().mean().backward()
+    t1 = time.time() - t0
+    torch.set_num_threads(cores)
+    step_1t = t1 * (16 * 4 + 1) / 3.0
+    return {"value": round(8 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "torch": torch.__version__, "step_seconds": [round(t, 2) for t in times],
+            "one_thread": {"value": round(8 / step_1t, 4), "unit": "images/sec", "cores": 1,
+                           "sample": f"1 image forward+backward ({t1:.1f} s) scaled by 65/3 to a config[0] step"},
+            "sample": f"3 steps after 1 warm-up of config[0]: {dataset} {H}x{H}, label_bs=unlabel_bs=4, fp32, "
+                      f"oracle/step_ref.py on torch-CPU ({dt:.1f} s/step)"}
+
+
+LAYER_NAMES = ["inc.conv1", "inc.conv2", "down1.conv1", "down1.conv2", "down2.conv1", "down2.conv2", "down3.conv1", "down3.conv2",
+               "down4.conv1", "down4.conv2", "up1.conv1", "up1.conv2", "up2.conv1", "up2.conv2", "up3.conv1", "up3.conv2",
+               "up4.conv1", "up4.conv2"]
+HBM_PEAK, HBM_UNIT = 8000.0, "GB/s"
+
+
+def tag_name(tag):
+    op = {0: "fwd", 1: "dgrad", 2: "wgrad"}[tag // 100]
+    t = tag % 100
+    return (LAYER_NAMES[t] if t < 18 else f"up{t - 19}.up"), op
+
+
+def layer_table(lib, mfma_peak):
+    """Per-layer roofline rows from the HIP-event pairs of the sampled steps (ustrun_profile_records): for every tagged
+    launch class (layer, op, images-in-launch) the mean duration, the launch's ALGORITHMIC flops and bytes, both achieved
+    rates, both roof fractions and the roof that binds it (the larger of flops/peak_mfma and bytes/peak_hbm)."""
+    from ustrun import _lib
+    buf = (_lib.ProfRec * 4096)()
+    n = lib.ustrun_profile_records(buf, 4096)
+    agg = {}
+    for r in buf[:max(n, 0)]:
+        if r.tag < 0:
+            continue
+        k = (r.tag, r.n)
+        a = agg.setdefault(k, [0, 0.0, r.flops, r.bytes])
+        a[0] += 1
+        a[1] += r.ms
+    rows = []
+    for (tag, nimg), (cnt, ms, fl, by) in sorted(agg.items()):
+        name, op = tag_name(tag)
+        t = ms / cnt * 1e-3
+        tf, gb = fl / t / 1e12, by / t / 1e9
+        rows.append({"layer": name, "op": op, "images": nimg, "launches": cnt, "ms": round(ms / cnt, 4), "alg_flops": fl, "alg_bytes": by,
+                     "tflops": round(tf, 1), "gbps": round(gb, 1), "frac_mfma": round(tf / mfma_peak, 4),
+                     "frac_hbm": round(gb / HBM_PEAK, 4),
+                     "bound": "mfma" if fl / (mfma_peak * 1e12) >= by / (HBM_PEAK * 1e9) else "hbm"})
+    return rows
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children (one process per GPU, RCCL)
+    BEFORE this process touches the GPU, relay rank 0's JSON line, exit with their status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -70,15 +155,19 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)                                # never returns; nothing above has initialised the GPU
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    rccl_ranks, backend = 1, None
     if world > 1:
         import torch.distributed as dist
         from ustrun import ddp
         ddp.init("nccl", device=dev)              # "nccl" is RCCL on ROCm
+        rccl_ranks, backend = dist.get_world_size(), dist.get_backend()
 
     from networks.unet_model import UNet
     from ustrun import _lib, synthetic
@@ -107,6 +196,7 @@ def main():
     for s in range(a.warmup):
         tr.step(*batches[s % nb], epoch_start=(s == 0))
     lib = _lib.lib()
+    lib.ustrun_profile_stream(torch.cuda.current_stream(dev).cuda_stream, 1)   # not the batch-1 forward's side stream
     sync()
     prof = not a.no_profile
     # the HIP-event pairs around every conv launch cost ~5 % of a step, so they sample the LAST min(2, K) steps of the
@@ -126,6 +216,7 @@ def main():
         dt = float(t)
     roof = None
     if prof:
+        layers = layer_table(lib, 157.3 if a.dtype == "f32" else 2500.0)
         ms, fl, by, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         lib.ustrun_profile_collect(0, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by), ctypes.byref(n))
         peak = 157.3 if a.dtype == "f32" else 2500.0
@@ -138,18 +229,29 @@ def main():
                 "alg_flops_per_launch": fl.value / max(n.value, 1), "alg_bytes_per_launch": by.value / max(n.value, 1),
                 "alg_gbps": round(by.value / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else 0.0,
                 "time_share_of_step": round(ms.value * 1e-3 / (dt * nprof / a.steps), 3)}
-        ms2, fl2, n2 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        lib.ustrun_profile_collect(1, ctypes.byref(ms2), ctypes.byref(fl2), None, ctypes.byref(n2))
+        ms2, fl2, by2, n2 = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        lib.ustrun_profile_collect(1, ctypes.byref(ms2), ctypes.byref(fl2), ctypes.byref(by2), ctypes.byref(n2))
         if ms2.value > 0:
             roof["wgrad"] = {"achieved": round(fl2.value / (ms2.value * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                              "frac": round(fl2.value / (ms2.value * 1e-3) / 1e12 / peak, 4),
+                             "alg_bytes_per_launch": by2.value / max(n2.value, 1), "traffic": None,
+                             "alg_gbps": round(by2.value / (ms2.value * 1e-3) / 1e9, 1),
                              "time_share_of_step": round(ms2.value * 1e-3 / (dt * nprof / a.steps), 3)}
+        # the north_star's HBM target is defined on the 64-channel full-resolution DoubleConv layers:
+        # per-layer rows of the largest launches (the student's four batched passes), both roofs, binding roof named
+        big = max((r["images"] for r in layers), default=0)
+        roof["layers"] = [r for r in layers if r["images"] == big and r["op"] == "fwd"]
+        roof["layers_bwd"] = [r for r in layers if r["images"] == big and r["op"] != "fwd" and
+                              r["layer"] in ("inc.conv2", "down1.conv2", "down2.conv2", "up4.conv1", "up4.conv2", "up4.up")]
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured offline with
         # rocprofv3 --pmc on this same command and committed under profiles/ (bench.py cannot run under two profilers)
         tpath = os.path.join(ROOT, "profiles", f"traffic_{a.dtype}.json")
         if os.path.exists(tpath):
             try:
-                roof["traffic"] = json.load(open(tpath))["hbm_bytes_per_launch"]
+                tj = json.load(open(tpath))
+                roof["traffic"] = tj["hbm_bytes_per_launch"]
+                if "wgrad" in roof:
+                    roof["wgrad"]["traffic"] = tj.get("wgrad_hbm_bytes_per_launch")
             except Exception:
                 pass
     if rank == 0:
@@ -161,6 +263,7 @@ def main():
                "config": {"workload": f"{a.dataset} {H}x{H}, {K}-class U-Net (31.0M params), batch={a.label_bs}+{a.unlabel_bs} per GPU, "
                                       f"SSL step = 3 teacher + 5(+1) student forwards, 4 backwards, CE+Dice, SGD+EMA",
                           "global_batch": (a.label_bs + a.unlabel_bs) * world, "parallelism": f"dp{world}", "fft_mix": a.fft},
+               "rccl_ranks": rccl_ranks, "collective_backend": backend,
                "roofline": roof, "cpu_baseline": None}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.dataset)

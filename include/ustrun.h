@@ -253,6 +253,11 @@ int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const float* x, const
                               void* workspace, void* scratch, float* const* grads, int accumulate, int part,
                               ustrun_stream_t s);
 
+/* test aid: tile configuration of the last halo-tiled bf16 3x3 convolution launched by this process, as
+ * TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF (0 before any) -- lets a parity test assert that its shape
+ * reached the production tile it was written for                                                   */
+int ustrun_debug_last_conv_variant(void);
+
 /* ---- optional launch profiler (bench.py): HIP events recorded on the launch stream around every
  * implicit-GEMM (kind 0) / weight-gradient (kind 1) launch while enabled; collect synchronises on
  * the recorded events, returns the sums and resets that kind.                                   */

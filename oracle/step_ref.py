@@ -103,7 +103,9 @@ class RefTrainer:
                 self.teacher[k].mul_(a).add_(self.student[k].detach(), alpha=1 - a)
 
     # -- one iteration ------------------------------------------------------------
-    def step(self, lb_x_w, lb_y, ulb_x_w, ulb_x_s, ulb_y, epoch_start=False):
+    def step(self, lb_x_w, lb_y, ulb_x_w, ulb_x_s, ulb_y, epoch_start=False, defer_update=False):
+        """defer_update: stop after loss.backward() with the gradients left in `.grad` (data-parallel tests average them
+        over replicas first); `finish_update()` then applies SGD + EMA + LR as the reference does."""
         ds, mode = self.dataset, self.mode
         B = len(ulb_x_s)
         epoch_num = self.iter_num // self.num_eval_iter
@@ -222,11 +224,16 @@ class RefTrainer:
         loss = sup + w * (l_ul + l_lu + w * l_s)
 
         loss.backward()
+        ulb_dice = sample_dice(ds, pl.numpy(), ulb_mask.numpy())
+        out = {"loss": float(loss.detach()), "sup": float(sup.detach()), "ul": float(l_ul.detach()), "lu": float(l_lu.detach()),
+               "s": float(l_s.detach()), "w": w, "ulb_dice": [float(v) for v in ulb_dice],
+               "mask_ratio": float(mask.mean())}
+        if not defer_update:
+            self.finish_update()
+        return out
+
+    def finish_update(self):
         self._sgd()
         self._ema()
         self.lr = H.poly_lr(self.base_lr, self.iter_num, self.max_iterations)   # Q10
         self.iter_num += 1
-        ulb_dice = sample_dice(ds, pl.numpy(), ulb_mask.numpy())
-        return {"loss": float(loss), "sup": float(sup), "ul": float(l_ul), "lu": float(l_lu),
-                "s": float(l_s), "w": w, "ulb_dice": [float(v) for v in ulb_dice],
-                "mask_ratio": float(mask.mean())}

@@ -66,3 +66,103 @@ def test_training_step_world2_parameters_stay_identical():
     res = [q.get() for _ in range(2)]
     assert all(r[1] for r in res)
     assert res[0][2] == res[1][2]
+
+
+# ---- reduced gradient == mean of R independent oracle replicas' gradients (SURVEY.md 8e verification) ----------------
+_KW = dict(max_iterations=300, threshold=0.52, patch_size=64, num_eval_iter=2)
+
+
+def _rank_batches(rank, steps):
+    from ustrun import synthetic
+    return [synthetic.batch("fundus", 2, 3, 64, 100 * s + rank) for s in range(steps)]
+
+
+def _worker_oracle(rank, world, port, q, steps):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import random
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "ust-run_amd")]
+    import torch.distributed as dist
+    from networks.unet_model import UNet
+    from oracle import unet_ref as U
+    from ustrun import ddp
+    from ustrun.trainer import SSLTrainer
+    torch.cuda.set_device(0)
+    ddp.init("gloo")
+    torch.manual_seed(1)
+    sd_s, sd_t = U.make_state_dict(3, 2, base=8), U.make_state_dict(3, 2, base=8)
+    stu, tea = UNet(3, 2, base_channels=8), UNet(3, 2, base_channels=8)
+    stu.load_state_dict({k: v.clone() for k, v in sd_s.items()})
+    tea.load_state_dict({k: v.clone() for k, v in sd_t.items()})
+    tr = SSLTrainer("fundus", stu.cuda(), tea.cuda(), grad_allreduce=ddp.make_grad_allreduce(world), world_size=world, fft="host", **_KW)
+    random.seed(1212 + rank); np.random.seed(1337 + rank)
+    grads = []
+    for s, b in enumerate(_rank_batches(rank, steps)):
+        tr.step(*[t.cuda() for t in b], epoch_start=(s % 2 == 0))
+        grads.append([(v / world).cpu() for v in tr.grad_views])      # flat_g holds the SUM over ranks
+    q.put((rank, grads, [p.detach().cpu() for p in stu.parameters()]))
+    dist.destroy_process_group()
+
+
+def test_reduced_gradient_is_the_mean_of_independent_oracle_replicas():
+    """Two HIP ranks (f32) against two CPU oracle replicas (oracle/step_ref.py) stepped in lockstep on the same per-rank
+    batches and RNG streams, with the oracle's gradients averaged over the replicas before its SGD: after every step the
+    all-reduced gradient / world equals the oracle mean (whole buffer rel-L2 <= 1e-4), and after the
+    trajectory the parameters agree."""
+    import random
+    import numpy as np
+    from oracle import unet_ref as U
+    from oracle.step_ref import RefTrainer
+    steps, world = 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_oracle, args=(r, world, port, q, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    # oracle replicas (this process, CPU) while the ranks run
+    torch.manual_seed(1)
+    sd_s, sd_t = U.make_state_dict(3, 2, base=8), U.make_state_dict(3, 2, base=8)
+    reps, rng = [], []
+    for r in range(world):
+        t = RefTrainer("fundus", sd_s, **_KW)
+        t.set_teacher(sd_t)
+        reps.append(t)
+        random.seed(1212 + r); np.random.seed(1337 + r)
+        rng.append((random.getstate(), np.random.get_state()))
+    batches = [_rank_batches(r, steps) for r in range(world)]
+    pk = U.param_keys(sd_s)
+    ref_grads = []
+    for s in range(steps):
+        for r, t in enumerate(reps):                       # each replica draws from its own RNG streams
+            random.setstate(rng[r][0]); np.random.set_state(rng[r][1])
+            t.step(*batches[r][s], epoch_start=(s % 2 == 0), defer_update=True)
+            rng[r] = (random.getstate(), np.random.get_state())
+        mean = [sum(t.student[k].grad for t in reps) / world for k in pk]
+        ref_grads.append([m.clone() for m in mean])
+        for t in reps:
+            for k, m in zip(pk, mean):
+                t.student[k].grad = m.clone()
+            t.finish_update()
+    res = {}
+    for _ in range(world):
+        rank, grads, params = q.get(timeout=300)
+        res[rank] = (grads, params)
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+
+    def rel(a, b):
+        num = sum(float((x.double() - y.double()).square().sum()) for x, y in zip(a, b))
+        den = sum(float(y.double().square().sum()) for y in b)
+        return (num / den) ** 0.5
+    for s in range(steps):
+        for r in range(world):
+            e = rel(res[r][0][s], ref_grads[s])
+            assert e < 1e-4, (s, r, e)
+        assert all(torch.equal(a, b) for a, b in zip(res[0][0][s], res[1][0][s]))      # identical on both ranks
+    for r in range(world):
+        e = rel(res[r][1], [reps[r].student[k].detach() for k in pk])
+        assert e < 1e-4, ("params", r, e)

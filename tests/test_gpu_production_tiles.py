@@ -1,0 +1,210 @@
+"""Exact-integer parity of the bf16 kernels AT THE SHAPES THAT SELECT THE PRODUCTION TILES.
+
+`conv3x3_halo_launch_bf16` picks its tile from the extent and the grid size: the 256-pixel x 128-channel tiles
+(<8,32,128,MI4> wide, <16,16,128,MI4> narrow) only from 512 blocks up, the 64-channel tiles <8,32,64,MI2,NT2> /
+<16,16,64,MI2,NT2> for Cout % 128 != 0, <8,16,128,MI2,NT2> and <8,16,64,MI1,NT2> for mid-sized / small grids.  The
+step of BASELINE.json configs[1] spends its time in the first four; the small operator tests (test_gpu_ops.py) only ever
+reach the last two.  Every case here asserts the tile it was written for (`ustrun_debug_last_conv_variant`) and checks
+forward (+ BatchNorm statistics), the input gradient (whole and split over two destinations with an offset window) and
+the weight gradient against torch-CPU on small-integer data: integers up to 2^8 are exact in bf16 and their sums exact
+in f32, so a fragment-layout, tap, halo, pass-constant or edge-mask slip shows as an O(1) error (rel 1e-6 bound).
+Sources carry BatchNorm affine + ReLU with power-of-two scales and integer shifts (the transforming loader, `XF`),
+gradients come from plain sources (the LDS-DMA loader); batched passes (`gN`, `gstride`) use different constants per
+pass and are compared with per-pass torch results.  Reference ops: networks/unet_parts.py:8-68 and their autograd.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def L():
+    from ustrun import _lib
+    return _lib
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc16(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda().bfloat16()
+
+
+def from_nhwc(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def r16(t):
+    return t.bfloat16().float()
+
+
+def pack16(w):
+    l = L()
+    co, ci = w.shape[:2]
+    n = 9 * ((ci + 7) // 8 * 8) * ((co + 7) // 8 * 8)
+    wf = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    wd = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    wg = w.contiguous().cuda()
+    l.check(l.lib().ustrun_pack_conv3x3(wg.data_ptr(), co, ci, wf.data_ptr(), wd.data_ptr(), 1, None))
+    return wf, wd
+
+
+def variant(th, tw, bn, mi, nt, pool, xf):
+    return th << 24 | tw << 16 | bn << 8 | mi << 4 | nt << 2 | (2 if pool else 0) | (1 if xf else 0)
+
+
+def vstr(v):
+    return "TH%d TW%d BN%d MI%d NT%d pool%d xf%d" % (v >> 24, (v >> 16) & 255, (v >> 8) & 255, (v >> 4) & 15, (v >> 2) & 3, (v >> 1) & 1, v & 1)
+
+
+# (id, N, source channels, Cout, H, W, groups, forward tile, input-gradient tile)
+#   tiles as (TH, TW, BN, MI, NT); the input gradient runs the same kernel with Cin/Cout swapped on a plain source
+CASES = [
+    # 256 px x 128 ch, wide rows: every wide layer (>= 32 px) of the step; dgrad the same tile
+    ("tall_wide_128", 8, (128,), 128, 128, 128, 2, (8, 32, 128, 4, 1), (8, 32, 128, 4, 1)),
+    # the concat conv of up4 (skip 64 ++ ConvTranspose 64 -> 64) at full resolution: 64-channel wide tile forward, the
+    # 128-channel tall tile with the two-destination epilogue for its input gradient
+    ("cat_128_to_64", 8, (64, 64), 64, 128, 128, 2, (8, 32, 64, 2, 2), (8, 32, 128, 4, 1)),
+    # 256 px x 128 ch with 16-pixel rows (extent < 32 px), ragged right / bottom edges
+    ("tall_narrow_512", 16, (512,), 512, 56, 24, 1, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1)),
+    # the bottleneck of the student's four batched passes as the step runs it: N = 64, 16 x 16, 1024 -> 1024
+    ("bottleneck_n64", 64, (1024,), 1024, 16, 16, 4, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1)),
+    # 64 -> 64 full-resolution layers (inc.conv2, up4.conv2): wide and narrow 64-channel tiles
+    ("c64_wide", 2, (64,), 64, 64, 64, 1, (8, 32, 64, 2, 2), (8, 32, 64, 2, 2)),
+    ("c64_narrow", 2, (64,), 64, 40, 24, 1, (16, 16, 64, 2, 2), (16, 16, 64, 2, 2)),
+    # mid-sized grid (>= 256 blocks of 8 x 16 px, < 512 tall blocks): two taps per barrier at 128 channels; its input
+    # gradient (512 -> 128 channels) is a small grid: 64-channel blocks with one sub-tile per wave
+    ("mid_grid_512", 8, (128,), 512, 32, 32, 1, (8, 16, 128, 2, 2), (8, 16, 64, 1, 2)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_production_tile_exact(case):
+    name, n, cs, co, h, w, G, vf, vd = case
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(len(name) * 131 + n)
+    ri = lambda lo, hi, *s: torch.randint(lo, hi + 1, s, generator=g).float()
+    ci = sum(cs)
+    gn = n // G
+    # source 0: raw conv output with per-pass BatchNorm affine + ReLU on load; source 1 (concat): a plain tensor of smaller
+    # extent placed at an offset (F.pad of unet_parts.py:62-63)
+    y0 = ri(-3, 3, n, cs[0], h, w)
+    sc = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (G, cs[0]), generator=g)]
+    sh = ri(-1, 1, G, cs[0])
+    scn = sc.repeat_interleave(gn, 0)[:, :, None, None]
+    shn = sh.repeat_interleave(gn, 0)[:, :, None, None]
+    a0 = torch.relu(y0 * scn + shn)
+    acts, srcs, keep = [a0], [], []
+    aff = torch.zeros(G, 4, cs[0])
+    aff[:, 0], aff[:, 1] = sc, sh
+    affg = aff.cuda()
+    y0g = nhwc16(y0)
+    keep += [affg, y0g]
+    srcs.append(l.nhwc_src(y0g.data_ptr(), cs[0], h, w, affg.data_ptr(), affg.data_ptr() + 4 * cs[0], relu=1,
+                           gN=gn if G > 1 else 0, gstride=4 * cs[0]))
+    if len(cs) == 2:
+        uh, uw, oy, ox = h - 2, w - 4, 1, 2
+        u = ri(-3, 3, n, cs[1], uh, uw)
+        acts.append(F.pad(u, [ox, w - uw - ox, oy, h - uh - oy]))
+        ug = nhwc16(u)
+        keep.append(ug)
+        srcs.append(l.nhwc_src(ug.data_ptr(), cs[1], uh, uw, off=(oy, ox)))
+    a = torch.cat(acts, 1).requires_grad_(True)
+    wt = ri(-2, 2, co, ci, 3, 3)
+    wr = wt.clone().requires_grad_(True)
+    dy = ri(-2, 2, n, co, h, w)
+    ref = F.conv2d(a, wr, None, 1, 1)
+    ref.backward(dy)
+    assert float(ref.detach().abs().max()) < 2 ** 24 and float(wr.grad.abs().max()) < 2 ** 24      # f32 sums stay exact
+
+    wf, wd = pack16(wt)
+    sarr = (l.Src * len(srcs))(*srcs)
+    out = torch.empty(n, h, w, co, device="cuda", dtype=torch.bfloat16)
+    rows_max = lib.ustrun_conv_mtiles(n, h, w, co)
+    stat = torch.full((rows_max, 2, co), 5.0, device="cuda")
+    rows = C.c_int(0)
+    l.check(lib.ustrun_conv3x3_fwd_rows(sarr, len(srcs), wf.data_ptr(), n, h, w, co, out.data_ptr(), stat.data_ptr(),
+                                        C.byref(rows), 1, None), "fwd")
+    got = lib.ustrun_debug_last_conv_variant()
+    assert got == variant(*vf, False, True), f"forward ran {vstr(got)}"
+    yc = from_nhwc(out.float())
+    assert rel(yc, r16(ref.detach())) < 1e-6
+    # statistics rows: per pass, sums of the STORED (bf16-rounded) outputs
+    assert rows.value % G == 0 and rows.value <= rows_max
+    st = stat[:rows.value].view(G, rows.value // G, 2, co).double().sum(1).cpu()
+    ys = yc.double().view(G, gn, co, h, w)
+    # (integer outputs: the 128-pixel f32 partial sums of y are exact; those of y^2 round, all terms positive)
+    assert float((st[:, 0] - ys.sum((1, 3, 4))).abs().max()) <= 1e-6 * float(ys.abs().sum((1, 3, 4)).max())
+    np.testing.assert_allclose(st[:, 1].numpy(), ys.square().sum((1, 3, 4)).numpy(), rtol=1e-5)
+
+    # input gradient: whole, then split into [source 0 | source 1 window]
+    dyg = nhwc16(dy)
+    da = torch.empty(n, h, w, ci, device="cuda", dtype=torch.bfloat16)
+    l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 1, None), "dgrad")
+    got = lib.ustrun_debug_last_conv_variant()
+    assert got == variant(*vd, False, False), f"input gradient ran {vstr(got)}"
+    assert rel(from_nhwc(da.float()), r16(a.grad)) < 1e-6
+    if len(cs) == 2:
+        d0 = torch.empty(n, h, w, cs[0], device="cuda", dtype=torch.bfloat16)
+        d1 = torch.full((n, uh, uw, cs[1]), 7.0, device="cuda", dtype=torch.bfloat16)
+        l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, d0.data_ptr(), cs[0], d1.data_ptr(),
+                                         uh, uw, oy, ox, 1, None), "dgrad split")
+        assert lib.ustrun_debug_last_conv_variant() == variant(*vd, False, False)
+        assert rel(from_nhwc(d0.float()), r16(a.grad[:, :cs[0]])) < 1e-6
+        assert rel(from_nhwc(d1.float()), r16(a.grad[:, cs[0]:, oy:oy + uh, ox:ox + uw])) < 1e-6
+
+    # weight gradient (all nine taps per block, split-K slabs + fixed-order reduce), then accumulated a second time
+    nb = lib.ustrun_wgrad_partials_bytes(9, ci, co, n * h * w)
+    part = torch.empty(nb // 4, device="cuda")
+    dw = torch.empty(co, ci, 3, 3, device="cuda")
+    l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 0, part.data_ptr(), nb, 1, None), "wgrad")
+    assert rel(dw.cpu(), wr.grad) < 1e-6
+    l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 1, part.data_ptr(), nb, 1, None), "wgrad acc")
+    assert rel(dw.cpu(), 2 * wr.grad) < 1e-6
+
+
+def test_convT_bf16_batched_passes_exact():
+    """ConvTranspose forward with per-pass BatchNorm constants on its source (the producer's raw output), at the
+    full-resolution level's shape class (128 -> 64 channels), and its weight gradient over the batched passes."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(77)
+    ri = lambda lo, hi, *s: torch.randint(lo, hi + 1, s, generator=g).float()
+    n, G, ci, co, h, w = 8, 4, 128, 64, 24, 40
+    gn = n // G
+    y = ri(-3, 3, n, ci, h, w)
+    sc = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (G, ci), generator=g)]
+    sh = ri(-1, 1, G, ci)
+    a = torch.relu(y * sc.repeat_interleave(gn, 0)[:, :, None, None] + sh.repeat_interleave(gn, 0)[:, :, None, None])
+    wt, b = ri(-2, 2, ci, co, 2, 2), ri(-2, 2, co)
+    du = ri(-2, 2, n, co, 2 * h, 2 * w)
+    ar, wr, br = a.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(ar, wr, br, stride=2)
+    ref.backward(du)
+    nel = 4 * ci * co
+    wf = torch.zeros(nel, dtype=torch.bfloat16, device="cuda")
+    wd = torch.zeros(nel, dtype=torch.bfloat16, device="cuda")
+    wg = wt.cuda()
+    l.check(lib.ustrun_pack_convT2x2(wg.data_ptr(), ci, co, wf.data_ptr(), wd.data_ptr(), 1, None))
+    aff = torch.zeros(G, 4, ci)
+    aff[:, 0], aff[:, 1] = sc, sh
+    affg, yg, bg, dug = aff.cuda(), nhwc16(y), b.cuda(), nhwc16(du)
+    src = l.nhwc_src(yg.data_ptr(), ci, h, w, affg.data_ptr(), affg.data_ptr() + 4 * ci, relu=1, gN=gn, gstride=4 * ci)
+    u = torch.empty(n, 2 * h, 2 * w, co, device="cuda", dtype=torch.bfloat16)
+    l.check(lib.ustrun_convT2x2_fwd(C.byref(src), wf.data_ptr(), bg.data_ptr(), n, h, w, co, u.data_ptr(), 1, None))
+    assert rel(from_nhwc(u.float()), r16(ref.detach())) < 1e-6
+    nb = max(lib.ustrun_wgrad_partials_bytes(4, ci, co, n * h * w), 512 * co * 4)
+    part = torch.empty(nb // 4, device="cuda")
+    dw, db = torch.empty(ci, co, 2, 2, device="cuda"), torch.empty(co, device="cuda")
+    l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, 1, None))
+    assert rel(dw.cpu(), wr.grad) < 1e-6 and rel(db.cpu(), br.grad) < 1e-6
+    da = torch.empty(n, h, w, ci, device="cuda", dtype=torch.bfloat16)
+    l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), 1, None))
+    assert rel(from_nhwc(da.float()), r16(ar.grad)) < 1e-6

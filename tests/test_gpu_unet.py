@@ -106,22 +106,113 @@ def test_reference_golden_small_spatial():
     np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", ["g3_unet_3_2_n4_256", "g3_unet_1_4_n2_288"])
-def test_reference_golden_full_size(name):
+def golden_argmax(g, logits):
+    """The fixture's arg-max record (tools/gen_goldens.py:128-133: packed bits for K = 2, every stride-th label
+    otherwise) against the arg-max of `logits` -> (flips, compared, smallest top-2 margin among the flipped pixels)."""
+    k = logits.shape[1]
+    amax = logits.argmax(1).numpy().astype(np.uint8)
+    top2 = logits.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]).numpy().reshape(-1)
+    if k == 2:
+        want = np.unpackbits(g["argmax"])[:amax.size]
+        flat, sel = amax.reshape(-1), slice(None)
+    else:
+        stride = max(1, amax.size // 65536)
+        want, flat, sel = g["argmax"], amax.reshape(-1)[::stride], slice(None, None, stride)
+    bad = flat != want
+    return int(bad.sum()), int(want.size), (float(margin[sel][bad].max()) if bad.any() else 0.0)
+
+
+@pytest.mark.parametrize("name", ["g3_unet_3_2_n4_256", "g3_unet_1_2_n2_384", "g3_unet_1_4_n2_288"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_reference_golden_full_size(name, dtype):
+    """Full-size forwards captured from the reference itself (fundus 256^2 N = 4, prostate 384^2 (train.py:416-418), MNMS
+    288^2 K = 4): f32 = the exact path, logits to 1e-3 and the arg-max masks compared bit for bit (a flip is accepted only
+    where the reference's own top-2 margin is within f32 rounding, 1e-4); bf16 = the production halo-tiled kernels at full
+    size: logits within 1e-2 rel-L2 (bf16 has an 8-bit mantissa; measured 3-4e-3), arg-max flips below 0.5 %."""
     g = load_golden(name)
     n, c, h, _, k = [int(v) for v in g["shape"]]
     torch.manual_seed(int(g["model_seed"]))
     sd = U.make_state_dict(c, k)
     gen = torch.Generator().manual_seed(int(g["input_seed"]))
     x = torch.randint(0, 256, (n, c, h, h), generator=gen).float() / 127.5 - 1
-    model = build_model(sd, c, k)
-    model.train()
+    from networks.unet_model import UNet
+    model = UNet(n_channels=c, n_classes=k, dtype=dtype)
+    model.load_state_dict({kk: v.detach().clone() for kk, v in sd.items()})
+    model = model.cuda().train()
     with torch.no_grad():
         logits = model(x.cuda()).cpu()
     flat = logits.flatten()
     idx = torch.from_numpy(g["sample_idx"])
-    np.testing.assert_allclose(flat[idx].numpy(), g["sample_val"], rtol=1e-3, atol=1e-4)
-    assert abs(float(flat.double().norm()) - float(g["logit_l2"])) <= 1e-4 * float(g["logit_l2"])
+    flips, total, worst = golden_argmax(g, logits)
+    print(f"{name} {dtype}: arg-max flips {flips}/{total}, largest margin among flips {worst:.2e}")
+    if dtype == "f32":
+        np.testing.assert_allclose(flat[idx].numpy(), g["sample_val"], rtol=1e-3, atol=1e-4)
+        assert abs(float(flat.double().norm()) - float(g["logit_l2"])) <= 1e-4 * float(g["logit_l2"])
+        assert worst < 1e-4, (flips, worst)              # bit-exact wherever the arg-max is decided beyond rounding
+        assert flips <= 1e-4 * total
+    else:
+        ref = torch.from_numpy(g["sample_val"]).double()
+        err = float((flat[idx].double() - ref).norm() / ref.norm())
+        assert err < 1e-2, err
+        assert abs(float(flat.double().norm()) - float(g["logit_l2"])) <= 1e-2 * float(g["logit_l2"])
+        assert flips <= 5e-3 * total, (flips, total)
+
+
+def test_reference_golden_full_size_backward():
+    """One forward + backward at fundus 256^2, N = 4, full width, against gradient norms and samples captured from the
+    reference (G3b): the f32 path; loss = logits.square().mean().  Bars: loss 1e-5, per-parameter gradient norms 2e-3,
+    BN running statistics 1e-4."""
+    g = load_golden("g3b_unet_3_2_n4_256_bwd")
+    n, c, h, _, k = [int(v) for v in g["shape"]]
+    torch.manual_seed(int(g["model_seed"]))
+    sd = U.make_state_dict(c, k)
+    gen = torch.Generator().manual_seed(int(g["input_seed"]))
+    x = torch.randint(0, 256, (n, c, h, h), generator=gen).float() / 127.5 - 1
+    model = build_model(sd, c, k).train()
+    logits = model(x.cuda())
+    loss = logits.square().mean()
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    norms = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-9)
+    samples = np.stack([p.grad.flatten()[torch.linspace(0, p.numel() - 1, 16).long().cuda()].cpu().numpy() for p in model.parameters()])
+    scale = np.abs(g["grad_samples"]).max(1, keepdims=True) + 1e-12
+    assert float(np.abs((samples - g["grad_samples"]) / scale).max()) < 5e-3
+    msd = model.state_dict()
+    rm = np.array([float(v.double().sum()) for kk, v in msd.items() if kk.endswith("running_mean")])
+    rv = np.array([float(v.double().sum()) for kk, v in msd.items() if kk.endswith("running_var")])
+    np.testing.assert_allclose(rm, g["rm_sums"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv, g["rv_sums"], rtol=1e-4, atol=1e-5)
+
+
+def test_bf16_config1_shape_tracks_f32():
+    """BASELINE.json configs[1]'s shape -- fundus 256^2, 16 images, full width, bf16 -- against the f32 HIP path on the same
+    weights and inputs: logits <= 1e-2 rel-L2 (bf16 operand rounding through 18 convolutions; measured ~4e-3), arg-max
+    agreement >= 99.5 %, and every parameter gradient of one backward within 5e-2 rel-L2 of the f32 path's (a wrong tap,
+    halo row or pass constant in a production tile moves a layer's gradient by O(1))."""
+    from networks.unet_model import UNet
+    torch.manual_seed(1337)
+    sd = U.make_state_dict(3, 2)
+    gen = torch.Generator().manual_seed(16)
+    x = (torch.randint(0, 256, (16, 3, 256, 256), generator=gen).float() / 127.5 - 1).cuda()
+    dl = torch.randn(16, 2, 256, 256, generator=gen).cuda() / (16 * 2 * 256 * 256)
+    out = {}
+    for dt in ("f32", "bf16"):
+        m = UNet(3, 2, dtype=dt)
+        m.load_state_dict({kk: v.clone() for kk, v in sd.items()})
+        m = m.cuda().train()
+        lg = m(x)
+        lg.backward(dl)
+        out[dt] = (lg.detach().float().cpu(), [p.grad.detach().cpu() for p in m.parameters()], [kk for kk, _ in m.named_parameters()])
+        del m, lg
+    l32, l16 = out["f32"][0], out["bf16"][0]
+    assert rel_l2(l16, l32) < 1e-2, rel_l2(l16, l32)
+    assert float((l16.argmax(1) == l32.argmax(1)).float().mean()) >= 0.995
+    errs = {kk: rel_l2(g16, g32) for kk, g16, g32 in zip(out["f32"][2], out["bf16"][1], out["f32"][1])}
+    worst = max(errs, key=errs.get)
+    print("bf16 vs f32 gradient rel-L2: worst %s %.3e, median %.3e" % (worst, errs[worst], float(np.median(list(errs.values())))))
+    assert errs[worst] < 5e-2, (worst, errs[worst])
 
 
 def test_cpu_tensor_is_refused():
@@ -153,6 +244,16 @@ def test_bf16_compute_tracks_f32(c, k, n, h, w, base):
     ref.square().mean().backward()
     errs = [rel_l2(p.grad.cpu(), ref_sd[key].grad) for (name, p), key in zip(m.named_parameters(), U.param_keys(ref_sd))]
     assert max(errs) < 0.8 and float(np.median(errs)) < 0.4, (max(errs), float(np.median(errs)))
+    # the discriminating bound: against the f32 HIP path on the same weights, whose only difference is bf16 rounding of
+    # operands and stored activations -- a wrong tap or fragment would move a layer by O(1)
+    m32 = UNet(c, k, base_channels=base, dtype="f32")
+    m32.load_state_dict({kk: v.clone() for kk, v in sd.items()})
+    m32 = m32.cuda().train()
+    l32 = m32(x.cuda())
+    assert rel_l2(lg.detach().cpu(), l32.detach().cpu()) < 1e-2
+    l32.square().mean().backward()
+    e32 = {n1: rel_l2(p.grad.cpu(), q.grad.cpu()) for (n1, p), (_, q) in zip(m.named_parameters(), m32.named_parameters())}
+    assert float(np.median(list(e32.values()))) < 5e-2, e32
 
 
 @pytest.mark.parametrize("dtype,base,n,hw", [("bf16", 64, 2, 32), ("f32", 16, 2, 32), ("bf16", 16, 3, 48)])

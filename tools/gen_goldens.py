@@ -133,6 +133,29 @@ def g3_unet_full(name, c, k, n, h):
          logit_l2=float(flat.double().norm()), sample_idx=idx, sample_val=flat[idx], argmax=packed)
 
 
+def g3b_unet_backward(name, c, k, n, h):
+    """One forward + backward of the reference UNet at a FULL-SIZE shape (same weights and input as G3): per-parameter
+    gradient norms + 16 samples per tensor for loss = logits.square().mean(), BN running-statistic sums after the call."""
+    torch.manual_seed(1337)
+    model = UNet(n_channels=c, n_classes=k)
+    g = torch.Generator().manual_seed(1337)
+    x = torch.randint(0, 256, (n, c, h, h), generator=g).float() / 127.5 - 1
+    model.train()
+    logits = model(x)
+    loss = logits.square().mean()
+    loss.backward()
+    norms, samples = [], []
+    for p in model.parameters():
+        gflat = p.grad.flatten()
+        norms.append(float(gflat.double().norm()))
+        samples.append(gflat[torch.linspace(0, gflat.numel() - 1, 16).long()].numpy())
+    bufs = model.state_dict()
+    save(name, model_seed=1337, input_seed=1337, shape=np.array([n, c, h, h, k]), loss=loss.detach(),
+         logit_l2=float(logits.detach().double().norm()), grad_norms=np.array(norms), grad_samples=np.stack(samples),
+         rm_sums=np.array([float(v.double().sum()) for kk, v in bufs.items() if kk.endswith("running_mean")]),
+         rv_sums=np.array([float(v.double().sum()) for kk, v in bufs.items() if kk.endswith("running_var")]))
+
+
 def g4_dice():
     rec = {}
     for K in (2, 4):
@@ -277,11 +300,15 @@ def g8_sgd():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "g3b":          # only the round-2 addition
+        g3b_unet_backward("g3b_unet_3_2_n4_256_bwd", 3, 2, 4, 256)
+        sys.exit(0)
     g1_blocks()
     g2_unet_small_spatial()
     g3_unet_full("g3_unet_3_2_n4_256", 3, 2, 4, 256)
     g3_unet_full("g3_unet_1_2_n2_384", 1, 2, 2, 384)
     g3_unet_full("g3_unet_1_4_n2_288", 1, 4, 2, 288)
+    g3b_unet_backward("g3b_unet_3_2_n4_256_bwd", 3, 2, 4, 256)
     g4_dice()
     g5_ramps()
     g6_metrics()

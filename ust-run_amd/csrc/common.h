@@ -94,6 +94,7 @@ bool halo_tall_tile(const IgemmArgs& a);
 int halo_stat_rows_used(const IgemmArgs& a);
 int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st);
 int halo_stat_rows(int N, int H, int W);
+int halo_last_variant();
 bool convT_fwd_supported(const IgemmArgs& a);
 bool convT_dgrad_supported(const IgemmArgs& a);
 int convT_fwd_launch_bf16(const IgemmArgs& a, hipStream_t st);

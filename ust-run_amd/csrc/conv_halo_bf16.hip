@@ -499,8 +499,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     }
 }
 
+int g_last_variant = 0;    // TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF of the last launch (tests: ustrun_debug_last_conv_variant)
+
 template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF>
 int launch_xf(const IgemmArgs& a, hipStream_t st) {
+    g_last_variant = TH << 24 | TW << 16 | BN << 8 | MI << 4 | NT << 2 | (POOL ? 2 : 0) | (XF ? 1 : 0);
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
     constexpr int DSLOTS = ((TH + 2) * (TW + 2) * 5 + 63) / 64 * 64;
     constexpr int AIT = (DSLOTS + 255) / 256, NSTG = (9 + NT - 1) / NT, BATCH = (AIT + NSTG - 2) / (NSTG - 1);
@@ -524,6 +527,8 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+int halo_last_variant() { return g_last_variant; }
 
 // stat rows the halo kernel writes for an N x H x W output (one per 8 x 16 pixels)
 int halo_stat_rows(int N, int H, int W) { return N * cdiv(H, 8) * cdiv(W, 16); }

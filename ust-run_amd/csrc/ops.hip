@@ -103,6 +103,8 @@ static ustrun_src_t src_slice(const ustrun_src_t& s, int g, int gN, int dtype) {
     return t;
 }
 
+extern "C" int ustrun_debug_last_conv_variant(void) { return halo_last_variant(); }
+
 extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W, int Cout,
                                   void* y, float* stat, int dtype, ustrun_stream_t s) {
     return ustrun_conv3x3_fwd_rows(srcs, nsrc, w_fwd, N, H, W, Cout, y, stat, nullptr, dtype, s);

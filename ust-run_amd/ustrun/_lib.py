@@ -78,6 +78,7 @@ SIGNATURES = {
     "ustrun_seg_loss_bwd": (i32, [fp, vp, fp, i32, i32, i32, i32, fp, fp, f32, f32, f32, fp, vp]),
     "ustrun_dice_counts": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ustrun_sgd_ema": (i32, [fp, fp, fp, fp, i64, f32, f32, f32, i32, f32, f32, vp]),
+    "ustrun_debug_last_conv_variant": (i32, []),
     "ustrun_profile_enable": (i32, [i32]),
     "ustrun_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ustrun_profile_stream": (i32, [vp, i32]),
