@@ -257,6 +257,13 @@ int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const float* x, const
  * TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF (0 before any) -- lets a parity test assert that its shape
  * reached the production tile it was written for                                                   */
 int ustrun_debug_last_conv_variant(void);
+/* test / tuning aid: process-wide kernel-selection flags, returns the previous value.  bit 0: run the 64 -> 64 channel
+ * full-resolution convolutions on the halo-tiled kernel instead of the weight-stationary row-streaming one (A/B timing
+ * inside one process); the last-variant code of the streaming kernel is 0x57530000 | XF                       */
+int ustrun_debug_flags(int flags);
+/* development aid: while a device buffer of >= 32 * blocks u64 is set here, the streaming kernel runs its phase-stamping
+ * diagnostic build and writes per-wave cycle sums there (tools/ab_ws64.py --diag); NULL restores the product kernel */
+int ustrun_debug_buffer(void* device_u64);
 
 /* ---- optional launch profiler (bench.py): HIP events recorded on the launch stream around every
  * implicit-GEMM (kind 0) / weight-gradient (kind 1) launch while enabled; collect synchronises on

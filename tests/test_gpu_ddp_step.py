@@ -101,8 +101,8 @@ def _worker_oracle(rank, world, port, q, steps):
     grads = []
     for s, b in enumerate(_rank_batches(rank, steps)):
         tr.step(*[t.cuda() for t in b], epoch_start=(s % 2 == 0))
-        grads.append([(v / world).cpu() for v in tr.grad_views])      # flat_g holds the SUM over ranks
-    q.put((rank, grads, [p.detach().cpu() for p in stu.parameters()]))
+        grads.append([(v / world).cpu().numpy() for v in tr.grad_views])      # flat_g holds the SUM over ranks
+    q.put((rank, grads, [p.detach().cpu().numpy() for p in stu.parameters()]))   # (numpy: pickled by value, no fd passing)
     dist.destroy_process_group()
 
 
@@ -149,7 +149,7 @@ def test_reduced_gradient_is_the_mean_of_independent_oracle_replicas():
     res = {}
     for _ in range(world):
         rank, grads, params = q.get(timeout=300)
-        res[rank] = (grads, params)
+        res[rank] = ([[torch.from_numpy(a) for a in g] for g in grads], [torch.from_numpy(a) for a in params])
     for p in procs:
         p.join(300)
         assert p.exitcode == 0

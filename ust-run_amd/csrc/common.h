@@ -95,6 +95,13 @@ int halo_stat_rows_used(const IgemmArgs& a);
 int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st);
 int halo_stat_rows(int N, int H, int W);
 int halo_last_variant();
+void set_last_variant(int v);
+// weight-stationary row-streaming kernel for 64 -> 64 channels at full resolution (conv_ws64_bf16.hip)
+bool ws64_supported(const IgemmArgs& a);
+int ws64_stat_rows(const IgemmArgs& a);
+int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st);
+void ws64_set_debug_buffer(void* p);
+extern int g_debug_flags;                  // ustrun_debug_flags: bit 0 = keep the 64 -> 64 layers on the tiled kernel
 bool convT_fwd_supported(const IgemmArgs& a);
 bool convT_dgrad_supported(const IgemmArgs& a);
 int convT_fwd_launch_bf16(const IgemmArgs& a, hipStream_t st);

@@ -529,6 +529,7 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int halo_last_variant() { return g_last_variant; }
+void set_last_variant(int v) { g_last_variant = v; }
 
 // stat rows the halo kernel writes for an N x H x W output (one per 8 x 16 pixels)
 int halo_stat_rows(int N, int H, int W) { return N * cdiv(H, 8) * cdiv(W, 16); }

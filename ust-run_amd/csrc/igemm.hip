@@ -280,6 +280,7 @@ int igemm_mtiles(int64_t M, int Cout) { (void)Cout; return cdiv(M, 128); }
 
 // stat rows actually written by the kernel igemm_launch will pick
 int igemm_stat_rows_used(const IgemmArgs& a, int dtype) {
+    if (dtype == USTRUN_BF16 && !(g_debug_flags & 1) && ws64_supported(a)) return ws64_stat_rows(a);
     if (dtype == USTRUN_BF16 && halo_supported(a)) return halo_stat_rows_used(a);
     return cdiv(a.M, 128);
 }
@@ -306,7 +307,8 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     for (int i = 0; i < a.nsrc; ++i) grouped |= a.src[i].gN > 0;
     USTRUN_CHECK(!grouped || dtype == USTRUN_BF16, "igemm: batched passes reached a kernel without per-pass BatchNorm constants");
     if (dtype == USTRUN_BF16) {
-        if (halo_supported(a)) rc = conv3x3_halo_launch_bf16(a, st);
+        if (!(g_debug_flags & 1) && ws64_supported(a)) rc = conv3x3_ws64_launch_bf16(a, st);
+        else if (halo_supported(a)) rc = conv3x3_halo_launch_bf16(a, st);
         else if (convT_fwd_supported(a)) rc = convT_fwd_launch_bf16(a, st);
         else if (convT_dgrad_supported(a)) rc = convT_dgrad_launch_bf16(a, st);
         else if (grouped) { set_error("igemm: batched passes reached a kernel without per-pass BatchNorm constants"); rc = 1; }

@@ -104,6 +104,9 @@ static ustrun_src_t src_slice(const ustrun_src_t& s, int g, int gN, int dtype) {
 }
 
 extern "C" int ustrun_debug_last_conv_variant(void) { return halo_last_variant(); }
+namespace ustrun { int g_debug_flags = 0; }
+extern "C" int ustrun_debug_buffer(void* device_u64) { ws64_set_debug_buffer(device_u64); return 0; }
+extern "C" int ustrun_debug_flags(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
 
 extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W, int Cout,
                                   void* y, float* stat, int dtype, ustrun_stream_t s) {

@@ -79,6 +79,8 @@ SIGNATURES = {
     "ustrun_dice_counts": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ustrun_sgd_ema": (i32, [fp, fp, fp, fp, i64, f32, f32, f32, i32, f32, f32, vp]),
     "ustrun_debug_last_conv_variant": (i32, []),
+    "ustrun_debug_flags": (i32, [i32]),
+    "ustrun_debug_buffer": (i32, [vp]),
     "ustrun_profile_enable": (i32, [i32]),
     "ustrun_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ustrun_profile_stream": (i32, [vp, i32]),
