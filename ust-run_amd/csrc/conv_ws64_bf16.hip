@@ -54,13 +54,18 @@ struct Cur {            // one group of 8 input rows of one item (or nothing)
 };
 
 // One iteration u of a block's group sequence (groups = 8 input rows of an item, S + 1 per item):
-//   load   group u      -> registers (buffer loads: out-of-image items read as zero without touching memory)
+//   fetch  group u      -> registers (buffer loads: out-of-image items read as zero without touching memory)
 //   write  group u - 1  -> ring bank (u - 1) % 3, transformed, under the MFMAs
 //   step   of group u - 2 (if it is not the first of its item): reads banks (u - 3) % 3 and (u - 2) % 3
-// FAST = the steady state (all three present, interior tile): one straight-line block the scheduler can interleave;
-// everything else (item boundaries, ragged edges, the block's last two iterations) takes the general body.
-// DIAG: a development build that stamps the phases of the steady-state iteration with s_memtime and adds the differences
-// per wave into p.dbg (read the SHARES, not the run time: the stamps fence the schedule); never launched by the product.
+// The iteration is ONE straight-line body that always runs in full: what does not apply (no step at an item's first group,
+// nothing left to fetch, pixels beyond a ragged edge) is switched off per lane through the buffer instructions' range check
+// (an offset with bit 31 set is dropped by the hardware) and through selects -- never through branches.  Alternative bodies
+// for the special cases were tried first: the register allocator then gives the loop-carried values (fetches in flight,
+// accumulators of the half whose epilogue is owed) different registers per path and the copies at the joins wait for the
+// fetches, serialising memory and MFMAs.  The price: an item's first iteration runs its 144 MFMAs on stale data for nothing
+// (one in S + 1).
+// DIAG: a development build that stamps the two halves and the barrier with s_memtime and adds the differences per wave into
+// p.dbg (read the SHARES, not the run time: the stamps fence the schedule); never launched by the product.
 __device__ __forceinline__ unsigned long long stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -82,7 +87,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
     const __bf16* srcp = (const __bf16*)S.ptr;
     const int H = a.Hb, W = a.Wb;
     const int sH = (int)S.sH, sW = (int)S.sW;
-    const unsigned img_bytes = (unsigned)(S.sN * 2);
+    // one buffer descriptor per tensor (ws64_supported keeps them under 2 GiB); the image goes into the scalar offset
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)srcp, 0, (int)min((long)a.N * S.sN * 2, 0x7fffffffL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out0, 0, (int)min((long)a.N * H * W * 128, 0x7fffffffL), 0x00020000);
+    const int img_bytes = (int)(S.sN * 2), out_bytes = H * W * 128;
 
     // ---- the block's weights: A fragments of v_mfma_f32_32x32x16_bf16, row = output channel 32 wn + l31, k = 8 lh + j
     // of the 16-channel step ks; packed layout [tap][Cin/8][Cout][8] -> one 16-byte load each.  The input gradient
@@ -98,13 +106,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
                 const int wt = wflip ? 8 - tap : tap;
                 Wr[tap][ks] = *(const bf16x8*)(Wp + (((long)wt * 8 + 2 * ks + lh) * 64 + 32 * wn + l31) * 8);
             }
-        // a use in front of the loop: the compiler otherwise keeps these loads "pending" at the loop head and drains
-        // vmcnt(0) -- the row fetches in flight -- before the first MFMA of every iteration
+        // A use in front of the loop: the compiler otherwise keeps these loads "pending" at the loop head and drains vmcnt(0)
+        // -- the row fetches in flight -- before the first MFMA of every iteration.  Constraint "a": the fragments live in
+        // the accumulator half of the register file, which MFMA reads directly; the 256 arch VGPRs stay free.
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+a"(Wr[tap][ks]));      // ("a": the fragments live in the accumulator file,
-                                                                                      //  which MFMA reads directly; the 256 arch VGPRs stay free)
+            for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+a"(Wr[tap][ks]));
     }
 
     // ---- staging geometry (the same for every group): item q = tid + 256 i of the group's [8 rows][34 px][8 octets] ----
@@ -118,12 +126,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
     }
     const int loff0 = (tid >> 3) * PITCH + (tid & 7) * 16;      // ring offset of item i: loff0 + i * 32 * PITCH
     const int afrag0 = l31 * PITCH + lh * 16;
+    // the ninth item exists for threads 0..127 only (2176 = 8.5 x 256): the others park theirs in a dummy region
+    const int wd8_dummy = RINGB + 4 * EWAVE + (tid & 127) * 16;
+    // epilogue: lane (pp, o) stores pixel pp (+16) of a row, channel octet o of the wave's 32 channels
+    const int pp = lane >> 2, o = lane & 3;
+    const int st_lane = (pp * 64 + 32 * wn + 8 * o) * 2;
 
     // ---- cursors over the block's sequence of groups: items [it0, it1), S + 1 groups each ----
     const int it0 = blockIdx.x * p.ipb, it1 = min(it0 + p.ipb, p.items);
     auto decode = [&](int item, int k) __attribute__((always_inline)) {
         Cur c;
-        c.valid = item < it1; c.item = item; c.k = k;
+        c.valid = item < it1; c.k = k;
+        item = min(item, it1 - 1);                 // (geometry stays inside the tensor when there is nothing left)
+        c.item = item;
         const int per = p.sx * p.sy;
         c.img = item / per;
         const int rem = item - c.img * per;
@@ -139,9 +154,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
         if (c.k < c.S) { Cur n = c; n.k = c.k + 1; return n; }
         return decode(c.item + 1, 0);
     };
-    Cur cl = decode(it0, 0), cw, cc;
-    cw.valid = cc.valid = 0; cw.item = cc.item = 0; cw.img = cc.img = 0; cw.x0 = cc.x0 = 0; cw.ybeg = cc.ybeg = 0;
-    cw.S = cc.S = 0; cw.k = cc.k = 0;
+    Cur cl = decode(it0, 0);
+    Cur cw = cl, cc = cl, cp = cl;       // write / step / owed-half cursors, nothing there yet
+    cw.valid = cc.valid = cp.valid = 0;
 
     // ONE register set: item i of the group fetched last iteration is transformed and written to the ring in the second half
     // of this iteration, and the same registers are refilled at once with item i of the next group -- every fetch gets exactly
@@ -156,21 +171,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 
-    // byte offsets of group c's items inside its image (0x80000000 = beyond num_records: the buffer load returns zero without
-    // touching memory) and their in-image mask.  Computed in the shadow of the first half's MFMAs.
+    // byte offsets of group c's items inside its image (bit 31 set = beyond num_records: the buffer load returns zero without
+    // touching memory) and their in-image mask; computed in the shadow of the first half's MFMAs
     unsigned offL[NR], okmL = 0;
+    unsigned xokm = 0;             // per item: its pixel column lies inside the image (changes with the item's strip only)
+    int xok_x0 = -1 << 20;
     auto offsets_one = [&](const Cur& c, int i) __attribute__((always_inline)) {
         const int y0g = c.ybeg - 1 + 8 * c.k;
         const int nrows = !c.valid ? 0 : (c.k == c.S ? 2 : 8);  // the item's last group: only its two halo rows are read
+        // rows of the group that exist: r < nrows and 0 <= y0g + r < H  (scalar: one 8-bit mask per group)
+        const int lo = max(0, -y0g), hi = min(nrows, H - y0g);
+        const unsigned ymask = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
         const int gbase = (y0g * sH + (c.x0 - 1) * sW) * 2;
-        const int r = rp[i] >> 8, px = rp[i] & 255;
-        const unsigned ok = (unsigned)(i < NR - 1 || tid < 128) & (unsigned)(r < nrows) & (unsigned)((unsigned)(y0g + r) < (unsigned)H) &
-                            (unsigned)((unsigned)(c.x0 - 1 + px) < (unsigned)W);
+        const unsigned ok = (ymask >> (rp[i] >> 8)) & (xokm >> i) & 1u;
         offL[i] = (unsigned)(gbase + goffb[i]) | ((ok ^ 1u) << 31);      // (no select: hipcc turns it into an exec-masked branch)
         okmL = (okmL & ~(1u << i)) | (ok << i);
     };
-    auto fetch_one = [&](const __amdgpu_buffer_rsrc_t rs, int i) __attribute__((always_inline)) {          // offL describes the group
-        stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, offL[i], 0, 0);
+    auto xok_update = [&](const Cur& c) __attribute__((always_inline)) {       // when the fetch cursor moves to another strip
+        if (c.x0 != xok_x0) {
+            xok_x0 = c.x0;
+            xokm = 0;
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+                xokm |= ((unsigned)(i < NR - 1 || tid < 128) & (unsigned)((unsigned)(c.x0 - 1 + (rp[i] & 255)) < (unsigned)W)) << i;
+        }
     };
     // BatchNorm affine + ReLU in f32, back to bf16, zero padding applied after the activation
     auto xform = [&](u32x4 raw, bool ok) __attribute__((always_inline)) {
@@ -207,6 +231,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
     // patch rows 2..5): the epilogue of one half runs under the MFMAs of the other, across the iteration boundary for
     // half 1.  acc persists across iterations. ----
     f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     int rowaddr[6];
     // fragment rows q = 0..3 of a half for kernel column dx, channel step ks (constants at every call site) ...
     auto frag_read = [&](auto half_c, int dx, int ks, bf16x8* pf) __attribute__((always_inline)) {
@@ -218,15 +246,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
     auto mma6 = [&](auto half_c, int dx, int ks, const bf16x8* pf) __attribute__((always_inline)) {
         constexpr int HF = decltype(half_c)::value;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)                // (alternating the two accumulators instead measured 2-4 % slower)
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
                 acc[2 * HF + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[dy * 3 + dx][ks], pf[i + dy], acc[2 * HF + i], 0, 0, 0);
-    };
-    auto mma_group = [&](auto half_c, int dx, int ks) __attribute__((always_inline)) {
-        bf16x8 pf[4];
-        frag_read(half_c, dx, ks, pf);
-        mma6(half_c, dx, ks, pf);
     };
     auto zero_half = [&](auto half_c) __attribute__((always_inline)) {
         constexpr int HF = decltype(half_c)::value;
@@ -252,167 +275,145 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
             }
         }
     };
-    auto epi_B = [&](auto half_c, int tt, const Cur& c, auto full_c) __attribute__((always_inline)) {     // tt = 0..3: row 2 HF + tt / 2, pixel half tt & 1
+    // tt = 0..3: row 2 HF + tt / 2 of the wave, pixel half tt & 1; `live`: the step exists (wave-uniform)
+    auto epi_B = [&](auto half_c, int tt, const Cur& c, bool live) __attribute__((always_inline)) {
         constexpr int HF = decltype(half_c)::value;
-        constexpr bool FULL = decltype(full_c)::value;
-        const int yo = c.ybeg + 8 * (c.k - 1) + 4 * wm;           // first output row of this wave
-        const int ylim = min(c.ybeg + p.seg, H);
-        const int pp = lane >> 2, o = lane & 3;
-        __bf16* outp = (__bf16*)a.out0 + (((long)c.img * H + yo) * W + c.x0) * 64 + 32 * wn + 8 * o;
         const int i = 2 * HF + (tt >> 1), px = 16 * (tt & 1) + pp;
-        const bf16x8 v = *(const bf16x8*)(Ew + (i * 32 + px) * EPITCH + o * 16);
-        const bool inimg = FULL || (yo + i < ylim && c.x0 + px < W);
-        if (inimg) *(bf16x8*)(outp + ((long)i * W + px) * 64) = v;
+        const int y = c.ybeg + 8 * (c.k - 1) + 4 * wm + i;
+        const int ylim = min(c.ybeg + p.seg, H);
+        u32x4 u = *(const u32x4*)(Ew + (i * 32 + px) * EPITCH + o * 16);
+        const bool inimg = live & (y < ylim) & (c.x0 + px < W);
+        const unsigned voff = (unsigned)(st_lane + (tt & 1) * 2048) | (inimg ? 0u : 0x80000000u);
+        // (the scalar offset is wave-uniform; said explicitly, or hipcc wraps the store in a waterfall loop)
+        __builtin_amdgcn_raw_buffer_store_b128(u, ro, voff, __builtin_amdgcn_readfirstlane(c.img * out_bytes + (y * W + c.x0) * 128), 0);
         if constexpr (STAT) {
 #pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = inimg ? u[e] : 0u;
+            const bf16x8 v = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = inimg ? (float)v[e] : 0.f;           // statistics see the stored values
+                const float f = (float)v[e];           // statistics see the stored values
                 s1[e] += f;
                 s2[e] += f * f;
             }
         }
     };
-    auto stat_flush = [&](const Cur& c) __attribute__((always_inline)) {       // after the item's last step: one partial row per (item, wm), this wave's 32 channels
+    auto stat_flush = [&](const Cur& c) __attribute__((always_inline)) {       // one partial row per (item, wm), this wave's 32 channels
         if constexpr (STAT) {
-            if (c.k == c.S) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 8; ++e) {
 #pragma unroll
-                    for (int d = 4; d < 64; d <<= 1) {
-                        s1[e] += __shfl_xor(s1[e], d);
-                        s2[e] += __shfl_xor(s2[e], d);
-                    }
+                for (int d = 4; d < 64; d <<= 1) {
+                    s1[e] += __shfl_xor(s1[e], d);
+                    s2[e] += __shfl_xor(s2[e], d);
                 }
-                if (lane < 4) {
-                    float* row = a.stat + ((long)(c.item * 2 + wm) * 2) * 64 + 32 * wn + 8 * lane;
-                    *(f32x4*)row = (f32x4){s1[0], s1[1], s1[2], s1[3]};
-                    *(f32x4*)(row + 4) = (f32x4){s1[4], s1[5], s1[6], s1[7]};
-                    *(f32x4*)(row + 64) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
-                    *(f32x4*)(row + 68) = (f32x4){s2[4], s2[5], s2[6], s2[7]};
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
             }
-        }
-    };
-    Cur cp = cw;               // the step whose second half's epilogue is still owed (pend)
-    bool pend = false;
-    auto drain = [&]() __attribute__((always_inline)) {       // the owed half, not overlapped (item boundaries, the block's end)
-        if (pend) {
-            epi_A(ic<1>{});
+            if (lane < 4) {
+                float* row = a.stat + ((long)(c.item * 2 + wm) * 2) * 64 + 32 * wn + 8 * lane;
+                *(f32x4*)row = (f32x4){s1[0], s1[1], s1[2], s1[3]};
+                *(f32x4*)(row + 4) = (f32x4){s1[4], s1[5], s1[6], s1[7]};
+                *(f32x4*)(row + 64) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
+                *(f32x4*)(row + 68) = (f32x4){s2[4], s2[5], s2[6], s2[7]};
+            }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) epi_B(ic<1>{}, t, cp, std::false_type{});
-            stat_flush(cp);
-            pend = false;
+            for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
         }
     };
 
     unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0, dt1 = 0;
-    int m = 0;             // iteration u mod 3: the step reads banks m and m + 1, the write goes to bank m + 2
-    auto iteration = [&]() __attribute__((always_inline)) {
-        const int bA = m, bB = m == 2 ? 0 : m + 1, bW = m == 0 ? 2 : m - 1;
-        const bool do_mma = cc.valid && cc.k >= 1;
-        // the step's fragment rows: patch rows 4 wm .. 4 wm + 5 of the 10 (8 in bank A, 2 in bank B)
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int r = 4 * wm + q;
-            const int slot = r < 8 ? bA * 8 + r : bB * 8 + (r - 8);
-            rowaddr[q] = slot * ROWB + afrag0;
-        }
+    bool pend = false;     // the previous iteration ran a step: the epilogue of its second half is owed (cursor cp)
+    load_consts(cl);
+    // The iteration, with the ring phase m = u mod 3 a compile-time constant (the loop below is unrolled three times): the step
+    // reads banks m and m + 1, the write goes to bank m + 2, and every LDS address is a lane constant plus an immediate.
+    // Patch rows 4 wm .. 4 wm + 5 of the step's 10 (8 in bank A, 2 in bank B): wave row wm = 0 reads bank A rows 0..5, wm = 1
+    // bank A rows 4..7 and bank B rows 0, 1 -- two lane bases, the row picked by an immediate.
+    const int frA = afrag0 + 4 * wm * ROWB;                       // + bank A * BANKB + q * ROWB          (q < 4 or wm == 0)
+    const int frB = afrag0 + (4 * wm - 8) * ROWB;                 // + bank B * BANKB + q * ROWB          (q >= 4 and wm == 1)
+    const bool hiB = wm == 1;
+    auto iteration = [&](auto m_c) __attribute__((always_inline)) {
+        constexpr int bA = decltype(m_c)::value, bB = bA == 2 ? 0 : bA + 1, bW = bA == 0 ? 2 : bA - 1;
+        const bool live = cc.valid && cc.k >= 1;
+        rowaddr[0] = frA + bA * BANKB; rowaddr[1] = rowaddr[0] + ROWB; rowaddr[2] = rowaddr[0] + 2 * ROWB; rowaddr[3] = rowaddr[0] + 3 * ROWB;
+        rowaddr[4] = hiB ? frB + bB * BANKB + 4 * ROWB : frA + bA * BANKB + 4 * ROWB;
+        rowaddr[5] = rowaddr[4] + ROWB;
         char* wdst = ring + bW * BANKB + loff0;
+        char* wd8 = tid < 128 ? wdst + 8 * (32 * PITCH) : smem + wd8_dummy;
         const Cur cn = advance(cl);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(srcp + (long)cl.img * S.sN), 0, (int)img_bytes, 0x00020000);
-        const bool fast = do_mma && cw.valid && cl.valid && cc.x0 + TW <= W && cc.ybeg + 8 * cc.k <= min(cc.ybeg + p.seg, H) &&
-                          (!pend || (cp.x0 + TW <= W && cp.ybeg + 8 * cp.k <= min(cp.ybeg + p.seg, H)));
-        if (fast) {
-            // ---- steady state: two straight-line blocks (one per half), each 12 groups of 4 fragment reads + 6 MFMAs with the
-            // reads of group g + 1 issued in front of the MFMAs of group g and everything else threaded between the groups ----
-            auto body = [&](auto pend_c) __attribute__((always_inline)) {
-                constexpr bool PEND = decltype(pend_c)::value;
-                bf16x8 pfa[4], pfb[4];
-                if constexpr (DIAG) dt0 = stamp();
-                zero_half(ic<0>{});
-                // half 0 (rows 0, 1)  ||  the owed epilogue of the previous step's half 1, this iteration's fetch offsets
-                frag_read(ic<0>{}, 0, 0, pfa);
-                frag_read(ic<0>{}, 0, 1, pfb); mma6(ic<0>{}, 0, 0, pfa); if constexpr (PEND) epi_A(ic<1>{});
-                frag_read(ic<0>{}, 0, 2, pfa); mma6(ic<0>{}, 0, 1, pfb); offsets_one(cl, 0);
-                frag_read(ic<0>{}, 0, 3, pfb); mma6(ic<0>{}, 0, 2, pfa); offsets_one(cl, 1);
-                frag_read(ic<0>{}, 1, 0, pfa); mma6(ic<0>{}, 0, 3, pfb); if constexpr (PEND) epi_B(ic<1>{}, 0, cp, std::true_type{});
-                frag_read(ic<0>{}, 1, 1, pfb); mma6(ic<0>{}, 1, 0, pfa); offsets_one(cl, 2);
-                frag_read(ic<0>{}, 1, 2, pfa); mma6(ic<0>{}, 1, 1, pfb); if constexpr (PEND) epi_B(ic<1>{}, 1, cp, std::true_type{});
-                frag_read(ic<0>{}, 1, 3, pfb); mma6(ic<0>{}, 1, 2, pfa); offsets_one(cl, 3);
-                frag_read(ic<0>{}, 2, 0, pfa); mma6(ic<0>{}, 1, 3, pfb); if constexpr (PEND) epi_B(ic<1>{}, 2, cp, std::true_type{});
-                frag_read(ic<0>{}, 2, 1, pfb); mma6(ic<0>{}, 2, 0, pfa); offsets_one(cl, 4); offsets_one(cl, 5);
-                frag_read(ic<0>{}, 2, 2, pfa); mma6(ic<0>{}, 2, 1, pfb); if constexpr (PEND) epi_B(ic<1>{}, 3, cp, std::true_type{});
-                frag_read(ic<0>{}, 2, 3, pfb); mma6(ic<0>{}, 2, 2, pfa); offsets_one(cl, 6); offsets_one(cl, 7);
-                mma6(ic<0>{}, 2, 3, pfb); offsets_one(cl, 8);
-                if constexpr (PEND) stat_flush(cp);           // (between the halves: half 0 of THIS step adds to the sums next)
-                if constexpr (DIAG) { dt1 = stamp(); dsum[1] += dt1 - dt0; dt0 = dt1; }
-                zero_half(ic<1>{});
-                // half 1 (rows 2, 3)  ||  the epilogue of half 0; item i: transform + ring write of the previous group's, then the
-                // same registers take this group's
-                char* wd8 = tid < 128 ? wdst + 8 * (32 * PITCH) : smem + RINGB + 4 * EWAVE + (tid - 128) * 16;
-                auto stage = [&](int i) __attribute__((always_inline)) {
-                    *(u32x4*)(i < NR - 1 ? wdst + i * (32 * PITCH) : wd8) = xform(stg[i], (okmW >> i) & 1u);
-                    fetch_one(rs, i);
-                };
-                frag_read(ic<1>{}, 0, 0, pfa);
-                frag_read(ic<1>{}, 0, 1, pfb); mma6(ic<1>{}, 0, 0, pfa); epi_A(ic<0>{});
-                frag_read(ic<1>{}, 0, 2, pfa); mma6(ic<1>{}, 0, 1, pfb); stage(0);
-                frag_read(ic<1>{}, 0, 3, pfb); mma6(ic<1>{}, 0, 2, pfa); stage(1);
-                frag_read(ic<1>{}, 1, 0, pfa); mma6(ic<1>{}, 0, 3, pfb); epi_B(ic<0>{}, 0, cc, std::true_type{});
-                frag_read(ic<1>{}, 1, 1, pfb); mma6(ic<1>{}, 1, 0, pfa); stage(2);
-                frag_read(ic<1>{}, 1, 2, pfa); mma6(ic<1>{}, 1, 1, pfb); epi_B(ic<0>{}, 1, cc, std::true_type{}); stage(3);
-                frag_read(ic<1>{}, 1, 3, pfb); mma6(ic<1>{}, 1, 2, pfa); stage(4);
-                frag_read(ic<1>{}, 2, 0, pfa); mma6(ic<1>{}, 1, 3, pfb); epi_B(ic<0>{}, 2, cc, std::true_type{}); stage(5);
-                frag_read(ic<1>{}, 2, 1, pfb); mma6(ic<1>{}, 2, 0, pfa); stage(6);
-                frag_read(ic<1>{}, 2, 2, pfa); mma6(ic<1>{}, 2, 1, pfb); epi_B(ic<0>{}, 3, cc, std::true_type{}); stage(7);
-                frag_read(ic<1>{}, 2, 3, pfb); mma6(ic<1>{}, 2, 2, pfa); stage(8);
-                mma6(ic<1>{}, 2, 3, pfb);
-                okmW = okmL;
-                load_consts(cl);          // for the group fetched above (queued behind its rows; used next iteration)
-                if constexpr (DIAG) { dt1 = stamp(); dsum[2] += dt1 - dt0; dt0 = dt1; dsum[5] += 1; }
-            };
-            if (pend) body(std::true_type{}); else body(std::false_type{});
-            cp = cc; pend = true;
-        } else {
-            // ---- general body: item boundaries (no step), ragged edges, the block's last iterations ----
-            drain();
-            if (cw.valid) {
+        xok_update(cl);
+        const int in_soff = __builtin_amdgcn_readfirstlane(cl.img * img_bytes);
+        // 24 groups (half, dx, ks) of 4 fragment reads + 6 MFMAs in one stream; the reads run TWO groups ahead of their MFMAs
+        // (one group = 192 MFMA cycles is less than an LDS round trip with four waves reading and writing)
+        bf16x8 pf[3][4];
+        auto stage = [&](int i) __attribute__((always_inline)) {
+            *(u32x4*)(i < NR - 1 ? wdst + i * (32 * PITCH) : wd8) = xform(stg[i], (okmW >> i) & 1u);
+            stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, offL[i], in_soff, 0);
+        };
+        auto read_group = [&](int gg) __attribute__((always_inline)) {       // gg = 0..23, folds to a constant
+            if (gg < 12) frag_read(ic<0>{}, gg / 4, gg % 4, pf[gg % 3]);
+            else if (gg < 24) frag_read(ic<1>{}, (gg - 12) / 4, (gg - 12) % 4, pf[gg % 3]);
+        };
+        if constexpr (DIAG) dt0 = stamp();
+        zero_half(ic<0>{});
+        read_group(0); read_group(1);
+        // ---- half 0 (rows 0, 1)  ||  the owed epilogue of the previous step's half 1, this iteration's fetch offsets ----
 #pragma unroll
-                for (int i = 0; i < NR; ++i)
-                    if (i < NR - 1 || wave < 2) *(u32x4*)(wdst + i * (32 * PITCH)) = xform(stg[i], (okmW >> i) & 1u);
-            }
-#pragma unroll
-            for (int i = 0; i < NR; ++i) offsets_one(cl, i);
-#pragma unroll
-            for (int i = 0; i < NR; ++i) fetch_one(rs, i);
-            okmW = okmL;
-            if (cl.valid) load_consts(cl);
-            if (do_mma) {
-                zero_half(ic<0>{}); zero_half(ic<1>{});
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { mma_group(ic<0>{}, dx, ks); mma_group(ic<1>{}, dx, ks); }
-                epi_A(ic<0>{});
-#pragma unroll
-                for (int t = 0; t < 4; ++t) epi_B(ic<0>{}, t, cc, std::false_type{});
-                cp = cc; pend = true;
-                drain();
-            }
+        for (int g = 0; g < 12; ++g) {
+            read_group(g + 2);
+            mma6(ic<0>{}, g / 4, g % 4, pf[g % 3]);
+            if (g == 0) epi_A(ic<1>{});
+            if (g == 1) offsets_one(cl, 0);
+            if (g == 2) offsets_one(cl, 1);
+            if (g == 3) epi_B(ic<1>{}, 0, cp, pend);
+            if (g == 4) offsets_one(cl, 2);
+            if (g == 5) epi_B(ic<1>{}, 1, cp, pend);
+            if (g == 6) offsets_one(cl, 3);
+            if (g == 7) epi_B(ic<1>{}, 2, cp, pend);
+            if (g == 8) { offsets_one(cl, 4); offsets_one(cl, 5); }
+            if (g == 9) epi_B(ic<1>{}, 3, cp, pend);
+            if (g == 10) { offsets_one(cl, 6); offsets_one(cl, 7); }
+            if (g == 11) offsets_one(cl, 8);
         }
+        // between the halves: half 0 of THIS step adds to the sums next
+        if (pend && cp.k == cp.S) stat_flush(cp);
+        if constexpr (DIAG) { dt1 = stamp(); dsum[1] += dt1 - dt0; dt0 = dt1; }
+        zero_half(ic<1>{});
+        // ---- half 1 (rows 2, 3)  ||  the epilogue of half 0; item i: transform + ring write of the previous group's, then the
+        // same registers take this group's ----
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            read_group(12 + g + 2);
+            mma6(ic<1>{}, g / 4, g % 4, pf[(12 + g) % 3]);
+            if (g == 0) epi_A(ic<0>{});
+            if (g == 1) stage(0);
+            if (g == 2) stage(1);
+            if (g == 3) epi_B(ic<0>{}, 0, cc, live);
+            if (g == 4) stage(2);
+            if (g == 5) { epi_B(ic<0>{}, 1, cc, live); stage(3); }
+            if (g == 6) stage(4);
+            if (g == 7) { epi_B(ic<0>{}, 2, cc, live); stage(5); }
+            if (g == 8) stage(6);
+            if (g == 9) { epi_B(ic<0>{}, 3, cc, live); stage(7); }
+            if (g == 10) stage(8);
+        }
+        okmW = okmL;
+        load_consts(cl);          // for the group fetched above (queued behind its rows; used next iteration)
+        if constexpr (DIAG) { dt1 = stamp(); dsum[2] += dt1 - dt0; dt0 = dt1; dsum[5] += 1; }
         // the ring bank written above is read from the next iteration on; the scratch is private to the wave
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (DIAG) { if (fast) { dt1 = stamp(); dsum[4] += dt1 - dt0; } }
+        if constexpr (DIAG) { dt1 = stamp(); dsum[4] += dt1 - dt0; }
+        cp = cc; pend = live;
         cc = cw; cw = cl; cl = cn;
-        m = m == 2 ? 0 : m + 1;
     };
-    load_consts(cl);
-    while (cl.valid || cw.valid || cc.valid) iteration();
-    drain();
+    while (true) {
+        if (!(cl.valid | cw.valid | cc.valid | (int)pend)) break;
+        iteration(ic<0>{});
+        if (!(cl.valid | cw.valid | cc.valid | (int)pend)) break;
+        iteration(ic<1>{});
+        if (!(cl.valid | cw.valid | cc.valid | (int)pend)) break;
+        iteration(ic<2>{});
+    }
     if constexpr (DIAG) {
         if (lane == 0 && p.dbg) {
 #pragma unroll
@@ -454,6 +455,7 @@ bool ws64_supported(const IgemmArgs& a) {
     const SrcDev& s = a.src[0];
     if (s.sC != 1 || s.esz != 2 || s.pool || s.off_y || s.off_x || s.H != a.Hb || s.W != a.Wb || s.sW != 64) return false;
     if (a.Ho != a.Hb || a.Wo != a.Wb || a.Wb < 32 || a.Hb < 16) return false;
+    if ((long)a.N * s.sN * 2 >= 0x7fffffffL || (long)a.N * a.Hb * a.Wb * 128 >= 0x7fffffffL) return false;     // one buffer descriptor each
     const WsPlan p = ws_plan(a);
     return p.items >= 192;              // smaller problems (the batch-1 forward): the tiled kernel fills the chip better
 }
