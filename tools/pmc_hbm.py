@@ -44,13 +44,21 @@ def main():
         for _, k, n, a, b, mb, us, g in rows:
             f.write(f"{k},{n},{a:.1f},{b:.1f},{mb:.2f},{us:.1f},{g:.0f}\n")
     if len(sys.argv) > 4:
-        conv = [r for r in rows if any(s in r[1] for s in ("conv3x3_halo_bf16", "igemm_bf16", "conv_first_fwd", "convT_bf16"))]
+        conv = [r for r in rows if any(s in r[1] for s in ("conv3x3_halo_bf16", "conv3x3_ws64", "igemm_bf16", "conv_first_fwd", "convT_bf16"))]
         n = sum(r[2] for r in conv)
         by = sum(r[0] for r in conv) * 1024
+        wg = [r for r in rows if any(s in r[1] for s in ("wgrad_halo", "wgradT_bf16", "wgrad_bf16_kernel"))]
+        nw = sum(r[2] for r in wg)
+        bw = sum(r[0] for r in wg) * 1024
+        ws = [r for r in rows if "conv3x3_ws64" in r[1]]
         json.dump({"counters": "FETCH_SIZE (KB, doubled per MI355X_MICROARCH HBM note) + WRITE_SIZE (KB), rocprofv3 --pmc, "
                                "separate passes, bench.py --steps 1 --warmup 1 --no-profile (2 steps in all)",
-                   "kernel_class": "conv (conv3x3_halo_bf16 + convT_bf16 + igemm_bf16 + conv_first_fwd)",
-                   "launches": n, "hbm_bytes_per_launch": by / max(n, 1)}, open(sys.argv[4], "w"), indent=1)
+                   "kernel_class": "conv (conv3x3_halo_bf16 + conv3x3_ws64 + convT_bf16 + igemm_bf16 + conv_first_fwd)",
+                   "launches": n, "hbm_bytes_per_launch": by / max(n, 1),
+                   "wgrad_kernel_class": "weight gradients (wgrad_halo*_bf16 + wgradT_bf16 + wgrad_bf16)",
+                   "wgrad_launches": nw, "wgrad_hbm_bytes_per_launch": bw / max(nw, 1),
+                   "ws64": [{"kernel": r[1], "launches": r[2], "hbm_MB_per_launch": round(r[5], 2)} for r in ws]},
+                  open(sys.argv[4], "w"), indent=1)
     for r in rows[:12]:
         print(f"{r[1][:70]:70s} n={r[2]:4d} {r[5]:9.1f} MB/launch {r[6]:8.1f} us {r[7]:7.0f} GB/s")
 

@@ -469,7 +469,10 @@ int bn_finalize_passes(float* stat, int mtiles, int passes, int C, int64_t count
     USTRUN_CHECK(stat && gamma && beta && scale && shift && mean && rstd, "bn_finalize: null pointer");
     USTRUN_CHECK(!update_running || (running_mean && running_var), "bn_finalize: running buffers missing");
     USTRUN_CHECK(mtiles > 0 && passes > 0 && C > 0 && count > 0, "bn_finalize: empty");
-    if (mtiles >= 512 && C % 32 == 0) {     // long table: two stages (the first one rewrites `stat` in place)
+    // Two stages from 96 rows up (the first one rewrites `stat` in place): one block per 32 channels pulls the whole table
+    // through ONE CU (262 KB for 256 rows x 4 passes: 24 us measured, 368 launches per step), the staged form spreads it over
+    // 32 x passes blocks per channel block (6 + 5.5 us).
+    if (mtiles >= 96 && C % 32 == 0) {
         int R = cdiv(mtiles, 32);
         while (mtiles % R == 1) ++R;         // every split needs two rows to park its sums in
         hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(mtiles, R), passes), dim3(256), 0, s, (float*)stat, mtiles,
