@@ -253,6 +253,29 @@ int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const float* x, const
                               void* workspace, void* scratch, float* const* grads, int accumulate, int part,
                               ustrun_stream_t s);
 
+/* ---- DeepLabV2-ResNet operators (reference networks/deeplabv2.py:10-33, networks/backbone/resnet.py:55-176; SURVEY.md 8f
+ * row 4), forward only.  Activations NHWC in the compute dtype like the U-Net's.                                          */
+/* torch conv weight [Cout][Cin][kh*kw] -> the forward pack of `taps` slices (bf16 [tap][Cin/8][Cout][8], f32 [tap][Cin][Cout]);
+ * w_fwd holds ustrun_pack_conv_elems() elements of the compute dtype                                                      */
+int ustrun_pack_conv(const float* w, int Cout, int Cin, int taps, void* w_fwd, int dtype, ustrun_stream_t s);
+int64_t ustrun_pack_conv_elems(int Cout, int Cin, int taps);
+/* k x k convolution (k = 1, 3, 5, 7), stride 1 or 2, dilation d, padding d * (k / 2) (nn.Conv2d of resnet.py:8-15,124 and
+ * deeplabv2.py:15-17) of the concatenated sources -> y [N, Ho, Wo, Cout] (compute dtype, or f32 when y_f32); bias optional;
+ * stat (optional): BatchNorm-statistics partial rows [rows][2][Cout], *stat_rows receives the row count                   */
+int ustrun_conv2d_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, const float* bias, int N, int Ho, int Wo, int Cout,
+                      int k, int stride, int dilation, void* y, int y_f32, float* stat, int* stat_rows, int dtype, ustrun_stream_t s);
+/* MaxPool2d(3, stride 2, padding 1) of relu(y * scale + shift) (resnet.py:127): [N,H,W,C] -> [N,(H+1)/2,(W+1)/2,C]       */
+int ustrun_maxpool3x3s2(const void* y, const float* scale, const float* shift, int N, int H, int W, int C, void* out, int dtype,
+                        ustrun_stream_t s);
+/* the bottleneck's join (resnet.py:97-103): out = relu(y * scale + shift + identity), identity = idn * iscale + ishift
+ * (the downsample branch's BatchNorm) or idn itself when iscale is NULL                                                   */
+int ustrun_bn_add_relu(const void* y, const float* scale, const float* shift, const void* idn, const float* iscale,
+                       const float* ishift, int64_t npix, int C, void* out, int dtype, ustrun_stream_t s);
+/* sum of up to four f32 NHWC maps [N,h,w,K] (the classifier's dilated branches, deeplabv2.py:26-28), resized bilinearly with
+ * align_corners=True to NCHW f32 [N,K,H,W] (deeplabv2.py:30)                                                               */
+int ustrun_sum_resize_bilinear(const float* const* maps, int nmaps, int N, int h, int w, int K, int H, int W, float* out,
+                               ustrun_stream_t s);
+
 /* test aid: tile configuration of the last halo-tiled bf16 3x3 convolution launched by this process, as
  * TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF (0 before any) -- lets a parity test assert that its shape
  * reached the production tile it was written for                                                   */

@@ -85,4 +85,8 @@ def test_200_step_trajectory_lands_on_the_oracle(dtype):
     early = steps <= 50
     np.testing.assert_allclose(loss[early], g["loss"][early], rtol=LOSS_RTOL_EARLY)
     assert float(np.abs(loss - g["loss"]).max()) <= LOSS_ATOL_LATE
-    np.testing.assert_allclose(norms, g["student_norms"], rtol=2e-2)
+    for st in (100,):                                       # half way: rounding-equivalent runs are still 1e-4 apart
+        assert abs(float(np.mean(val[st][1])) - float(np.mean(g[f"val_teacher_{st}"]))) <= DICE_TOL
+        assert abs(float(np.mean(val[st][0])) - float(np.mean(g[f"val_student_{st}"]))) <= DICE_TOL
+    # final parameters, tensor by tensor (BatchNorm biases have norms of 0.02: absolute floor)
+    np.testing.assert_allclose(norms, g["student_norms"], rtol=2e-2, atol=2e-3)

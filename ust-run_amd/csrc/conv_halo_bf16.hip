@@ -537,6 +537,7 @@ int halo_stat_rows(int N, int H, int W) { return N * cdiv(H, 8) * cdiv(W, 16); }
 // can this conv3x3-shaped problem run on the halo kernel?
 bool halo_supported(const IgemmArgs& a) {
     if (a.nseg != 9 || a.nz != 1 || a.s_in != 1 || a.s_out != 1 || a.segw != 3) return false;
+    if (!((a.d0 == -1 && a.dstep == 1) || (a.d0 == 1 && a.dstep == -1))) return false;      // (dilated 3x3: the generic kernel)
     bool pool = false;
     if (a.out_esz != 2 || (a.C0 & 7) || ((a.Cout - a.C0) & 7) || a.bias) return false;     // (3x3 convs here carry no bias)
     for (int i = 0; i < a.nsrc; ++i) {

@@ -451,6 +451,7 @@ void ws64_set_debug_buffer(void* p) { g_ws64_dbg = p; }
 
 bool ws64_supported(const IgemmArgs& a) {
     if (a.nseg != 9 || a.nz != 1 || a.s_in != 1 || a.s_out != 1 || a.segw != 3 || a.nsrc != 1) return false;
+    if (!((a.d0 == -1 && a.dstep == 1) || (a.d0 == 1 && a.dstep == -1))) return false;
     if (a.Cin != 64 || a.Cout != 64 || a.C0 != 64 || a.out_esz != 2 || a.bias) return false;
     const SrcDev& s = a.src[0];
     if (s.sC != 1 || s.esz != 2 || s.pool || s.off_y || s.off_x || s.H != a.Hb || s.W != a.Wb || s.sW != 64) return false;

@@ -289,7 +289,7 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     USTRUN_CHECK(dtype_ok(dtype), "igemm: dtype %d not built", dtype);
     USTRUN_CHECK(a.M > 0 && a.Cout > 0 && a.Cin > 0, "igemm: empty problem");
     USTRUN_CHECK(a.Hb < 65536 && a.Wb < 65536, "igemm: extent too large");
-    USTRUN_CHECK(a.nseg >= 1 && a.nseg <= 9 && a.nz >= 1 && a.nz <= 4, "igemm: bad segment/parity count");
+    USTRUN_CHECK(a.nseg >= 1 && a.nseg <= 49 && a.nz >= 1 && a.nz <= 4, "igemm: bad segment/parity count");
     int csum = 0;
     bool pool = false;
     for (int i = 0; i < a.nsrc; ++i) { csum += a.src[i].C; pool |= a.src[i].pool != 0; }
