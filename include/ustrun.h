@@ -261,7 +261,8 @@ int ustrun_pack_conv(const float* w, int Cout, int Cin, int taps, void* w_fwd, i
 int64_t ustrun_pack_conv_elems(int Cout, int Cin, int taps);
 /* k x k convolution (k = 1, 3, 5, 7), stride 1 or 2, dilation d, padding d * (k / 2) (nn.Conv2d of resnet.py:8-15,124 and
  * deeplabv2.py:15-17) of the concatenated sources -> y [N, Ho, Wo, Cout] (compute dtype, or f32 when y_f32); bias optional;
- * stat (optional): BatchNorm-statistics partial rows [rows][2][Cout], *stat_rows receives the row count                   */
+ * stat (optional): BatchNorm-statistics partial rows [rows][2][Cout] -- the buffer must hold ustrun_conv_mtiles(N, Ho, Wo,
+ * Cout) rows (which kernel serves the launch decides how many are written), *stat_rows receives the count written       */
 int ustrun_conv2d_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, const float* bias, int N, int Ho, int Wo, int Cout,
                       int k, int stride, int dilation, void* y, int y_f32, float* stat, int* stat_rows, int dtype, ustrun_stream_t s);
 /* MaxPool2d(3, stride 2, padding 1) of relu(y * scale + shift) (resnet.py:127): [N,H,W,C] -> [N,(H+1)/2,(W+1)/2,C]       */

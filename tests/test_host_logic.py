@@ -108,3 +108,24 @@ def test_load_resumes_from_the_runs_own_checkpoint_like_the_reference():
     body = body[:body.index("max_epoch =")]
     assert "'../model/{}/{}/checkpoint.pth'.format(args.dataset, args.save_name)" in body
     assert "args.load_path" not in body
+
+
+def test_deeplab_mirror_keeps_the_reference_state_dict_surface():
+    """networks/deeplabv2.py + networks/backbone/resnet.py: 626 (resnet101) state_dict entries named like the reference's
+    (backbone.layer3.22.bn3.running_var ... classifier.3.bias), 42.6 M + classifier parameters, dilation plan of
+    replace_stride_with_dilation=[False, True, True] (resnet.py:193-200)."""
+    import torch
+    from networks.deeplabv2 import DeepLabV2
+    torch.manual_seed(0)
+    m = DeepLabV2("resnet101", 2, pretrained=False)
+    sd = m.state_dict()
+    assert len(sd) == 632, len(sd)
+    for k in ("backbone.conv1.weight", "backbone.layer1.0.downsample.1.running_mean", "backbone.layer3.22.bn3.running_var",
+              "backbone.layer4.2.conv3.weight", "classifier.0.weight", "classifier.3.bias"):
+        assert k in sd, k
+    assert tuple(sd["classifier.2.weight"].shape) == (2, 2048, 3, 3)
+    b = m.backbone
+    assert (b.layer2[0].conv2.stride, b.layer3[0].conv2.stride, b.layer4[0].conv2.stride) == ((2, 2), (1, 1), (1, 1))
+    assert (b.layer3[0].conv2.dilation, b.layer3[1].conv2.dilation, b.layer4[0].conv2.dilation, b.layer4[1].conv2.dilation) == \
+        ((1, 1), (2, 2), (2, 2), (4, 4))
+    assert [c.dilation[0] for c in m.classifier] == [6, 12, 18, 24] and all(c.padding == c.dilation for c in m.classifier)

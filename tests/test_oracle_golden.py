@@ -211,3 +211,37 @@ def test_ema_alpha_and_sgd_trajectory():
         tr._sgd()
         close(tr.student["w"], g8[f"p{s + 1}"], rtol=1e-6, atol=1e-7)
         tr.lr = H.poly_lr(0.03, s, 30000)
+
+
+# ---- G10: DeepLabV2-ResNet --------------------------------------------------------------------
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize("name,arch", [("g10_deeplabv2_r50_n2_96x80", "resnet50"), ("g10_deeplabv2_r101_n1_128", "resnet101")])
+def test_deeplab_oracle_matches_reference_goldens(name, arch):
+    """oracle/deeplab_ref.py against outputs captured from the reference's networks/deeplabv2.py: the mirror's initial weights
+    (same seed) are the reference's, train-mode logits / feature norms / running statistics and eval-mode logits agree."""
+    from oracle import deeplab_ref as D
+    g = load_golden(name)
+    n, _, h, w, k = [int(v) for v in g["shape"]]
+    sd = D.make_state_dict(arch, k, int(g["model_seed"]))
+    pk = [kk for kk, v in sd.items() if v.is_floating_point() and "running" not in kk]
+    np.testing.assert_allclose(np.array([float(sd[kk].double().sum()) for kk in pk]), g["weight_sums"], rtol=1e-12, atol=1e-12)
+    gen = torch.Generator().manual_seed(int(g["input_seed"]))
+    x = torch.randint(0, 256, (n, 3, h, w), generator=gen).float() / 127.5 - 1
+    with torch.no_grad():
+        sdf = {kk: v.clone() for kk, v in sd.items()}
+        feats = D.backbone_features(x, sdf, arch, True)
+        np.testing.assert_allclose([float(f.double().norm()) for f in feats], g["feat_l2"], rtol=1e-4)
+        assert [list(f.shape) for f in feats] == g["feat_shape"].tolist()
+        logits = D.deeplabv2_forward(x, sd, arch, True)
+        flat = logits.flatten()
+        idx = torch.from_numpy(g["sample_idx"])
+        # (two f32 evaluations of 53 BatchNorm layers -- explicit scale/shift here, F.batch_norm there -- differ by ~1e-4 rel)
+        rl2 = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+        assert rl2(flat[idx].numpy(), g["sample_val"]) < 5e-4
+        assert abs(float(flat.double().norm()) - float(g["logit_l2"])) <= 1e-4 * float(g["logit_l2"])
+        np.testing.assert_allclose([float(v.double().sum()) for kk, v in sd.items() if kk.endswith("running_mean")], g["rm_sums"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose([float(v.double().sum()) for kk, v in sd.items() if kk.endswith("running_var")], g["rv_sums"], rtol=1e-4, atol=1e-5)
+        ev = D.deeplabv2_forward(x, sd, arch, False).flatten()
+        assert rl2(ev[idx].numpy(), g["eval_val"]) < 5e-4

@@ -156,6 +156,49 @@ def g3b_unet_backward(name, c, k, n, h):
          rv_sums=np.array([float(v.double().sum()) for kk, v in bufs.items() if kk.endswith("running_var")]))
 
 
+def g10_deeplab(name, arch, nclass, n, h, w, seed=1337):
+    """The reference's DeepLabV2 (networks/deeplabv2.py) on a seeded input: train-mode logits (samples + checksums), the
+    backbone feature norms, running-statistic sums after that call, then eval-mode logits.  The constructor always loads
+    ../../checkpoints/pretrained/<arch>.pth (base.py:12, resnet.py:179-181), which does not exist here: torch.load is
+    stubbed to return an empty dict for the construction (load_state_dict(strict=False) then keeps the seeded init)."""
+    from networks.deeplabv2 import DeepLabV2
+    real_load = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        torch.manual_seed(seed)
+        model = DeepLabV2(arch, nclass)
+    finally:
+        torch.load = real_load
+    wsum = weight_sums(model)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randint(0, 256, (n, 3, h, w), generator=g).float() / 127.5 - 1
+    model.train()
+    with torch.no_grad():
+        feats = model.backbone.base_forward(x)
+    # a fresh model for the logits so that the running statistics below are those of exactly ONE train-mode call
+    torch.load = lambda *a, **k: {}
+    try:
+        torch.manual_seed(seed)
+        model = DeepLabV2(arch, nclass)
+    finally:
+        torch.load = real_load
+    model.train()
+    with torch.no_grad():
+        logits = model(x)
+    sd = model.state_dict()
+    rm = np.array([float(v.double().sum()) for k, v in sd.items() if k.endswith("running_mean")])
+    rv = np.array([float(v.double().sum()) for k, v in sd.items() if k.endswith("running_var")])
+    model.eval()
+    with torch.no_grad():
+        logits_eval = model(x)
+    flat, flat_e = logits.flatten(), logits_eval.flatten()
+    idx = torch.randperm(flat.numel(), generator=g)[:4096]
+    save(name, model_seed=seed, input_seed=seed + 1, shape=np.array([n, 3, h, w, nclass]), weight_sums=wsum,
+         feat_l2=np.array([float(f.double().norm()) for f in feats]), feat_shape=np.array([list(f.shape) for f in feats]),
+         logit_l2=float(flat.double().norm()), logit_sum=float(flat.double().sum()), sample_idx=idx, sample_val=flat[idx],
+         eval_l2=float(flat_e.double().norm()), eval_val=flat_e[idx], rm_sums=rm, rv_sums=rv)
+
+
 def g4_dice():
     rec = {}
     for K in (2, 4):
@@ -300,6 +343,10 @@ def g8_sgd():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":          # DeepLabV2-ResNet (round 2)
+        g10_deeplab("g10_deeplabv2_r50_n2_96x80", "resnet50", 2, 2, 96, 80)
+        g10_deeplab("g10_deeplabv2_r101_n1_128", "resnet101", 2, 1, 128, 128)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g3b":          # only the round-2 addition
         g3b_unet_backward("g3b_unet_3_2_n4_256_bwd", 3, 2, 4, 256)
         sys.exit(0)
@@ -309,6 +356,8 @@ if __name__ == "__main__":
     g3_unet_full("g3_unet_1_2_n2_384", 1, 2, 2, 384)
     g3_unet_full("g3_unet_1_4_n2_288", 1, 4, 2, 288)
     g3b_unet_backward("g3b_unet_3_2_n4_256_bwd", 3, 2, 4, 256)
+    g10_deeplab("g10_deeplabv2_r50_n2_96x80", "resnet50", 2, 2, 96, 80)
+    g10_deeplab("g10_deeplabv2_r101_n1_128", "resnet101", 2, 1, 128, 128)
     g4_dice()
     g5_ramps()
     g6_metrics()

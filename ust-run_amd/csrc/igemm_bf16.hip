@@ -209,10 +209,12 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IgemmArgs a, c
                 const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const RowInfo ri = rowinfo[row];
                 if (ri.n >= 0 && cok) {
-                    const float v = rndt<2>(acc[i][j][r] + bias);   // statistics see the stored value
+                    const bool o32 = a.out_esz == 4;                  // (f32 outputs: the DeepLabV2 classifier maps)
+                    const float v = o32 ? acc[i][j][r] + bias : rndt<2>(acc[i][j][r] + bias);   // statistics see the stored value
                     const int oy = (ri.yx >> 16) * a.s_out + oyz, ox = (ri.yx & 0xffff) * a.s_out + oxz;
                     if (col < a.C0) {
-                        st1t<2>(a.out0, (((long)ri.n * a.Ho + oy) * a.Wo + ox) * a.C0 + col, v);
+                        const long oi = (((long)ri.n * a.Ho + oy) * a.Wo + ox) * a.C0 + col;
+                        if (o32) st1t<4>(a.out0, oi, v); else st1t<2>(a.out0, oi, v);
                     } else {
                         const int y1 = oy - a.o1y, x1 = ox - a.o1x;
                         if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
