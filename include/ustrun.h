@@ -265,6 +265,13 @@ int64_t ustrun_pack_conv_elems(int Cout, int Cin, int taps);
  * Cout) rows (which kernel serves the launch decides how many are written), *stat_rows receives the count written       */
 int ustrun_conv2d_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, const float* bias, int N, int Ho, int Wo, int Cout,
                       int k, int stride, int dilation, void* y, int y_f32, float* stat, int* stat_rows, int dtype, ustrun_stream_t s);
+/* a k x k convolution over FEW input channels (the 7x7 / stride-2 stem, resnet.py:124) as `nrows` row segments of a source the
+ * caller has zero-padded and describes window-wise: src->C = the k * Cin contiguous NHWC elements of one kernel row rounded up
+ * to a multiple of 8, src->sW = Cin (pixel stride in elements), src->sH / sN = the padded tensor's strides, src->H / W = the
+ * rows / window starts available; output pixel (y, x), segment s reads the window at (stride*y + s, stride*x); weights packed
+ * by ustrun_pack_conv as [Cout][src->C]["taps" = nrows]                                                                    */
+int ustrun_conv_rowwin_fwd(const ustrun_src_t* src, const void* w_fwd, int N, int Ho, int Wo, int Cout, int nrows, int stride, void* y,
+                           float* stat, int* stat_rows, int dtype, ustrun_stream_t s);
 /* MaxPool2d(3, stride 2, padding 1) of relu(y * scale + shift) (resnet.py:127): [N,H,W,C] -> [N,(H+1)/2,(W+1)/2,C]       */
 int ustrun_maxpool3x3s2(const void* y, const float* scale, const float* shift, int N, int H, int W, int C, void* out, int dtype,
                         ustrun_stream_t s);
@@ -272,6 +279,12 @@ int ustrun_maxpool3x3s2(const void* y, const float* scale, const float* shift, i
  * (the downsample branch's BatchNorm) or idn itself when iscale is NULL                                                   */
 int ustrun_bn_add_relu(const void* y, const float* scale, const float* shift, const void* idn, const float* iscale,
                        const float* ishift, int64_t npix, int C, void* out, int dtype, ustrun_stream_t s);
+/* the classifier's dilated 3x3 branches (deeplabv2.py:15-17,26-28) evaluated as ONE 1x1 GEMM z [N,h,w,nrates*9*K] (column
+ * (r*9+tap)*K+k = sum_c x[c] w_r[k][c][tap], from ustrun_conv2d_fwd with k = 1) followed by this shifted add:
+ * out[N,h,w,K] = bias_sum[k] + sum_{r,tap} z[p + rates[r]*(tap/3-1, tap%3-1)][(r*9+tap)*K+k], zero outside the image;
+ * rates: host array of nrates (<= 4) ints                                                                                  */
+int ustrun_aspp_gather(const float* z, int N, int h, int w, int K, int nrates, const int* host_rates, const float* bias_sum,
+                       float* out, ustrun_stream_t s);
 /* sum of up to four f32 NHWC maps [N,h,w,K] (the classifier's dilated branches, deeplabv2.py:26-28), resized bilinearly with
  * align_corners=True to NCHW f32 [N,K,H,W] (deeplabv2.py:30)                                                               */
 int ustrun_sum_resize_bilinear(const float* const* maps, int nmaps, int N, int h, int w, int K, int H, int W, float* out,

@@ -209,12 +209,13 @@ def test_deeplab_vs_oracle(dtype):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 3, 72, 104, generator=g)
     with torch.no_grad():
-        ref = D.deeplabv2_forward(x, {k: v.clone() for k, v in sd.items()}, "resnet50", True)
+        sdo = {k: v.clone() for k, v in sd.items()}          # (its running statistics move with the train-mode call, like the model's)
+        ref = D.deeplabv2_forward(x, sdo, "resnet50", True)
         got = m(x.cuda()).cpu()
         assert got.shape == ref.shape
         e_train = rel(got, ref)
         m.eval()
-        ref_e = D.deeplabv2_forward(x, sd, "resnet50", False)
+        ref_e = D.deeplabv2_forward(x, sdo, "resnet50", False)
         e_eval = rel(m(x.cuda()).cpu(), ref_e)
         print(f"deeplab {dtype}: train rel-L2 {e_train:.2e}, eval {e_eval:.2e}")
         if dtype == "f32":

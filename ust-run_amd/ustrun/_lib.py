@@ -81,8 +81,10 @@ SIGNATURES = {
     "ustrun_pack_conv": (i32, [fp, i32, i32, i32, vp, i32, vp]),
     "ustrun_pack_conv_elems": (i64, [i32, i32, i32]),
     "ustrun_conv2d_fwd": (i32, [PSrc, i32, vp, fp, i32, i32, i32, i32, i32, i32, i32, vp, i32, fp, C.POINTER(C.c_int), i32, vp]),
+    "ustrun_conv_rowwin_fwd": (i32, [PSrc, vp, i32, i32, i32, i32, i32, i32, vp, fp, C.POINTER(C.c_int), i32, vp]),
     "ustrun_maxpool3x3s2": (i32, [vp, fp, fp, i32, i32, i32, i32, vp, i32, vp]),
     "ustrun_bn_add_relu": (i32, [vp, fp, fp, vp, fp, fp, i64, i32, vp, i32, vp]),
+    "ustrun_aspp_gather": (i32, [fp, i32, i32, i32, i32, i32, C.POINTER(C.c_int), fp, fp, vp]),
     "ustrun_sum_resize_bilinear": (i32, [C.POINTER(vp), i32, i32, i32, i32, i32, i32, i32, fp, vp]),
     "ustrun_debug_last_conv_variant": (i32, []),
     "ustrun_debug_flags": (i32, [i32]),
