@@ -104,6 +104,8 @@ void ws64_set_debug_buffer(void* p);
 extern int g_debug_flags;                  // ustrun_debug_flags: bit 0 = keep the 64 -> 64 layers on the tiled kernel
 bool convT_fwd_supported(const IgemmArgs& a);
 bool convT_dgrad_supported(const IgemmArgs& a);
+bool conv1x1_supported(const IgemmArgs& a);
+int conv1x1_launch_bf16(const IgemmArgs& a, hipStream_t st);
 int convT_fwd_launch_bf16(const IgemmArgs& a, hipStream_t st);
 int convT_dgrad_launch_bf16(const IgemmArgs& a, hipStream_t st);
 int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, void* wf, void* wd, hipStream_t st);

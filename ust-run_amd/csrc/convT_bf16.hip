@@ -30,10 +30,15 @@ __device__ __forceinline__ int fastmod(int v, int d, float inv) {      // v mod 
     return r;
 }
 
-// DG = false: forward (a.src[0] = activation source, a.Cin = Cin, a.Cout = Cout, out0 = u, bias)
-// DG = true : dgrad   (a.src[0] = du [N,2H,2W,Cout] contiguous, a.Cin = Cout, a.Cout = Cin, out0 = da)
-template <int BN, int BK, bool DG>
+// MODE 0: forward (a.src[0] = activation source, a.Cin = Cin, a.Cout = Cout, out0 = u, bias)
+// MODE 1: dgrad   (a.src[0] = du [N,2H,2W,Cout] contiguous, a.Cin = Cout, a.Cout = Cin, out0 = da)
+// MODE 2: a plain 1x1 convolution (round 2: the bottleneck GEMMs of DeepLabV2-ResNet, reference networks/backbone/resnet.py:
+//         12-13,66,70): [M x Cin] x [Cin x Cout] with the forward's loader (producer's BatchNorm + ReLU on load), the
+//         dgrad's plain epilogue, optional bias, and BatchNorm-statistics partials (one row per 128-pixel tile) of the
+//         rounded outputs
+template <int BN, int BK, int MODE>
 __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, const int mt_total, const int nt_total) {
+    constexpr bool DG = MODE == 1, PLAIN = MODE == 2;
     constexpr int BM = 128;
     constexpr int WN = BN / 64, WM = 4 / WN, MI = BM / (32 * WM);
     constexpr int CPR = BK / 8;                 // 16-byte groups per pixel per chunk
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     long bcol;                                   // element offset of the thread's column in K-row 0
     {
         const int n = n0 + (tid % BN);
-        if (DG) {
+        if (DG || PLAIN) {
             bcol = (long)n * 8;
         } else {
             const int tap = n / a.Cout, co = n - tap * a.Cout;
@@ -200,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     char* ep = smem + wave * (32 * EPITCH);
     const int colw = n0 + wn * 64;               // first of this wave's 64 columns
     int tap = 0, co0 = colw;
-    if (!DG) { tap = colw / a.Cout; co0 = colw - tap * a.Cout; }
+    if (!DG && !PLAIN) { tap = colw / a.Cout; co0 = colw - tap * a.Cout; }
+    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};          // PLAIN: BatchNorm-statistics partials of this lane's two channels
     const float bias0 = (!DG && a.bias) ? a.bias[co0 + l31] : 0.f, bias1 = (!DG && a.bias) ? a.bias[co0 + 32 + l31] : 0.f;
     __bf16* outp = (__bf16*)a.out0;
     const long tapoff = (long)(tap >> 1) * 2 * W + (tap & 1);
@@ -211,7 +217,12 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                *(__bf16*)(ep + row * EPITCH + (j * 32 + l31) * 2) = (__bf16)(acc[i][j][r] + (j ? bias1 : bias0));
+                const __bf16 hv = (__bf16)(acc[i][j][r] + (j ? bias1 : bias0));
+                *(__bf16*)(ep + row * EPITCH + (j * 32 + l31) * 2) = hv;
+                if constexpr (PLAIN) {      // rows past M carry zero activations and 1x1 convs in front of a BatchNorm have no bias
+                    const float f = (float)hv;
+                    st1[j] += f; st2[j] += f * f;
+                }
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
             const int d = wm * 32 * MI + 32 * i + row;
             const long m = m0 + d;
             if (m < a.M) {
-                if (DG) {
+                if (DG || PLAIN) {
                     *(bf16x8*)(outp + m * a.Cout + colw + ch * 8) = v8;
                 } else {
                     const int x = fastmod(x0r + d, W, invW);
@@ -235,15 +246,38 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    if constexpr (PLAIN) {
+        if (a.stat) {       // fixed order: lane halves, then the WM waves that share these columns -> row mtile of [rows][2][Cout]
+            __syncthreads();
+            float* red = (float*)smem;            // [WM][2][BN]
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                st1[j] += __shfl_xor(st1[j], 32);
+                st2[j] += __shfl_xor(st2[j], 32);
+                if (lh == 0) {
+                    red[(wm * 2 + 0) * BN + wn * 64 + j * 32 + l31] = st1[j];
+                    red[(wm * 2 + 1) * BN + wn * 64 + j * 32 + l31] = st2[j];
+                }
+            }
+            __syncthreads();
+            for (int t = tid; t < 2 * BN; t += 256) {
+                const int q = t / BN, cc = t % BN;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) v += red[(w * 2 + q) * BN + cc];
+                a.stat[((long)mtile * 2 + q) * a.Cout + n0 + cc] = v;
+            }
+        }
+    }
 }
 
-template <int BN, int BK, bool DG>
+template <int BN, int BK, int MODE>
 int launch_cfg(const IgemmArgs& a, hipStream_t st) {
-    const int ncols = DG ? a.Cout : 4 * a.Cout;
+    const int ncols = MODE == 0 ? 4 * a.Cout : a.Cout;
     const int mt = cdiv(a.M, 128), nt = ncols / BN;
     const size_t lds = 2 * (size_t)128 * BK * 2 + 2 * (size_t)(BK / 8) * BN * 16;
     dim3 grid(mt * nt), block(256);
-    hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, DG>), grid, block, lds, st, a, mt, nt);
+    hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, MODE>), grid, block, lds, st, a, mt, nt);
     USTRUN_LAUNCH_CHECK("convT_bf16");
     return 0;
 }
@@ -278,11 +312,24 @@ bool convT_dgrad_supported(const IgemmArgs& a) {
 }
 
 int convT_fwd_launch_bf16(const IgemmArgs& a, hipStream_t st) {
-    return launch_cfg<256, 32, false>(a, st);
+    return launch_cfg<256, 32, 0>(a, st);
+}
+// a 1x1 convolution at stride 1 over one bf16 NHWC source (ustrun_conv2d_fwd, k = 1)
+bool conv1x1_supported(const IgemmArgs& a) {
+    if (a.nz != 1 || a.nseg != 1 || a.s_out != 1 || a.s_in != 1 || a.d0 != 0) return false;
+    if (!common_ok(a)) return false;
+    const SrcDev& s = a.src[0];
+    if (s.LH != a.Hb || s.LW != a.Wb || (s.sN & 7) || (s.sH & 7) || (s.sW & 7) || s.gN > 0) return false;
+    return a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.C0 == a.Cout && a.Ho == a.Hb && a.Wo == a.Wb;
+}
+int conv1x1_launch_bf16(const IgemmArgs& a, hipStream_t st) {
+    if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 256) return launch_cfg<256, 32, 2>(a, st);
+    if (a.Cout % 128 == 0) return launch_cfg<128, 64, 2>(a, st);
+    return launch_cfg<64, 64, 2>(a, st);
 }
 int convT_dgrad_launch_bf16(const IgemmArgs& a, hipStream_t st) {
-    if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 512) return launch_cfg<256, 32, true>(a, st);
-    return launch_cfg<128, 64, true>(a, st);
+    if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 512) return launch_cfg<256, 32, 1>(a, st);
+    return launch_cfg<128, 64, 1>(a, st);
 }
 
 }  // namespace ustrun

@@ -49,15 +49,17 @@ template <int V> using ic = std::integral_constant<int, V>;
 //   bottom : s_waitcnt vmcnt(0): this top's transfers have landed; barrier.
 // A wave's stage used to be DMA issue -> fragment reads -> 16 MFMAs -> wait -> transform -> barrier in sequence, ~700
 // cycles outside the 512 MFMA cycles, more than the SIMD's other wave can cover.
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF>
+// DIL: dilation of the 3x3 taps (1 everywhere in the U-Net; 2 and 4 for the dilated bottlenecks of DeepLabV2-ResNet, reference
+// networks/backbone/resnet.py:8-10,193-200): the halo is DIL pixels wide and tap (ty, tx) reads DIL * (ty, tx) into the patch.
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
     static_assert(BK == 32, "80-byte patch rows hold one 32-channel chunk");
-    constexpr int HW2 = TW + 2;
+    constexpr int HW2 = TW + 2 * DIL;
     constexpr int SR = 32 / TW;                 // tile rows per 32-pixel sub-tile (2 or 1)
     constexpr int WM = TH / (SR * MI), WN = 4 / WM;
     static_assert(WM * WN == 4 && BN == WN * 64, "4 waves, 64 channels per wave");
-    constexpr int HP = (TH + 2) * HW2;          // halo pixels
+    constexpr int HP = (TH + 2 * DIL) * HW2;    // halo pixels
     constexpr int PITCH = 80;                   // patch row: 4 x 16 B of channels + 16 B pad
     constexpr int DSLOTS = (HP * 5 + 63) / 64 * 64;   // direct staging: 16-byte LDS slots incl. the pad slots, whole waves
     constexpr int XSLOTS = (HP * 4 + 63) / 64 * 64;   // transform staging: (pixel, channel group) items, whole waves
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     auto src_setup = [&](const SrcDev& S) {
         a_floor = S.relu ? 0.f : -__builtin_inff();
         dq1 = S.sW; dq2 = S.sH;
-        const int by = y0 - 1 - S.off_y, bx = x0 - 1 - S.off_x;
+        const int by = y0 - DIL - S.off_y, bx = x0 - DIL - S.off_x;
         aokm = 0;
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                     bf[k][ks][1] = *(const bf16x8*)(Bp + k * (BCH * 16) + (2 * ks * BN + 32) * 16);
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
-                        af[k][ks][i] = *(const bf16x8*)(Afrag + ((tap / 3 + SR * i) * HW2 + tap % 3) * PITCH + ks * 32);
+                        af[k][ks][i] = *(const bf16x8*)(Afrag + ((DIL * (tap / 3) + SR * i) * HW2 + DIL * (tap % 3)) * PITCH + ks * 32);
                 }
             }
             // SKEW: the items the previous stage fetched (landed: that stage ended on vmcnt(0)), transformed under the MFMAs
@@ -501,17 +503,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
 
 int g_last_variant = 0;    // TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF of the last launch (tests: ustrun_debug_last_conv_variant)
 
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF>
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1>
 int launch_xf(const IgemmArgs& a, hipStream_t st) {
     g_last_variant = TH << 24 | TW << 16 | BN << 8 | MI << 4 | NT << 2 | (POOL ? 2 : 0) | (XF ? 1 : 0);
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
-    constexpr int DSLOTS = ((TH + 2) * (TW + 2) * 5 + 63) / 64 * 64;
+    constexpr int DSLOTS = ((TH + 2 * DIL) * (TW + 2 * DIL) * 5 + 63) / 64 * 64;
     constexpr int AIT = (DSLOTS + 255) / 256, NSTG = (9 + NT - 1) / NT, BATCH = (AIT + NSTG - 2) / (NSTG - 1);
     const size_t rawb = XF ? (size_t)BATCH * (POOL ? 4 : 1) * 4096 : 0;
     const size_t fixed = 2 * (size_t)DSLOTS * 16 + 2 * NT * (size_t)(BK / 8) * BN * 16 + 512;
     const size_t lds = fixed + (XF && fixed + 2 * rawb <= 81920 ? 2 : 1) * rawb;
     dim3 grid(a.N * ty * tx * nt), block(256);
-    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF>), grid, block, lds, st, a, tx, ty, nt);
+    if constexpr (DIL > 1) {       // (up to 93 KB for the dilation-4 patch pair: one block per CU, above the 64 KB default)
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+    }
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;
 }
@@ -529,6 +539,7 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int halo_last_variant() { return g_last_variant; }
+static int halo_dilation(const IgemmArgs& a) { return a.dstep < 0 ? -a.dstep : a.dstep; }
 void set_last_variant(int v) { g_last_variant = v; }
 
 // stat rows the halo kernel writes for an N x H x W output (one per 8 x 16 pixels)
@@ -537,7 +548,8 @@ int halo_stat_rows(int N, int H, int W) { return N * cdiv(H, 8) * cdiv(W, 16); }
 // can this conv3x3-shaped problem run on the halo kernel?
 bool halo_supported(const IgemmArgs& a) {
     if (a.nseg != 9 || a.nz != 1 || a.s_in != 1 || a.s_out != 1 || a.segw != 3) return false;
-    if (!((a.d0 == -1 && a.dstep == 1) || (a.d0 == 1 && a.dstep == -1))) return false;      // (dilated 3x3: the generic kernel)
+    const int dil = a.dstep < 0 ? -a.dstep : a.dstep;
+    if (a.d0 != -a.dstep || !(dil == 1 || dil == 2 || dil == 4)) return false;      // (other rates: the generic kernel)
     bool pool = false;
     if (a.out_esz != 2 || (a.C0 & 7) || ((a.Cout - a.C0) & 7) || a.bias) return false;     // (3x3 convs here carry no bias)
     for (int i = 0; i < a.nsrc; ++i) {
@@ -549,6 +561,7 @@ bool halo_supported(const IgemmArgs& a) {
     if (a.nsrc == 2 && (a.src[0].C % BK)) return false;
     if (pool && (a.nsrc != 1 || a.Cout % 128)) return false;
     if (a.Hb < 4 || a.Wb < 8) return false;      // tiny extents: the generic kernel wastes less
+    if (dil > 1 && (pool || a.nsrc != 1)) return false;
     return true;
 }
 
@@ -559,6 +572,7 @@ bool halo_tall_tile(const IgemmArgs& a) {
 
 // BatchNorm-statistics rows written by the configuration conv3x3_halo_launch_bf16 picks
 int halo_stat_rows_used(const IgemmArgs& a) {
+    if (halo_dilation(a) > 1) return a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
     bool pool = false;
     for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
     const bool wide = a.Wb >= 32;
@@ -570,7 +584,19 @@ int halo_stat_rows_used(const IgemmArgs& a) {
     return wide ? a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 32) : a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16);
 }
 
+// dilated 3x3 (DeepLabV2-ResNet layer3 / layer4): the 8 x 16-pixel tiles keep the (8 + 2d) x (16 + 2d) patch pair small
+template <int DIL>
+static int launch_dilated(const IgemmArgs& a, hipStream_t st) {
+    bool xf = false;
+    for (int i = 0; i < a.nsrc; ++i) xf |= a.src[i].scale != nullptr || a.src[i].relu != 0;
+    if (a.Cout % 128 == 0)
+        return xf ? launch_xf<8, 16, 128, 32, 2, false, 2, true, DIL>(a, st) : launch_xf<8, 16, 128, 32, 2, false, 2, false, DIL>(a, st);
+    return xf ? launch_xf<8, 16, 64, 32, 1, false, 2, true, DIL>(a, st) : launch_xf<8, 16, 64, 32, 1, false, 2, false, DIL>(a, st);
+}
+
 int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st) {
+    if (halo_dilation(a) == 2) return launch_dilated<2>(a, st);
+    if (halo_dilation(a) == 4) return launch_dilated<4>(a, st);
     bool pool = false;
     for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
     const bool wide = a.Wb >= 32;                 // 32-pixel rows: conflict-free A fragment reads

@@ -310,6 +310,7 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
         if (!(g_debug_flags & 1) && ws64_supported(a)) rc = conv3x3_ws64_launch_bf16(a, st);
         else if (halo_supported(a)) rc = conv3x3_halo_launch_bf16(a, st);
         else if (convT_fwd_supported(a)) rc = convT_fwd_launch_bf16(a, st);
+        else if (conv1x1_supported(a)) rc = conv1x1_launch_bf16(a, st);
         else if (convT_dgrad_supported(a)) rc = convT_dgrad_launch_bf16(a, st);
         else if (grouped) { set_error("igemm: batched passes reached a kernel without per-pass BatchNorm constants"); rc = 1; }
         else rc = igemm_launch_bf16(a, st);
