@@ -166,3 +166,51 @@ def test_reduced_gradient_is_the_mean_of_independent_oracle_replicas():
     for r in range(world):
         e = rel(res[r][1], [reps[r].student[k].detach() for k in pk])
         assert e < 1e-4, ("params", r, e)
+
+
+def test_grad_reducer_on_rccl_single_rank():
+    """The data-parallel exchange on the REAL backend (RCCL), as far as one GPU allows: a world-size-1 `nccl` process group, the
+    GradReducer's three overlapped all-reduces (start_tail between the backward halves from the autograd thread, start_mid,
+    finish) and the 1/world scale in the fused SGD.  With one rank every all-reduce is the identity, so parameters after two
+    steps must be bit-identical to a run without any collective -- what is exercised is RCCL's stream ordering against the
+    backward stream and the async work handles, which gloo cannot show."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl1, args=(_free_port(), q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    ok, backend, nranks = q.get(timeout=10)
+    assert backend == "nccl" and nranks == 1 and ok
+
+
+def _worker_rccl1(port, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import random
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "ust-run_amd")]
+    import torch.distributed as dist
+    from networks.unet_model import UNet
+    from ustrun import ddp, synthetic
+    from ustrun.trainer import SSLTrainer
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    finals = []
+    for use_reducer in (True, False):
+        torch.manual_seed(1337)
+        model = UNet(3, 2, base_channels=16, dtype="bf16").cuda()
+        ema = UNet(3, 2, base_channels=16, dtype="bf16").cuda()
+        tr = SSLTrainer("fundus", model, ema, patch_size=64, grad_allreduce=ddp.GradReducer(1) if use_reducer else None, world_size=1,
+                        fft="device")
+        random.seed(1212); np.random.seed(1337)
+        for step in range(2):
+            b = [t.cuda() for t in synthetic.batch("fundus", 2, 3, 64, 100 * step)]
+            tr.step(*b, epoch_start=(step == 0))
+        torch.cuda.synchronize()
+        finals.append((tr.flat_p.clone(), tr.flat_t.clone()))
+    ok = torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1]) and bool(torch.isfinite(finals[0][0]).all())
+    q.put((ok, dist.get_backend(), dist.get_world_size()))
+    dist.destroy_process_group()

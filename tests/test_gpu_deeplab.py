@@ -234,3 +234,42 @@ def test_deeplab_refuses_cpu_and_training_graph():
     m = m.cuda().train()
     with pytest.raises(NotImplementedError, match="forward-only"):
         m(torch.zeros(1, 3, 64, 64, device="cuda"))
+
+
+def test_rowwin_stem_and_aspp_gather_direct():
+    """The two reshaped operators on their own, exact integers: the 7x7 / stride-2 stem as 7 row-window segments of the padded
+    NHWC input (ustrun_conv_rowwin_fwd) against F.conv2d, and the classifier's shifted add (ustrun_aspp_gather) of a 1x1 GEMM's
+    columns against the sum of four dilated 3x3 convolutions with bias."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(31)
+    n, h, w = 2, 29, 34
+    x = torch.randint(-3, 4, (n, 3, h, w), generator=g).float()
+    wt = torch.randint(-2, 3, (64, 3, 7, 7), generator=g).float()
+    ref = F.conv2d(x, wt, None, 2, 3)
+    ho, wo = ref.shape[-2:]
+    for dt in (0, 1):
+        td = torch.bfloat16 if dt else torch.float32
+        xp = F.pad(x.permute(0, 2, 3, 1), (0, 0, 3, 4, 3, 3)).to(td).contiguous().cuda()        # [n, h+6, w+7, 3]
+        wr = F.pad(wt.permute(0, 2, 3, 1).reshape(64, 7, 21), (0, 3)).permute(0, 2, 1).contiguous().cuda()   # [co][24][ky]
+        wf = torch.zeros(lib.ustrun_pack_conv_elems(64, 24, 7), dtype=td, device="cuda")
+        l.check(lib.ustrun_pack_conv(wr.data_ptr(), 64, 24, 7, wf.data_ptr(), dt, None))
+        hp, wp = h + 6, w + 7
+        src = l.Src(xp.data_ptr(), None, None, 24, hp, wp - 7, hp * wp * 3, wp * 3, 3, 1, 0, 0, 0, 0, 0, 0, 0)
+        y = torch.empty(n, ho, wo, 64, device="cuda", dtype=td)
+        l.check(lib.ustrun_conv_rowwin_fwd(C.byref(src), wf.data_ptr(), n, ho, wo, 64, 7, 2, y.data_ptr(), None, None, dt, None))
+        assert rel(from_nhwc(y), ref.bfloat16().float() if dt else ref) < 1e-6
+    # shifted add: z holds, per pixel, the 1x1 products of every (rate, tap, class)
+    K, ci, hh, ww = 3, 16, 21, 17
+    feat = torch.randint(-3, 4, (n, ci, hh, ww), generator=g).float()
+    ws = [torch.randint(-2, 3, (K, ci, 3, 3), generator=g).float() for _ in range(4)]
+    bs = [torch.randint(-2, 3, (K,), generator=g).float() for _ in range(4)]
+    rates = (6, 12, 18, 24)
+    want = sum(F.conv2d(feat, ws[r], bs[r], 1, rates[r], rates[r]) for r in range(4))
+    wall = torch.stack([wq.reshape(K, ci, 9).permute(2, 0, 1) for wq in ws], 0).reshape(4 * 9 * K, ci)       # row (r*9+tap)*K+k
+    z = torch.einsum("nchw,oc->nhwo", feat, wall).contiguous().cuda()
+    bsum = sum(bs).cuda()
+    out = torch.empty(n, hh, ww, K, device="cuda")
+    rr = (C.c_int * 4)(*rates)
+    l.check(lib.ustrun_aspp_gather(z.data_ptr(), n, hh, ww, K, 4, rr, bsum.data_ptr(), out.data_ptr(), None))
+    assert rel(from_nhwc(out), want) < 1e-6
