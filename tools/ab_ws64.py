@@ -81,12 +81,15 @@ def main():
                 dbg.zero_()
                 fn()
                 torch.cuda.synchronize()
+                t_diag = timed(fn, 5)                      # wall time of the stamped build itself -> the in-kernel clock
                 d = dbg.view(256, 4, 8).double()
                 it = d[..., 5].clamp(min=1)
                 ph = [float((d[..., k] / it).mean()) for k in range(5)]
                 print(f"       diag {name}: cycles per steady iteration: half 0 (72 MFMAs + owed epilogue + offsets) {ph[1]:.0f} | half 1 (72 MFMAs + "
                       f"epilogue + transform/ring writes/fetches) {ph[2]:.0f} | barrier {ph[4]:.0f} | sum {sum(ph):.0f} (MFMA floor 4608); "
-                      f"fast iterations per wave {float(it.mean()):.1f}", flush=True)
+                      f"fast iterations per wave {float(it.mean()):.1f}; stamped launch {t_diag:.4f} ms -> in-kernel clock "
+                      f"{float((d[..., 1] + d[..., 2] + d[..., 4]).max()) / (t_diag * 1e-3) / 1e9:.2f} GHz (a lower bound: the slowest wave's "
+                      f"stamped cycles, which leave out the non-steady iterations, / wall)", flush=True)
             lib.ustrun_debug_buffer(None)
         print(f"       outputs bit-identical between the two kernels: {same}; stat sums rel diff "
               f"{float((outs[0][2] - outs[1][2]).abs().max() / outs[1][2].abs().max()):.2e}", flush=True)
