@@ -254,7 +254,7 @@ int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const float* x, const
                               ustrun_stream_t s);
 
 /* ---- DeepLabV2-ResNet operators (reference networks/deeplabv2.py:10-33, networks/backbone/resnet.py:55-176; SURVEY.md 8f
- * row 4), forward only.  Activations NHWC in the compute dtype like the U-Net's.                                          */
+ * row 4), forward and backward.  Activations NHWC in the compute dtype like the U-Net's.                                   */
 /* torch conv weight [Cout][Cin][kh*kw] -> the forward pack of `taps` slices (bf16 [tap][Cin/8][Cout][8], f32 [tap][Cin][Cout]);
  * w_fwd holds ustrun_pack_conv_elems() elements of the compute dtype                                                      */
 int ustrun_pack_conv(const float* w, int Cout, int Cin, int taps, void* w_fwd, int dtype, ustrun_stream_t s);
@@ -289,6 +289,32 @@ int ustrun_aspp_gather(const float* z, int N, int h, int w, int K, int nrates, c
  * align_corners=True to NCHW f32 [N,K,H,W] (deeplabv2.py:30)                                                               */
 int ustrun_sum_resize_bilinear(const float* const* maps, int nmaps, int N, int h, int w, int K, int H, int W, float* out,
                                ustrun_stream_t s);
+
+/* ---- DeepLabV2-ResNet backward (autograd of the modules above).  Input gradients of the stride-1 convolutions are
+ * ustrun_conv2d_fwd launches over dy with the flipped / transposed weights (packed by ustrun_pack_conv from
+ * w.flip(2,3).transpose(0,1)); BatchNorm backward is ustrun_bn_bwd_reduce / _apply (a BatchNorm that is NOT followed by a ReLU
+ * -- bn3, the projection shortcut's -- passes scale = 0, shift = 1 so that the kernels' ReLU mask is all ones).                */
+/* weight gradient of ustrun_conv2d_fwd's convolution (k = 1 or 3): dw[Cout][Cin][k][k] (torch layout, f32); partials: scratch
+ * of ustrun_wgrad_partials_bytes(k*k, Cin, Cout, N*Ho*Wo) bytes                                                              */
+int ustrun_conv2d_wgrad(const ustrun_src_t* srcs, int nsrc, const void* dy, int N, int Ho, int Wo, int Cout, int k, int stride,
+                        int dilation, float* dw, int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s);
+/* weight gradient of ustrun_conv_rowwin_fwd: dw[Cout][src->C][nrows] (the layout its weights were packed from)               */
+int ustrun_conv_rowwin_wgrad(const ustrun_src_t* src, const void* dy, int N, int Ho, int Wo, int Cout, int nrows, int stride, float* dw,
+                             int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s);
+/* gradient of the bottleneck's join with respect to its pre-ReLU sum: g = (a + b) * (ref > 0) over n elements (n % 4 == 0);
+ * b = NULL: one contribution, ref = NULL: no ReLU (the max-pool output feeding layer1)                                       */
+int ustrun_relu_bwd_add(const void* a, const void* b, const void* ref, int64_t n, void* g, int dtype, ustrun_stream_t s);
+/* MaxPool2d(3, 2, 1) backward: dp [N,(H+1)/2,(W+1)/2,C] -> da [N,H,W,C] (gradient of the ACTIVATED tensor relu(y*scale+shift),
+ * whose ReLU the following ustrun_bn_bwd_* applies); the first maximum of a window wins (torch's rule); gather, fixed order   */
+int ustrun_maxpool3x3s2_bwd(const void* dp, const void* y, const float* scale, const float* shift, int N, int H, int W, int C, void* da,
+                            int dtype, ustrun_stream_t s);
+/* adjoint of ustrun_sum_resize_bilinear for one map: dout NCHW f32 [N,K,H,W] -> dlow NHWC f32 [N,h,w,K]                      */
+int ustrun_sum_resize_bilinear_bwd(const float* dout, int N, int h, int w, int K, int H, int W, float* dlow, ustrun_stream_t s);
+/* adjoint of ustrun_aspp_gather: dz [N,h,w,zc_padded] in the compute dtype (columns >= nrates*9*K are zero)                  */
+int ustrun_aspp_scatter(const float* dlow, int N, int h, int w, int K, int nrates, const int* host_rates, int zc_padded, void* dz,
+                        int dtype, ustrun_stream_t s);
+/* out[c] (+)= sum over rows of x[row][c] (f32, f64 accumulation, fixed order): the classifier biases' gradient              */
+int ustrun_colsum(const float* x, int64_t rows, int C, float* out, int accumulate, ustrun_stream_t s);
 
 /* test aid: tile configuration of the last halo-tiled bf16 3x3 convolution launched by this process, as
  * TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF (0 before any) -- lets a parity test assert that its shape

@@ -1,6 +1,6 @@
 """GPU parity of the DeepLabV2-ResNet forward (reference networks/deeplabv2.py:10-33,
 networks/backbone/resnet.py:55-176): the new operators against torch-CPU, the network against the CPU oracle
-(oracle/deeplab_ref.py) and against outputs captured from the reference itself (G10).  Forward only this round."""
+(oracle/deeplab_ref.py) and against outputs captured from the reference itself (G10).  Backward: test_gpu_deeplab_bwd.py."""
 import ctypes as C
 
 import numpy as np
@@ -232,8 +232,8 @@ def test_deeplab_refuses_cpu_and_training_graph():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 64, 64))
     m = m.cuda().train()
-    with pytest.raises(NotImplementedError, match="forward-only"):
-        m(torch.zeros(1, 3, 64, 64, device="cuda"))
+    with pytest.raises(NotImplementedError, match="records no autograd graph"):      # the stand-alone feature path; DeepLabV2.forward
+        m.backbone(torch.zeros(1, 3, 64, 64, device="cuda"))                         # itself is differentiable (test_gpu_deeplab_bwd)
 
 
 def test_rowwin_stem_and_aspp_gather_direct():

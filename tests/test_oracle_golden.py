@@ -245,3 +245,29 @@ def test_deeplab_oracle_matches_reference_goldens(name, arch):
         np.testing.assert_allclose([float(v.double().sum()) for kk, v in sd.items() if kk.endswith("running_var")], g["rv_sums"], rtol=1e-4, atol=1e-5)
         ev = D.deeplabv2_forward(x, sd, arch, False).flatten()
         assert rl2(ev[idx].numpy(), g["eval_val"]) < 5e-4
+
+
+def test_deeplab_oracle_gradients_match_reference_golden():
+    """oracle/deeplab_ref.py under torch autograd in float64 against the gradients captured from the reference's DeepLabV2 itself
+    in float64 (G10b): every parameter's gradient norm and 64 sampled entries, 1e-7 relative (two float64 evaluations)."""
+    from oracle import deeplab_ref as D
+    g = load_golden("g10b_deeplabv2_r50_n2_96x80_bwd")
+    n, _, h, w, k = [int(v) for v in g["shape"]]
+    sd = D.make_state_dict("resnet50", k, int(g["model_seed"]))
+    gen = torch.Generator().manual_seed(int(g["input_seed"]))
+    x = torch.randint(0, 256, (n, 3, h, w), generator=gen).float() / 127.5 - 1
+    R = torch.randn(n, k, h, w, generator=gen)
+    sdo = {}
+    for kk, v in sd.items():
+        v = v.clone().double() if v.is_floating_point() else v.clone()
+        sdo[kk] = v.requires_grad_(True) if v.is_floating_point() and "running" not in kk else v
+    out = D.deeplabv2_forward(x.double(), sdo, "resnet50", True)
+    (out * R.double()).sum().backward()
+    assert abs(float(out.detach().norm()) - float(g["logit_l2"])) <= 1e-9 * float(g["logit_l2"])
+    names = [str(s) for s in g["names"]]
+    assert names == [kk for kk, v in sdo.items() if v.requires_grad]
+    for i, kk in enumerate(names):
+        flat = sdo[kk].grad.flatten()
+        assert abs(float(flat.norm()) - g["grad_l2"][i]) <= 1e-7 * g["grad_l2"][i] + 1e-12, kk
+        np.testing.assert_allclose(flat[torch.from_numpy(g["sample_idx"][i])].numpy(), g["sample_val"][i], rtol=1e-6,
+                                   atol=1e-7 * g["grad_l2"][i], err_msg=kk)

@@ -199,6 +199,36 @@ def g10_deeplab(name, arch, nclass, n, h, w, seed=1337):
          eval_l2=float(flat_e.double().norm()), eval_val=flat_e[idx], rm_sums=rm, rv_sums=rv)
 
 
+def g10b_deeplab_backward(name, arch, nclass, n, h, w, seed=1337):
+    """The reference's DeepLabV2 under autograd, in FLOAT64 (the float32 gradient of fifty train-mode BatchNorms at batch 2 is
+    only good to ~2e-2, see tests/test_gpu_deeplab_bwd.py): train-mode forward, loss = <logits, R>, every parameter's gradient
+    as its L2 norm plus 64 sampled entries."""
+    from networks.deeplabv2 import DeepLabV2
+    real_load = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        torch.manual_seed(seed)
+        model = DeepLabV2(arch, nclass)
+    finally:
+        torch.load = real_load
+    wsum = weight_sums(model)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randint(0, 256, (n, 3, h, w), generator=g).float() / 127.5 - 1
+    R = torch.randn(n, nclass, h, w, generator=g)
+    model = model.double().train()
+    out = model(x.double())
+    (out * R.double()).sum().backward()
+    names, norms, idxs, vals = [], [], [], []
+    for k, p in model.named_parameters():
+        flat = p.grad.flatten()
+        idx = torch.randperm(flat.numel(), generator=g)[:64]
+        if idx.numel() < 64:
+            idx = torch.cat([idx, idx.new_zeros(64 - idx.numel())])
+        names.append(k); norms.append(float(flat.norm())); idxs.append(idx.numpy()); vals.append(flat[idx].numpy())
+    save(name, model_seed=seed, input_seed=seed + 1, shape=np.array([n, 3, h, w, nclass]), weight_sums=wsum, names=np.array(names),
+         grad_l2=np.array(norms), sample_idx=np.stack(idxs), sample_val=np.stack(vals), logit_l2=float(out.detach().norm()))
+
+
 def g4_dice():
     rec = {}
     for K in (2, 4):
@@ -347,6 +377,9 @@ if __name__ == "__main__":
         g10_deeplab("g10_deeplabv2_r50_n2_96x80", "resnet50", 2, 2, 96, 80)
         g10_deeplab("g10_deeplabv2_r101_n1_128", "resnet101", 2, 1, 128, 128)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g10b":         # DeepLabV2-ResNet backward (round 2)
+        g10b_deeplab_backward("g10b_deeplabv2_r50_n2_96x80_bwd", "resnet50", 2, 2, 96, 80)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g3b":          # only the round-2 addition
         g3b_unet_backward("g3b_unet_3_2_n4_256_bwd", 3, 2, 4, 256)
         sys.exit(0)
@@ -358,6 +391,7 @@ if __name__ == "__main__":
     g3b_unet_backward("g3b_unet_3_2_n4_256_bwd", 3, 2, 4, 256)
     g10_deeplab("g10_deeplabv2_r50_n2_96x80", "resnet50", 2, 2, 96, 80)
     g10_deeplab("g10_deeplabv2_r101_n1_128", "resnet101", 2, 1, 128, 128)
+    g10b_deeplab_backward("g10b_deeplabv2_r50_n2_96x80_bwd", "resnet50", 2, 2, 96, 80)
     g4_dice()
     g5_ramps()
     g6_metrics()

@@ -138,6 +138,7 @@ struct WgradArgs {
     int N, Hb, Wb; long M;   // base grid = pixels summed over
     int nseg, segw, d0, astep; // A side: in pixel = base + d0 + (s/segw, s%segw)*astep
     int dy_s;                  // dY pixel = base*dy_s + (dy_s == 2 ? (s/2, s%2) : (0,0))
+    int ashift;                // strided convolution: in pixel = (base << ashift) + d0 + ... (generic kernels only)
     int dyH, dyW;              // dY extent
     float* partials;           // [ksplit][nseg][Cin][Cout]
     float* bias_partials;      // wgradT only: [ksplit][Cout] column sums of dY, or null

@@ -3,7 +3,9 @@
 // implicit-GEMM kernels (k x k taps on a regular grid, stride 1 / 2, any dilation: the 7x7 stem, the 1x1 and dilated 3x3
 // convolutions of the bottlenecks, the four dilated classifier convolutions), the stem's 3x3 / stride-2 max-pool of the
 // activated tensor, the bottleneck's residual join relu(bn3(y) + identity), and the bilinear resize (align_corners) of the
-// summed classifier maps to the input extent.  Forward only this round.
+// summed classifier maps to the input extent -- and their backward counterparts (weight gradients on the generic TN GEMMs,
+// input gradients as convolutions with flipped weights through the same forward entry point, the join / max-pool / resize /
+// shifted-add adjoints).
 #include "common.h"
 #include "loader.h"
 
@@ -122,6 +124,148 @@ __global__ __launch_bounds__(256) void aspp_gather_kernel(const float* __restric
     }
 }
 
+// ---- backward -------------------------------------------------------------------------------------------------------------
+// g = (a + b) * (ref > 0): the gradient of the bottleneck's join relu(bn3(y3) + identity) with respect to its pre-ReLU sum, formed
+// from the two gradients that reach the block's output (the next block's conv1 input gradient and its identity branch); b = null:
+// one contribution; ref = null: no ReLU in between (the stem's max-pool output)
+template <int ESZ>
+__global__ __launch_bounds__(256) void relu_bwd_add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ ref, long total4, float* __restrict__ g) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
+        f32x4 v = ld4t<ESZ>(a, e * 4);
+        if (b) v += ld4t<ESZ>(b, e * 4);
+        if (ref) {
+            const f32x4 r = ld4t<ESZ>(ref, e * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = r[j] > 0.f ? v[j] : 0.f;
+        }
+        st4t<ESZ>(g, e * 4, v);
+    }
+}
+
+// MaxPool2d(3, 2, 1) backward as a gather (fixed summation order, no atomics): input pixel (iy, ix) belongs to up to 2 x 2
+// windows; each window's arg-max of relu(y * scale + shift) is recomputed in torch's scan order (rows, then columns; a strict >
+// keeps the FIRST maximum) and the window's gradient is taken when that arg-max is this pixel.  thread = (input pixel, 4 channels)
+template <int ESZ>
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ y,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift, int N,
+                                                              int H, int W, int C, int Ho, int Wo, float* __restrict__ da) {
+    const int C4 = C / 4;
+    const long total = (long)N * H * W * C4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c4 = (int)(e % C4);
+        long t = e / C4;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const int n = (int)(t / H);
+        const f32x4 sc = *(const f32x4*)(scale + 4 * c4), sh = *(const f32x4*)(shift + 4 * c4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int oy0 = iy >> 1, ox0 = ix >> 1;                       // windows oy with 2*oy-1 <= iy <= 2*oy+1: iy/2 and (iy+1)/2
+        const int oy1 = (iy + 1) >> 1, ox1 = (ix + 1) >> 1;
+#pragma unroll 1
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            if (oy >= Ho) continue;
+#pragma unroll 1
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                if (ox >= Wo) continue;
+                f32x4 best = {-1.f, -1.f, -1.f, -1.f};                // below every activation (>= 0): the first in-image pixel is taken
+                int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const int py = 2 * oy - 1 + q / 3, px = 2 * ox - 1 + q % 3;
+                    if (py < 0 || py >= H || px < 0 || px >= W) continue;
+                    const f32x4 v = relu4(ld4t<ESZ>(y, (((long)n * H + py) * W + px) * C + 4 * c4) * sc + sh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (v[j] > best[j]) { best[j] = v[j]; bi[j] = q; }
+                }
+                const int mine = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
+                const f32x4 g = ld4t<ESZ>(dp, (((long)n * Ho + oy) * Wo + ox) * C + 4 * c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += bi[j] == mine ? g[j] : 0.f;
+            }
+        }
+        st4t<ESZ>(da, e * 4, acc);
+    }
+}
+
+// adjoint of sum_resize_kernel for one map: dlow[n][ly][lx][k] = sum over the output pixels whose bilinear footprint holds
+// (ly, lx) of their weight * dout; the candidate range is generous and every candidate is tested with the forward's own
+// arithmetic, the sum runs in a fixed order.  thread = (low pixel, class)
+__global__ __launch_bounds__(256) void sum_resize_bwd_kernel(const float* __restrict__ dout, int N, int h, int w, int K, int H, int W,
+                                                            float* __restrict__ dlow) {
+    const long total = (long)N * h * w * K;
+    const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int k = (int)(e % K);
+        long t = e / K;
+        const int lx = (int)(t % w); t /= w;
+        const int ly = (int)(t % h);
+        const int n = (int)(t / h);
+        int ya = 0, yb = H - 1, xa = 0, xb = W - 1;
+        if (ry > 0.f) { ya = max(0, (int)floorf((ly - 1) / ry) - 1); yb = min(H - 1, (int)ceilf((ly + 1) / ry) + 1); }
+        if (rx > 0.f) { xa = max(0, (int)floorf((lx - 1) / rx) - 1); xb = min(W - 1, (int)ceilf((lx + 1) / rx) + 1); }
+        float acc = 0.f;
+        for (int oy = ya; oy <= yb; ++oy) {
+            const float fy = ry * oy;
+            const int y0 = (int)fy, y1 = y0 + (y0 < h - 1);
+            const float fr = fy - y0;
+            const float wy = (y0 == ly ? 1.f - fr : 0.f) + (y1 == ly ? fr : 0.f);
+            if (y0 != ly && y1 != ly) continue;
+            float row = 0.f;
+            for (int ox = xa; ox <= xb; ++ox) {
+                const float fx = rx * ox;
+                const int x0 = (int)fx, x1 = x0 + (x0 < w - 1);
+                const float fc = fx - x0;
+                if (x0 != lx && x1 != lx) continue;
+                const float wx = (x0 == lx ? 1.f - fc : 0.f) + (x1 == lx ? fc : 0.f);
+                row += wx * dout[(((long)n * K + k) * H + oy) * W + ox];
+            }
+            acc += wy * row;
+        }
+        dlow[e] = acc;
+    }
+}
+
+// adjoint of aspp_gather_kernel: dz[p][(r*9+tap)*K+k] = dlow[p - rate_r * (tap/3-1, tap%3-1)][k] (zero outside), written in the
+// compute dtype with the column count padded to ZCp (zero columns) so that the matrix-core kernels take it
+template <int ESZ>
+__global__ __launch_bounds__(256) void aspp_scatter_kernel(const float* __restrict__ dlow, int N, int h, int w, int K, int nr, int r0,
+                                                          int r1, int r2, int r3, int ZCp, float* __restrict__ dz) {
+    const long total = (long)N * h * w * ZCp;
+    const int ZC = nr * 9 * K;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int col = (int)(e % ZCp);
+        long t = e / ZCp;
+        const int x = (int)(t % w); t /= w;
+        const int y = (int)(t % h);
+        const int n = (int)(t / h);
+        float v = 0.f;
+        if (col < ZC) {
+            const int k = col % K, rt = col / K, tap = rt % 9, r = rt / 9;
+            const int rate = r == 0 ? r0 : (r == 1 ? r1 : (r == 2 ? r2 : r3));
+            const int yy = y - rate * (tap / 3 - 1), xx = x - rate * (tap % 3 - 1);
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = dlow[(((long)n * h + yy) * w + xx) * K + k];
+        }
+        st1t<ESZ>(dz, e, v);
+    }
+}
+
+// out[c] (+)= sum over rows of x[row][c] (f32): one block per column, fixed order (thread-strided sums, then a tree in LDS)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long rows, int C, float* __restrict__ out, int accumulate) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (long r = threadIdx.x; r < rows; r += 256) s += (double)x[r * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)red[0];
+}
+
 int stream_blocks(long total) { long b = (total + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 }  // namespace
@@ -238,4 +382,112 @@ extern "C" int ustrun_aspp_gather(const float* z, int N, int h, int w, int K, in
                        r[0], r[1], r[2], r[3], bias_sum, out);
     USTRUN_LAUNCH_CHECK("aspp_gather");
     return 0;
+}
+
+// ---- backward entry points --------------------------------------------------------------------------------------------------
+#define USTRUN_BY_DTYPE(KERNEL, BLOCKS, ...)                                                                                    \
+    do {                                                                                                                        \
+        if (dtype == USTRUN_BF16) hipLaunchKernelGGL(KERNEL<2>, dim3(BLOCKS), dim3(256), 0, (hipStream_t)s, __VA_ARGS__);       \
+        else hipLaunchKernelGGL(KERNEL<4>, dim3(BLOCKS), dim3(256), 0, (hipStream_t)s, __VA_ARGS__);                            \
+    } while (0)
+
+extern "C" int ustrun_relu_bwd_add(const void* a, const void* b, const void* ref, int64_t n, void* g, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(a && g && n > 0 && n % 4 == 0 && dtype_ok(dtype), "relu_bwd_add: bad args");
+    USTRUN_BY_DTYPE(relu_bwd_add_kernel, stream_blocks(n / 4), (const float*)a, (const float*)b, (const float*)ref, (long)(n / 4), (float*)g);
+    USTRUN_LAUNCH_CHECK("relu_bwd_add");
+    return 0;
+}
+
+extern "C" int ustrun_maxpool3x3s2_bwd(const void* dp, const void* y, const float* scale, const float* shift, int N, int H, int W, int C,
+                                       void* da, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(dp && y && scale && shift && da && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && dtype_ok(dtype), "maxpool3x3s2_bwd: bad args");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    USTRUN_BY_DTYPE(maxpool3x3s2_bwd_kernel, stream_blocks((long)N * H * W * (C / 4)), (const float*)dp, (const float*)y, scale, shift, N, H,
+                    W, C, Ho, Wo, (float*)da);
+    USTRUN_LAUNCH_CHECK("maxpool3x3s2_bwd");
+    return 0;
+}
+
+extern "C" int ustrun_sum_resize_bilinear_bwd(const float* dout, int N, int h, int w, int K, int H, int W, float* dlow, ustrun_stream_t s) {
+    USTRUN_CHECK(dout && dlow && N > 0 && h > 0 && w > 0 && K > 0 && H > 0 && W > 0, "sum_resize_bilinear_bwd: bad args");
+    hipLaunchKernelGGL(sum_resize_bwd_kernel, dim3(stream_blocks((long)N * h * w * K)), dim3(256), 0, (hipStream_t)s, dout, N, h, w, K, H, W,
+                       dlow);
+    USTRUN_LAUNCH_CHECK("sum_resize_bilinear_bwd");
+    return 0;
+}
+
+extern "C" int ustrun_aspp_scatter(const float* dlow, int N, int h, int w, int K, int nrates, const int* rates, int zc_padded, void* dz,
+                                   int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(dlow && rates && dz && N > 0 && h > 0 && w > 0 && K > 0 && nrates >= 1 && nrates <= 4 && dtype_ok(dtype) &&
+                 zc_padded >= nrates * 9 * K, "aspp_scatter: bad args");
+    int r[4] = {1, 1, 1, 1};
+    for (int i = 0; i < nrates; ++i) r[i] = rates[i];
+    USTRUN_BY_DTYPE(aspp_scatter_kernel, stream_blocks((long)N * h * w * zc_padded), dlow, N, h, w, K, nrates, r[0], r[1], r[2], r[3],
+                    zc_padded, (float*)dz);
+    USTRUN_LAUNCH_CHECK("aspp_scatter");
+    return 0;
+}
+
+extern "C" int ustrun_colsum(const float* x, int64_t rows, int C, float* out, int accumulate, ustrun_stream_t s) {
+    USTRUN_CHECK(x && out && rows > 0 && C > 0 && C <= 65535, "colsum: bad args");
+    hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, (hipStream_t)s, x, (long)rows, C, out, accumulate);
+    USTRUN_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+// weight gradient of ustrun_conv2d_fwd's convolution: dw[Cout][Cin][k][k] (torch layout, f32) = sum over output pixels of
+// loader(srcs)(stride * p + dilation * (tap - k/2)) x dy(p)
+extern "C" int ustrun_conv2d_wgrad(const ustrun_src_t* srcs, int nsrc, const void* dy, int N, int Ho, int Wo, int Cout, int k, int stride,
+                                   int dilation, float* dw, int accumulate, float* partials, int64_t partials_bytes, int dtype,
+                                   ustrun_stream_t s) {
+    USTRUN_CHECK(srcs && (nsrc == 1 || nsrc == 2) && dy && dw && partials && N > 0 && Ho > 0 && Wo > 0 && Cout > 0, "conv2d_wgrad: bad args");
+    USTRUN_CHECK((k == 1 || k == 3) && (stride == 1 || stride == 2) && dilation >= 1, "conv2d_wgrad: k=%d stride=%d dilation=%d", k, stride,
+                 dilation);
+    WgradArgs a = {};
+    a.nsrc = nsrc; a.Cin = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        USTRUN_CHECK(srcs[i].ptr && srcs[i].C > 0 && !srcs[i].pool && srcs[i].gN == 0, "conv2d_wgrad: bad source %d", i);
+        a.src[i] = make_src(srcs[i], dtype); a.Cin += srcs[i].C;
+    }
+    a.dy = (const float*)dy; a.Cout = Cout; a.dy_esz = act_esz(dtype);
+    a.N = N; a.Hb = Ho; a.Wb = Wo; a.M = (long)N * Ho * Wo;
+    a.nseg = k * k; a.segw = k; a.d0 = -dilation * (k / 2); a.astep = dilation; a.dy_s = 1; a.dyH = Ho; a.dyW = Wo;
+    a.ashift = stride == 2 ? 1 : 0;
+    a.partials = partials;
+    int slabs;
+    if (dtype == USTRUN_BF16 && wgrad_halo_supported(a)) {
+        int per;
+        wgrad_halo_plan(a, &slabs, &per);
+        USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 9 * a.Cin * Cout * 4, "conv2d_wgrad: partials too small");
+        prof_begin(1, 2.0 * a.M * 9 * a.Cin * Cout, 2.0 * ((double)a.M * a.Cin + (double)a.M * Cout) + 36.0 * a.Cin * Cout, (hipStream_t)s);
+        const int rc = wgrad_halo_launch_bf16(a, slabs, per, (hipStream_t)s);
+        prof_end((hipStream_t)s);
+        USTRUN_TRY(rc);
+        return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 2, accumulate, (hipStream_t)s);
+    }
+    wgrad_plan(a.nseg, a.Cin, Cout, a.M, &a.ksplit, &a.kchunk, &slabs);
+    USTRUN_CHECK(partials_bytes >= (int64_t)slabs * a.nseg * a.Cin * Cout * 4, "conv2d_wgrad: partials too small");
+    USTRUN_TRY(wgrad_launch(a, dtype, (hipStream_t)s));
+    return reduce_partials(partials, slabs, a.nseg, a.Cin, Cout, dw, 0, accumulate, (hipStream_t)s);
+}
+
+// weight gradient of ustrun_conv_rowwin_fwd: dw[Cout][src->C][nrows] (the layout its weights were packed from)
+extern "C" int ustrun_conv_rowwin_wgrad(const ustrun_src_t* src, const void* dy, int N, int Ho, int Wo, int Cout, int nrows, int stride,
+                                        float* dw, int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(src && src->ptr && dy && dw && partials && N > 0 && Ho > 0 && Wo > 0 && Cout > 0 && nrows >= 1 && nrows <= 9 &&
+                 (stride == 1 || stride == 2), "conv_rowwin_wgrad: bad args");
+    USTRUN_CHECK(src->sC == 1 && !src->pool && src->gN == 0 && (stride * (Ho - 1) + nrows) <= src->H && stride * (Wo - 1) < src->W,
+                 "conv_rowwin_wgrad: the padded source [%d x %d] does not cover the windows", src->H, src->W);
+    WgradArgs a = {};
+    a.nsrc = 1; a.src[0] = make_src(*src, dtype); a.Cin = src->C;
+    a.dy = (const float*)dy; a.Cout = Cout; a.dy_esz = act_esz(dtype);
+    a.N = N; a.Hb = Ho; a.Wb = Wo; a.M = (long)N * Ho * Wo;
+    a.nseg = nrows; a.segw = 1; a.d0 = 0; a.astep = 1; a.dy_s = 1; a.dyH = Ho; a.dyW = Wo;
+    a.ashift = stride == 2 ? 1 : 0;
+    a.partials = partials;
+    int slabs;
+    wgrad_plan(a.nseg, a.Cin, Cout, a.M, &a.ksplit, &a.kchunk, &slabs);
+    USTRUN_CHECK(partials_bytes >= (int64_t)slabs * a.nseg * a.Cin * Cout * 4, "conv_rowwin_wgrad: partials too small");
+    USTRUN_TRY(wgrad_launch(a, dtype, (hipStream_t)s));
+    return reduce_partials(partials, slabs, a.nseg, a.Cin, Cout, dw, 0, accumulate, (hipStream_t)s);
 }

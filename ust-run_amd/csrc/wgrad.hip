@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a, co
                 const int n = (int)(m / hw);
                 const int rem = (int)(m - (long)n * hw);
                 const int by = rem / a.Wb, bx = rem - by * a.Wb;
-                const int iy = by + ady, ix = bx + adx;
+                const int iy = (by << a.ashift) + ady, ix = (bx << a.ashift) + adx;
                 if (vecA) {
                     const int ly = iy - S.off_y, lx = ix - S.off_x;
                     if (cg < a.Cin && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW) {

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_bf16_kernel(const WgradArgs a, 
 }  // namespace
 
 bool wgradT_supported(const WgradArgs& a) {
-    if (a.nseg != 4 || a.segw != 2 || a.dy_s != 2 || a.astep != 0 || a.d0 != 0 || a.dy_esz != 2 || a.nsrc != 1) return false;
+    if (a.nseg != 4 || a.segw != 2 || a.dy_s != 2 || a.astep != 0 || a.d0 != 0 || a.ashift != 0 || a.dy_esz != 2 || a.nsrc != 1) return false;
     const SrcDev& s = a.src[0];
     if (s.esz != 2 || s.sC != 1 || s.pool || s.off_y || s.off_x || s.LH != a.Hb || s.LW != a.Wb) return false;
     if ((s.relu && !s.scale) || (s.sW & 7)) return false;

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
 }  // namespace
 
 bool wgrad_halo_supported(const WgradArgs& a) {
-    if (a.nseg != 9 || a.segw != 3 || a.dy_s != 1 || a.astep != 1 || a.d0 != -1 || a.dy_esz != 2) return false;
+    if (a.nseg != 9 || a.segw != 3 || a.dy_s != 1 || a.astep != 1 || a.d0 != -1 || a.ashift != 0 || a.dy_esz != 2) return false;
     for (int i = 0; i < a.nsrc; ++i)
         if (a.src[i].sC != 1 || a.src[i].esz != 2 || (a.src[i].C % 64) || (a.src[i].relu && !a.src[i].scale && !a.src[i].pool) || (a.src[i].pool && (a.nsrc != 1 || !a.src[i].relu))) return false;
     if (a.Cin % 64 || a.Cout % 64) return false;

@@ -3,7 +3,8 @@
 Same constructor surface (`DeepLabV2(backbone, nclass)`), the same `backbone` / `classifier` members and state_dict keys;
 `base_forward` = dilated ResNet features -> four dilated 3x3 classifier convolutions (rates 6, 12, 18, 24, with bias) summed
 -> bilinear resize (align_corners=True) to the input extent, all in libustrun.so.  `pretrained=False` and `dtype` are
-additive keywords (the reference always loads ../../checkpoints/pretrained/<arch>.pth, base.py:12).  Forward only this round.
+additive keywords (the reference always loads ../../checkpoints/pretrained/<arch>.pth, base.py:12).  Under autograd (train mode)
+the call is differentiable with respect to the parameters: ustrun.resnet_engine.DeepLabFn runs the backward in libustrun.so.
 """
 from networks.backbone.base import BaseNet
 
@@ -23,4 +24,4 @@ class DeepLabV2(BaseNet):
 
     def base_forward(self, x):
         from ustrun import resnet_engine as E
-        return E.deeplabv2_forward(self, x)
+        return E.deeplabv2_apply(self, x)

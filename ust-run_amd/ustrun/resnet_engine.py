@@ -5,7 +5,14 @@ Internal tensors are NHWC in the compute dtype.  Only raw convolution outputs `y
 materialised: BatchNorm + ReLU of a producer is applied by its consumer's loader, the residual join
 relu(bn3(y3) + identity) is one pass (identity = the block input, or bn_d(y_d) of the projection shortcut, evaluated in the
 same pass).  Train mode takes batch statistics from the convolution epilogues (f64 finalize, running buffers updated in
-place); eval mode uses the running buffers.  Forward only.
+place); eval mode uses the running buffers.
+
+Backward (train mode): `deeplabv2_forward(..., tape=[])` records what each operator kept, `deeplabv2_backward` walks the tape
+in reverse -- BatchNorm backward as reduce + apply (ustrun_bn_bwd_*), weight gradients on the TN GEMMs (ustrun_conv2d_wgrad),
+input gradients as convolutions of dy with the flipped / transposed weights through ustrun_conv2d_fwd (the two stride-2
+convolutions through a zero-inserted dy), the join / max-pool / resize / shifted-add adjoints of resnet_ops.hip.  `DeepLabFn`
+is the torch.autograd.Function through which `DeepLabV2.forward` is differentiable with respect to its parameters (the input
+image receives no gradient, as in the reference's training loops).
 """
 from __future__ import annotations
 
@@ -21,10 +28,11 @@ _DT = {"f32": L.F32, "bf16": L.BF16}
 
 class Act:
     """An NHWC tensor plus how to read it: raw conv output with (scale, shift) + ReLU pending, or a finished activation."""
-    __slots__ = ("t", "aff", "relu", "N", "H", "W", "C")
+    __slots__ = ("t", "aff", "relu", "N", "H", "W", "C", "keep")
 
     def __init__(self, t, N, H, W, Cc, aff=None, relu=0):
         self.t, self.N, self.H, self.W, self.C, self.aff, self.relu = t, N, H, W, Cc, aff, relu
+        self.keep = None
 
     def src(self):
         if self.aff is None:
@@ -128,10 +136,12 @@ def stem(net, x, dt, train):
         L.check(lib.ustrun_bn_eval_affine(co, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                                           bn.running_var.data_ptr(), float(bn.eps), aff[0].data_ptr(), aff[1].data_ptr(), stream_ptr()),
                 "ustrun_bn_eval_affine")
-    return Act(y, N, Ho, Wo, co, aff=aff, relu=1)
+    a = Act(y, N, Ho, Wo, co, aff=aff, relu=1)
+    a.keep = (xp, src, win, k, st, Cin)               # the weight gradient reads the same windows
+    return a
 
 
-def bottleneck(blk, x, dt, train):
+def bottleneck(blk, x, dt, train, tape=None):
     """resnet.py:78-105 on a finished activation x -> the block's finished activation."""
     lib = L.lib()
     y1 = conv_bn(x, None, blk.conv1, blk.bn1, dt, train)
@@ -145,22 +155,25 @@ def bottleneck(blk, x, dt, train):
     out = torch.empty_like(y3.t)
     L.check(lib.ustrun_bn_add_relu(y3.t.data_ptr(), y3.aff[0].data_ptr(), y3.aff[1].data_ptr(), idn.data_ptr(), isc, ish,
                                    y3.N * y3.H * y3.W, y3.C, out.data_ptr(), dt, stream_ptr()), "ustrun_bn_add_relu")
-    return Act(out, y3.N, y3.H, y3.W, y3.C)
+    o = Act(out, y3.N, y3.H, y3.W, y3.C)
+    if tape is not None:
+        tape.append(("block", blk, x, y1, y2, y3, yd if blk.downsample is not None else None, o))
+    return o
 
 
-def _check_input(net, x):
+def _check_input(net, x, differentiable=False):
     if not x.is_cuda:
         raise RuntimeError("ResNet / DeepLabV2 run on an MI355X through libustrun.so: there is no CPU fallback for this path")
     if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:
         raise RuntimeError(f"expected a float32 input [N,3,H,W], got {x.dtype} {tuple(x.shape)}")
-    if torch.is_grad_enabled() and net.training and any(p.requires_grad for p in net.parameters()):
-        raise NotImplementedError("DeepLabV2-ResNet is forward-only in this build: call it under torch.no_grad() "
-                                  "(train-mode BatchNorm statistics are computed and the running buffers updated)")
+    if not differentiable and torch.is_grad_enabled() and net.training and any(p.requires_grad for p in net.parameters()):
+        raise NotImplementedError("the stand-alone ResNet feature path records no autograd graph: call it under torch.no_grad(), "
+                                  "or train through DeepLabV2.forward (ustrun.resnet_engine.DeepLabFn)")
 
 
-def backbone_features(net, x):
+def backbone_features(net, x, tape=None):
     """resnet.py:159-171 -> [c1, c2, c3, c4] as finished NHWC activations."""
-    _check_input(net, x)
+    _check_input(net, x, differentiable=tape is not None)
     lib = L.lib()
     dt = _DT[net.compute_dtype]
     train = net.training
@@ -171,10 +184,12 @@ def backbone_features(net, x):
     L.check(lib.ustrun_maxpool3x3s2(y0.t.data_ptr(), y0.aff[0].data_ptr(), y0.aff[1].data_ptr(), y0.N, y0.H, y0.W, y0.C, p.data_ptr(),
                                     dt, stream_ptr()), "ustrun_maxpool3x3s2")
     a = Act(p, y0.N, Hp, Wp, y0.C)
+    if tape is not None:
+        tape.append(("stem", net, y0, a))
     feats = []
     for stage in (net.layer1, net.layer2, net.layer3, net.layer4):
         for blk in stage:
-            a = bottleneck(blk, a, dt, train)
+            a = bottleneck(blk, a, dt, train, tape)
         feats.append(a)
     return feats
 
@@ -200,13 +215,13 @@ def _classifier_gemm(net, dt):
     return net._ustrun_cls
 
 
-def deeplabv2_forward(net, x):
+def deeplabv2_forward(net, x, tape=None):
     """deeplabv2.py:22-33: logits NCHW float32 [N, nclass, H, W].  The four dilated 3x3 branches (Cout = nclass = 2: a
     64-column MFMA tile would be 97 % idle, 2.1-2.6 ms each at N = 8) run as ONE 1x1 GEMM with nrates*9*nclass columns followed
     by a shifted add (a convolution is linear in its taps)."""
     lib = L.lib()
     N, _, H, W = x.shape
-    c4 = backbone_features(net.backbone, x)[-1]
+    c4 = backbone_features(net.backbone, x, tape)[-1]
     dt = _DT[net.backbone.compute_dtype]
     K = net.classifier[0].weight.shape[0]
     wf, bias_sum, ZC = _classifier_gemm(net, dt)
@@ -221,4 +236,244 @@ def deeplabv2_forward(net, x):
     out = torch.empty(N, K, H, W, device=x.device)
     arr = (C.c_void_p * 4)(low.data_ptr(), None, None, None)
     L.check(lib.ustrun_sum_resize_bilinear(arr, 1, N, c4.H, c4.W, K, H, W, out.data_ptr(), stream_ptr()), "ustrun_sum_resize_bilinear")
+    if tape is not None:
+        tape.append(("head", net, c4, (N, K, H, W)))
     return out
+
+
+# ---- backward ---------------------------------------------------------------------------------------------------------------
+class _Scratch:
+    """Grow-only device scratch shared by the backward's launches (one stream: reuse is ordered)."""
+    def __init__(self):
+        self.buf, self.const = {}, {}
+
+    def get(self, name, nbytes, dev):
+        b = self.buf.get(name)
+        if b is None or b.numel() < nbytes or b.device != dev:
+            b = self.buf[name] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        return b
+
+    def noact(self, Cc, dev):
+        """(scale, shift) = (0, 1): the BatchNorm-backward kernels' ReLU mask (y*scale+shift > 0) becomes all ones"""
+        k = (Cc, dev)
+        if k not in self.const:
+            self.const[k] = (torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev))
+        return self.const[k]
+
+
+_scratch = _Scratch()
+
+
+def _packed_dgrad(conv, dt):
+    """pack of the input-gradient convolution's weight: w.flip(2, 3).transpose(0, 1) as a conv weight [Cin][Cout][k][k]"""
+    key = (conv.weight.data_ptr(), conv.weight._version, dt)
+    if getattr(conv, "_ustrun_dpack_key", None) != key:
+        lib = L.lib()
+        co, ci, kh, kw = conv.weight.shape
+        wd = conv.weight.detach().flip(2, 3).transpose(0, 1).contiguous()
+        buf = torch.zeros(lib.ustrun_pack_conv_elems(ci, co, kh * kw), dtype=_tdtype(dt), device=wd.device)
+        L.check(lib.ustrun_pack_conv(wd.data_ptr(), ci, co, kh * kw, buf.data_ptr(), dt, stream_ptr()), "ustrun_pack_conv")
+        conv._ustrun_dpack, conv._ustrun_dpack_key = buf, key
+    return conv._ustrun_dpack
+
+
+def _bn_backward(y, da, relu, bn, grads, dt):
+    """autograd of train-mode BatchNorm (+ReLU): da = gradient of the (activated) output, y = the raw convolution output with its
+    forward constants -> dy; fills grads[bn.weight], grads[bn.bias]."""
+    lib = L.lib()
+    dev = y.t.device
+    sc, sh = (y.aff[0], y.aff[1]) if relu else _scratch.noact(y.C, dev)
+    npix = y.N * y.H * y.W
+    pb = lib.ustrun_bn_bwd_partials_bytes(npix, y.C)
+    part = _scratch.get("bn", pb, dev)
+    coef = torch.empty(3, y.C, device=dev)
+    dg, db = torch.empty(y.C, device=dev), torch.empty(y.C, device=dev)
+    L.check(lib.ustrun_bn_bwd_reduce(da.data_ptr(), None, y.t.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.aff[2].data_ptr(),
+                                     y.aff[3].data_ptr(), bn.weight.data_ptr(), y.N, y.H, y.W, y.C, dg.data_ptr(), db.data_ptr(), 0,
+                                     coef.data_ptr(), part.data_ptr(), pb, dt, stream_ptr()), "ustrun_bn_bwd_reduce")
+    dy = torch.empty_like(y.t)
+    L.check(lib.ustrun_bn_bwd_apply(da.data_ptr(), None, y.t.data_ptr(), sc.data_ptr(), sh.data_ptr(), coef.data_ptr(), y.N, y.H, y.W,
+                                    y.C, dy.data_ptr(), dt, stream_ptr()), "ustrun_bn_bwd_apply")
+    grads[bn.weight], grads[bn.bias] = dg, db
+    return dy
+
+
+def _conv_wgrad(x, dy, y, conv, grads, dt):
+    """grads[conv.weight] from the loader's view of the input Act x and the raw-output gradient dy (shape of y)"""
+    lib = L.lib()
+    co, ci, k, _ = conv.weight.shape
+    s, d = conv.stride[0], conv.dilation[0]
+    pb = lib.ustrun_wgrad_partials_bytes(k * k, ci, co, y.N * y.H * y.W)
+    part = _scratch.get("wgrad", pb, dy.device)
+    dw = torch.empty_like(conv.weight)
+    src = x.src()
+    L.check(lib.ustrun_conv2d_wgrad(C.byref(src), 1, dy.data_ptr(), y.N, y.H, y.W, co, k, s, d, dw.data_ptr(), 0, part.data_ptr(), pb, dt,
+                                    stream_ptr()), "ustrun_conv2d_wgrad")
+    grads[conv.weight] = dw
+
+
+def _zero_insert(t, H, W):
+    """[N,h,w,C] -> [N,H,W,C] with t at the even positions (the adjoint of a stride-2 subsampling; tensor plumbing)"""
+    z = torch.zeros(t.shape[0], H, W, t.shape[3], dtype=t.dtype, device=t.device)
+    z[:, ::2, ::2][:, :t.shape[1], :t.shape[2]] = t
+    return z
+
+
+def _conv_dgrad(dy, y, x, conv, dt):
+    """gradient of the convolution's input (an Act of x's shape) from dy (shape of y): a convolution of dy with the flipped,
+    transposed weight; stride 2: 3x3 over the zero-inserted dy, 1x1 at the low resolution then zero-inserted."""
+    lib = L.lib()
+    co, ci, k, _ = conv.weight.shape
+    s, d = conv.stride[0], conv.dilation[0]
+    wd = _packed_dgrad(conv, dt)
+    if s == 2 and k == 3:
+        dy, Hs, Ws = _zero_insert(dy, x.H, x.W), x.H, x.W
+    elif s == 2:
+        Hs, Ws = y.H, y.W
+    else:
+        Hs, Ws = x.H, x.W
+    src = L.nhwc_src(dy.data_ptr(), co, Hs, Ws)
+    dx = torch.empty(x.N, Hs, Ws, ci, dtype=dy.dtype, device=dy.device)
+    L.check(lib.ustrun_conv2d_fwd(C.byref(src), 1, wd.data_ptr(), None, x.N, Hs, Ws, ci, k, 1, d, dx.data_ptr(), 0, None, None, dt,
+                                  stream_ptr()), "ustrun_conv2d_fwd")
+    if s == 2 and k == 1:
+        dx = _zero_insert(dx, x.H, x.W)
+    return dx
+
+
+def _join(a, b, ref, dt):
+    lib = L.lib()
+    g = torch.empty_like(a)
+    L.check(lib.ustrun_relu_bwd_add(a.data_ptr(), None if b is None else b.data_ptr(), None if ref is None else ref.data_ptr(), a.numel(),
+                                    g.data_ptr(), dt, stream_ptr()), "ustrun_relu_bwd_add")
+    return g
+
+
+def _block_backward(rec, G, dt, grads):
+    """G = gradient of the block's pre-ReLU join sum -> the two gradients reaching the block input (conv1 path, identity path)"""
+    _, blk, x, y1, y2, y3, yd, _ = rec
+    dy3 = _bn_backward(y3, G, False, blk.bn3, grads, dt)
+    _conv_wgrad(y2, dy3, y3, blk.conv3, grads, dt)
+    da2 = _conv_dgrad(dy3, y3, y2, blk.conv3, dt)
+    dy2 = _bn_backward(y2, da2, True, blk.bn2, grads, dt)
+    _conv_wgrad(y1, dy2, y2, blk.conv2, grads, dt)
+    da1 = _conv_dgrad(dy2, y2, y1, blk.conv2, dt)
+    dy1 = _bn_backward(y1, da1, True, blk.bn1, grads, dt)
+    _conv_wgrad(x, dy1, y1, blk.conv1, grads, dt)
+    dxa = _conv_dgrad(dy1, y1, x, blk.conv1, dt)
+    if yd is None:
+        return dxa, G
+    dyd = _bn_backward(yd, G, False, blk.downsample[1], grads, dt)
+    _conv_wgrad(x, dyd, yd, blk.downsample[0], grads, dt)
+    return dxa, _conv_dgrad(dyd, yd, x, blk.downsample[0], dt)
+
+
+def _head_backward(rec, dlogits, dt, grads):
+    """deeplabv2.py:26-30 backward: dlogits NCHW f32 -> classifier gradients and the gradient of c4"""
+    lib = L.lib()
+    _, net, c4, (N, K, H, W) = rec
+    dev = dlogits.device
+    nr = len(net.classifier)
+    dlow = torch.empty(N, c4.H, c4.W, K, device=dev)
+    L.check(lib.ustrun_sum_resize_bilinear_bwd(dlogits.data_ptr(), N, c4.H, c4.W, K, H, W, dlow.data_ptr(), stream_ptr()),
+            "ustrun_sum_resize_bilinear_bwd")
+    db = torch.empty(K, device=dev)
+    L.check(lib.ustrun_colsum(dlow.data_ptr(), N * c4.H * c4.W, K, db.data_ptr(), 0, stream_ptr()), "ustrun_colsum")
+    ZC = nr * 9 * K
+    ZCp = (ZC + 63) // 64 * 64
+    dz = torch.empty(N, c4.H, c4.W, ZCp, dtype=_tdtype(dt), device=dev)
+    rates = (C.c_int * 4)(*[c.dilation[0] for c in net.classifier])
+    L.check(lib.ustrun_aspp_scatter(dlow.data_ptr(), N, c4.H, c4.W, K, nr, rates, ZCp, dz.data_ptr(), dt, stream_ptr()), "ustrun_aspp_scatter")
+    Cin = c4.C
+    # weight gradients: one TN GEMM c4^T x dz -> [ZCp][Cin], rows (r*9+tap)*K+k
+    pb = lib.ustrun_wgrad_partials_bytes(1, Cin, ZCp, N * c4.H * c4.W)
+    part = _scratch.get("wgrad", pb, dev)
+    dwall = torch.empty(ZCp, Cin, device=dev)
+    src = c4.src()
+    L.check(lib.ustrun_conv2d_wgrad(C.byref(src), 1, dz.data_ptr(), N, c4.H, c4.W, ZCp, 1, 1, 1, dwall.data_ptr(), 0, part.data_ptr(), pb, dt,
+                                    stream_ptr()), "ustrun_conv2d_wgrad")
+    dw = dwall[:ZC].reshape(nr, 9, K, Cin).permute(0, 2, 3, 1).reshape(nr, K, Cin, 3, 3)
+    for r, c in enumerate(net.classifier):
+        grads[c.weight] = dw[r].contiguous()
+        grads[c.bias] = db.clone()
+    # input gradient: dz x Wall -> [.., Cin]; the transposed, column-padded weight as a 1x1 convolution [Cin][ZCp]
+    key = tuple((c.weight.data_ptr(), c.weight._version) for c in net.classifier) + (dt, ZCp)
+    if getattr(net, "_ustrun_clsd_key", None) != key:
+        wall = torch.stack([c.weight.detach().reshape(K, Cin, 9).permute(2, 0, 1) for c in net.classifier], 0).reshape(ZC, Cin)
+        wd = torch.nn.functional.pad(wall.t(), (0, ZCp - ZC)).contiguous()                          # [Cin][ZCp]
+        buf = torch.zeros(lib.ustrun_pack_conv_elems(Cin, ZCp, 1), dtype=_tdtype(dt), device=dev)
+        L.check(lib.ustrun_pack_conv(wd.data_ptr(), Cin, ZCp, 1, buf.data_ptr(), dt, stream_ptr()), "ustrun_pack_conv")
+        net._ustrun_clsd, net._ustrun_clsd_key = buf, key
+    dc4 = torch.empty_like(c4.t)
+    zsrc = L.nhwc_src(dz.data_ptr(), ZCp, c4.H, c4.W)
+    L.check(lib.ustrun_conv2d_fwd(C.byref(zsrc), 1, net._ustrun_clsd.data_ptr(), None, N, c4.H, c4.W, Cin, 1, 1, 1, dc4.data_ptr(), 0, None,
+                                  None, dt, stream_ptr()), "ustrun_conv2d_fwd")
+    return dc4
+
+
+def _stem_backward(rec, dpool, dt, grads):
+    """resnet.py:160-163 backward: gradient of the max-pool output -> stem BatchNorm and 7x7 weight gradients"""
+    lib = L.lib()
+    _, net, y0, p = rec
+    dev = dpool.device
+    da0 = torch.empty_like(y0.t)
+    L.check(lib.ustrun_maxpool3x3s2_bwd(dpool.data_ptr(), y0.t.data_ptr(), y0.aff[0].data_ptr(), y0.aff[1].data_ptr(), y0.N, y0.H, y0.W,
+                                        y0.C, da0.data_ptr(), dt, stream_ptr()), "ustrun_maxpool3x3s2_bwd")
+    dy0 = _bn_backward(y0, da0, True, net.bn1, grads, dt)
+    xp, src, win, k, st, Cin = y0.keep
+    co = y0.C
+    pb = lib.ustrun_wgrad_partials_bytes(k, win, co, y0.N * y0.H * y0.W)
+    part = _scratch.get("wgrad", pb, dev)
+    dwr = torch.empty(co, win, k, device=dev)                                    # [co][kx*Cin + ci][ky]
+    L.check(lib.ustrun_conv_rowwin_wgrad(C.byref(src), dy0.data_ptr(), y0.N, y0.H, y0.W, co, k, st, dwr.data_ptr(), 0, part.data_ptr(), pb,
+                                         dt, stream_ptr()), "ustrun_conv_rowwin_wgrad")
+    grads[net.conv1.weight] = dwr[:, :k * Cin].reshape(co, k, Cin, k).permute(0, 2, 3, 1).contiguous()      # [co][ci][ky][kx]
+
+
+def deeplabv2_backward(net, tape, dlogits):
+    """Walk the tape of one train-mode deeplabv2_forward in reverse: {parameter: gradient (f32, the parameter's shape)}."""
+    dt = _DT[net.backbone.compute_dtype]
+    grads = {}
+    dlogits = dlogits.contiguous().float()
+    rec = tape[-1]
+    assert rec[0] == "head"
+    dc4 = _head_backward(rec, dlogits, dt, grads)
+    G = _join(dc4, None, rec[2].t, dt)                           # through the last block's ReLU
+    for rec in reversed(tape[1:-1]):
+        dxa, dxb = _block_backward(rec, G, dt, grads)
+        x = rec[2]
+        prev_is_block = rec is not tape[1]
+        G = _join(dxa, dxb, x.t if prev_is_block else None, dt)   # the previous block's ReLU; none after the max-pool
+    _stem_backward(tape[0], G, dt, grads)
+    return grads
+
+
+class DeepLabFn(torch.autograd.Function):
+    """logits = DeepLabV2(x) with parameter gradients from deeplabv2_backward.  The parameters enter as inputs only so that autograd
+    routes their gradients; the engine reads them from the module."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        tape = []
+        out = deeplabv2_forward(net, x, tape)
+        ctx.net, ctx.tape, ctx.params = net, tape, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if ctx.tape is None:
+            raise RuntimeError("DeepLabFn: the forward's activations were released by an earlier backward")
+        grads = deeplabv2_backward(ctx.net, ctx.tape, dlogits)
+        ctx.tape = None
+        byid = {id(k): v for k, v in grads.items()}
+        named = list(ctx.net.parameters())
+        return (None, None) + tuple(byid.get(id(p)) if p.requires_grad else None for p in named)
+
+
+def deeplabv2_apply(net, x):
+    """DeepLabV2.base_forward: differentiable when autograd is recording and the module trains, plain forward otherwise."""
+    params = list(net.parameters())
+    if torch.is_grad_enabled() and net.training and any(p.requires_grad for p in params):      # eval mode: no graph, as before
+        _check_input(net.backbone, x, differentiable=True)
+        return DeepLabFn.apply(net, x, *params)
+    return deeplabv2_forward(net, x)
