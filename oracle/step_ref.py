@@ -48,8 +48,9 @@ class RefTrainer:
     def __init__(self, dataset, sd, base_lr=0.03, max_iterations=None, threshold=0.95,
                  ema_decay=0.99, consistency=1.0, consistency_rampup=200.0, cutmix_prob=1.0,
                  LB=0.01, increase=1.0005, queue_len=10, num_eval_iter=500, momentum=0.9,
-                 weight_decay=1e-4, patch_size=None):
+                 weight_decay=1e-4, patch_size=None, forward=None):
         cfg = DATASETS[dataset]
+        self.forward = forward or U.unet_forward      # (x, sd, train=...) -> logits; oracle/deeplab_ref for the DeepLabV2 row
         self.dataset = dataset
         self.n_classes, self.mode, self.n_part = cfg[2], cfg[3], cfg[4]
         self.patch = patch_size or cfg[1]
@@ -77,7 +78,7 @@ class RefTrainer:
 
     # -- pieces -------------------------------------------------------------------
     def _fwd(self, sd, x, train=True):
-        return U.unet_forward(x, sd, train=train)
+        return self.forward(x, sd, train=train)
 
     def _pl(self, logits):
         return L.pseudo_label(logits, self.threshold, self.mode)

@@ -114,10 +114,13 @@ def test_head_adjoints():
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("n,ci,co,h,w,k,s,d", [(2, 64, 128, 12, 15, 1, 1, 1), (2, 128, 64, 13, 16, 1, 2, 1), (2, 64, 64, 14, 12, 3, 2, 1),
                                                (1, 128, 128, 16, 16, 3, 1, 1), (2, 64, 64, 15, 13, 3, 1, 2), (1, 128, 64, 12, 12, 3, 1, 4),
-                                               (1, 256, 128, 9, 10, 1, 1, 1)])
+                                               (1, 256, 128, 9, 10, 1, 1, 1), (2, 128, 256, 13, 16, 1, 2, 1), (2, 128, 128, 14, 12, 3, 2, 1),
+                                               (1, 128, 128, 15, 13, 3, 1, 2), (1, 256, 128, 12, 12, 3, 1, 4), (3, 128, 128, 9, 7, 1, 1, 1)])
 def test_conv2d_wgrad_general(n, ci, co, h, w, k, s, d, dt):
     """Weight gradients of 1x1 / 3x3 convolutions with stride 2 and dilation 2 / 4, with BatchNorm+ReLU evaluated by the loader:
-    exact small integers against torch.nn.grad.conv2d_weight."""
+    exact small integers against torch.nn.grad.conv2d_weight.  Channel counts that are multiples of 128 take the one-tap-per-block
+    bf16 kernel (wgrad_tap_bf16.hip; pixel counts that are not multiples of its 64-pixel stage, split-K tails), the 64-channel
+    ones the generic kernel, 3x3 / stride 1 / undilated the halo kernel."""
     l = L()
     lib = l.lib()
     g = torch.Generator().manual_seed(ci + 3 * co + k + s + d)
@@ -347,3 +350,64 @@ def test_deeplab_backward_reference_golden():
     cos = dots / (n1 * n2) ** 0.5
     print(f"deeplab backward vs reference golden: worst norm deviation {worst[0]:.2e} ({worst[1]}), sample cosine {cos:.5f}")
     assert worst[0] < 3e-2 and cos > 0.999
+
+
+def test_ssl_step_with_deeplab_matches_oracle():
+    """The whole semi-supervised iteration (ustrun.trainer.SSLTrainer, reference train.py:577-858) around a DeepLabV2-ResNet50
+    instead of the U-Net -- BASELINE.json configs[4]'s model; BUSI's grey image feeds three equal channels -- against the CPU
+    oracle step with oracle/deeplab_ref as its forward: loss terms, per-sample Dice, consistency weight; then the parameter
+    UPDATE of the first step (cosine >= 0.995: the gradient's float32 conditioning, test_deeplab_backward_vs_oracle_f32),
+    the teacher's EMA, BatchNorm counters, and that the weight packs follow the fused in-place SGD (second step's losses)."""
+    import random
+    from oracle import deeplab_ref as D
+    from oracle.step_ref import RefTrainer
+    from networks.deeplabv2 import DeepLabV2
+    from ustrun.trainer import SSLTrainer
+    from test_gpu_step import synth
+    B, H, steps = 2, 64, 2
+    sd_s = D.make_state_dict("resnet50", 2, 31)
+    sd_t = D.make_state_dict("resnet50", 2, 32)
+    kw = dict(max_iterations=300, threshold=0.52, patch_size=H, num_eval_iter=2, base_lr=1e-6)
+    fwd = lambda x, sd, train=True: D.deeplabv2_forward(x.expand(-1, 3, -1, -1), sd, "resnet50", train)
+    ref = RefTrainer("BUSI", sd_s, forward=fwd, **kw)
+    ref.set_teacher(sd_t)
+    stu, tea = DeepLabV2("resnet50", 2, pretrained=False), DeepLabV2("resnet50", 2, pretrained=False)
+    stu.load_state_dict({k: v.clone() for k, v in sd_s.items()})
+    tea.load_state_dict({k: v.clone() for k, v in sd_t.items()})
+    trn = SSLTrainer("BUSI", stu.cuda(), tea.cuda(), **kw)
+    assert trn.batch_passes is False
+    p0 = {k: v.detach().cpu().clone() for k, v in stu.named_parameters()}
+    batches = [synth("BUSI", B, 1, H, 300 + s) for s in range(steps)]
+    random.seed(11); np.random.seed(11)
+    ref_out, ref_p1 = [], None
+    for s, b in enumerate(batches):
+        ref_out.append(ref.step(*b, epoch_start=(s == 0)))
+        if s == 0:
+            ref_p1 = {k: ref.student[k].detach().clone() for k in p0}
+    random.seed(11); np.random.seed(11)
+    got, p1 = [], None
+    for s, b in enumerate(batches):
+        trn.step(*[t.cuda() for t in b], epoch_start=(s == 0))
+        got.append(trn.scalars())
+        if s == 0:
+            p1 = {k: v.detach().cpu().clone() for k, v in stu.named_parameters()}
+    for s, (r, o) in enumerate(zip(ref_out, got)):
+        for key in ("sup", "ul", "lu", "s", "loss"):
+            np.testing.assert_allclose(o[key], r[key], rtol=3e-3 if s == 0 else 3e-2, atol=1e-4, err_msg=f"step {s} {key}")
+        assert o["w"] == r["w"]
+        np.testing.assert_allclose(o["ulb_dice"], r["ulb_dice"], rtol=2e-2, atol=2e-3)
+    dots = n1 = n2 = 0.0
+    for k in p0:
+        a, b = (p1[k] - p0[k]).double(), (ref_p1[k] - p0[k]).double()
+        dots += float((a * b).sum()); n1 += float((a * a).sum()); n2 += float((b * b).sum())
+    cos, ratio = dots / (n1 * n2) ** 0.5, (n1 / n2) ** 0.5
+    print(f"deeplab ssl step: first-step update cosine {cos:.5f}, norm ratio {ratio:.4f}; losses {[round(o['loss'], 5) for o in got]} "
+          f"vs oracle {[round(r['loss'], 5) for r in ref_out]}")
+    assert cos > 0.995 and abs(ratio - 1) < 2e-2 and n2 > 0
+    msd, tsd = stu.state_dict(), tea.state_dict()
+    for k, v in ref.teacher.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(tsd[k]) == int(v) and int(msd[k]) == int(ref.student[k]), k
+    num = sum(float((tsd[k].cpu().double() - v.detach().double()).square().sum()) for k, v in ref.teacher.items() if v.is_floating_point())
+    den = sum(float(v.detach().double().square().sum()) for v in ref.teacher.values() if v.is_floating_point())
+    assert (num / den) ** 0.5 < 2e-3

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """GPU box: forward throughput of DeepLabV2-ResNet101 at BASELINE.json configs[4]'s shape (BUSI 512x512, 2 classes) through
 libustrun.so -- images/s, achieved TFLOP/s of the convolution launches (HIP-event pairs, algorithmic flops) and the share of
-time by kernel class.  Forward only (what this round builds of SURVEY.md 8f row 4).
+time by kernel class; --backward times forward + backward (every parameter's gradient, ustrun.resnet_engine.DeepLabFn).
 
-    python tools/bench_deeplab.py [--n 16] [--hw 512] [--dtype bf16] [--mode train|eval] [--reps 5] [--arch resnet101]
+    python tools/bench_deeplab.py [--n 16] [--hw 512] [--dtype bf16] [--mode train|eval] [--reps 5] [--arch resnet101] [--backward]
 """
 import argparse
 import ctypes
@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--mode", default="train")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--arch", default="resnet101")
+    ap.add_argument("--backward", action="store_true")
     a = ap.parse_args()
     from networks.deeplabv2 import DeepLabV2
     from ustrun import _lib
@@ -32,6 +33,8 @@ def main():
     m = DeepLabV2(a.arch, 2, pretrained=False, dtype=a.dtype).cuda()
     m.train(a.mode == "train")
     x = torch.randn(a.n, 3, a.hw, a.hw, device="cuda")
+    if a.backward:
+        return bench_backward(a, m, x, lib, _lib)
     with torch.no_grad():
         m(x)
         torch.cuda.synchronize()
@@ -58,6 +61,74 @@ def main():
     print(f"DeepLabV2-{a.arch} {a.mode}-mode forward, N={a.n} {a.hw}x{a.hw}, {a.dtype}: {dt * 1e3:.2f} ms = {a.n / dt:.1f} images/s; "
           f"{n} convolution launches: {ms:.2f} ms, {fl / 1e9 / a.n:.1f} GFLOP/image algorithmic, {fl / ms / 1e9:.0f} TFLOP/s, "
           f"{by / ms / 1e6:.0f} GB/s algorithmic; convolutions are {ms / (dt * 1e3) * 100:.0f} % of the forward")
+
+
+def phase_times(step):
+    """torch.cuda.Event pairs around the engine's backward helpers for one step: {helper: ms} (the events serialise nothing,
+    the helpers already run back to back on one stream)"""
+    from ustrun import resnet_engine as E
+    names = ["_bn_backward", "_conv_wgrad", "_conv_dgrad", "_join", "_zero_insert", "_head_backward", "_stem_backward", "conv_bn",
+             "stem", "bottleneck"]
+    recs, orig = {k: [] for k in names}, {k: getattr(E, k) for k in names}
+
+    def wrap(k):
+        def f(*args, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig[k](*args, **kw)
+            e1.record()
+            recs[k].append((e0, e1))
+            return r
+        return f
+
+    for k in names:
+        setattr(E, k, wrap(k))
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        for k in names:
+            setattr(E, k, orig[k])
+    return {k: sum(e0.elapsed_time(e1) for e0, e1 in v) for k, v in recs.items()}
+
+
+def bench_backward(a, m, x, lib, _lib):
+    dl = torch.randn(a.n, 2, a.hw, a.hw, device="cuda")
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        m(x).backward(dl)
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.reps
+    lib.ustrun_profile_enable(1)
+    step()
+    torch.cuda.synchronize()
+    lib.ustrun_profile_enable(0)
+    buf = (_lib.ProfRec * 8192)()
+    n = lib.ustrun_profile_records(buf, 8192)
+    out = []
+    for kind, name in ((0, "forward + input-gradient convolutions"), (1, "weight-gradient GEMMs")):
+        rs = [r for r in buf[:n] if r.kind == kind]
+        ms, fl = sum(r.ms for r in rs), sum(r.flops for r in rs)
+        out.append(f"{len(rs)} {name}: {ms:.2f} ms, {fl / max(ms, 1e-9) / 1e9:.0f} TFLOP/s")
+        if os.environ.get("USTRUN_BENCH_VERBOSE"):
+            for r in sorted(rs, key=lambda r: -r.ms)[:16]:
+                print(f"   kind {kind} {r.ms:8.3f} ms  {r.flops / 1e9:9.1f} GF  {r.flops / r.ms / 1e9:7.0f} TF/s  {r.bytes / 1e6:8.1f} MB")
+    for k in (0, 1):
+        msd, fld, byd, nd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        lib.ustrun_profile_collect(k, ctypes.byref(msd), ctypes.byref(fld), ctypes.byref(byd), ctypes.byref(nd))
+    print(f"DeepLabV2-{a.arch} train-mode forward + backward, N={a.n} {a.hw}x{a.hw}, {a.dtype}: {dt * 1e3:.2f} ms = {a.n / dt:.1f} images/s; "
+          + "; ".join(out) + f"; peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    ph = phase_times(step)
+    print("   stream time by engine helper (ms; bottleneck = the whole forward block, conv_bn inside it; _conv_dgrad includes _zero_insert): "
+          + ", ".join(f"{k} {v:.2f}" for k, v in ph.items()))
 
 
 if __name__ == "__main__":

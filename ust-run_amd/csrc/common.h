@@ -151,6 +151,9 @@ int wgradT_launch_bf16(const WgradArgs& a, hipStream_t st);
 int wgrad_plan(int nseg, int Cin, int Cout, int64_t M, int* ksplit, long* kchunk, int* slabs);
 int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);
 int wgrad_launch_bf16(const WgradArgs& a, hipStream_t st);
+bool wgrad_tap_supported(const WgradArgs& a);      // one tap per block: 1x1 / dilated / strided convolutions (wgrad_tap_bf16.hip)
+int wgrad_tap_plan(const WgradArgs& a, int* ksplit, long* kchunk);
+int wgrad_tap_launch_bf16(const WgradArgs& a, hipStream_t st);
 bool wgrad_halo_supported(const WgradArgs& a);
 int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per);
 int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t st);

@@ -236,6 +236,13 @@ extern "C" int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int6
         const int halo = (int)((1024 + pairs - 1) / pairs) + 1;
         if (halo > slabs) slabs = halo;
     }
+    if (Cin % 128 == 0 && Cout % 128 == 0 && nseg <= 9) {        // the one-tap-per-block bf16 kernel (1x1 / dilated / strided)
+        WgradArgs t = {};
+        t.Cin = Cin; t.Cout = Cout; t.nseg = nseg; t.M = npix;
+        int kt; long ct;
+        wgrad_tap_plan(t, &kt, &ct);
+        if (kt > slabs) slabs = kt;
+    }
     if (nseg == 4 && Cin % 128 == 0 && Cout % 32 == 0) {         // the ConvTranspose all-taps bf16 kernel
         int kt; long ct;
         wgradT_plan(Cin, Cout, npix, &kt, &ct);

@@ -465,6 +465,16 @@ extern "C" int ustrun_conv2d_wgrad(const ustrun_src_t* srcs, int nsrc, const voi
         USTRUN_TRY(rc);
         return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 2, accumulate, (hipStream_t)s);
     }
+    if (dtype == USTRUN_BF16 && wgrad_tap_supported(a)) {
+        wgrad_tap_plan(a, &a.ksplit, &a.kchunk);
+        USTRUN_CHECK(partials_bytes >= (int64_t)a.ksplit * a.nseg * a.Cin * Cout * 4, "conv2d_wgrad: partials too small");
+        double in_elems = (double)N * srcs[0].H * srcs[0].W * srcs[0].C;
+        prof_begin(1, 2.0 * a.M * a.nseg * a.Cin * Cout, 2.0 * (in_elems + (double)a.M * Cout) + 4.0 * a.nseg * a.Cin * Cout, (hipStream_t)s);
+        const int rc = wgrad_tap_launch_bf16(a, (hipStream_t)s);
+        prof_end((hipStream_t)s);
+        USTRUN_TRY(rc);
+        return reduce_partials(partials, a.ksplit, a.nseg, a.Cin, Cout, dw, 0, accumulate, (hipStream_t)s);
+    }
     wgrad_plan(a.nseg, a.Cin, Cout, a.M, &a.ksplit, &a.kchunk, &slabs);
     USTRUN_CHECK(partials_bytes >= (int64_t)slabs * a.nseg * a.Cin * Cout * 4, "conv2d_wgrad: partials too small");
     USTRUN_TRY(wgrad_launch(a, dtype, (hipStream_t)s));

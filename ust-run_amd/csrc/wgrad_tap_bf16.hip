@@ -1,0 +1,261 @@
+// wgrad_tap_bf16.hip -- weight gradient of a 1x1 / dilated / strided k x k convolution on the bf16 matrix cores, one TAP per
+// block (the DeepLabV2-ResNet bottlenecks and classifier: reference networks/backbone/resnet.py:78-105, deeplabv2.py:15-17):
+//
+//   dW[tap][ci][co] = sum_p act(x[stride * p + dilation * (tap - k/2)][ci]) * dy[p][co]          p over the output grid
+//
+// A "TN" GEMM over pixels whose operands are both pixel-major in HBM.  A block owns 128 ci x 128 co of one tap and a
+// contiguous range of output pixels (split-K over space), 64 pixels per stage, double-buffered; the tiles stay
+// [pixel][channel] in LDS (256-byte rows, 64-byte segments XORed by the pixel index) and the MFMA fragments come from the
+// transposing LDS read (ds_read_b64_tr_b16), as in wgradT_bf16.hip.  The activation tile goes global -> registers ->
+// [BatchNorm affine + ReLU in f32, zero outside the image] -> bf16 -> LDS, the dy tile global -> registers -> LDS: the loads
+// of stage s+1 are issued before the MFMAs of stage s and written to the other buffer after them.  The taps of one pixel range run next to each other on one XCD (block order below),
+// so the nine shifted reads of x and the nine reads of dy meet in that XCD's L2.  Partial slabs [ksplit][tap][ci][co] f32 are
+// summed in a fixed order by reduce_partials.
+#include "common.h"
+#include "loader.h"
+
+namespace ustrun {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+constexpr int TM = 128, TN = 128, KP = 64, RB = 256;   // tile, pixels per stage, LDS row pitch (bytes)
+
+// rows k0 + 8*(l>>5) + {0..3 | 4..7}, columns col0 + 16*((l>>4)&1) + 4*(l&3) .. +3, delivered column-major
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, int lane) {
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int colb = (col0 + 16 * ((lane >> 4) & 1) + 4 * p) * 2;
+    const int r0 = k0 + 8 * (lane >> 5) + q, r1 = r0 + 4;      // r1 & 3 == r0 & 3
+    const int off = colb ^ ((r0 & 3) << 6);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * RB + off));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * RB + off));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+// v / d and the remainder for 0 <= v < 2^24 through the float reciprocal (two fix-up steps make it exact)
+__device__ __forceinline__ int fdiv(int v, int d, float invd, int& rem) {
+    int q = (int)(((float)v + 0.5f) * invd);
+    int r = v - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+}
+
+// grid = (ci tiles * co tiles * taps * ksplit)
+template <bool PLAIN>
+__global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs a, const int mtn, const int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                      // 2 x [KP][TM] bf16
+    char* Bs = smem + 2 * KP * RB;        // 2 x [KP][TN] bf16
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware order (1-D grid, workgroups go round-robin over the 8 XCDs): every XCD takes a contiguous range of the
+    // (slice-major, tile-minor) order, so all (tap, ci, co) tiles of one pixel slice share one XCD's L2
+    const int nblk = gridDim.x, tiles = nblk / a.ksplit;
+    int lin;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = blockIdx.x % 8, jj = blockIdx.x / 8;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + jj;
+    }
+    const int ks = lin / tiles;
+    int tile = lin - ks * tiles;
+    const int ntile = tile % ntn; tile /= ntn;
+    const int mtile = tile % mtn;
+    const int seg = tile / mtn;
+    const int ci0 = mtile * TM, co0 = ntile * TN;
+    const int ady = a.d0 + (seg / a.segw) * a.astep, adx = a.d0 + (seg % a.segw) * a.astep;
+    const int kbeg = (int)((long)ks * a.kchunk);
+    const int kend = (kbeg + a.kchunk < a.M) ? (int)(kbeg + a.kchunk) : (int)a.M;
+    const int Wb = a.Wb, Hb = a.Hb;
+    const float invW = 1.f / (float)Wb, invH = 1.f / (float)Hb;
+
+    // ---- A items: pixel row (tid >> 4) + 16 i, 8-channel group tid & 15 ----
+    const SrcDev& S = a.src[0];
+    const int c8 = tid & 15;
+    const int cl = ci0 + 8 * c8;
+    const bool aff = S.scale != nullptr;
+    f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
+    if (aff) {
+        asc0 = *(const f32x4*)(S.scale + cl); asc1 = *(const f32x4*)(S.scale + cl + 4);
+        ash0 = *(const f32x4*)(S.shift + cl); ash1 = *(const f32x4*)(S.shift + cl + 4);
+    }
+    const float floor_ = S.relu ? 0.f : -__builtin_inff();
+    const __bf16* sp = (const __bf16*)S.ptr + cl;
+    const int arow = tid >> 4;
+    const int sN = (int)S.sN, sH = (int)S.sH, sW = (int)S.sW;        // element offsets fit 31 bits (host check)
+    bf16x8 av[4];
+    unsigned aok = 0;
+    // every load is issued unconditionally from an in-range address (pixel 0 for rows outside the range / the image) and the
+    // row is zeroed at the LDS write: a load under a per-row branch gets its own basic block and its own wait
+    auto load_A = [&](int k0) {
+        aok = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = k0 + arow + 16 * i;
+            int ok = m < kend;
+            int off = m * sW;                                // PLAIN: 1x1, stride 1, pixel-linear source
+            if (!PLAIN) {
+                int x, y;
+                const int r = fdiv(ok ? m : 0, Wb, invW, x);
+                const int n = fdiv(r, Hb, invH, y);
+                const int ly = (y << a.ashift) + ady - S.off_y, lx = (x << a.ashift) + adx - S.off_x;
+                ok &= (int)((unsigned)ly < (unsigned)S.LH) & (int)((unsigned)lx < (unsigned)S.LW);       // bitwise: no exec-mask region
+                off = n * sN + ly * sH + lx * sW;
+            }
+            av[i] = *(const bf16x8*)(sp + (ok ? off : 0));
+            aok |= (unsigned)ok << i;
+        }
+    };
+    auto write_A = [&](char* dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = arow + 16 * i;
+            const bool ok = (aok >> i) & 1u;
+            bf16x8 h = av[i];
+            {   // branch-free: identity constants (1, 0, floor = -inf) for a finished activation -- bf16 -> f32 -> bf16 is exact
+                f32x4 lo = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]} * asc0 + ash0;
+                f32x4 hi = (f32x4){(float)h[4], (float)h[5], (float)h[6], (float)h[7]} * asc1 + ash1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { lo[q] = __builtin_fmaxf(lo[q], floor_); hi[q] = __builtin_fmaxf(hi[q], floor_); }
+                h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+                h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+            }
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            u32x4 bits = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bits[q] = ok ? bits[q] : 0u;       // rows outside the range / the image are zero
+            *(u32x4*)(dst + row * RB + ((c8 * 16) ^ ((row & 3) << 6))) = bits;
+        }
+    };
+    // ---- dy tile: the same (row, 8-channel group) items, a pure copy.  It goes through registers like the activation tile
+    // and NOT by LDS-DMA: with a DMA in flight hipcc puts s_waitcnt vmcnt(0) in front of the stage's first ds_read (it cannot
+    // tell the two LDS buffers apart), which also drains the activation prefetch before the MFMAs instead of after them.
+    const __bf16* dyp = (const __bf16*)a.dy + co0 + 8 * c8;
+    const int dyC = a.Cout;
+    bf16x8 bv[4];
+    auto load_B = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = k0 + arow + 16 * i;
+            // rows past the tensor read pixel 0: any finite value will do, their A rows are zero
+            bv[i] = *(const bf16x8*)(dyp + (m < (int)a.M ? m : 0) * dyC);
+        }
+    };
+    auto write_B = [&](char* dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = arow + 16 * i;
+            *(bf16x8*)(dst + row * RB + ((c8 * 16) ^ ((row & 3) << 6))) = bv[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kbeg < kend) {
+        load_A(kbeg);
+        load_B(kbeg);
+        write_A(As);
+        write_B(Bs);
+    }
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (int k0 = kbeg; k0 < kend; k0 += KP) {
+        const bool more = k0 + KP < kend;
+        if (more) {
+            load_A(k0 + KP);
+            load_B(k0 + KP);
+        }
+        const char* At = As + buf * (KP * RB);
+        const char* Bt = Bs + buf * (KP * RB);
+#pragma unroll
+        for (int kk = 0; kk < KP / 16; ++kk) {
+            const bf16x8 a0 = tr_frag(At, kk * 16, wm * 64, lane);
+            const bf16x8 a1 = tr_frag(At, kk * 16, wm * 64 + 32, lane);
+            const bf16x8 b0 = tr_frag(Bt, kk * 16, wn * 64, lane);
+            const bf16x8 b1 = tr_frag(Bt, kk * 16, wn * 64 + 32, lane);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            write_A(As + (buf ^ 1) * (KP * RB));
+            write_B(Bs + (buf ^ 1) * (KP * RB));
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // slab [ks][tap][Cin][Cout]: rows of D are ci (registers), the 32 lanes of a row are consecutive co
+    float* slab = a.partials + ((long)ks * a.nseg + seg) * a.Cin * a.Cout;
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = co0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                slab[(long)ci * a.Cout + co] = acc[i][j][r];
+            }
+    }
+}
+
+bool pixel_linear(const WgradArgs& a) {
+    const SrcDev& s = a.src[0];
+    return a.nseg == 1 && a.ashift == 0 && a.d0 == 0 && s.off_y == 0 && s.off_x == 0 && s.LH == a.Hb && s.LW == a.Wb &&
+           s.sH == (long)a.Wb * s.sW && s.sN == (long)a.Hb * s.sH;
+}
+
+}  // namespace
+
+bool wgrad_tap_supported(const WgradArgs& a) {
+    if (a.dy_s != 1 || a.dy_esz != 2 || a.nsrc != 1 || a.nseg < 1 || a.nseg > 9 || a.ashift > 1) return false;
+    const SrcDev& s = a.src[0];
+    if (s.esz != 2 || s.sC != 1 || s.pool || s.gN > 0 || (s.relu && !s.scale)) return false;
+    if ((s.sW & 7) || (s.sH & 7) || (s.sN & 7)) return false;                 // 16-byte loads of 8 channels
+    if (a.dyH != a.Hb || a.dyW != a.Wb || a.M >= (1L << 24)) return false;    // float-reciprocal pixel decomposition
+    if ((long)a.N * s.sN >= (1L << 31) || a.M * a.Cout >= (1L << 31)) return false;      // 32-bit element offsets
+    return a.Cin % TM == 0 && a.Cout % TN == 0;
+}
+
+// split-K plan: about one resident wave of blocks (2 per CU), at least four 64-pixel stages per block
+int wgrad_tap_plan(const WgradArgs& a, int* ksplit, long* kchunk) {
+    const long tiles = (long)(a.Cin / TM) * (a.Cout / TN) * a.nseg;
+    long ks = (512 + tiles - 1) / tiles;
+    if (ks > a.M / (4 * KP)) ks = a.M / (4 * KP);
+    if (ks < 1) ks = 1;
+    long chunk = (a.M + ks - 1) / ks;
+    chunk = (chunk + KP - 1) / KP * KP;
+    *kchunk = chunk; *ksplit = (int)((a.M + chunk - 1) / chunk);
+    return 0;
+}
+
+int wgrad_tap_launch_bf16(const WgradArgs& a, hipStream_t st) {
+    const int mtn = a.Cin / TM, ntn = a.Cout / TN;
+    dim3 grid(mtn * ntn * a.nseg * a.ksplit), block(256);
+    if (pixel_linear(a)) hipLaunchKernelGGL(wgrad_tap_bf16_kernel<true>, grid, block, 4 * KP * RB, st, a, mtn, ntn);
+    else hipLaunchKernelGGL(wgrad_tap_bf16_kernel<false>, grid, block, 4 * KP * RB, st, a, mtn, ntn);
+    USTRUN_LAUNCH_CHECK("wgrad_tap_bf16");
+    return 0;
+}
+
+}  // namespace ustrun

@@ -66,6 +66,9 @@ parser.add_argument('--fft', default='device', choices=['host', 'device'])
 parser.add_argument('--data_root', type=str, default='../../data')
 parser.add_argument('--log_every', type=int, default=50)
 parser.add_argument('--synthetic_pool', type=int, default=8, help='distinct synthetic batches kept resident and cycled (0: a fresh batch every step)')
+parser.add_argument('--backbone', default='resnet101', choices=['resnet50', 'resnet101'],
+                    help='--model deeplabv2: the dilated ResNet of networks/deeplabv2.py (BASELINE.json configs[4])')
+parser.add_argument('--image_size', type=int, default=0, help='patch extent override (0: the dataset default; configs[4] runs BUSI at 512)')
 
 
 def make_loaders(args, C, H, dev=None):
@@ -99,12 +102,21 @@ def train(args, snapshot_path):
     dev = torch.device("cuda", local)
     ddp.init(device=dev)
     C, H, K, _, _, max_it = DATASETS[args.dataset]
+    H = args.image_size or H
     args.max_iterations = max_it                       # per-dataset schedule of the reference (train.py:412,423,434)
 
     def create_model(ema=False):
-        if args.model != 'unet':
-            raise SystemExit("only --model unet exists on the reference's path (train.py:496-503)")
-        model = UNet(n_channels=C, n_classes=K, dtype=args.backend_dtype)
+        if args.model == 'deeplabv2':
+            # the reference defines networks/deeplabv2.py but its create_model never builds it (train.py:496-503; SURVEY.md 8f
+            # row 4): same SSL step around it here.  Seeded init unless ../../checkpoints/pretrained/<arch>.pth exists
+            # (base.py:12); a 1-channel dataset feeds three equal channels.
+            from networks.deeplabv2 import DeepLabV2
+            ck = "../../checkpoints/pretrained/%s.pth" % args.backbone
+            model = DeepLabV2(args.backbone, K, pretrained=os.path.exists(ck), dtype=args.backend_dtype)
+        elif args.model != 'unet':
+            raise SystemExit("--model is 'unet' (the reference's path, train.py:496-503) or 'deeplabv2' (networks/deeplabv2.py)")
+        else:
+            model = UNet(n_channels=C, n_classes=K, dtype=args.backend_dtype)
         if ema:
             for p in model.parameters():
                 p.detach_()
@@ -115,7 +127,7 @@ def train(args, snapshot_path):
                          threshold=args.threshold, ema_decay=args.ema_decay, consistency=args.consistency,
                          consistency_rampup=args.consistency_rampup, cutmix_prob=args.cutmix_prob, LB=args.LB,
                          increase=args.increase, queue_len=args.queue_len, num_eval_iter=args.num_eval_iter,
-                         grad_allreduce=ddp.make_grad_allreduce(world), world_size=world, fft=args.fft)
+                         grad_allreduce=ddp.make_grad_allreduce(world), world_size=world, fft=args.fft, patch_size=H)
     loader = make_loaders(args, C, H, dev)
     from ustrun import synthetic
     from ustrun.evaluate import validate

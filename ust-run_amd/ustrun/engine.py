@@ -68,6 +68,9 @@ def _weights_key(model):
 def invalidate_packed(model):
     """Call after parameters were modified behind autograd's back (e.g. the fused SGD kernel)."""
     model._ustrun_packed_key = None
+    if not hasattr(model, "outc"):               # a DeepLabV2 / ResNet: its packs are cached per convolution
+        from . import resnet_engine
+        resnet_engine.invalidate_packs()
 
 
 def _ensure_packed(model, d):

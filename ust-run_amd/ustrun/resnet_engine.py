@@ -44,9 +44,18 @@ def _tdtype(dt):
     return torch.bfloat16 if dt == L.BF16 else torch.float32
 
 
+_GEN = [0]
+
+
+def invalidate_packs():
+    """Parameters were rewritten behind autograd's back (the fused SGD + EMA kernel updates the flat buffer in place and leaves
+    `weight._version` alone): every cached weight pack is stale.  ustrun.engine.invalidate_packed calls this."""
+    _GEN[0] += 1
+
+
 def _packed(conv, dt):
     """forward pack of a conv's weight, cached on the module until the weight changes"""
-    key = (conv.weight.data_ptr(), conv.weight._version, dt)
+    key = (conv.weight.data_ptr(), conv.weight._version, dt, _GEN[0])
     if getattr(conv, "_ustrun_pack_key", None) != key:
         lib = L.lib()
         co, ci, kh, kw = conv.weight.shape
@@ -111,7 +120,7 @@ def stem(net, x, dt, train):
     extra = (win - k * Cin + Cin - 1) // Cin                                       # whole pixels the rounded-up window reaches past
     xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 0, pad, pad + extra, pad, pad)).to(_tdtype(dt)).contiguous()
     Hp, Wp = H + 2 * pad, W + 2 * pad + extra
-    key = (conv.weight.data_ptr(), conv.weight._version, dt, "rowwin")
+    key = (conv.weight.data_ptr(), conv.weight._version, dt, "rowwin", _GEN[0])
     if getattr(conv, "_ustrun_pack_key", None) != key:
         co = conv.weight.shape[0]
         w = conv.weight.detach().permute(0, 2, 3, 1).reshape(co, k, k * Cin)       # [co][ky][kx*Cin + ci]
@@ -201,7 +210,7 @@ def to_nchw(a):
 def _classifier_gemm(net, dt):
     """The four dilated classifier convolutions as one 1x1 weight [nrates*9*K, 2048, 1, 1] (row (r*9+tap)*K+k) and the sum of
     their biases; cached until a classifier parameter changes."""
-    key = tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in net.classifier) + (dt,)
+    key = tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in net.classifier) + (dt, _GEN[0])
     if getattr(net, "_ustrun_cls_key", None) != key:
         lib = L.lib()
         K, Cin = net.classifier[0].weight.shape[:2]
@@ -266,7 +275,7 @@ _scratch = _Scratch()
 
 def _packed_dgrad(conv, dt):
     """pack of the input-gradient convolution's weight: w.flip(2, 3).transpose(0, 1) as a conv weight [Cin][Cout][k][k]"""
-    key = (conv.weight.data_ptr(), conv.weight._version, dt)
+    key = (conv.weight.data_ptr(), conv.weight._version, dt, _GEN[0])
     if getattr(conv, "_ustrun_dpack_key", None) != key:
         lib = L.lib()
         co, ci, kh, kw = conv.weight.shape
@@ -397,7 +406,7 @@ def _head_backward(rec, dlogits, dt, grads):
         grads[c.weight] = dw[r].contiguous()
         grads[c.bias] = db.clone()
     # input gradient: dz x Wall -> [.., Cin]; the transposed, column-padded weight as a 1x1 convolution [Cin][ZCp]
-    key = tuple((c.weight.data_ptr(), c.weight._version) for c in net.classifier) + (dt, ZCp)
+    key = tuple((c.weight.data_ptr(), c.weight._version) for c in net.classifier) + (dt, ZCp, _GEN[0])
     if getattr(net, "_ustrun_clsd_key", None) != key:
         wall = torch.stack([c.weight.detach().reshape(K, Cin, 9).permute(2, 0, 1) for c in net.classifier], 0).reshape(ZC, Cin)
         wd = torch.nn.functional.pad(wall.t(), (0, ZCp - ZC)).contiguous()                          # [Cin][ZCp]
@@ -467,11 +476,24 @@ class DeepLabFn(torch.autograd.Function):
         ctx.tape = None
         byid = {id(k): v for k, v in grads.items()}
         named = list(ctx.net.parameters())
+        sink = getattr(ctx.net, "_ustrun_grad_sink", None)
+        if sink is not None:
+            # the trainer's flat gradient buffer (ustrun.trainer.SSLTrainer): written by the first backward of a step, added to
+            # by the following ones -- one multi-tensor launch instead of autograd's per-parameter accumulation
+            gl = [byid[id(p)] for p in named]
+            if getattr(ctx.net, "_ustrun_sink_fresh", True):
+                torch._foreach_copy_(list(sink), gl)
+            else:
+                torch._foreach_add_(list(sink), gl)
+            ctx.net._ustrun_sink_fresh = False
+            return (None, None) + (None,) * len(named)
         return (None, None) + tuple(byid.get(id(p)) if p.requires_grad else None for p in named)
 
 
 def deeplabv2_apply(net, x):
     """DeepLabV2.base_forward: differentiable when autograd is recording and the module trains, plain forward otherwise."""
+    if x.dim() == 4 and x.shape[1] == 1:
+        x = x.expand(-1, 3, -1, -1)              # a grey image (BUSI, prostate) as three equal channels: the backbone's stem is 3-channel
     params = list(net.parameters())
     if torch.is_grad_enabled() and net.training and any(p.requires_grad for p in params):      # eval mode: no graph, as before
         _check_input(net.backbone, x, differentiable=True)

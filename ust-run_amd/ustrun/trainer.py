@@ -203,7 +203,8 @@ class SSLTrainer:
         self.grad_allreduce = grad_allreduce             # callable(flat_g): SUM over ranks (RCCL all-reduce)
         self.world_size = world_size
         self.fft = fft
-        self.batch_passes = batch_passes                 # run the 3 teacher / 4 student passes as one batched call each
+        # run the 3 teacher / 4 student passes as one batched call each (the U-Net engine; a DeepLabV2 runs them one by one)
+        self.batch_passes = batch_passes and hasattr(model, "forward_passes")
         self.iter_num = 0
         self.first_step = True
         self.optimizer = SGDState(self)                  # what the reference's checkpoint helpers call `optimizer`
