@@ -171,9 +171,10 @@ def test_sgd_ema_matches_torch_sgd_trajectory():
         lr = H.poly_lr(0.03, s, 30000)
 
 
-@pytest.mark.parametrize("C,S,LB", [(3, 32, 0.1), (1, 64, 0.05), (3, 256, 0.01)])
+@pytest.mark.parametrize("C,S,LB", [(3, 32, 0.1), (1, 64, 0.05), (3, 256, 0.01), (1, 384, 0.01), (1, 512, 0.01), (1, 100, 0.04)])
 def test_freq_mix_device_matches_numpy_fft(C, S, LB):
-    """Device amplitude mix vs the oracle's numpy FFT restatement (pinned to the reference by G7)."""
+    """Device amplitude mix vs the oracle's numpy FFT restatement (pinned to the reference by G7).  Window half-widths b = 3, 3, 2,
+    3 (7 x 7 at 384), 5 (11 x 11 at 512: bands of 4 window rows per block, > 64 KB of twiddles in LDS) and 4 (9 x 9, bands of 3)."""
     from ustrun.fftmix import freq_mix_device
     g = torch.Generator().manual_seed(C + S)
     n = 3

@@ -25,7 +25,11 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--backward", action="store_true")
+    ap.add_argument("--ssl", action="store_true", help="the whole semi-supervised step (ustrun.trainer.SSLTrainer) around the model: "
+                    "BUSI shapes, label_bs = unlabel_bs = --n")
     a = ap.parse_args()
+    if a.ssl:
+        return bench_ssl(a)
     from networks.deeplabv2 import DeepLabV2
     from ustrun import _lib
     lib = _lib.lib()
@@ -61,6 +65,32 @@ def main():
     print(f"DeepLabV2-{a.arch} {a.mode}-mode forward, N={a.n} {a.hw}x{a.hw}, {a.dtype}: {dt * 1e3:.2f} ms = {a.n / dt:.1f} images/s; "
           f"{n} convolution launches: {ms:.2f} ms, {fl / 1e9 / a.n:.1f} GFLOP/image algorithmic, {fl / ms / 1e9:.0f} TFLOP/s, "
           f"{by / ms / 1e6:.0f} GB/s algorithmic; convolutions are {ms / (dt * 1e3) * 100:.0f} % of the forward")
+
+
+def bench_ssl(a):
+    """BASELINE.json configs[4]: BUSI 512x512, 2-class DeepLabV2-ResNet, the reference's SSL step (3 teacher + 5(+1) student
+    forwards, 4 backwards, CE + Dice, fused SGD + EMA) -- images/s = (label_bs + unlabel_bs) / step time."""
+    import random
+    import numpy as np
+    from networks.deeplabv2 import DeepLabV2
+    from ustrun import synthetic
+    from ustrun.trainer import SSLTrainer
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    stu = DeepLabV2(a.arch, 2, pretrained=False, dtype=a.dtype).cuda()
+    tea = DeepLabV2(a.arch, 2, pretrained=False, dtype=a.dtype).cuda()
+    trn = SSLTrainer("BUSI", stu, tea, base_lr=1e-6, patch_size=a.hw, fft="device")
+    pool = [[t.cuda() for t in synthetic.batch("BUSI", a.n, 1, a.hw, 77 + i)] for i in range(2)]
+    for i in range(2):
+        trn.step(*pool[i % 2], epoch_start=(i == 0))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.reps):
+        trn.step(*pool[i % 2])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.reps
+    sc = trn.scalars()
+    print(f"DeepLabV2-{a.arch} SSL step, BUSI {a.hw}x{a.hw}, label_bs = unlabel_bs = {a.n}, {a.dtype}: {dt * 1e3:.1f} ms/step = "
+          f"{2 * a.n / dt:.1f} images/s; loss {sc['loss']:.4f}; peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 
 
 def phase_times(step):

@@ -4,26 +4,28 @@
 // of `trg` (blend ratio r), keeps src's phase, and inverse-transforms.  Only those bins change, so by
 // linearity   out = src + Re IDFT( r (|F_trg| - |F_src|) e^{j arg F_src} )   restricted to the window:
 // a (2b+1)^2-bin forward DFT of both images (kernel 1, direct summation with twiddle tables in LDS)
-// and a (2b+1)^2-term correction per pixel (kernel 2).  b = floor(min(H,W)*L) = 2 at 256/288, 3 at 384.
+// and a (2b+1)^2-term correction per pixel (kernel 2).  b = floor(min(H,W)*L) = 2 at 256/288, 3 at 384, 5 at 512.
 #include "common.h"
 
 namespace ustrun {
 namespace {
 
-constexpr int MAXNB = 7;            // (2b+1) <= 7 (b = 2 at 256/288, 3 at 384)
+constexpr int MAXNB = 11;           // (2b+1) <= 11 (b = 2 at 256/288, 3 at 384, 5 at 512)
 constexpr float TWO_PI = 6.283185307179586f;
 
 // bins[((img*C + c)*2 + which)*RS + rs][u][v] = sum over the block's rows of I[y,x] e^{-2 pi j (fu y/H + fv x/W)},
-// fu = u-b, fv = v-b.  grid = (n*C*2, RS row splits); every thread keeps all (2b+1)^2 bins in registers and
-// makes ONE pass over its pixels; the RS partial rows are summed by the consumer.
+// fu = u-b, fv = v-b.  grid = (n*C*2, RS row splits, bands of UB window rows u); every thread keeps its band's UB x (2b+1)
+// bins in registers (the whole window up to 7 x 7; 9 x 9 and 11 x 11 in bands of 3 and 4 rows) and makes ONE pass over
+// its pixels; the RS partial rows are summed by the consumer.
 constexpr int RS = 8;
 
-template <int NB>
+template <int NB, int UB>
 __global__ __launch_bounds__(256) void dft_bins_kernel(const float* __restrict__ src, const float* __restrict__ trg,
                                                       int C, int H, int W, float2* __restrict__ bins) {
     extern __shared__ float2 tw[];     // [NB][H] then [NB][W]
-    __shared__ float red[4][2 * NB * NB];
+    __shared__ float red[4][2 * UB * NB];
     constexpr int b = NB / 2;
+    const int u0 = blockIdx.z * UB;
     float2* twy = tw; float2* twx = tw + NB * H;
     const int ic = blockIdx.x >> 1, which = blockIdx.x & 1;
     const float* img = (which ? trg : src) + (long)ic * H * W;
@@ -38,9 +40,9 @@ __global__ __launch_bounds__(256) void dft_bins_kernel(const float* __restrict__
         twx[t] = make_float2(c, s);
     }
     __syncthreads();
-    float2 acc[NB][NB];
+    float2 acc[UB][NB];
 #pragma unroll
-    for (int u = 0; u < NB; ++u)
+    for (int u = 0; u < UB; ++u)
 #pragma unroll
         for (int v = 0; v < NB; ++v) acc[u][v] = make_float2(0.f, 0.f);
     const int rows = (H + RS - 1) / RS, y0 = blockIdx.y * rows, y1 = min(H, y0 + rows);
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(256) void dft_bins_kernel(const float* __restrict__
 #pragma unroll
         for (int v = 0; v < NB; ++v) { const float2 c2 = twx[v * W + x]; tx[v] = make_float2(val * c2.x, val * c2.y); }
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const float2 a = twy[u * H + y];
+        for (int u = 0; u < UB; ++u) {
+            const float2 a = twy[min(u0 + u, NB - 1) * H + y];      // (rows past the window in the last band: computed, not stored)
 #pragma unroll
             for (int v = 0; v < NB; ++v) {
                 acc[u][v].x += a.x * tx[v].x - a.y * tx[v].y;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void dft_bins_kernel(const float* __restrict__
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int u = 0; u < NB; ++u)
+    for (int u = 0; u < UB; ++u)
 #pragma unroll
         for (int v = 0; v < NB; ++v) {
             float re = acc[u][v].x, im = acc[u][v].y;
@@ -71,9 +73,9 @@ __global__ __launch_bounds__(256) void dft_bins_kernel(const float* __restrict__
             if (lane == 0) { red[wave][2 * (u * NB + v)] = re; red[wave][2 * (u * NB + v) + 1] = im; }
         }
     __syncthreads();
-    if (threadIdx.x < NB * NB) {
+    if (threadIdx.x < UB * NB && u0 * NB + threadIdx.x < NB * NB) {
         const int t = threadIdx.x;
-        bins[((long)blockIdx.x * RS + blockIdx.y) * NB * NB + t] =
+        bins[((long)blockIdx.x * RS + blockIdx.y) * NB * NB + u0 * NB + t] =
             make_float2(red[0][2 * t] + red[1][2 * t] + red[2][2 * t] + red[3][2 * t],
                         red[0][2 * t + 1] + red[1][2 * t + 1] + red[2][2 * t + 1] + red[3][2 * t + 1]);
     }
@@ -148,16 +150,26 @@ extern "C" int ustrun_freq_mix(const float* src, const float* trg, const float* 
     USTRUN_CHECK(work_bytes >= ustrun_freq_mix_work_bytes(n, C, b), "freq_mix: work buffer too small");
     const size_t lds1 = (size_t)nb * (H + W) * sizeof(float2);
     const size_t lds2 = lds1 + (size_t)nb * nb * sizeof(float2);
-    USTRUN_CHECK(lds2 <= 64 * 1024, "freq_mix: extent %dx%d too large for the twiddle tables", H, W);
-    dim3 g1(n * C * 2, RS);
+    USTRUN_CHECK(lds2 <= 160 * 1024, "freq_mix: extent %dx%d too large for the twiddle tables", H, W);
+#define USTRUN_DFT_BINS(NB_, UB_)                                                                                              \
+    do {                                                                                                                       \
+        if (lds1 > 64 * 1024)                                                                                                  \
+            hipFuncSetAttribute((const void*)dft_bins_kernel<NB_, UB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);\
+        hipLaunchKernelGGL((dft_bins_kernel<NB_, UB_>), dim3(n * C * 2, RS, (NB_ + UB_ - 1) / UB_), dim3(256), lds1,           \
+                           (hipStream_t)s, src, trg, C, H, W, (float2*)work);                                                  \
+    } while (0)
     switch (nb) {
-        case 1: hipLaunchKernelGGL(dft_bins_kernel<1>, g1, dim3(256), lds1, (hipStream_t)s, src, trg, C, H, W, (float2*)work); break;
-        case 3: hipLaunchKernelGGL(dft_bins_kernel<3>, g1, dim3(256), lds1, (hipStream_t)s, src, trg, C, H, W, (float2*)work); break;
-        case 5: hipLaunchKernelGGL(dft_bins_kernel<5>, g1, dim3(256), lds1, (hipStream_t)s, src, trg, C, H, W, (float2*)work); break;
-        default: hipLaunchKernelGGL(dft_bins_kernel<7>, g1, dim3(256), lds1, (hipStream_t)s, src, trg, C, H, W, (float2*)work); break;
+        case 1: USTRUN_DFT_BINS(1, 1); break;
+        case 3: USTRUN_DFT_BINS(3, 3); break;
+        case 5: USTRUN_DFT_BINS(5, 5); break;
+        case 7: USTRUN_DFT_BINS(7, 7); break;
+        case 9: USTRUN_DFT_BINS(9, 3); break;
+        default: USTRUN_DFT_BINS(11, 4); break;
     }
+#undef USTRUN_DFT_BINS
     USTRUN_LAUNCH_CHECK("dft_bins");
     int tiles = cdiv((long)H * W, 256 * 8);
+    if (lds2 > 64 * 1024) hipFuncSetAttribute((const void*)freq_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(freq_apply_kernel, dim3(tiles, n * C), dim3(256), lds2, (hipStream_t)s, src, (const float2*)work, ratios,
                        C, H, W, b, out);
     USTRUN_LAUNCH_CHECK("freq_apply");
