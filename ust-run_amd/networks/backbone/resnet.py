@@ -4,8 +4,8 @@ Same constructor signatures, attributes and submodule names as the reference, re
 state_dict keys and, under the same torch seed, the same initial weights (tests/test_abi.py-style check in
 tests/test_host_logic.py) -- built from a stage table instead of the reference's hand-written members.  `base_forward` runs on
 libustrun.so through ustrun.resnet_engine: every convolution is an implicit GEMM on the matrix cores with the producer's
-BatchNorm + ReLU applied on load, the residual join is one fused pass.  Forward only this round (train- and eval-mode
-BatchNorm); BasicBlock nets (resnet18/34) are on no path of the reference's DeepLabV2 (base.py:12) and are not built.
+BatchNorm + ReLU applied on load, the residual join is one fused pass; the backward runs through DeepLabV2.forward
+(ustrun.resnet_engine.DeepLabFn), the stand-alone feature path records no autograd graph.  BasicBlock nets (resnet18/34) are on no path of the reference's DeepLabV2 (base.py:12) and are not built.
 """
 import torch
 import torch.nn as nn
