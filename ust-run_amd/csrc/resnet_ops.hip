@@ -473,7 +473,8 @@ extern "C" int ustrun_conv2d_wgrad(const ustrun_src_t* srcs, int nsrc, const voi
         const int rc = wgrad_tap_launch_bf16(a, (hipStream_t)s);
         prof_end((hipStream_t)s);
         USTRUN_TRY(rc);
-        return reduce_partials(partials, a.ksplit, a.nseg, a.Cin, Cout, dw, 0, accumulate, (hipStream_t)s);
+        // 1x1: the slabs are [Cout][Cin] = the torch layout already (plain streaming sum); k x k: [tap][Cin][Cout] -> transposed
+        return reduce_partials(partials, a.ksplit, a.nseg, a.Cin, Cout, dw, a.nseg == 1 ? 2 : 0, accumulate, (hipStream_t)s);
     }
     wgrad_plan(a.nseg, a.Cin, Cout, a.M, &a.ksplit, &a.kchunk, &slabs);
     USTRUN_CHECK(partials_bytes >= (int64_t)slabs * a.nseg * a.Cin * Cout * 4, "conv2d_wgrad: partials too small");

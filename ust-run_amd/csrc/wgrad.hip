@@ -309,7 +309,10 @@ int reduce_partials(const float* partials, int nslab, int nseg, int Cin, int Cou
     int eblocks = cdiv(total / 4 + 1, 256);
     if (eblocks > 2048) eblocks = 2048;
     long sstride = total;
-    while (nslab > GRP) {                      // parallel fixed-order tree over long slab lists (in place)
+    // the transposing pass runs one block per 32 x 32 channel tile and walks the slab list serially: with few tiles (<= 256:
+    // a 256 -> 256 layer has 64) fold the list down to one slab first, on a full grid
+    const bool fold_all = layout != 2 && (long)cdiv(Cin, 32) * cdiv(Cout, 32) <= 256 && nslab > 2;
+    while (nslab > (fold_all ? 1 : GRP)) {     // parallel fixed-order tree over long slab lists (in place)
         const int groups = cdiv(nslab, GRP);
         hipLaunchKernelGGL(reduce_groups_kernel, dim3(eblocks, groups), dim3(256), 0, st, const_cast<float*>(partials), nslab,
                            total, sstride);

@@ -10,7 +10,7 @@
 // [BatchNorm affine + ReLU in f32, zero outside the image] -> bf16 -> LDS, the dy tile global -> registers -> LDS: the loads
 // of stage s+1 are issued before the MFMAs of stage s and written to the other buffer after them.  The taps of one pixel range run next to each other on one XCD (block order below),
 // so the nine shifted reads of x and the nine reads of dy meet in that XCD's L2.  Partial slabs [ksplit][tap][ci][co] f32 are
-// summed in a fixed order by reduce_partials.
+// summed in a fixed order by reduce_partials (1x1: slabs already in the torch layout, see SWAP).
 #include "common.h"
 #include "loader.h"
 
@@ -50,7 +50,9 @@ __device__ __forceinline__ int fdiv(int v, int d, float invd, int& rem) {
 }
 
 // grid = (ci tiles * co tiles * taps * ksplit)
-template <bool PLAIN>
+// SWAP (1x1 convolutions): the MFMA operands trade places, D rows are co and its lanes ci, so the slab comes out as [co][ci] --
+// the torch layout of a 1x1 weight -- and the fixed-order streaming sum finishes it without a transposing pass.
+template <bool PLAIN, bool SWAP>
 __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs a, const int mtn, const int ntn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                      // 2 x [KP][TM] bf16
@@ -97,6 +99,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
     unsigned aok = 0;
     // every load is issued unconditionally from an in-range address (pixel 0 for rows outside the range / the image) and the
     // row is zeroed at the LDS write: a load under a per-row branch gets its own basic block and its own wait
+    // pixel coordinates of this thread's four rows, carried from stage to stage (one float-reciprocal decomposition at the start)
+    int px[4], py[4], pn[4];
+    const bool wide = Wb >= KP;
+    if (!PLAIN) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = fdiv(kbeg + arow + 16 * i, Wb, invW, px[i]);
+            pn[i] = fdiv(r, Hb, invH, py[i]);
+        }
+    }
     auto load_A = [&](int k0) {
         aok = 0;
 #pragma unroll
@@ -105,12 +117,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
             int ok = m < kend;
             int off = m * sW;                                // PLAIN: 1x1, stride 1, pixel-linear source
             if (!PLAIN) {
-                int x, y;
-                const int r = fdiv(ok ? m : 0, Wb, invW, x);
-                const int n = fdiv(r, Hb, invH, y);
-                const int ly = (y << a.ashift) + ady - S.off_y, lx = (x << a.ashift) + adx - S.off_x;
+                const int ly = (py[i] << a.ashift) + ady - S.off_y, lx = (px[i] << a.ashift) + adx - S.off_x;
                 ok &= (int)((unsigned)ly < (unsigned)S.LH) & (int)((unsigned)lx < (unsigned)S.LW);       // bitwise: no exec-mask region
-                off = n * sN + ly * sH + lx * sW;
+                off = pn[i] * sN + ly * sH + lx * sW;
+                // the next stage's pixel, KP further along the row-major order: one branch-free carry when a row holds at least
+                // KP pixels, the float-reciprocal decomposition otherwise (wave-uniform choice)
+                if (wide) {
+                    px[i] += KP;
+                    const int cx = px[i] >= Wb;
+                    px[i] -= cx ? Wb : 0; py[i] += cx;
+                    const int cy = py[i] >= Hb;
+                    py[i] -= cy ? Hb : 0; pn[i] += cy;
+                } else {
+                    const int r = fdiv(m + KP, Wb, invW, px[i]);
+                    pn[i] = fdiv(r, Hb, invH, py[i]);
+                }
             }
             av[i] = *(const bf16x8*)(sp + (ok ? off : 0));
             aok |= (unsigned)ok << i;
@@ -190,10 +211,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
             const bf16x8 a1 = tr_frag(At, kk * 16, wm * 64 + 32, lane);
             const bf16x8 b0 = tr_frag(Bt, kk * 16, wn * 64, lane);
             const bf16x8 b1 = tr_frag(Bt, kk * 16, wn * 64 + 32, lane);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            if (SWAP) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
+            } else {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
         if (more) {
             write_A(As + (buf ^ 1) * (KP * RB));
@@ -203,19 +231,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
         buf ^= 1;
     }
 
-    // slab [ks][tap][Cin][Cout]: rows of D are ci (registers), the 32 lanes of a row are consecutive co
     float* slab = a.partials + ((long)ks * a.nseg + seg) * a.Cin * a.Cout;
     const int l31 = lane & 31, lh = lane >> 5;
+    if (SWAP) {
+        // slab [ks][Cout][Cin]: rows of D are co (registers), the 32 lanes of a row are consecutive ci
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = co0 + wn * 64 + j * 32 + l31;
+        for (int i = 0; i < 2; ++i) {
+            const int ci = ci0 + wm * 64 + i * 32 + l31;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = ci0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                slab[(long)ci * a.Cout + co] = acc[i][j][r];
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    slab[(long)co * a.Cin + ci] = acc[i][j][r];
+                }
+        }
+    } else {
+        // slab [ks][tap][Cin][Cout]: rows of D are ci (registers), the 32 lanes of a row are consecutive co
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = co0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = ci0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    slab[(long)ci * a.Cout + co] = acc[i][j][r];
+                }
+        }
     }
 }
 
@@ -237,10 +280,11 @@ bool wgrad_tap_supported(const WgradArgs& a) {
     return a.Cin % TM == 0 && a.Cout % TN == 0;
 }
 
-// split-K plan: about one resident wave of blocks (2 per CU), at least four 64-pixel stages per block
+// split-K plan: at most one resident round of blocks (2 per CU), at least four 64-pixel stages per block
 int wgrad_tap_plan(const WgradArgs& a, int* ksplit, long* kchunk) {
     const long tiles = (long)(a.Cin / TM) * (a.Cout / TN) * a.nseg;
-    long ks = (512 + tiles - 1) / tiles;
+    long ks = 512 / tiles;                 // rounded DOWN: 36 tiles x 15 slices = 540 blocks ran as 512 + a second round of 28
+                                           // (0.21 ms for a 0.11 ms job); 14 slices = 504 blocks finish in one round
     if (ks > a.M / (4 * KP)) ks = a.M / (4 * KP);
     if (ks < 1) ks = 1;
     long chunk = (a.M + ks - 1) / ks;
@@ -252,8 +296,9 @@ int wgrad_tap_plan(const WgradArgs& a, int* ksplit, long* kchunk) {
 int wgrad_tap_launch_bf16(const WgradArgs& a, hipStream_t st) {
     const int mtn = a.Cin / TM, ntn = a.Cout / TN;
     dim3 grid(mtn * ntn * a.nseg * a.ksplit), block(256);
-    if (pixel_linear(a)) hipLaunchKernelGGL(wgrad_tap_bf16_kernel<true>, grid, block, 4 * KP * RB, st, a, mtn, ntn);
-    else hipLaunchKernelGGL(wgrad_tap_bf16_kernel<false>, grid, block, 4 * KP * RB, st, a, mtn, ntn);
+    if (pixel_linear(a)) hipLaunchKernelGGL((wgrad_tap_bf16_kernel<true, true>), grid, block, 4 * KP * RB, st, a, mtn, ntn);
+    else if (a.nseg == 1) hipLaunchKernelGGL((wgrad_tap_bf16_kernel<false, true>), grid, block, 4 * KP * RB, st, a, mtn, ntn);
+    else hipLaunchKernelGGL((wgrad_tap_bf16_kernel<false, false>), grid, block, 4 * KP * RB, st, a, mtn, ntn);
     USTRUN_LAUNCH_CHECK("wgrad_tap_bf16");
     return 0;
 }
