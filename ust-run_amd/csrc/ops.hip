@@ -236,7 +236,7 @@ extern "C" int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int6
         const int halo = (int)((1024 + pairs - 1) / pairs) + 1;
         if (halo > slabs) slabs = halo;
     }
-    if (Cin % 128 == 0 && Cout % 128 == 0 && nseg <= 9) {        // the one-tap-per-block bf16 kernel (1x1 / dilated / strided)
+    if (Cin % 64 == 0 && Cout % 64 == 0 && nseg <= 9) {          // the one-tap-per-block bf16 kernel (1x1 / dilated / strided)
         WgradArgs t = {};
         t.Cin = Cin; t.Cout = Cout; t.nseg = nseg; t.M = npix;
         int kt; long ct;

@@ -3,7 +3,7 @@
 //
 //   dW[tap][ci][co] = sum_p act(x[stride * p + dilation * (tap - k/2)][ci]) * dy[p][co]          p over the output grid
 //
-// A "TN" GEMM over pixels whose operands are both pixel-major in HBM.  A block owns 128 ci x 128 co of one tap and a
+// A "TN" GEMM over pixels whose operands are both pixel-major in HBM.  A block owns 128 (or 64) ci x 128 (or 64) co of one tap and a
 // contiguous range of output pixels (split-K over space), 64 pixels per stage, double-buffered; the tiles stay
 // [pixel][channel] in LDS (256-byte rows, 64-byte segments XORed by the pixel index) and the MFMA fragments come from the
 // transposing LDS read (ds_read_b64_tr_b16), as in wgradT_bf16.hip.  The activation tile goes global -> registers ->
@@ -23,16 +23,19 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-constexpr int TM = 128, TN = 128, KP = 64, RB = 256;   // tile, pixels per stage, LDS row pitch (bytes)
+constexpr int KP = 64;   // pixels per stage; tiles are TM ci x TN co (128 or 64 each), LDS rows TM*2 / TN*2 bytes
+
+// 64-byte segments of a row are XOR-permuted by the row index so that the 4 rows of a transposed read fall on different bank
+// segments (256-byte rows: 4 segments, row & 3; 128-byte rows: 2 segments, (row >> 1) & 1)
+template <int RB> __device__ __forceinline__ int seg_swz(int row) { return RB >= 256 ? (row & 3) : ((row >> 1) & 1); }
 
 // rows k0 + 8*(l>>5) + {0..3 | 4..7}, columns col0 + 16*((l>>4)&1) + 4*(l&3) .. +3, delivered column-major
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, int lane) {
+template <int RB> __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, int lane) {
     const int q = (lane & 15) >> 2, p = lane & 3;
     const int colb = (col0 + 16 * ((lane >> 4) & 1) + 4 * p) * 2;
-    const int r0 = k0 + 8 * (lane >> 5) + q, r1 = r0 + 4;      // r1 & 3 == r0 & 3
-    const int off = colb ^ ((r0 & 3) << 6);
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * RB + off));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * RB + off));
+    const int r0 = k0 + 8 * (lane >> 5) + q, r1 = r0 + 4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * RB + (colb ^ (seg_swz<RB>(r0) << 6))));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * RB + (colb ^ (seg_swz<RB>(r1) << 6))));
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -52,11 +55,15 @@ __device__ __forceinline__ int fdiv(int v, int d, float invd, int& rem) {
 // grid = (ci tiles * co tiles * taps * ksplit)
 // SWAP (1x1 convolutions): the MFMA operands trade places, D rows are co and its lanes ci, so the slab comes out as [co][ci] --
 // the torch layout of a 1x1 weight -- and the fixed-order streaming sum finishes it without a transposing pass.
-template <bool PLAIN, bool SWAP>
+template <int TM, int TN, bool PLAIN, bool SWAP>
 __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs a, const int mtn, const int ntn) {
+    constexpr int RBA = TM * 2, RBB = TN * 2;                 // LDS row pitches (bytes)
+    constexpr int AQ = TM / 8, AROWS = 256 / AQ, AP = KP / AROWS;      // 16-byte items per row, rows per pass, passes
+    constexpr int BQ = TN / 8, BROWS = 256 / BQ, BP = KP / BROWS;
+    constexpr int MI = TM / 64, NI = TN / 64;                 // 32 x 32 MFMA tiles per wave (waves 2 x 2)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                      // 2 x [KP][TM] bf16
-    char* Bs = smem + 2 * KP * RB;        // 2 x [KP][TN] bf16
+    char* Bs = smem + 2 * KP * RBA;       // 2 x [KP][TN] bf16
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,9 +88,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
     const int Wb = a.Wb, Hb = a.Hb;
     const float invW = 1.f / (float)Wb, invH = 1.f / (float)Hb;
 
-    // ---- A items: pixel row (tid >> 4) + 16 i, 8-channel group tid & 15 ----
+    // ---- A items: pixel row tid / AQ + AROWS i, 8-channel group tid % AQ ----
     const SrcDev& S = a.src[0];
-    const int c8 = tid & 15;
+    const int c8 = tid % AQ;
     const int cl = ci0 + 8 * c8;
     const bool aff = S.scale != nullptr;
     f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
@@ -93,27 +100,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
     }
     const float floor_ = S.relu ? 0.f : -__builtin_inff();
     const __bf16* sp = (const __bf16*)S.ptr + cl;
-    const int arow = tid >> 4;
+    const int arow = tid / AQ;
     const int sN = (int)S.sN, sH = (int)S.sH, sW = (int)S.sW;        // element offsets fit 31 bits (host check)
-    bf16x8 av[4];
+    bf16x8 av[AP];
     unsigned aok = 0;
     // every load is issued unconditionally from an in-range address (pixel 0 for rows outside the range / the image) and the
     // row is zeroed at the LDS write: a load under a per-row branch gets its own basic block and its own wait
     // pixel coordinates of this thread's four rows, carried from stage to stage (one float-reciprocal decomposition at the start)
-    int px[4], py[4], pn[4];
+    int px[AP], py[AP], pn[AP];
     const bool wide = Wb >= KP;
     if (!PLAIN) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = fdiv(kbeg + arow + 16 * i, Wb, invW, px[i]);
+        for (int i = 0; i < AP; ++i) {
+            const int r = fdiv(kbeg + arow + AROWS * i, Wb, invW, px[i]);
             pn[i] = fdiv(r, Hb, invH, py[i]);
         }
     }
     auto load_A = [&](int k0) {
         aok = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = k0 + arow + 16 * i;
+        for (int i = 0; i < AP; ++i) {
+            const int m = k0 + arow + AROWS * i;
             int ok = m < kend;
             int off = m * sW;                                // PLAIN: 1x1, stride 1, pixel-linear source
             if (!PLAIN) {
@@ -139,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
     };
     auto write_A = [&](char* dst) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = arow + 16 * i;
+        for (int i = 0; i < AP; ++i) {
+            const int row = arow + AROWS * i;
             const bool ok = (aok >> i) & 1u;
             bf16x8 h = av[i];
             {   // branch-free: identity constants (1, 0, floor = -inf) for a finished activation -- bf16 -> f32 -> bf16 is exact
@@ -155,36 +162,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
             u32x4 bits = __builtin_bit_cast(u32x4, h);
 #pragma unroll
             for (int q = 0; q < 4; ++q) bits[q] = ok ? bits[q] : 0u;       // rows outside the range / the image are zero
-            *(u32x4*)(dst + row * RB + ((c8 * 16) ^ ((row & 3) << 6))) = bits;
+            *(u32x4*)(dst + row * RBA + ((c8 * 16) ^ (seg_swz<RBA>(row) << 6))) = bits;
         }
     };
     // ---- dy tile: the same (row, 8-channel group) items, a pure copy.  It goes through registers like the activation tile
     // and NOT by LDS-DMA: with a DMA in flight hipcc puts s_waitcnt vmcnt(0) in front of the stage's first ds_read (it cannot
     // tell the two LDS buffers apart), which also drains the activation prefetch before the MFMAs instead of after them.
-    const __bf16* dyp = (const __bf16*)a.dy + co0 + 8 * c8;
+    const int b8 = tid % BQ, brow = tid / BQ;
+    const __bf16* dyp = (const __bf16*)a.dy + co0 + 8 * b8;
     const int dyC = a.Cout;
-    bf16x8 bv[4];
+    bf16x8 bv[BP];
     auto load_B = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = k0 + arow + 16 * i;
+        for (int i = 0; i < BP; ++i) {
+            const int m = k0 + brow + BROWS * i;
             // rows past the tensor read pixel 0: any finite value will do, their A rows are zero
             bv[i] = *(const bf16x8*)(dyp + (m < (int)a.M ? m : 0) * dyC);
         }
     };
     auto write_B = [&](char* dst) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = arow + 16 * i;
-            *(bf16x8*)(dst + row * RB + ((c8 * 16) ^ ((row & 3) << 6))) = bv[i];
+        for (int i = 0; i < BP; ++i) {
+            const int row = brow + BROWS * i;
+            *(bf16x8*)(dst + row * RBB + ((b8 * 16) ^ (seg_swz<RBB>(row) << 6))) = bv[i];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -203,29 +211,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
             load_A(k0 + KP);
             load_B(k0 + KP);
         }
-        const char* At = As + buf * (KP * RB);
-        const char* Bt = Bs + buf * (KP * RB);
+        const char* At = As + buf * (KP * RBA);
+        const char* Bt = Bs + buf * (KP * RBB);
 #pragma unroll
         for (int kk = 0; kk < KP / 16; ++kk) {
-            const bf16x8 a0 = tr_frag(At, kk * 16, wm * 64, lane);
-            const bf16x8 a1 = tr_frag(At, kk * 16, wm * 64 + 32, lane);
-            const bf16x8 b0 = tr_frag(Bt, kk * 16, wn * 64, lane);
-            const bf16x8 b1 = tr_frag(Bt, kk * 16, wn * 64 + 32, lane);
-            if (SWAP) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
-            } else {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-            }
+            bf16x8 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = tr_frag<RBA>(At, kk * 16, wm * (TM / 2) + 32 * i, lane);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = tr_frag<RBB>(Bt, kk * 16, wn * (TN / 2) + 32 * j, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            write_A(As + (buf ^ 1) * (KP * RB));
-            write_B(Bs + (buf ^ 1) * (KP * RB));
+            write_A(As + (buf ^ 1) * (KP * RBA));
+            write_B(Bs + (buf ^ 1) * (KP * RBB));
         }
         __syncthreads();
         buf ^= 1;
@@ -236,26 +240,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
     if (SWAP) {
         // slab [ks][Cout][Cin]: rows of D are co (registers), the 32 lanes of a row are consecutive ci
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ci = ci0 + wm * 64 + i * 32 + l31;
+        for (int i = 0; i < MI; ++i) {
+            const int ci = ci0 + wm * (TM / 2) + i * 32 + l31;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int co = co0 + wn * (TN / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     slab[(long)co * a.Cin + ci] = acc[i][j][r];
                 }
         }
     } else {
         // slab [ks][tap][Cin][Cout]: rows of D are ci (registers), the 32 lanes of a row are consecutive co
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int co = co0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < NI; ++j) {
+            const int co = co0 + wn * (TN / 2) + j * 32 + l31;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ci = ci0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int ci = ci0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     slab[(long)ci * a.Cout + co] = acc[i][j][r];
                 }
         }
@@ -270,6 +274,9 @@ bool pixel_linear(const WgradArgs& a) {
 
 }  // namespace
 
+static int tile_m(const WgradArgs& a) { return a.Cin % 128 == 0 ? 128 : 64; }
+static int tile_n(const WgradArgs& a) { return a.Cout % 128 == 0 ? 128 : 64; }
+
 bool wgrad_tap_supported(const WgradArgs& a) {
     if (a.dy_s != 1 || a.dy_esz != 2 || a.nsrc != 1 || a.nseg < 1 || a.nseg > 9 || a.ashift > 1) return false;
     const SrcDev& s = a.src[0];
@@ -277,12 +284,12 @@ bool wgrad_tap_supported(const WgradArgs& a) {
     if ((s.sW & 7) || (s.sH & 7) || (s.sN & 7)) return false;                 // 16-byte loads of 8 channels
     if (a.dyH != a.Hb || a.dyW != a.Wb || a.M >= (1L << 24)) return false;    // float-reciprocal pixel decomposition
     if ((long)a.N * s.sN >= (1L << 31) || a.M * a.Cout >= (1L << 31)) return false;      // 32-bit element offsets
-    return a.Cin % TM == 0 && a.Cout % TN == 0;
+    return a.Cin % 64 == 0 && a.Cout % 64 == 0;
 }
 
 // split-K plan: at most one resident round of blocks (2 per CU), at least four 64-pixel stages per block
 int wgrad_tap_plan(const WgradArgs& a, int* ksplit, long* kchunk) {
-    const long tiles = (long)(a.Cin / TM) * (a.Cout / TN) * a.nseg;
+    const long tiles = (long)(a.Cin / tile_m(a)) * (a.Cout / tile_n(a)) * a.nseg;
     long ks = 512 / tiles;                 // rounded DOWN: 36 tiles x 15 slices = 540 blocks ran as 512 + a second round of 28
                                            // (0.21 ms for a 0.11 ms job); 14 slices = 504 blocks finish in one round
     if (ks > a.M / (4 * KP)) ks = a.M / (4 * KP);
@@ -293,14 +300,24 @@ int wgrad_tap_plan(const WgradArgs& a, int* ksplit, long* kchunk) {
     return 0;
 }
 
-int wgrad_tap_launch_bf16(const WgradArgs& a, hipStream_t st) {
+template <int TM, int TN>
+static int launch_tile(const WgradArgs& a, hipStream_t st) {
     const int mtn = a.Cin / TM, ntn = a.Cout / TN;
     dim3 grid(mtn * ntn * a.nseg * a.ksplit), block(256);
-    if (pixel_linear(a)) hipLaunchKernelGGL((wgrad_tap_bf16_kernel<true, true>), grid, block, 4 * KP * RB, st, a, mtn, ntn);
-    else if (a.nseg == 1) hipLaunchKernelGGL((wgrad_tap_bf16_kernel<false, true>), grid, block, 4 * KP * RB, st, a, mtn, ntn);
-    else hipLaunchKernelGGL((wgrad_tap_bf16_kernel<false, false>), grid, block, 4 * KP * RB, st, a, mtn, ntn);
+    constexpr int lds = 2 * KP * (TM + TN) * 2;
+    if (pixel_linear(a)) hipLaunchKernelGGL((wgrad_tap_bf16_kernel<TM, TN, true, true>), grid, block, lds, st, a, mtn, ntn);
+    else if (a.nseg == 1) hipLaunchKernelGGL((wgrad_tap_bf16_kernel<TM, TN, false, true>), grid, block, lds, st, a, mtn, ntn);
+    else hipLaunchKernelGGL((wgrad_tap_bf16_kernel<TM, TN, false, false>), grid, block, lds, st, a, mtn, ntn);
     USTRUN_LAUNCH_CHECK("wgrad_tap_bf16");
     return 0;
+}
+
+int wgrad_tap_launch_bf16(const WgradArgs& a, hipStream_t st) {
+    const int tm = tile_m(a), tn = tile_n(a);
+    if (tm == 128 && tn == 128) return launch_tile<128, 128>(a, st);
+    if (tm == 128) return launch_tile<128, 64>(a, st);
+    if (tn == 128) return launch_tile<64, 128>(a, st);
+    return launch_tile<64, 64>(a, st);
 }
 
 }  // namespace ustrun
