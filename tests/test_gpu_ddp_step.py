@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, deeplab=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import random
     import sys
@@ -35,14 +35,22 @@ def _worker(rank, world, port, q):
     torch.cuda.set_device(0)
     ddp.init("gloo")
     torch.manual_seed(1337)
-    model = UNet(3, 2, base_channels=16, dtype="bf16").cuda()
-    ema = UNet(3, 2, base_channels=16, dtype="bf16").cuda()
-    tr = SSLTrainer("fundus", model, ema, patch_size=64, grad_allreduce=ddp.make_grad_allreduce(world), world_size=world,
-                    fft="device")
-    assert tr.dec_off > 0
+    if deeplab:      # BASELINE.json configs[4]'s model under the same exchange: one all-reduce of its flat gradient buffer
+        from networks.deeplabv2 import DeepLabV2
+        model = DeepLabV2("resnet50", 2, pretrained=False, dtype="bf16").cuda()
+        ema = DeepLabV2("resnet50", 2, pretrained=False, dtype="bf16").cuda()
+        tr = SSLTrainer("fundus", model, ema, patch_size=64, base_lr=1e-6, grad_allreduce=ddp.make_grad_allreduce(world),
+                        world_size=world, fft="device")
+        assert tr.batch_passes is False and tr.dec_off == 0
+    else:
+        model = UNet(3, 2, base_channels=16, dtype="bf16").cuda()
+        ema = UNet(3, 2, base_channels=16, dtype="bf16").cuda()
+        tr = SSLTrainer("fundus", model, ema, patch_size=64, grad_allreduce=ddp.make_grad_allreduce(world), world_size=world,
+                        fft="device")
+        assert tr.dec_off > 0
     random.seed(1212 + rank); np.random.seed(1337 + rank)
     ok = True
-    for step in range(3):
+    for step in range(2 if deeplab else 3):
         b = [t.cuda() for t in synthetic.batch("fundus", 2, 3, 64, 100 * step + rank)]
         tr.step(*b, epoch_start=(step == 0))
         ok = ok and ddp.params_identical_across_ranks(tr.flat_p) and ddp.params_identical_across_ranks(tr.flat_t)
@@ -53,11 +61,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_training_step_world2_parameters_stay_identical():
+@pytest.mark.parametrize("deeplab", [False, True])
+def test_training_step_world2_parameters_stay_identical(deeplab):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, deeplab)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

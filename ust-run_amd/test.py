@@ -34,6 +34,8 @@ parser.add_argument('--test_batches', type=int, default=8, help='synthetic batch
 parser.add_argument('--backend_dtype', default='f32', choices=['f32', 'bf16'])
 parser.add_argument('--seed', type=int, default=1337)
 parser.add_argument('--load_path', type=str, default='', help='state_dict file (default: the reference\'s path)')
+parser.add_argument('--backbone', default='resnet101', choices=['resnet50', 'resnet101'], help='--model deeplabv2')
+parser.add_argument('--image_size', type=int, default=0, help='patch extent override (0: the dataset default)')
 
 DOMAINS = {"fundus": 4, "prostate": 6, "MNMS": 4, "BUSI": 1}     # test.py:209-223
 
@@ -51,13 +53,18 @@ def main(args):
     from ustrun.evaluate import validate
     from ustrun.trainer import DATASETS
     C, H, K = DATASETS[args.dataset][:3]
+    H = args.image_size or H
     args.domain_num = min(args.domain_num, DOMAINS[args.dataset])
-    if args.model != 'unet':
-        raise SystemExit("only --model unet exists on the reference's path")
+    if args.model not in ('unet', 'deeplabv2'):
+        raise SystemExit("--model is 'unet' (the reference's path) or 'deeplabv2' (train.py --model deeplabv2 of this build)")
     if args.save_img:
         raise SystemExit("--save_img (cv2 contour drawing, util.py:300-360) is outside this build's scope")
-    model = UNet(n_channels=C, n_classes=K, dtype=args.backend_dtype).cuda()
-    path = args.load_path or '../model/{}/{}/unet_avg_dice_best_model.pth'.format(args.dataset, args.save_name)
+    if args.model == 'deeplabv2':
+        from networks.deeplabv2 import DeepLabV2
+        model = DeepLabV2(args.backbone, K, pretrained=False, dtype=args.backend_dtype).cuda()
+    else:
+        model = UNet(n_channels=C, n_classes=K, dtype=args.backend_dtype).cuda()
+    path = args.load_path or '../model/{}/{}/{}_avg_dice_best_model.pth'.format(args.dataset, args.save_name, args.model)
     model.load_state_dict(torch.load(path, map_location="cuda"))
     return validate(args.dataset, model, make_loaders(args, C, H), epoch=args.lb_domain)
 
