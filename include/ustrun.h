@@ -290,6 +290,12 @@ int ustrun_aspp_gather(const float* z, int N, int h, int w, int K, int nrates, c
 int ustrun_sum_resize_bilinear(const float* const* maps, int nmaps, int N, int h, int w, int K, int H, int W, float* out,
                                ustrun_stream_t s);
 
+/* the same row windows written out as GEMM rows: out [N*Ho*Wo][k_padded] in the compute dtype, column s * src->C + j = element j of
+ * the window of kernel row s, columns >= nrows * src->C zero (k_padded % 8 == 0).  With it the stem is ONE 1x1 convolution over
+ * k_padded "channels" (ustrun_conv2d_fwd / ustrun_conv2d_wgrad with k = 1) on the fast GEMM kernels                             */
+int ustrun_rowwin_patches(const ustrun_src_t* src, int N, int Ho, int Wo, int nrows, int stride, int k_padded, void* out, int dtype,
+                          ustrun_stream_t s);
+
 /* ---- DeepLabV2-ResNet backward (autograd of the modules above).  Input gradients of the stride-1 convolutions are
  * ustrun_conv2d_fwd launches over dy with the flipped / transposed weights (packed by ustrun_pack_conv from
  * w.flip(2,3).transpose(0,1)); BatchNorm backward is ustrun_bn_bwd_reduce / _apply (a BatchNorm that is NOT followed by a ReLU

@@ -273,3 +273,36 @@ def test_rowwin_stem_and_aspp_gather_direct():
     rr = (C.c_int * 4)(*rates)
     l.check(lib.ustrun_aspp_gather(z.data_ptr(), n, hh, ww, K, 4, rr, bsum.data_ptr(), out.data_ptr(), None))
     assert rel(from_nhwc(out), want) < 1e-6
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_rowwin_patches_exact(dt):
+    """ustrun_rowwin_patches: the stem's seven 24-element row windows per output pixel as one 192-column GEMM row (zero tail), and
+    the 1x1 GEMM over them equal to the 7x7 / stride-2 convolution -- exact small integers, odd extents."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(77)
+    n, h, w = 2, 31, 26
+    td = torch.bfloat16 if dt else torch.float32
+    x = torch.randint(-3, 4, (n, 3, h, w), generator=g).float()
+    wt = torch.randint(-2, 3, (64, 3, 7, 7), generator=g).float()
+    ref = F.conv2d(x, wt, None, 2, 3)
+    ho, wo = ref.shape[-2:]
+    xp = F.pad(x.permute(0, 2, 3, 1), (0, 0, 3, 4, 3, 3)).to(td).contiguous().cuda()        # [n, h+6, w+7, 3]
+    hp, wp = h + 6, w + 7
+    src = l.Src(xp.data_ptr(), None, None, 24, hp, wp - 7, hp * wp * 3, wp * 3, 3, 1, 0, 0, 0, 0, 0, 0, 0)
+    pt = torch.full((n, ho, wo, 192), 9.0, device="cuda", dtype=td)
+    l.check(lib.ustrun_rowwin_patches(C.byref(src), n, ho, wo, 7, 2, 192, pt.data_ptr(), dt, None))
+    flat = xp.float().cpu().reshape(n, hp, wp * 3)
+    want = torch.zeros(n, ho, wo, 192)
+    for s in range(7):
+        for xx in range(wo):
+            want[:, :, xx, s * 24:(s + 1) * 24] = flat[:, s:s + 2 * ho:2, 6 * xx:6 * xx + 24][:, :ho]
+    assert torch.equal(pt.float().cpu(), want)
+    wk = F.pad(F.pad(wt.permute(0, 2, 3, 1).reshape(64, 7, 21), (0, 3)).reshape(64, 168), (0, 24)).contiguous().cuda()   # [co][ky*24+kx*3+ci]
+    wf = torch.zeros(lib.ustrun_pack_conv_elems(64, 192, 1), dtype=td, device="cuda")
+    l.check(lib.ustrun_pack_conv(wk.data_ptr(), 64, 192, 1, wf.data_ptr(), dt, None))
+    psrc = l.nhwc_src(pt.data_ptr(), 192, ho, wo)
+    y = torch.empty(n, ho, wo, 64, device="cuda", dtype=td)
+    l.check(lib.ustrun_conv2d_fwd(C.byref(psrc), 1, wf.data_ptr(), None, n, ho, wo, 64, 1, 1, 1, y.data_ptr(), 0, None, None, dt, None))
+    assert rel(from_nhwc(y), ref.bfloat16().float() if dt else ref) < 1e-6

@@ -266,6 +266,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)red[0];
 }
 
+// Row-window patches of a zero-padded NHWC source as GEMM rows: out[m][s * win + j] = xp[n][stride * y + s][stride * x * Cin + j]
+// (s < nrows kernel rows, j < win = the kernel row's k * Cin contiguous elements rounded up to 8; columns >= nrows * win are
+// zero).  The 7x7 / stride-2 stem becomes a plain 1x1 GEMM over 192 columns on the fast kernels, forward and weight gradient,
+// instead of seven 24-wide segments on the generic one.  thread = (output pixel, 8-element group); the source groups are only
+// 2-byte aligned (pixel stride 3 elements), the stores are 16-byte aligned.
+template <int ESZ>
+__global__ __launch_bounds__(256) void rowwin_patches_kernel(const float* __restrict__ xp, long sN, long sH, int Cin, int N, int Ho, int Wo,
+                                                            int nrows, int win, int stride, int Kp, float* __restrict__ out) {
+    const int G = Kp / 8, gw = win / 8;
+    const long total = (long)N * Ho * Wo * G;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int g = (int)(e % G);
+        long m = e / G;
+        const int x = (int)(m % Wo); m /= Wo;
+        const int y = (int)(m % Ho);
+        const int n = (int)(m / Ho);
+        const int srow = g / gw, j = (g - srow * gw) * 8;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (srow < nrows) {
+            const long src = n * sN + (long)(stride * y + srow) * sH + (long)stride * x * Cin + j;
+            lo = ld4t<ESZ>(xp, src); hi = ld4t<ESZ>(xp, src + 4);      // (unaligned vector loads: fine for global memory on gfx950)
+        }
+        st4t<ESZ>(out, e * 8, lo);
+        st4t<ESZ>(out, e * 8 + 4, hi);
+    }
+}
+
 int stream_blocks(long total) { long b = (total + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 }  // namespace
@@ -501,4 +528,20 @@ extern "C" int ustrun_conv_rowwin_wgrad(const ustrun_src_t* src, const void* dy,
     USTRUN_CHECK(partials_bytes >= (int64_t)slabs * a.nseg * a.Cin * Cout * 4, "conv_rowwin_wgrad: partials too small");
     USTRUN_TRY(wgrad_launch(a, dtype, (hipStream_t)s));
     return reduce_partials(partials, slabs, a.nseg, a.Cin, Cout, dw, 0, accumulate, (hipStream_t)s);
+}
+
+// patches of a padded NHWC source as GEMM rows [N*Ho*Wo][k_padded] (see rowwin_patches_kernel): src as for ustrun_conv_rowwin_fwd
+extern "C" int ustrun_rowwin_patches(const ustrun_src_t* src, int N, int Ho, int Wo, int nrows, int stride, int k_padded, void* out, int dtype,
+                                     ustrun_stream_t s) {
+    USTRUN_CHECK(src && src->ptr && out && N > 0 && Ho > 0 && Wo > 0 && nrows >= 1 && nrows <= 9 && (stride == 1 || stride == 2) &&
+                 dtype_ok(dtype), "rowwin_patches: bad args");
+    USTRUN_CHECK(src->sC == 1 && src->C % 8 == 0 && k_padded % 8 == 0 && k_padded >= nrows * src->C && !src->pool && !src->scale && !src->f32,
+                 "rowwin_patches: window %d / padded K %d", src->C, k_padded);
+    USTRUN_CHECK((stride * (Ho - 1) + nrows) <= src->H && stride * (Wo - 1) < src->W,
+                 "rowwin_patches: the padded source [%d x %d] does not cover the windows", src->H, src->W);
+    const long total = (long)N * Ho * Wo * (k_padded / 8);
+    USTRUN_BY_DTYPE(rowwin_patches_kernel, stream_blocks(total), (const float*)src->ptr, (long)src->sN, (long)src->sH, (int)src->sW, N, Ho, Wo,
+                    nrows, src->C, stride, k_padded, (float*)out);
+    USTRUN_LAUNCH_CHECK("rowwin_patches");
+    return 0;
 }

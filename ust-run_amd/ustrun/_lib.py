@@ -86,6 +86,7 @@ SIGNATURES = {
     "ustrun_bn_add_relu": (i32, [vp, fp, fp, vp, fp, fp, i64, i32, vp, i32, vp]),
     "ustrun_aspp_gather": (i32, [fp, i32, i32, i32, i32, i32, C.POINTER(C.c_int), fp, fp, vp]),
     "ustrun_sum_resize_bilinear": (i32, [C.POINTER(vp), i32, i32, i32, i32, i32, i32, i32, fp, vp]),
+    "ustrun_rowwin_patches": (i32, [PSrc, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "ustrun_relu_bwd_add": (i32, [vp, vp, vp, i64, vp, i32, vp]),
     "ustrun_maxpool3x3s2_bwd": (i32, [vp, vp, fp, fp, i32, i32, i32, i32, vp, i32, vp]),
     "ustrun_sum_resize_bilinear_bwd": (i32, [fp, i32, i32, i32, i32, i32, i32, fp, vp]),

@@ -109,33 +109,40 @@ def conv_bn(src_act, x_nchw, conv, bn, dt, train):
 def stem(net, x, dt, train):
     """resnet.py:124-126,160-162: the 7x7 / stride-2 / padding-3 convolution of the 3-channel NCHW input + BatchNorm constants.
     The input is re-laid as zero-padded NHWC in the compute dtype (tensor plumbing), where the 7 pixels x 3 channels of one
-    kernel row are 21 contiguous elements: the convolution runs as 7 row segments of a 24-wide window (ustrun_conv_rowwin_fwd)
-    instead of 49 taps of 3 channels."""
+    kernel row are 21 contiguous elements; `ustrun_rowwin_patches` writes, per output pixel, its 7 row windows of 24 elements as
+    one GEMM row of 192 columns (168 + 24 zeros), and the convolution is ONE 1x1 GEMM over those "channels" on the fast kernel
+    (0.53 ms as seven 24-wide segments on the generic kernel -> patches + GEMM; the weight gradient reuses the patches:
+    1.2 ms -> a plain TN GEMM).  Returns Act(raw y, BatchNorm constants) with the patches kept for the backward."""
     lib = L.lib()
     conv, bn = net.conv1, net.bn1
     N, Cin, H, W = x.shape
     k, st, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
     win = (k * Cin + 7) // 8 * 8                                                   # 24
+    Kp = (k * win + 63) // 64 * 64                                                 # 192: whole 64-column tiles for the GEMM kernels
     extra = (win - k * Cin + Cin - 1) // Cin                                       # whole pixels the rounded-up window reaches past
     xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 0, pad, pad + extra, pad, pad)).to(_tdtype(dt)).contiguous()
     Hp, Wp = H + 2 * pad, W + 2 * pad + extra
-    key = (conv.weight.data_ptr(), conv.weight._version, dt, "rowwin", _GEN[0])
-    if getattr(conv, "_ustrun_pack_key", None) != key:
-        co = conv.weight.shape[0]
-        w = conv.weight.detach().permute(0, 2, 3, 1).reshape(co, k, k * Cin)       # [co][ky][kx*Cin + ci]
-        w = torch.nn.functional.pad(w, (0, win - k * Cin)).permute(0, 2, 1).contiguous()     # [co][win][ky]: "Cin" = win, taps = ky
-        buf = torch.zeros(lib.ustrun_pack_conv_elems(co, win, k), dtype=_tdtype(dt), device=x.device)
-        L.check(lib.ustrun_pack_conv(w.data_ptr(), co, win, k, buf.data_ptr(), dt, stream_ptr()), "ustrun_pack_conv")
-        conv._ustrun_pack, conv._ustrun_pack_key = buf, key
     co = conv.weight.shape[0]
-    src = L.Src(xp.data_ptr(), None, None, win, Hp, Wp - (win + Cin - 1) // Cin + 1, Hp * Wp * Cin, Wp * Cin, Cin, 1, 0, 0, 0, 0, 0, 0, 0)
+    key = (conv.weight.data_ptr(), conv.weight._version, dt, "patches", _GEN[0])
+    if getattr(conv, "_ustrun_pack_key", None) != key:
+        w = conv.weight.detach().permute(0, 2, 3, 1).reshape(co, k, k * Cin)       # [co][ky][kx*Cin + ci]
+        w = torch.nn.functional.pad(w, (0, win - k * Cin)).reshape(co, k * win)    # [co][ky*win + kx*Cin + ci]
+        w = torch.nn.functional.pad(w, (0, Kp - k * win)).contiguous()             # zero weights meet the windows' overhang
+        buf = torch.zeros(lib.ustrun_pack_conv_elems(co, Kp, 1), dtype=_tdtype(dt), device=x.device)
+        L.check(lib.ustrun_pack_conv(w.data_ptr(), co, Kp, 1, buf.data_ptr(), dt, stream_ptr()), "ustrun_pack_conv")
+        conv._ustrun_pack, conv._ustrun_pack_key = buf, key
+    wsrc = L.Src(xp.data_ptr(), None, None, win, Hp, Wp - (win + Cin - 1) // Cin + 1, Hp * Wp * Cin, Wp * Cin, Cin, 1, 0, 0, 0, 0, 0, 0, 0)
+    patches = torch.empty(N, Ho, Wo, Kp, dtype=_tdtype(dt), device=x.device)
+    L.check(lib.ustrun_rowwin_patches(C.byref(wsrc), N, Ho, Wo, k, st, Kp, patches.data_ptr(), dt, stream_ptr()), "ustrun_rowwin_patches")
+    pa = Act(patches, N, Ho, Wo, Kp)
+    src = pa.src()
     y = torch.empty(N, Ho, Wo, co, dtype=_tdtype(dt), device=x.device)
     aff = torch.empty(4, co, device=x.device)
     stat = torch.empty(lib.ustrun_conv_mtiles(N, Ho, Wo, co), 2, co, device=x.device) if train else None
     used = C.c_int(0)
-    L.check(lib.ustrun_conv_rowwin_fwd(C.byref(src), conv._ustrun_pack.data_ptr(), N, Ho, Wo, co, k, st, y.data_ptr(),
-                                       stat.data_ptr() if train else None, C.byref(used), dt, stream_ptr()), "ustrun_conv_rowwin_fwd")
+    L.check(lib.ustrun_conv2d_fwd(C.byref(src), 1, conv._ustrun_pack.data_ptr(), None, N, Ho, Wo, co, 1, 1, 1, y.data_ptr(), 0,
+                                  stat.data_ptr() if train else None, C.byref(used), dt, stream_ptr()), "ustrun_conv2d_fwd")
     if train:
         L.check(lib.ustrun_bn_finalize(stat.data_ptr(), used.value, co, N * Ho * Wo, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(),
@@ -146,7 +153,7 @@ def stem(net, x, dt, train):
                                           bn.running_var.data_ptr(), float(bn.eps), aff[0].data_ptr(), aff[1].data_ptr(), stream_ptr()),
                 "ustrun_bn_eval_affine")
     a = Act(y, N, Ho, Wo, co, aff=aff, relu=1)
-    a.keep = (xp, src, win, k, st, Cin)               # the weight gradient reads the same windows
+    a.keep = (pa, win, k, Cin)                        # the weight gradient is a TN GEMM over the same patches
     return a
 
 
@@ -429,14 +436,15 @@ def _stem_backward(rec, dpool, dt, grads):
     L.check(lib.ustrun_maxpool3x3s2_bwd(dpool.data_ptr(), y0.t.data_ptr(), y0.aff[0].data_ptr(), y0.aff[1].data_ptr(), y0.N, y0.H, y0.W,
                                         y0.C, da0.data_ptr(), dt, stream_ptr()), "ustrun_maxpool3x3s2_bwd")
     dy0 = _bn_backward(y0, da0, True, net.bn1, grads, dt)
-    xp, src, win, k, st, Cin = y0.keep
-    co = y0.C
-    pb = lib.ustrun_wgrad_partials_bytes(k, win, co, y0.N * y0.H * y0.W)
+    pa, win, k, Cin = y0.keep
+    co, Kp = y0.C, pa.C
+    pb = lib.ustrun_wgrad_partials_bytes(1, Kp, co, y0.N * y0.H * y0.W)
     part = _scratch.get("wgrad", pb, dev)
-    dwr = torch.empty(co, win, k, device=dev)                                    # [co][kx*Cin + ci][ky]
-    L.check(lib.ustrun_conv_rowwin_wgrad(C.byref(src), dy0.data_ptr(), y0.N, y0.H, y0.W, co, k, st, dwr.data_ptr(), 0, part.data_ptr(), pb,
-                                         dt, stream_ptr()), "ustrun_conv_rowwin_wgrad")
-    grads[net.conv1.weight] = dwr[:, :k * Cin].reshape(co, k, Cin, k).permute(0, 2, 3, 1).contiguous()      # [co][ci][ky][kx]
+    dwp = torch.empty(co, Kp, device=dev)                                        # [co][ky*win + kx*Cin + ci]
+    src = pa.src()
+    L.check(lib.ustrun_conv2d_wgrad(C.byref(src), 1, dy0.data_ptr(), y0.N, y0.H, y0.W, co, 1, 1, 1, dwp.data_ptr(), 0, part.data_ptr(), pb, dt,
+                                    stream_ptr()), "ustrun_conv2d_wgrad")
+    grads[net.conv1.weight] = dwp[:, :k * win].reshape(co, k, win)[:, :, :k * Cin].reshape(co, k, k, Cin).permute(0, 3, 1, 2).contiguous()
 
 
 def deeplabv2_backward(net, tape, dlogits):
