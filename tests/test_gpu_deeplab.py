@@ -306,3 +306,25 @@ def test_rowwin_patches_exact(dt):
     y = torch.empty(n, ho, wo, 64, device="cuda", dtype=td)
     l.check(lib.ustrun_conv2d_fwd(C.byref(psrc), 1, wf.data_ptr(), None, n, ho, wo, 64, 1, 1, 1, y.data_ptr(), 0, None, None, dt, None))
     assert rel(from_nhwc(y), ref.bfloat16().float() if dt else ref) < 1e-6
+
+
+def test_deeplab_tta_matches_the_reference_formula():
+    """BaseNet.forward(x, tta=True) (base.py:24-45): ten views -- five scales, each plain and mirrored -- softmaxed, un-mirrored,
+    resized back and summed, against the same formula evaluated with the CPU oracle as `base_forward` (eval mode, f32)."""
+    from oracle import deeplab_ref as D
+    sd = D.make_state_dict("resnet50", 3, 41)
+    m = _model("resnet50", 3, 41, "f32").eval()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 3, 48, 64, generator=g)
+    with torch.no_grad():
+        got = m(x.cuda(), tta=True).cpu()
+        h, w = x.shape[-2:]
+        want = None
+        for scale in (0.5, 0.75, 1.0, 1.5, 2.0):
+            cur = F.interpolate(x, size=(int(h * scale), int(w * scale)), mode="bilinear", align_corners=True)
+            for flip in (False, True):
+                out = F.softmax(D.deeplabv2_forward(cur.flip(3) if flip else cur, sd, "resnet50", False), dim=1)
+                out = F.interpolate(out.flip(3) if flip else out, (h, w), mode="bilinear", align_corners=True)
+                want = out if want is None else want + out
+    assert got.shape == want.shape and rel(got, want) < 1e-4
+    assert abs(float(got.sum(1).mean()) - 10.0) < 1e-4          # ten probability maps
