@@ -201,7 +201,7 @@ def _field_stats(got, ref, median=None):
 
 def _hip_grads(sd, dtype, x, R):
     from networks.deeplabv2 import DeepLabV2
-    m = DeepLabV2("resnet50", 2, pretrained=False, dtype=dtype)
+    m = DeepLabV2("resnet50", R.shape[1], pretrained=False, dtype=dtype)
     m.load_state_dict(sd)
     m = m.cuda().train()
     out = m(x.cuda())
@@ -215,19 +215,20 @@ def _hip_grads(sd, dtype, x, R):
     return out.detach().cpu(), got
 
 
-@pytest.mark.parametrize("h,w", [(96, 80), (100, 76)])
-def test_deeplab_backward_vs_oracle_f32(h, w):
+@pytest.mark.parametrize("h,w,K", [(96, 80, 2), (100, 76, 4)])
+def test_deeplab_backward_vs_oracle_f32(h, w, K):
     """resnet50 DeepLabV2, train mode, loss = <logits, R>: every parameter's gradient against torch autograd over the CPU oracle
     evaluated in FLOAT64.  Fifty train-mode BatchNorms at batch 2 on 12 x 10 maps make the gradient ill-conditioned: the oracle's
     own float32 evaluation sits 2-3e-2 rel-L2 (per tensor) from its float64 one (cosine 0.9998).  That float32 oracle is the
     yardstick: worst per-tensor error <= 2x the yardstick's worst, cosine within 5e-4 of the yardstick's (measured: 2.2e-2 vs
     2.9e-2, 0.99986 vs 0.99979).  100 x 76 makes the extents entering the two stride-2 convolutions odd (25 x 19 -> 13 x 10:
-    the zero-inserted gradient has a dangling last row and column) and the pooled map odd."""
+    the zero-inserted gradient has a dangling last row and column) and the pooled map odd; four classes (M&Ms) make the
+    classifier GEMM 144 columns wide (padded to 192)."""
     from oracle import deeplab_ref as D
-    sd = D.make_state_dict("resnet50", 2, 23)
+    sd = D.make_state_dict("resnet50", K, 23)
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 3, h, w, generator=g)
-    R = torch.randn(2, 2, h, w, generator=g)
+    R = torch.randn(2, K, h, w, generator=g)
     ref_out, ref = _oracle_grads(x, sd, "resnet50", R, torch.float64)
     _, o32 = _oracle_grads(x, sd, "resnet50", R, torch.float32)
     out, got = _hip_grads(sd, "f32", x, R)
