@@ -115,12 +115,14 @@ def test_head_adjoints():
 @pytest.mark.parametrize("n,ci,co,h,w,k,s,d", [(2, 64, 128, 12, 15, 1, 1, 1), (2, 128, 64, 13, 16, 1, 2, 1), (2, 64, 64, 14, 12, 3, 2, 1),
                                                (1, 128, 128, 16, 16, 3, 1, 1), (2, 64, 64, 15, 13, 3, 1, 2), (1, 128, 64, 12, 12, 3, 1, 4),
                                                (1, 256, 128, 9, 10, 1, 1, 1), (2, 128, 256, 13, 16, 1, 2, 1), (2, 128, 128, 14, 12, 3, 2, 1),
-                                               (1, 128, 128, 15, 13, 3, 1, 2), (1, 256, 128, 12, 12, 3, 1, 4), (3, 128, 128, 9, 7, 1, 1, 1)])
+                                               (1, 128, 128, 15, 13, 3, 1, 2), (1, 256, 128, 12, 12, 3, 1, 4), (3, 128, 128, 9, 7, 1, 1, 1),
+                                               (1, 128, 128, 7, 70, 3, 1, 2), (1, 64, 128, 9, 131, 3, 2, 1), (2, 128, 64, 5, 67, 1, 2, 1)])
 def test_conv2d_wgrad_general(n, ci, co, h, w, k, s, d, dt):
     """Weight gradients of 1x1 / 3x3 convolutions with stride 2 and dilation 2 / 4, with BatchNorm+ReLU evaluated by the loader:
     exact small integers against torch.nn.grad.conv2d_weight.  Channel counts that are multiples of 128 take the one-tap-per-block
     bf16 kernel (wgrad_tap_bf16.hip; pixel counts that are not multiples of its 64-pixel stage, split-K tails), the 64-channel
-    ones the generic kernel, 3x3 / stride 1 / undilated the halo kernel."""
+    ones the generic kernel, 3x3 / stride 1 / undilated the halo kernel.  Rows of 64+ output pixels take the kernel's carried-coordinate
+    path (one branch-free carry per 64-pixel stage), narrower ones its per-stage decomposition."""
     l = L()
     lib = l.lib()
     g = torch.Generator().manual_seed(ci + 3 * co + k + s + d)
