@@ -35,7 +35,7 @@ def from_nhwc(t):
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("n,ci,co,h,w,k,s,d,bias", [(2, 64, 64, 17, 23, 1, 1, 1, False), (2, 256, 128, 16, 12, 1, 2, 1, False),
                                                     (1, 64, 64, 19, 21, 3, 2, 1, False), (2, 128, 128, 14, 18, 3, 1, 2, False),
-                                                    (2, 256, 256, 12, 12, 3, 1, 4, False), (1, 512, 2, 16, 20, 3, 1, 6, True),
+                                                    (2, 256, 256, 12, 12, 3, 1, 4, False), (1, 128, 128, 24, 20, 3, 1, 4, False), (1, 512, 2, 16, 20, 3, 1, 6, True),
                                                     (1, 512, 4, 9, 9, 3, 1, 24, True)])
 def test_conv2d_general(n, ci, co, h, w, k, s, d, bias, dt):
     """1x1 / 3x3 with stride 2 and dilation 2, 4, 6, 24 (padding = dilation, most taps out of the image at rate 24), bias,

@@ -572,6 +572,7 @@ bool halo_tall_tile(const IgemmArgs& a) {
 
 // BatchNorm-statistics rows written by the configuration conv3x3_halo_launch_bf16 picks
 int halo_stat_rows_used(const IgemmArgs& a) {
+    if (halo_dilation(a) == 4 && a.Cout % 128 == 0) return a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16);       // 16 x 16 tiles, two rows each
     if (halo_dilation(a) > 1) return a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
     bool pool = false;
     for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
@@ -584,13 +585,20 @@ int halo_stat_rows_used(const IgemmArgs& a) {
     return wide ? a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 32) : a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16);
 }
 
-// dilated 3x3 (DeepLabV2-ResNet layer3 / layer4): the 8 x 16-pixel tiles keep the (8 + 2d) x (16 + 2d) patch pair small
+// dilated 3x3 (DeepLabV2-ResNet layer3 / layer4): 8 x 16-pixel tiles keep the (8 + 2d) x (16 + 2d) patch pair small at rate 2
 template <int DIL>
 static int launch_dilated(const IgemmArgs& a, hipStream_t st) {
     bool xf = false;
     for (int i = 0; i < a.nsrc; ++i) xf |= a.src[i].scale != nullptr || a.src[i].relu != 0;
-    if (a.Cout % 128 == 0)
+    if (a.Cout % 128 == 0) {
+        // rate 4: the (8 + 8) x (16 + 8) patch of an 8 x 16 tile is three times its output and its pair of buffers leaves room
+        // for ONE block per CU anyway -- a 16 x 16 tile (24 x 24 patch: 2.25 x) with the 4 x 2 wave tile does twice the MFMA
+        // work per stage in that one block: 0.49 -> 0.39 ms on layer4's 512 -> 512 convolutions (627 -> 786 TF/s).  Rate 2
+        // keeps the small tile (two blocks per CU; the large one measured 0.089 -> 0.108 ms there).
+        if (DIL == 4)
+            return xf ? launch_xf<16, 16, 128, 32, 4, false, 1, true, DIL>(a, st) : launch_xf<16, 16, 128, 32, 4, false, 1, false, DIL>(a, st);
         return xf ? launch_xf<8, 16, 128, 32, 2, false, 2, true, DIL>(a, st) : launch_xf<8, 16, 128, 32, 2, false, 2, false, DIL>(a, st);
+    }
     return xf ? launch_xf<8, 16, 64, 32, 1, false, 2, true, DIL>(a, st) : launch_xf<8, 16, 64, 32, 1, false, 2, false, DIL>(a, st);
 }
 
