@@ -60,6 +60,16 @@ def main():
         rows = sorted(((r.ms, r.flops, r.bytes) for r in buf[:n]), reverse=True)
         for ms_, fl_, by_ in rows[:24]:
             print(f"   {ms_:8.3f} ms  {fl_ / 1e9:9.1f} GF  {fl_ / ms_ / 1e9:7.0f} TF/s  {by_ / 1e6:8.1f} MB  {by_ / ms_ / 1e6:7.0f} GB/s  AI {fl_ / by_:6.0f}")
+        import collections
+        cls = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        for r in buf[:n]:
+            c = cls[(round(r.flops / 1e9, 1), round(r.bytes / 1e6, 1))]
+            c[0] += 1; c[1] += r.ms; c[2] += r.flops
+        if os.environ.get("USTRUN_BENCH_SEQ"):
+            print("   launch order:", " ".join(f"{r.flops / 1e9:.0f}:{r.ms * 1e3:.0f}" for r in buf[:n]))
+        print("   by launch class (GFLOP, MB): launches, total ms, TF/s")
+        for k, (cnt, ms_, fl_) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
+            print(f"   {k[0]:8.1f} GF {k[1]:8.1f} MB  x{cnt:3d}  {ms_:7.3f} ms  {fl_ / ms_ / 1e9:6.0f} TF/s")
     msd, fld, byd, nd = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
     lib.ustrun_profile_collect(0, ctypes.byref(msd), ctypes.byref(fld), ctypes.byref(byd), ctypes.byref(nd))
     print(f"DeepLabV2-{a.arch} {a.mode}-mode forward, N={a.n} {a.hw}x{a.hw}, {a.dtype}: {dt * 1e3:.2f} ms = {a.n / dt:.1f} images/s; "
