@@ -326,6 +326,16 @@ int ustrun_colsum(const float* x, int64_t rows, int C, float* out, int accumulat
  * TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF (0 before any) -- lets a parity test assert that its shape
  * reached the production tile it was written for                                                   */
 int ustrun_debug_last_conv_variant(void);
+/* the 1x1 / ConvTranspose GEMM kernel (convT_bf16.hip) reports 0x43540000 | (BN / 32) << 8 | (BK / 32) << 4 | MODE there
+ * (MODE 0 ConvTranspose forward, 1 its input gradient, 2 a 1x1 convolution).
+ * Same for the last weight-gradient launch: the one-tap-per-block kernel (wgrad_tap_bf16.hip) reports
+ * 0x54000000 | (TM / 64) << 20 | (TN / 64) << 16 | loader << 12 | ksplit (loader 2 = pixel-linear 1x1, 1 = one shifted tap,
+ * 0 = k x k taps); the all-taps halo kernel 0x48000000 | ksplit; 0 before any / for the generic kernels         */
+int ustrun_debug_last_wgrad_variant(void);
+/* test aid, host only (no launch, no device access): the number of BatchNorm-statistics rows the kernel that would serve a
+ * k x k convolution of a dense NHWC source [N, Cin] -> [N, Ho, Wo, Cout] writes.  tests/test_host_logic.py sweeps shapes
+ * with it: the count must never exceed ustrun_conv_mtiles(N, Ho, Wo, Cout), which is what callers allocate           */
+int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k, int stride, int dilation, int pooled, int dtype);
 /* test / tuning aid: process-wide kernel-selection flags, returns the previous value.  bit 0: run the 64 -> 64 channel
  * full-resolution convolutions on the halo-tiled kernel instead of the weight-stationary row-streaming one (A/B timing
  * inside one process); the last-variant code of the streaming kernel is 0x57530000 | XF                       */

@@ -1,0 +1,298 @@
+"""configs[4] (DeepLabV2-ResNet @512^2, BASELINE.json) at the tiles and the size it is benchmarked on:
+
+* exact small-integer cases through the C ABI at the shapes that SELECT each production variant of the 1x1 GEMM kernel
+  (convT_bf16_kernel<256,32,2>, <128,64,2>, <64,64,2>), of the one-tap weight-gradient kernel with split-K > 1
+  (wgrad_tap_bf16.hip: 1x1, dilated rate 2 / 4, stride 2, 128- and 64-wide tiles, the slab fold + transposing reduce) and of the
+  rate-4 16 x 16-pixel halo tile on a ragged map -- each asserting the variant it ran (ustrun_debug_last_conv_variant /
+  ustrun_debug_last_wgrad_variant);
+* guard-zone tests: the BatchNorm-statistics overflow ADVICE r2 found (streaming 64 -> 64 kernel, 432 rows into 400), and the
+  operators the first bf16 DeepLabV2 forward reaches on odd extents (the r2_dl1 fault's neighbourhood) with every tensor
+  embedded between poisoned (inputs: NaN) and sentinel (outputs) zones;
+* the network at 512 x 512 against a fixture captured from the reference's own modules (f32), and bf16 eval against f32.
+Reference: networks/backbone/resnet.py:78-105,159-171, networks/deeplabv2.py:22-33."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def L():
+    from ustrun import _lib
+    return _lib
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc(t, dt):
+    t = t.permute(0, 2, 3, 1).contiguous().cuda()
+    return t.bfloat16() if dt else t
+
+
+def from_nhwc(t):
+    return t.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+GUARD = 4096          # elements of poison / sentinel on either side
+
+
+def guarded(t, poison):
+    """A copy of `t` (device) embedded in a larger buffer whose surroundings hold `poison`; returns (view, whole buffer)."""
+    flat = torch.full((t.numel() + 2 * GUARD,), poison, dtype=t.dtype, device="cuda")
+    flat[GUARD:GUARD + t.numel()] = t.reshape(-1)
+    return flat[GUARD:GUARD + t.numel()].view(t.shape), flat
+
+
+def guards_intact(flat, n, poison):
+    lo, hi = flat[:GUARD], flat[GUARD + n:]
+    if poison != poison:     # NaN
+        return bool(torch.isnan(lo.float()).all()) and bool(torch.isnan(hi.float()).all())
+    return bool((lo == poison).all()) and bool((hi == poison).all())
+
+
+def ct_variant(bn, bk, mode):
+    return 0x43540000 | (bn // 32) << 8 | (bk // 32) << 4 | mode
+
+
+@pytest.mark.parametrize("ci,co,want", [(256, 1024, ct_variant(256, 32, 2)), (1024, 256, ct_variant(128, 64, 2)),
+                                        (64, 64, ct_variant(64, 64, 2)), (256, 64, ct_variant(64, 64, 2))])
+def test_conv1x1_production_tiles(ci, co, want):
+    """The bottleneck GEMMs at the shapes DeepLabV2 @512^2 runs them (N = 2, 64 x 64 maps: M = 8192 pixels): BatchNorm affine +
+    ReLU on load, bf16 outputs, statistics rows of the stored values; 256 -> 1024 reaches the 256-column tile (18.9 % of the
+    forward + backward kernel time in profiles/r02_deeplab_fwdbwd_n8_kernel_stats.csv), 1024 -> 256 the 128-column one."""
+    l = L()
+    lib = l.lib()
+    n, h, w = 2, 64, 64
+    g = torch.Generator().manual_seed(ci + co)
+    y0 = torch.randint(-3, 4, (n, ci, h, w), generator=g).float()
+    sc = torch.randint(1, 3, (ci,), generator=g).float()
+    sh = torch.randint(-2, 3, (ci,), generator=g).float()
+    x = torch.relu(y0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    wt = torch.randint(-2, 3, (co, ci, 1, 1), generator=g).float()
+    ref = F.conv2d(x, wt)
+    wf = torch.zeros(lib.ustrun_pack_conv_elems(co, ci, 1), dtype=torch.bfloat16, device="cuda")
+    wg = wt.cuda()
+    l.check(lib.ustrun_pack_conv(wg.data_ptr(), co, ci, 1, wf.data_ptr(), 1, None))
+    yg, yflat = guarded(nhwc(y0, 1), float("nan"))
+    scg, shg = sc.cuda(), sh.cuda()
+    src = l.nhwc_src(yg.data_ptr(), ci, h, w, scg.data_ptr(), shg.data_ptr(), relu=1)
+    out, oflat = guarded(torch.zeros(n, h, w, co, device="cuda", dtype=torch.bfloat16), 7.0)
+    rows = lib.ustrun_conv_mtiles(n, h, w, co)
+    stat, sflat = guarded(torch.zeros(rows, 2, co, device="cuda"), 7.0)
+    used = C.c_int(0)
+    l.check(lib.ustrun_conv2d_fwd(C.byref(src), 1, wf.data_ptr(), None, n, h, w, co, 1, 1, 1, out.data_ptr(), 0, stat.data_ptr(), C.byref(used),
+                                  1, None))
+    assert lib.ustrun_debug_last_conv_variant() == want, hex(lib.ustrun_debug_last_conv_variant())
+    stored = ref.bfloat16().float()
+    assert torch.equal(from_nhwc(out), stored)
+    assert guards_intact(oflat, out.numel(), 7.0) and guards_intact(sflat, stat.numel(), 7.0)
+    assert 0 < used.value <= rows
+    np.testing.assert_allclose(stat[:used.value, 0].double().sum(0).cpu().numpy(), stored.double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(stat[:used.value, 1].double().sum(0).cpu().numpy(), stored.double().square().sum((0, 2, 3)).numpy(), rtol=1e-5)
+
+
+def wt_variant(tm, tn, loader, ksplit):
+    return 0x54000000 | (tm // 64) << 20 | (tn // 64) << 16 | loader << 12 | ksplit
+
+
+@pytest.mark.parametrize("n,ci,co,h,w,k,s,d,tm,tn,loader", [
+    (2, 256, 128, 64, 64, 1, 1, 1, 128, 128, 2),       # layer-style 1x1, pixel-linear loader, 128-wide tiles
+    (2, 64, 256, 64, 64, 1, 1, 1, 64, 128, 2),         # layer1: 64-wide ci tile
+    (2, 256, 64, 64, 64, 1, 1, 1, 128, 64, 2),         # layer1: 64-wide co tile
+    (2, 128, 128, 64, 64, 3, 1, 2, 128, 128, 0),       # dilated rate 2 (layer3)
+    (2, 64, 64, 64, 72, 3, 1, 4, 64, 64, 0),           # dilated rate 4, 64-wide tiles, ragged rows
+    (2, 128, 128, 128, 128, 3, 2, 1, 128, 128, 0),     # stride 2, 3x3 (layer2.0.conv2)
+    (2, 128, 256, 128, 130, 1, 2, 1, 128, 128, 1)])    # stride 2, 1x1 (layer2.0.downsample): one shifted tap
+def test_wgrad_tap_split_k(n, ci, co, h, w, k, s, d, tm, tn, loader):
+    """Weight gradients on the one-tap-per-block kernel with M >= 8192 output pixels, so that the split-K plan (wgrad_tap_plan) runs
+    several slices per tile and the slab fold + (k x k: transposing) reduce are reached by an EXACT test -- every case of
+    test_conv2d_wgrad_general has M <= 490 and ksplit = 1.  BatchNorm affine + ReLU on the activation load, accumulate on the
+    second call."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(ci + 3 * co + k + s + d)
+    y0 = torch.randint(-3, 4, (n, ci, h, w), generator=g).float()
+    sc = torch.randint(1, 3, (ci,), generator=g).float()
+    sh = torch.randint(-2, 3, (ci,), generator=g).float()
+    x = torch.relu(y0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ho, wo = (h + 2 * (d * (k // 2)) - d * (k - 1) - 1) // s + 1, (w + 2 * (d * (k // 2)) - d * (k - 1) - 1) // s + 1
+    assert n * ho * wo >= 8192
+    dy = torch.randint(-2, 3, (n, co, ho, wo), generator=g).float()
+    want = torch.nn.grad.conv2d_weight(x, (co, ci, k, k), dy, s, d * (k // 2), d)
+    yg, dyg = nhwc(y0, 1), nhwc(dy, 1)
+    scg, shg = sc.cuda(), sh.cuda()
+    src = l.nhwc_src(yg.data_ptr(), ci, h, w, scg.data_ptr(), shg.data_ptr(), relu=1)
+    pb = lib.ustrun_wgrad_partials_bytes(k * k, ci, co, n * ho * wo)
+    part = torch.empty(pb, dtype=torch.uint8, device="cuda")
+    dw, dflat = guarded(torch.full((co, ci, k, k), 3.0, device="cuda"), 7.0)
+    l.check(lib.ustrun_conv2d_wgrad(C.byref(src), 1, dyg.data_ptr(), n, ho, wo, co, k, s, d, dw.data_ptr(), 0, part.data_ptr(), pb, 1, None))
+    v = lib.ustrun_debug_last_wgrad_variant()
+    assert v & ~0xfff == wt_variant(tm, tn, loader, 0), hex(v)
+    assert (v & 0xfff) > 1, f"split-K {v & 0xfff}: the shape was chosen to split"
+    assert torch.equal(dw.cpu(), want)
+    l.check(lib.ustrun_conv2d_wgrad(C.byref(src), 1, dyg.data_ptr(), n, ho, wo, co, k, s, d, dw.data_ptr(), 1, part.data_ptr(), pb, 1, None))
+    assert torch.equal(dw.cpu(), 2 * want)
+    assert guards_intact(dflat, dw.numel(), 7.0)
+
+
+def test_rate4_tile_on_a_ragged_map():
+    """layer4's dilated rate-4 convolutions run 16 x 16-pixel x 128-channel tiles (4 x 2 wave tile, 24 x 24 patch): 72 x 88 is a
+    multiple of neither tile extent, N = 1; exact integers + statistics rows, variant asserted."""
+    l = L()
+    lib = l.lib()
+    n, ci, co, h, w, d = 1, 128, 128, 72, 88, 4
+    g = torch.Generator().manual_seed(99)
+    x = torch.randint(-3, 4, (n, ci, h, w), generator=g).float()
+    wt = torch.randint(-2, 3, (co, ci, 3, 3), generator=g).float()
+    ref = F.conv2d(x, wt, None, 1, d, d)
+    wf = torch.zeros(lib.ustrun_pack_conv_elems(co, ci, 9), dtype=torch.bfloat16, device="cuda")
+    wg = wt.cuda()
+    l.check(lib.ustrun_pack_conv(wg.data_ptr(), co, ci, 9, wf.data_ptr(), 1, None))
+    xg, xflat = guarded(nhwc(x, 1), float("nan"))
+    src = l.nhwc_src(xg.data_ptr(), ci, h, w)
+    out, oflat = guarded(torch.zeros(n, h, w, co, device="cuda", dtype=torch.bfloat16), 7.0)
+    rows = lib.ustrun_conv_mtiles(n, h, w, co)
+    stat, sflat = guarded(torch.zeros(rows, 2, co, device="cuda"), 7.0)
+    used = C.c_int(0)
+    l.check(lib.ustrun_conv2d_fwd(C.byref(src), 1, wf.data_ptr(), None, n, h, w, co, 3, 1, d, out.data_ptr(), 0, stat.data_ptr(), C.byref(used), 1,
+                                  None))
+    v = lib.ustrun_debug_last_conv_variant()
+    assert (v >> 24, (v >> 16) & 255, (v >> 8) & 255, (v >> 4) & 15) == (16, 16, 128, 4), hex(v)
+    stored = ref.bfloat16().float()
+    assert torch.equal(from_nhwc(out), stored)
+    assert guards_intact(oflat, out.numel(), 7.0) and guards_intact(sflat, stat.numel(), 7.0)
+    np.testing.assert_allclose(stat[:used.value, 0].double().sum(0).cpu().numpy(), stored.double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("n,h,w", [(8, 72, 72), (9, 72, 72), (16, 48, 48), (6, 136, 40)])
+def test_streaming_kernel_statistics_stay_inside_the_published_rows(n, h, w):
+    """the weight-stationary 64 -> 64 kernel writes 2 rows per strip segment; ustrun_conv_mtiles did not bound that
+    (N = 8 at 72 x 72 -- DeepLabV2 layer1.conv2 at the MNMS patch -- wrote 432 rows into a 400-row tensor, 16 KB into the
+    caching allocator's neighbouring block).  The buffer here is exactly the published size, between sentinels."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(n + h)
+    y0 = torch.randint(-3, 4, (n, 64, h, w), generator=g).float()
+    sc = torch.randint(1, 3, (64,), generator=g).float()
+    sh = torch.randint(-2, 3, (64,), generator=g).float()
+    x = torch.relu(y0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    wt = torch.randint(-2, 3, (64, 64, 3, 3), generator=g).float()
+    ref = F.conv2d(x, wt, None, 1, 1)
+    wf = torch.zeros(lib.ustrun_pack_conv_elems(64, 64, 9), dtype=torch.bfloat16, device="cuda")
+    wg = wt.cuda()
+    l.check(lib.ustrun_pack_conv(wg.data_ptr(), 64, 64, 9, wf.data_ptr(), 1, None))
+    yg = nhwc(y0, 1)
+    scg, shg = sc.cuda(), sh.cuda()
+    src = l.nhwc_src(yg.data_ptr(), 64, h, w, scg.data_ptr(), shg.data_ptr(), relu=1)
+    out, oflat = guarded(torch.zeros(n, h, w, 64, device="cuda", dtype=torch.bfloat16), 7.0)
+    rows = lib.ustrun_conv_mtiles(n, h, w, 64)
+    stat, sflat = guarded(torch.zeros(rows, 2, 64, device="cuda"), 7.0)
+    used = C.c_int(0)
+    l.check(lib.ustrun_conv2d_fwd(C.byref(src), 1, wf.data_ptr(), None, n, h, w, 64, 3, 1, 1, out.data_ptr(), 0, stat.data_ptr(), C.byref(used), 1,
+                                  None))
+    assert lib.ustrun_debug_last_conv_variant() == 0x57530001, hex(lib.ustrun_debug_last_conv_variant())     # 'WS' | XF
+    assert used.value == lib.ustrun_debug_conv_stat_rows(n, h, w, 64, 64, 3, 1, 1, 0, 1) <= rows
+    assert guards_intact(sflat, stat.numel(), 7.0) and guards_intact(oflat, out.numel(), 7.0)
+    stored = ref.bfloat16().float()
+    assert torch.equal(from_nhwc(out), stored)
+    np.testing.assert_allclose(stat[:used.value, 0].double().sum(0).cpu().numpy(), stored.double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+
+
+# the operators the first bf16 DeepLabV2 (resnet50) forward reaches on the r2_dl1 input (2 x 3 x 72 x 104): stem 1x1 GEMM over
+# row-window patches at 36 x 52, layer1 (18 x 26) 1x1 / 3x3, the two stride-2 convolutions into 9 x 13, dilated 3x3 at 9 x 13,
+# the classifier GEMM with f32 output.  (n, ci, co, h, w, k, s, d, f32_out)
+R2_DL1_OPS = [(2, 192, 64, 36, 52, 1, 1, 1, 0), (2, 64, 64, 18, 26, 1, 1, 1, 0), (2, 64, 64, 18, 26, 3, 1, 1, 0), (2, 64, 256, 18, 26, 1, 1, 1, 0),
+              (2, 128, 128, 18, 26, 3, 2, 1, 0), (2, 256, 512, 18, 26, 1, 2, 1, 0), (2, 256, 256, 9, 13, 3, 1, 2, 0),
+              (2, 512, 512, 9, 13, 3, 1, 4, 0), (2, 2048, 72, 9, 13, 1, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("n,ci,co,h,w,k,s,d,f32_out", R2_DL1_OPS)
+def test_odd_extent_operators_between_guard_zones(n, ci, co, h, w, k, s, d, f32_out):
+    """gpurun_out/r2_dl1.log (round 2): a GPU memory access fault inside the first bf16 DeepLabV2 forward on a 2 x 3 x 72 x 104 input,
+    at the start of an allocation granule, in code that was never committed (DESIGN.md section 8 records what is and is not known).
+    Every operator that forward reaches, at its extents there (N H W not a multiple of any tile), in bf16, with the input between
+    NaN zones (an out-of-range read that is USED shows up as NaN), the output and the statistics rows between sentinel zones (an
+    out-of-range write shows up as a changed sentinel), against exact integers."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(ci + co + k + d + h)
+    x = torch.randint(-2, 3, (n, ci, h, w), generator=g).float()
+    wt = torch.randint(-1, 2, (co, ci, k, k), generator=g).float()
+    ref = F.conv2d(x, wt, None, s, d * (k // 2), d)
+    ho, wo = ref.shape[-2:]
+    wf = torch.zeros(lib.ustrun_pack_conv_elems(co, ci, k * k), dtype=torch.bfloat16, device="cuda")
+    wg = wt.cuda()
+    l.check(lib.ustrun_pack_conv(wg.data_ptr(), co, ci, k * k, wf.data_ptr(), 1, None))
+    xg, xflat = guarded(nhwc(x, 1), float("nan"))
+    src = l.nhwc_src(xg.data_ptr(), ci, h, w)
+    od = torch.float32 if f32_out else torch.bfloat16
+    out, oflat = guarded(torch.zeros(n, ho, wo, co, device="cuda", dtype=od), 7.0)
+    rows = lib.ustrun_conv_mtiles(n, ho, wo, co)
+    stat, sflat = guarded(torch.zeros(rows, 2, co, device="cuda"), 7.0)
+    used = C.c_int(0)
+    l.check(lib.ustrun_conv2d_fwd(C.byref(src), 1, wf.data_ptr(), None, n, ho, wo, co, k, s, d, out.data_ptr(), f32_out,
+                                  None if f32_out else stat.data_ptr(), C.byref(used), 1, None))
+    torch.cuda.synchronize()
+    got = from_nhwc(out)
+    assert bool(torch.isfinite(got).all())
+    assert torch.equal(got, ref if f32_out else ref.bfloat16().float())
+    assert guards_intact(oflat, out.numel(), 7.0) and guards_intact(sflat, stat.numel(), 7.0) and guards_intact(xflat, xg.numel(), float("nan"))
+    if not f32_out:
+        assert 0 < used.value <= rows
+        assert bool(torch.isfinite(stat[:used.value]).all())
+
+
+def _model(arch, k, seed, dtype):
+    from networks.deeplabv2 import DeepLabV2
+    torch.manual_seed(seed)
+    return DeepLabV2(arch, k, pretrained=False, dtype=dtype).cuda()
+
+
+def test_deeplab_512_reference_golden_and_bf16_eval():
+    """configs[4] at its real extent: ResNet-101 DeepLabV2 on one 512 x 512 image against outputs captured from the reference's own
+    modules (tools/gen_goldens.py r3: g10_deeplabv2_r101_n1_512) -- train-mode logits (4096 samples + L2), backbone feature norms,
+    running statistics after the call, eval-mode logits -- on the f32 path; then the bf16 path in EVAL mode against the f32 path
+    (running statistics, no batch-statistics amplification: bound 4e-2 as at the small extents).  At 512^2 the 1x1 GEMMs run 64 x 64
+    maps (M = 4096 per image) and the dilated layers their production tiles."""
+    g = load_golden("g10_deeplabv2_r101_n1_512")
+    n, _, h, w, k = [int(v) for v in g["shape"]]
+    assert (n, h, w) == (1, 512, 512)
+    m = _model("resnet101", k, int(g["model_seed"]), "f32").train()
+    gen = torch.Generator().manual_seed(int(g["input_seed"]))
+    x = (torch.randint(0, 256, (n, 3, h, w), generator=gen).float() / 127.5 - 1).cuda()
+    import copy
+    m2 = copy.deepcopy(m)
+    with torch.no_grad():
+        feats = m2.backbone.base_forward(x)
+        logits = m(x)
+    np.testing.assert_allclose([float(f.double().norm()) for f in feats], g["feat_l2"], rtol=2e-4)
+    idx = torch.from_numpy(g["sample_idx"])
+    flat = logits.flatten().cpu()
+    e_train = rel(flat[idx], torch.from_numpy(g["sample_val"]))
+    assert e_train < 1e-3, e_train
+    assert abs(float(flat.double().norm()) - float(g["logit_l2"])) <= 2e-4 * float(g["logit_l2"])
+    sd = m.state_dict()
+    np.testing.assert_allclose([float(v.double().sum()) for kk, v in sd.items() if kk.endswith("running_mean")], g["rm_sums"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose([float(v.double().sum()) for kk, v in sd.items() if kk.endswith("running_var")], g["rv_sums"], rtol=1e-3, atol=2e-4)
+    m.eval()
+    with torch.no_grad():
+        ev = m(x)
+    e_eval = rel(ev.flatten().cpu()[idx], torch.from_numpy(g["eval_val"]))
+    assert e_eval < 5e-4, e_eval
+    from networks.deeplabv2 import DeepLabV2
+    mb = DeepLabV2("resnet101", k, pretrained=False, dtype="bf16")
+    mb.load_state_dict(sd)
+    mb = mb.cuda().eval()
+    with torch.no_grad():
+        evb = mb(x)
+    e_bf16 = rel(evb, ev)
+    print(f"deeplab r101 512^2: train vs reference {e_train:.2e}, eval {e_eval:.2e}, bf16 eval vs f32 {e_bf16:.2e}")
+    assert e_bf16 < 4e-2, e_bf16

@@ -163,11 +163,13 @@ def test_reference_golden_full_size(name, dtype):
         assert flips <= 2e-2 * total and worst < 0.1, (flips, total, worst)
 
 
-def test_reference_golden_full_size_backward():
-    """One forward + backward at fundus 256^2, N = 4, full width, against gradient norms and samples captured from the
-    reference (G3b): the f32 path; loss = logits.square().mean().  Bars: loss 1e-5, per-parameter gradient norms 2e-3,
-    BN running statistics 1e-4."""
-    g = load_golden("g3b_unet_3_2_n4_256_bwd")
+@pytest.mark.parametrize("name", ["g3b_unet_3_2_n4_256_bwd", "g3b_unet_1_2_n2_384_bwd", "g3b_unet_1_4_n2_288_bwd"])
+def test_reference_golden_full_size_backward(name):
+    """One forward + backward at the real extent of configs[1] (fundus 256^2, N = 4), configs[2] (prostate 384^2, N = 2) and
+    configs[3] (M&Ms 288^2, 4 classes, N = 2), full width, against gradient norms and samples captured from the reference (G3b;
+    round 3 added the 384^2 and 288^2 fixtures: tools/gen_goldens.py r3): the f32 path; loss = logits.square().mean().  Bars:
+    loss 1e-5, per-parameter gradient norms 2e-3, BN running statistics 1e-4."""
+    g = load_golden(name)
     n, c, h, _, k = [int(v) for v in g["shape"]]
     torch.manual_seed(int(g["model_seed"]))
     sd = U.make_state_dict(c, k)

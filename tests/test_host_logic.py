@@ -129,3 +129,31 @@ def test_deeplab_mirror_keeps_the_reference_state_dict_surface():
     assert (b.layer3[0].conv2.dilation, b.layer3[1].conv2.dilation, b.layer4[0].conv2.dilation, b.layer4[1].conv2.dilation) == \
         ((1, 1), (2, 2), (2, 2), (4, 4))
     assert [c.dilation[0] for c in m.classifier] == [6, 12, 18, 24] and all(c.padding == c.dilation for c in m.classifier)
+
+
+def test_statistics_rows_never_exceed_the_published_bound():
+    """callers size the BatchNorm-statistics buffer with ustrun_conv_mtiles; every kernel family that may serve
+    the launch must stay inside it.  Host-only sweep of the row counts (ustrun_debug_conv_stat_rows builds the same launch
+    description as the entry points and asks the dispatcher, without launching): the U-Net's layer shapes at every patch size
+    the drivers accept, the DeepLabV2-ResNet layer shapes (1x1, dilated, strided, 64 -> 64 at the MNMS patch: the shape that
+    overflowed in round 2 -- 432 rows into 400 at N = 8, 72 x 72), pooled sources, both dtypes."""
+    from ustrun import _lib as L
+    lib = L.lib()
+    worst = 0.0
+    n = 0
+    for dt in (L.F32, L.BF16):
+        for N in (1, 2, 3, 4, 8, 9, 16, 17, 32, 64):
+            for H, W in [(h, w) for h in (8, 16, 18, 24, 33, 36, 48, 64, 65, 72, 96, 128, 129, 144, 192, 256, 288) for w in (h, h + 8, 2 * h + 2)]:
+                for Cin, Cout, k, st, dil, pooled in [(64, 64, 3, 1, 1, 0), (3, 64, 3, 1, 1, 0), (1, 64, 3, 1, 1, 0), (64, 128, 3, 1, 1, 1),
+                                                      (128, 64, 3, 1, 1, 0), (128, 128, 3, 1, 1, 0), (256, 256, 3, 1, 2, 0),
+                                                      (512, 512, 3, 1, 4, 0), (64, 256, 1, 1, 1, 0), (256, 64, 1, 1, 1, 0),
+                                                      (1024, 256, 1, 1, 1, 0), (128, 128, 3, 2, 1, 0), (256, 512, 1, 2, 1, 0),
+                                                      (192, 64, 1, 1, 1, 0), (72, 24, 3, 1, 1, 0)]:
+                    used = lib.ustrun_debug_conv_stat_rows(N, H, W, Cin, Cout, k, st, dil, pooled, dt)
+                    cap = lib.ustrun_conv_mtiles(N, H, W, Cout)
+                    assert 0 < used <= cap, (dt, N, H, W, Cin, Cout, k, st, dil, pooled, used, cap)
+                    worst = max(worst, used / cap)
+                    n += 1
+    assert n > 5000 and worst == 1.0       # the bound is tight somewhere: it is a bound of the kernels, not a padded guess
+    # the round-2 overflow shape, by name
+    assert lib.ustrun_debug_conv_stat_rows(8, 72, 72, 64, 64, 3, 1, 1, 0, L.BF16) == 432 <= lib.ustrun_conv_mtiles(8, 72, 72, 64)

@@ -271,3 +271,58 @@ def test_deeplab_oracle_gradients_match_reference_golden():
         assert abs(float(flat.norm()) - g["grad_l2"][i]) <= 1e-7 * g["grad_l2"][i] + 1e-12, kk
         np.testing.assert_allclose(flat[torch.from_numpy(g["sample_idx"][i])].numpy(), g["sample_val"][i], rtol=1e-6,
                                    atol=1e-7 * g["grad_l2"][i], err_msg=kk)
+
+
+@_pytest.mark.parametrize("name", ["g3b_unet_1_2_n2_384_bwd", "g3b_unet_1_4_n2_288_bwd"])
+def test_unet_full_size_backward_oracle(name):
+    """Round 3: the oracle's forward + backward at configs[2] / configs[3]'s real extents against the reference's own
+    (gradient norms, 16 samples per tensor, running statistics): pins oracle/unet_ref.py where the GPU test uses it."""
+    g = load_golden(name)
+    n, c, h, _, k = [int(v) for v in g["shape"]]
+    torch.manual_seed(int(g["model_seed"]))
+    sd = U.clone_sd(U.make_state_dict(c, k), requires_grad=True)
+    gen = torch.Generator().manual_seed(int(g["input_seed"]))
+    x = torch.randint(0, 256, (n, c, h, h), generator=gen).float() / 127.5 - 1
+    logits = U.unet_forward(x, sd, train=True)
+    loss = logits.square().mean()
+    loss.backward()
+    close(loss, g["loss"], rtol=1e-5)
+    pk = U.param_keys(sd)
+    norms = np.array([float(sd[kk].grad.double().norm()) for kk in pk])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=1e-3, atol=1e-9)
+    samples = np.stack([sd[kk].grad.flatten()[torch.linspace(0, sd[kk].numel() - 1, 16).long()].numpy() for kk in pk])
+    errs = np.linalg.norm(samples - g["grad_samples"], axis=1) / (np.linalg.norm(g["grad_samples"], axis=1) + 1e-30)
+    assert float(np.median(errs)) < 5e-3 and float(errs.max()) < 5e-2, (float(np.median(errs)), float(errs.max()))
+    rm = np.array([float(v.double().sum()) for kk, v in sd.items() if kk.endswith("running_mean")])
+    rv = np.array([float(v.double().sum()) for kk, v in sd.items() if kk.endswith("running_var")])
+    np.testing.assert_allclose(rm, g["rm_sums"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv, g["rv_sums"], rtol=1e-4, atol=1e-5)
+
+
+def test_deeplab_oracle_matches_the_512_golden():
+    """Round 3: configs[4]'s real extent (ResNet-101, one 512 x 512 image) -- the oracle against the reference's train-mode logits,
+    feature norms and running statistics (g10_deeplabv2_r101_n1_512)."""
+    test_deeplab_oracle_matches_reference_goldens("g10_deeplabv2_r101_n1_512", "resnet101")
+
+
+@_pytest.mark.parametrize("K", [2, 4])
+def test_dice_loss_with_mask_remaining_modes(K):
+    """Round 3: the DiceLossWithMask combinations no reference script calls (losses.py:236-268) -- class
+    weights, sigmoid per class (5-D target), softmax + multi (full and class-broadcast targets), raw inputs -- values and
+    gradients captured from the reference (tools/gen_goldens.py g4b)."""
+    g = load_golden("g4b_losses_rest")
+    tgt, mask = t(g[f"K{K}.tgt"]), t(g[f"K{K}.mask"])
+    tml, mml = t(g[f"K{K}.tgt_ml"]), t(g[f"K{K}.mask_ml"])
+    w = [float(v) for v in g[f"K{K}.weight"]]
+    cases = {"sm_w": dict(target=tgt, softmax=True, weight=w), "sm_mask_w": dict(target=tgt, mask=mask, softmax=True, weight=w),
+             "sg_pc": dict(target=tgt.unsqueeze(1), sigmoid=True), "sg_pc_mask_w": dict(target=tgt.unsqueeze(1), mask=mask, sigmoid=True, weight=w),
+             "sm_multi": dict(target=tml, softmax=True, multi=True), "sm_multi_mask": dict(target=tml, mask=mml, softmax=True, multi=True),
+             "sm_multi_bcast": dict(target=tgt.float(), mask=mask, softmax=True, multi=True),
+             "raw_pc": dict(target=tgt), "raw_pc_mask_w": dict(target=tgt, mask=mask, weight=w),
+             "raw_multi": dict(target=tml, multi=True), "raw_multi_mask": dict(target=tml, mask=mml, multi=True)}
+    for tag, kw in cases.items():
+        lg = t(g[f"K{K}.logits"]).clone().requires_grad_(True)
+        val = L.dice_loss_with_mask(lg, n_classes=K, **kw)
+        val.backward()
+        close(val, g[f"K{K}.{tag}.val"], rtol=1e-5)
+        close(lg.grad, g[f"K{K}.{tag}.grad"], rtol=1e-4, atol=1e-8)

@@ -266,6 +266,42 @@ def g4_dice():
     save("g4_losses", **rec)
 
 
+def g4b_dice_rest():
+    """The DiceLossWithMask mode combinations no reference script calls (losses.py:236-268): class weights, sigmoid per class
+    (the target then arrives 5-D: squeeze(1) must leave [B,1,H,W] for the one-hot encoder), softmax + multi (one global Dice
+    over the soft-maxed maps, target broadcast over classes or full), and raw inputs (no activation) in both forms; value and
+    gradient with respect to the logits each, masks included (Q4 applies to the per-class forms)."""
+    rec = {}
+    for K in (2, 4):
+        torch.manual_seed(140 + K)
+        dl = losses.DiceLossWithMask(K)
+        logits = torch.randn(2, K, 16, 16)
+        tgt = torch.randint(0, K, (2, 1, 16, 16))
+        mask = (torch.rand(2, 1, 16, 16) > 0.4).float()
+        tgt_ml = (torch.rand(2, K, 16, 16) > 0.5).float()
+        mask_ml = (torch.rand(2, K, 16, 16) > 0.4).float()
+        w = [0.5 + 0.25 * i for i in range(K)]
+        rec[f"K{K}.logits"], rec[f"K{K}.tgt"], rec[f"K{K}.mask"] = logits, tgt, mask
+        rec[f"K{K}.tgt_ml"], rec[f"K{K}.mask_ml"], rec[f"K{K}.weight"] = tgt_ml, mask_ml, np.array(w)
+        cases = (("sm_w", dict(target=tgt, softmax=True, weight=w)),
+                 ("sm_mask_w", dict(target=tgt, mask=mask, softmax=True, weight=w)),
+                 ("sg_pc", dict(target=tgt.unsqueeze(1), sigmoid=True)),
+                 ("sg_pc_mask_w", dict(target=tgt.unsqueeze(1), mask=mask, sigmoid=True, weight=w)),
+                 ("sm_multi", dict(target=tgt_ml, softmax=True, multi=True)),
+                 ("sm_multi_mask", dict(target=tgt_ml, mask=mask_ml, softmax=True, multi=True)),
+                 ("sm_multi_bcast", dict(target=tgt.float(), mask=mask, softmax=True, multi=True)),
+                 ("raw_pc", dict(target=tgt)),
+                 ("raw_pc_mask_w", dict(target=tgt, mask=mask, weight=w)),
+                 ("raw_multi", dict(target=tgt_ml, multi=True)),
+                 ("raw_multi_mask", dict(target=tgt_ml, mask=mask_ml, multi=True)))
+        for tag, kw in cases:
+            lg = logits.clone().requires_grad_(True)
+            val = dl(lg, **kw)
+            val.backward()
+            rec[f"K{K}.{tag}.val"], rec[f"K{K}.{tag}.grad"] = val, lg.grad
+    save("g4b_losses_rest", **rec)
+
+
 def g5_ramps():
     save("g5_ramps", table=np.array([ramps.sigmoid_rampup(e, 200) for e in range(0, 201)]),
          zero_len=np.array([ramps.sigmoid_rampup(3, 0)]),
@@ -379,6 +415,15 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g10b":         # DeepLabV2-ResNet backward (round 2)
         g10b_deeplab_backward("g10b_deeplabv2_r50_n2_96x80_bwd", "resnet50", 2, 2, 96, 80)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r3":           # round 3: configs[2..4] at their real sizes, the rest of DiceLossWithMask
+        g10_deeplab("g10_deeplabv2_r101_n1_512", "resnet101", 2, 1, 512, 512)
+        g3b_unet_backward("g3b_unet_1_2_n2_384_bwd", 1, 2, 2, 384)
+        g3b_unet_backward("g3b_unet_1_4_n2_288_bwd", 1, 4, 2, 288)
+        g4b_dice_rest()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g4b":
+        g4b_dice_rest()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g3b":          # only the round-2 addition
         g3b_unet_backward("g3b_unet_3_2_n4_256_bwd", 3, 2, 4, 256)

@@ -32,6 +32,9 @@ void set_error(const char* fmt, ...);
         if (rc_) return rc_;      \
     } while (0)
 
+// errors.hip: raise a kernel's dynamic-LDS limit once per (kernel, device); nonzero + message on failure
+int ensure_dynamic_lds(const void* fn, int bytes, const char* who);
+
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -86,6 +89,7 @@ struct IgemmArgs {
     int out_esz;             // element size of out0/out1 (4 or 2)
 };
 int igemm_mtiles(int64_t M, int Cout);
+int stat_rows_within_bound(int used, int N, int H, int W, int Cout, const char* who);   // ops.hip: used <= ustrun_conv_mtiles, or error
 int igemm_stat_rows_used(const IgemmArgs& a, int dtype);
 int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st);
 int igemm_launch_bf16(const IgemmArgs& a, hipStream_t st);
@@ -154,6 +158,8 @@ int wgrad_launch_bf16(const WgradArgs& a, hipStream_t st);
 bool wgrad_tap_supported(const WgradArgs& a);      // one tap per block: 1x1 / dilated / strided convolutions (wgrad_tap_bf16.hip)
 int wgrad_tap_plan(const WgradArgs& a, int* ksplit, long* kchunk);
 int wgrad_tap_launch_bf16(const WgradArgs& a, hipStream_t st);
+int wgrad_last_variant();
+void set_last_wgrad_variant(int v);
 bool wgrad_halo_supported(const WgradArgs& a);
 int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per);
 int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t st);

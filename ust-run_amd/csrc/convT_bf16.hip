@@ -277,6 +277,7 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const int mt = cdiv(a.M, 128), nt = ncols / BN;
     const size_t lds = 2 * (size_t)128 * BK * 2 + 2 * (size_t)(BK / 8) * BN * 16;
     dim3 grid(mt * nt), block(256);
+    set_last_variant(0x43540000 | (BN / 32) << 8 | (BK / 32) << 4 | MODE);       // 'CT' | BN/32 | BK/32 | MODE (tests)
     hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, MODE>), grid, block, lds, st, a, mt, nt);
     USTRUN_LAUNCH_CHECK("convT_bf16");
     return 0;

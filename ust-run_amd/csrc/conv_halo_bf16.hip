@@ -513,14 +513,8 @@ int launch_xf(const IgemmArgs& a, hipStream_t st) {
     const size_t fixed = 2 * (size_t)DSLOTS * 16 + 2 * NT * (size_t)(BK / 8) * BN * 16 + 512;
     const size_t lds = fixed + (XF && fixed + 2 * rawb <= 81920 ? 2 : 1) * rawb;
     dim3 grid(a.N * ty * tx * nt), block(256);
-    if constexpr (DIL > 1) {       // (up to 93 KB for the dilation-4 patch pair: one block per CU, above the 64 KB default)
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
-        }
-    }
+    if constexpr (DIL > 1)         // (up to 93 KB for the dilation-4 patch pair: one block per CU, above the 64 KB default)
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL>, 160 * 1024, "conv3x3_halo_bf16"));
     hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;

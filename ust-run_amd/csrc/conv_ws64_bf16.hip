@@ -470,18 +470,14 @@ int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     bool xf = false;
     set_last_variant(0x57530000 | ((a.src[0].scale != nullptr || a.src[0].relu != 0) ? 1 : 0));     // 'WS' | XF
     xf |= a.src[0].scale != nullptr || a.src[0].relu != 0;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_ws64_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        (void)hipFuncSetAttribute((const void*)conv3x3_ws64_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        (void)hipFuncSetAttribute((const void*)conv3x3_ws64_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        (void)hipFuncSetAttribute((const void*)conv3x3_ws64_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        attr_done = true;
-    }
+    USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64_kernel<true, true>, LDSB, "conv3x3_ws64_bf16"));
+    USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64_kernel<true, false>, LDSB, "conv3x3_ws64_bf16"));
+    USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64_kernel<false, true>, LDSB, "conv3x3_ws64_bf16"));
+    USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64_kernel<false, false>, LDSB, "conv3x3_ws64_bf16"));
     const bool stat = a.stat != nullptr;
     if (p.dbg) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_ws64_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        (void)hipFuncSetAttribute((const void*)conv3x3_ws64_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64_kernel<true, true, true>, LDSB, "conv3x3_ws64_bf16 (diag)"));
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64_kernel<false, false, true>, LDSB, "conv3x3_ws64_bf16 (diag)"));
         if (xf) hipLaunchKernelGGL((conv3x3_ws64_kernel<true, true, true>), dim3(grid), dim3(256), LDSB, st, a, p);
         else hipLaunchKernelGGL((conv3x3_ws64_kernel<false, false, true>), dim3(grid), dim3(256), LDSB, st, a, p);
         USTRUN_LAUNCH_CHECK("conv3x3_ws64_bf16 (diag)");

@@ -7,6 +7,27 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 }
+// ---- dynamic LDS above the 64 KB default: the attribute is per kernel AND per device; set it once for each pair and
+// report a failed set here instead of as an opaque launch error later ----
+#include <mutex>
+#include <set>
+#include <utility>
+namespace ustrun {
+int ensure_dynamic_lds(const void* fn, int bytes, const char* who) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, long>> done;      // (kernel, device << 24 | bytes rounded up to KB)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    USTRUN_CHECK(e == hipSuccess, "%s: hipGetDevice failed: %s", who, hipGetErrorString(e));
+    const std::pair<const void*, long> key(fn, (long)dev << 24 | (long)((bytes + 1023) >> 10));
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count(key)) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    USTRUN_CHECK(e == hipSuccess, "%s: cannot raise the dynamic LDS limit to %d bytes on device %d: %s", who, bytes, dev, hipGetErrorString(e));
+    done.insert(key);
+    return 0;
+}
+}
 extern "C" int ustrun_version(void) { return USTRUN_VERSION; }
 extern "C" const char* ustrun_last_error(void) { return ustrun::get_error(); }
 

@@ -153,8 +153,7 @@ extern "C" int ustrun_freq_mix(const float* src, const float* trg, const float* 
     USTRUN_CHECK(lds2 <= 160 * 1024, "freq_mix: extent %dx%d too large for the twiddle tables", H, W);
 #define USTRUN_DFT_BINS(NB_, UB_)                                                                                              \
     do {                                                                                                                       \
-        if (lds1 > 64 * 1024)                                                                                                  \
-            hipFuncSetAttribute((const void*)dft_bins_kernel<NB_, UB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);\
+        if (lds1 > 64 * 1024) USTRUN_TRY(ensure_dynamic_lds((const void*)dft_bins_kernel<NB_, UB_>, (int)lds1, "dft_bins"));          \
         hipLaunchKernelGGL((dft_bins_kernel<NB_, UB_>), dim3(n * C * 2, RS, (NB_ + UB_ - 1) / UB_), dim3(256), lds1,           \
                            (hipStream_t)s, src, trg, C, H, W, (float2*)work);                                                  \
     } while (0)
@@ -169,7 +168,7 @@ extern "C" int ustrun_freq_mix(const float* src, const float* trg, const float* 
 #undef USTRUN_DFT_BINS
     USTRUN_LAUNCH_CHECK("dft_bins");
     int tiles = cdiv((long)H * W, 256 * 8);
-    if (lds2 > 64 * 1024) hipFuncSetAttribute((const void*)freq_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (lds2 > 64 * 1024) USTRUN_TRY(ensure_dynamic_lds((const void*)freq_apply_kernel, (int)lds2, "freq_apply"));
     hipLaunchKernelGGL(freq_apply_kernel, dim3(tiles, n * C), dim3(256), lds2, (hipStream_t)s, src, (const float2*)work, ratios,
                        C, H, W, b, out);
     USTRUN_LAUNCH_CHECK("freq_apply");

@@ -65,10 +65,46 @@ extern "C" int ustrun_pack_convT2x2(const float* w, int Cin, int Cout, void* w_f
 }
 
 // upper bound of the BatchNorm-statistics rows over every kernel that may serve the launch; the
-// wrapper zero-fills the buffer when the chosen kernel writes fewer (extents not multiples of 16)
+// wrapper zero-fills the buffer when the chosen kernel writes fewer (extents not multiples of 16).
+// Three families write rows: the linear kernels (one per 128 pixels), the halo-tiled kernels (at most one per 8 x 16
+// pixels <= 2 per 16 x 16 tile) and the streaming 64 -> 64 kernel (two per strip segment: 2 N cdiv(W, 32) sy with sy up to
+// cdiv(H, 8) segments per strip -- round 2 left this family out of the bound and a 72 x 72, N = 8 layer wrote 432 rows into
+// 400).  Every entry point that takes `stat` checks its kernel's row count against this bound before it launches.
 extern "C" int ustrun_conv_mtiles(int N, int H, int W, int Cout) {
     const int lin = igemm_mtiles((int64_t)N * H * W, Cout), tiled = N * cdiv(H, 16) * 2 * cdiv(W, 16);
-    return lin > tiled ? lin : tiled;
+    const int stream = Cout == 64 ? 2 * N * cdiv(W, 32) * cdiv(H, 8) : 0;
+    const int m = lin > tiled ? lin : tiled;
+    return m > stream ? m : stream;
+}
+
+// the published bound is a contract: a kernel that would write more rows than callers were told to allocate must not launch
+static int check_stat_rows(int used, int N, int H, int W, int Cout, const char* who) {
+    const int cap = ustrun_conv_mtiles(N, H, W, Cout);
+    USTRUN_CHECK(used <= cap, "%s: the kernel for N=%d %dx%d Cout=%d writes %d statistics rows, ustrun_conv_mtiles promises %d", who, N, H,
+                 W, Cout, used, cap);
+    return 0;
+}
+namespace ustrun { int stat_rows_within_bound(int used, int N, int H, int W, int Cout, const char* who) { return check_stat_rows(used, N, H, W, Cout, who); } }
+
+// Host-only: the number of statistics rows the kernel serving a k x k convolution of a dense NHWC source would write (no
+// launch, no device access) -- tests sweep shapes with it against ustrun_conv_mtiles without a GPU.
+extern "C" int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k, int stride, int dilation, int pooled,
+                                           int dtype) {
+    IgemmArgs a = {};
+    ustrun_src_t sd = {};
+    const int Hs = (pooled ? 2 : 1) * ((Ho - 1) * stride + 1), Ws = (pooled ? 2 : 1) * ((Wo - 1) * stride + 1);
+    sd.ptr = (const void*)16; sd.C = Cin; sd.H = Hs; sd.W = Ws;
+    sd.sC = 1; sd.sW = Cin; sd.sH = (int64_t)Ws * Cin; sd.sN = (int64_t)Hs * Ws * Cin;
+    sd.pool = pooled; sd.relu = pooled;
+    a.nsrc = 1; a.src[0] = make_src(sd, dtype); a.Cin = Cin;
+    a.W = (const float*)16; a.Cout = Cout;
+    a.N = N; a.Hb = Ho; a.Wb = Wo; a.M = N * Ho * Wo;
+    a.s_in = stride; a.nseg = k * k; a.segw = k; a.d0 = -dilation * (k / 2); a.dstep = dilation;
+    a.nz = 1; a.s_out = 1;
+    a.out0 = (float*)16; a.C0 = Cout; a.Ho = Ho; a.Wo = Wo; a.out_esz = act_esz(dtype);
+    a.stat = (float*)16;
+    if (k == 3 && stride == 1 && dilation == 1 && Cin <= 4 && Cout == 64 && !pooled) return conv_first_stat_rows(N, Ho, Wo, dtype);
+    return igemm_stat_rows_used(a, dtype);
 }
 
 static int check_srcs(const ustrun_src_t* srcs, int nsrc, const char* who) {
@@ -104,6 +140,7 @@ static ustrun_src_t src_slice(const ustrun_src_t& s, int g, int gN, int dtype) {
 }
 
 extern "C" int ustrun_debug_last_conv_variant(void) { return halo_last_variant(); }
+extern "C" int ustrun_debug_last_wgrad_variant(void) { return wgrad_last_variant(); }
 namespace ustrun { int g_debug_flags = 0; }
 extern "C" int ustrun_debug_buffer(void* device_u64) { ws64_set_debug_buffer(device_u64); return 0; }
 extern "C" int ustrun_debug_flags(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
@@ -149,6 +186,7 @@ extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const
     if (stat) {
         const int rows = ustrun_conv_mtiles(N, H, W, Cout);
         const int used = first ? conv_first_stat_rows(N, H, W, dtype) : igemm_stat_rows_used(a, dtype);
+        USTRUN_TRY(check_stat_rows(used, N, H, W, Cout, "conv3x3_fwd"));
         if (stat_rows) *stat_rows = used;                 // the caller finalizes exactly these rows
         else if (used < rows) {
             hipError_t e = hipMemsetAsync(stat, 0, (size_t)rows * 2 * Cout * sizeof(float), (hipStream_t)s);

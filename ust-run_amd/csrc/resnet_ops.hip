@@ -332,6 +332,7 @@ extern "C" int ustrun_conv2d_fwd(const ustrun_src_t* srcs, int nsrc, const void*
     a.nz = 1; a.s_out = 1;
     a.out0 = (float*)y; a.out1 = nullptr; a.C0 = Cout; a.Ho = Ho; a.Wo = Wo;
     a.bias = bias; a.stat = stat; a.out_esz = y_f32 ? 4 : act_esz(dtype);
+    if (stat) USTRUN_TRY(stat_rows_within_bound(igemm_stat_rows_used(a, dtype), N, Ho, Wo, Cout, "conv2d_fwd"));
     if (stat_rows) *stat_rows = igemm_stat_rows_used(a, dtype);
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
@@ -355,6 +356,7 @@ extern "C" int ustrun_conv_rowwin_fwd(const ustrun_src_t* src, const void* w_fwd
     a.nz = 1; a.s_out = 1;
     a.out0 = (float*)y; a.out1 = nullptr; a.C0 = Cout; a.Ho = Ho; a.Wo = Wo;
     a.bias = nullptr; a.stat = stat; a.out_esz = act_esz(dtype);
+    if (stat) USTRUN_TRY(stat_rows_within_bound(igemm_stat_rows_used(a, dtype), N, Ho, Wo, Cout, "conv_rowwin_fwd"));
     if (stat_rows) *stat_rows = igemm_stat_rows_used(a, dtype);
     return igemm_launch(a, dtype, (hipStream_t)s);
 }

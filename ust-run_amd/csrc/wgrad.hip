@@ -276,6 +276,7 @@ int wgrad_plan(int nseg, int Cin, int Cout, int64_t M, int* ksplit, long* kchunk
 int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
     USTRUN_CHECK(dtype_ok(dtype), "wgrad: dtype %d not built", dtype);
     USTRUN_CHECK(a.M > 0 && a.Cin > 0 && a.Cout > 0, "wgrad: empty problem");
+    set_last_wgrad_variant(0);
     int csum = 0;
     for (int i = 0; i < a.nsrc; ++i) csum += a.src[i].C;
     USTRUN_CHECK(csum == a.Cin, "wgrad: source channels %d != Cin %d", csum, a.Cin);

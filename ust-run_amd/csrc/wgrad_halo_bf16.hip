@@ -531,6 +531,7 @@ int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
 
 int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t st) {
     dim3 grid((a.Cin / 64) * (a.Cout / 64), ksplit), block(256);
+    set_last_wgrad_variant(0x48000000 | (ksplit & 0xfff));
     if (a.src[0].pool) {
         hipLaunchKernelGGL(wgrad_halo_bf16_kernel<true>, grid, block, 2 * ATILE + 2 * DTILE, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
     } else {

@@ -312,8 +312,14 @@ static int launch_tile(const WgradArgs& a, hipStream_t st) {
     return 0;
 }
 
+int g_last_wgrad_variant = 0;
+int wgrad_last_variant() { return g_last_wgrad_variant; }
+void set_last_wgrad_variant(int v) { g_last_wgrad_variant = v; }
+
 int wgrad_tap_launch_bf16(const WgradArgs& a, hipStream_t st) {
     const int tm = tile_m(a), tn = tile_n(a);
+    // 'T' | TM/64 | TN/64 | loader (2 = pixel-linear 1x1, 1 = one tap, 0 = taps) | ksplit   (tests: ustrun_debug_last_wgrad_variant)
+    g_last_wgrad_variant = 0x54000000 | (tm / 64) << 20 | (tn / 64) << 16 | (pixel_linear(a) ? 2 : (a.nseg == 1 ? 1 : 0)) << 12 | (a.ksplit & 0xfff);
     if (tm == 128 && tn == 128) return launch_tile<128, 128>(a, st);
     if (tm == 128) return launch_tile<128, 64>(a, st);
     if (tn == 128) return launch_tile<64, 128>(a, st);

@@ -178,9 +178,9 @@ def train(args, snapshot_path):
             util.save_osmancheckpoint(epoch + 1, ema_model, model, trainer.optimizer, best["avg"], best["iter"], best["stu_avg"],
                                       best["stu_iter"], os.path.join(snapshot_path, "checkpoint.pth"))
             logging.info('save checkpoint to {}'.format(os.path.join(snapshot_path, "checkpoint.pth")))
-        if world > 1:      # the other ranks wait here, not inside the next step's all-reduce (RCCL watchdog) while rank 0 validates
-            import torch.distributed as dist
-            dist.barrier()
+        if world > 1:      # the other ranks wait on a host-side gloo group with a long timeout while rank 0 validates: a barrier
+            from ustrun.ddp import wait_for_rank0      # on the RCCL group would sit under the same watchdog as the all-reduce
+            wait_for_rank0()
 
 
 if __name__ == "__main__":

@@ -95,6 +95,8 @@ SIGNATURES = {
     "ustrun_conv2d_wgrad": (i32, [PSrc, i32, vp, i32, i32, i32, i32, i32, i32, i32, fp, i32, fp, i64, i32, vp]),
     "ustrun_conv_rowwin_wgrad": (i32, [PSrc, vp, i32, i32, i32, i32, i32, i32, fp, i32, fp, i64, i32, vp]),
     "ustrun_debug_last_conv_variant": (i32, []),
+    "ustrun_debug_conv_stat_rows": (i32, [i32] * 10),
+    "ustrun_debug_last_wgrad_variant": (i32, []),
     "ustrun_debug_flags": (i32, [i32]),
     "ustrun_debug_buffer": (i32, [vp]),
     "ustrun_profile_enable": (i32, [i32]),

@@ -21,6 +21,9 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+_WAIT = [None]
+
+
 def init(backend=None, device=None):
     """Join the process group described by the torchrun environment (RANK/WORLD_SIZE/MASTER_*)."""
     rank, local, world = env_world()
@@ -29,6 +32,18 @@ def init(backend=None, device=None):
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
     return rank, local, world
+
+
+def wait_for_rank0(timeout_s=6 * 3600):
+    """Park the other ranks while rank 0 validates and saves at an epoch end.  A barrier on the RCCL group is itself a
+    collective under that group's watchdog timeout, so a long validation would trip it just the same; the wait runs on a
+    host-side gloo group with its own long timeout instead (created on first use, by every rank)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    if _WAIT[0] is None:
+        import datetime
+        _WAIT[0] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s))
+    dist.monitored_barrier(_WAIT[0], timeout=__import__("datetime").timedelta(seconds=timeout_s))
 
 
 class GradReducer:

@@ -259,14 +259,16 @@ def deeplabv2_forward(net, x, tape=None):
 
 # ---- backward ---------------------------------------------------------------------------------------------------------------
 class _Scratch:
-    """Grow-only device scratch shared by the backward's launches (one stream: reuse is ordered)."""
+    """Grow-only device scratch shared by the backward's launches.  Reuse is ordered by the stream, so the buffers are keyed
+    by (name, device, current stream): a backward on another stream or device gets its own set instead of aliasing."""
     def __init__(self):
         self.buf, self.const = {}, {}
 
     def get(self, name, nbytes, dev):
-        b = self.buf.get(name)
-        if b is None or b.numel() < nbytes or b.device != dev:
-            b = self.buf[name] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        key = (name, dev, torch.cuda.current_stream(dev).cuda_stream)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = self.buf[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
         return b
 
     def noact(self, Cc, dev):
@@ -503,7 +505,13 @@ def deeplabv2_apply(net, x):
     if x.dim() == 4 and x.shape[1] == 1:
         x = x.expand(-1, 3, -1, -1)              # a grey image (BUSI, prostate) as three equal channels: the backbone's stem is 3-channel
     params = list(net.parameters())
-    if torch.is_grad_enabled() and net.training and any(p.requires_grad for p in params):      # eval mode: no graph, as before
+    wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    if wants_grad and net.training:
         _check_input(net.backbone, x, differentiable=True)
         return DeepLabFn.apply(net, x, *params)
+    if wants_grad:
+        # the reference module is differentiable in eval mode too (frozen-BatchNorm fine-tuning); this backward only knows
+        # train-mode BatchNorm, and returning logits without a grad_fn would fail silently
+        raise NotImplementedError("DeepLabV2 in eval mode records no autograd graph here: call it under torch.no_grad(), or "
+                                  "switch the module to train() to differentiate it")
     return deeplabv2_forward(net, x)
