@@ -259,8 +259,9 @@ def _model(arch, k, seed, dtype):
 def test_deeplab_512_reference_golden_and_bf16_eval():
     """configs[4] at its real extent: ResNet-101 DeepLabV2 on one 512 x 512 image against outputs captured from the reference's own
     modules (tools/gen_goldens.py r3: g10_deeplabv2_r101_n1_512) -- train-mode logits (4096 samples + L2), backbone feature norms,
-    running statistics after the call, eval-mode logits -- on the f32 path; then the bf16 path in EVAL mode against the f32 path
-    (running statistics, no batch-statistics amplification: bound 4e-2 as at the small extents).  At 512^2 the 1x1 GEMMs run 64 x 64
+    running statistics after the call, eval-mode logits -- on the f32 path; then the bf16 path in EVAL mode against the f32 path,
+    bounded by 1.3 x a torch-CPU emulation of bf16 rounding on the oracle (measured 0.33 on this random-init ResNet-101: see the
+    comment at the assertion).  At 512^2 the 1x1 GEMMs run 64 x 64
     maps (M = 4096 per image) and the dilated layers their production tiles."""
     g = load_golden("g10_deeplabv2_r101_n1_512")
     n, _, h, w, k = [int(v) for v in g["shape"]]
@@ -294,5 +295,15 @@ def test_deeplab_512_reference_golden_and_bf16_eval():
     with torch.no_grad():
         evb = mb(x)
     e_bf16 = rel(evb, ev)
-    print(f"deeplab r101 512^2: train vs reference {e_train:.2e}, eval {e_eval:.2e}, bf16 eval vs f32 {e_bf16:.2e}")
-    assert e_bf16 < 4e-2, e_bf16
+    # Yardstick, no HIP code involved: the CPU oracle with every convolution's operands and stored outputs rounded to bf16 against
+    # the oracle in f32, same weights / running statistics / input.  A random-init ResNet-101 adds rounding error block by block
+    # (tools/study_bf16_resnet.py: ~0.4 by the last block for ANY bf16 implementation, 0.09 for the reference's own fp16
+    # autocast); the kernels themselves are pinned exactly by the integer tests above.
+    from oracle import deeplab_ref as D
+    from test_gpu_deeplab import _bf16_emulation
+    sdc = {kk: v.detach().cpu().clone() for kk, v in sd.items()}
+    with torch.no_grad():
+        ref32 = D.deeplabv2_forward(x.cpu(), {kk: v.clone() for kk, v in sdc.items()}, "resnet101", False)
+        yard = rel(_bf16_emulation(x.cpu(), sdc, "resnet101", False), ref32)
+    print(f"deeplab r101 512^2: train vs reference {e_train:.2e}, eval {e_eval:.2e}, bf16 eval vs f32 {e_bf16:.2e} (torch-CPU bf16-rounding emulation {yard:.2e})")
+    assert e_bf16 < 1.3 * yard + 2e-2, (e_bf16, yard)
