@@ -203,6 +203,21 @@ int ustrun_seg_loss_bwd(const float* logits, const void* target, const float* ma
                         int HW, int mode, const float* sums, const float* gscale_dev, float gscale,
                         float ce_weight, float dice_weight, float* dlogits, ustrun_stream_t s);
 
+/* ---- DiceLossWithMask.forward in every mode combination of utils/losses.py:236-268 (the two the step uses run fused with
+ * their CE / BCE terms in ustrun_seg_loss_*; this pair serves the rest of the signature: class weights, sigmoid per class,
+ * softmax + multi, raw inputs).  act: 0 none, 1 softmax over classes, 2 sigmoid.  multi = 0: per-class Dice on the one-hot of a
+ * class-index target [N,HW] (int64 or f32: target_is_i64), mask f32 [N,HW] or NULL encoded as the reference does (class 0:
+ * all ones, class k >= 1: mask == 1 -- Q4), mean over classes of weight[k] * dice_k (weight_host: K host floats or NULL = 1).
+ * multi = 1: ONE Dice over all of [N,K,HW]; target / mask f32 [N,K,HW], or [N,HW] broadcast over the classes when
+ * target_per_pixel / mask_per_pixel is set.  fwd: out[0] = loss, out[1..3K] = the sums the backward needs (1 + 3K floats);
+ * partials as ustrun_loss_partials_bytes.  bwd: dlogits = gscale * gscale_dev[0] * dloss/dlogits.                     */
+int ustrun_dice_fwd(const float* logits, const void* target, int target_is_i64, int target_per_pixel, const float* mask,
+                    int mask_per_pixel, int N, int K, int HW, int act, int multi, const float* weight_host, float* out,
+                    float* partials, int64_t partials_bytes, ustrun_stream_t s);
+int ustrun_dice_bwd(const float* logits, const void* target, int target_is_i64, int target_per_pixel, const float* mask,
+                    int mask_per_pixel, int N, int K, int HW, int act, int multi, const float* weight_host, const float* sums,
+                    const float* gscale_dev, float gscale, float* dlogits, ustrun_stream_t s);
+
 /* ---- per-sample binary overlap counts for the numpy Dice of utils/metrics.py:114-146 ---------
  * counts[n][c] = {|pred|, |gt|, |pred & gt|} with pred/gt binarised as (x == cls[c]) or (x != 0). */
 int ustrun_dice_counts(const void* pred, const void* gt, int pred_is_i64, int gt_is_i64, int N,
@@ -338,7 +353,9 @@ int ustrun_debug_last_wgrad_variant(void);
 int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k, int stride, int dilation, int pooled, int dtype);
 /* test / tuning aid: process-wide kernel-selection flags, returns the previous value.  bit 0: run the 64 -> 64 channel
  * full-resolution convolutions on the halo-tiled kernel instead of the weight-stationary row-streaming one (A/B timing
- * inside one process); the last-variant code of the streaming kernel is 0x57530000 | XF                       */
+ * inside one process); bit 1: the four-wave build of the streaming kernel for every launch, bit 2: the eight-wave build for every
+ * launch (default: eight waves for plain sources without statistics -- the input gradients --, four waves otherwise).
+ * The last-variant code of the streaming kernel is 0x57530000 | (eight waves ? 0x100 : 0) | XF                  */
 int ustrun_debug_flags(int flags);
 /* development aid: while a device buffer of >= 32 * blocks u64 is set here, the streaming kernel runs its phase-stamping
  * diagnostic build and writes per-wave cycle sums there (tools/ab_ws64.py --diag); NULL restores the product kernel */

@@ -37,6 +37,35 @@ def test_dice_loss_module_matches_reference_goldens(K):
         np.testing.assert_allclose(lg.grad.cpu().numpy(), g[f"K{K}.{tag}.grad"], rtol=2e-4, atol=1e-8)
 
 
+@pytest.mark.parametrize("K", [2, 4])
+def test_dice_loss_module_remaining_modes_match_reference_goldens(K):
+    """The rest of DiceLossWithMask's signature (losses.py:236-268; no reference script calls these): class weights, sigmoid per
+    class (5-D target), softmax + multi (full and class-broadcast target / mask), raw inputs -- value and gradient against what the
+    reference itself returned (tools/gen_goldens.py g4b), through ustrun_dice_fwd/_bwd."""
+    from utils.losses import DiceLossWithMask
+    g = load_golden("g4b_losses_rest")
+    dl = DiceLossWithMask(K)
+    tgt, mask = t(g[f"K{K}.tgt"]).cuda(), t(g[f"K{K}.mask"]).cuda()
+    tml, mml = t(g[f"K{K}.tgt_ml"]).cuda(), t(g[f"K{K}.mask_ml"]).cuda()
+    w = [float(v) for v in g[f"K{K}.weight"]]
+    cases = {"sm_w": dict(target=tgt, softmax=True, weight=w), "sm_mask_w": dict(target=tgt, mask=mask, softmax=True, weight=w),
+             "sg_pc": dict(target=tgt.unsqueeze(1), sigmoid=True), "sg_pc_mask_w": dict(target=tgt.unsqueeze(1), mask=mask, sigmoid=True, weight=w),
+             "sm_multi": dict(target=tml, softmax=True, multi=True), "sm_multi_mask": dict(target=tml, mask=mml, softmax=True, multi=True),
+             "sm_multi_bcast": dict(target=tgt.float(), mask=mask, softmax=True, multi=True),
+             "raw_pc": dict(target=tgt), "raw_pc_mask_w": dict(target=tgt, mask=mask, weight=w),
+             "raw_multi": dict(target=tml, multi=True), "raw_multi_mask": dict(target=tml, mask=mml, multi=True)}
+    for tag, kw in cases.items():
+        lg = t(g[f"K{K}.logits"]).cuda().requires_grad_(True)
+        val = dl(lg, **kw)
+        (2.0 * val).backward()                                    # (an upstream factor: the device-side gradient scale is used)
+        np.testing.assert_allclose(float(val.detach()), float(g[f"K{K}.{tag}.val"]), rtol=2e-5, err_msg=tag)
+        np.testing.assert_allclose(lg.grad.cpu().numpy(), 2.0 * g[f"K{K}.{tag}.grad"], rtol=2e-4, atol=1e-8, err_msg=tag)
+    with pytest.raises(AssertionError):
+        dl(t(g[f"K{K}.logits"]).cuda(), tgt.squeeze(1))          # losses.py:253: one-hot of a 3-D target does not match
+    with pytest.raises(AssertionError):
+        dl(t(g[f"K{K}.logits"]).cuda(), tgt, softmax=True, sigmoid=True)
+
+
 @pytest.mark.parametrize("mode,K,N,H", [("softmax", 2, 3, 40), ("softmax", 4, 2, 33), ("sigmoid", 2, 3, 40)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_seg_loss_vs_oracle(mode, K, N, H, masked):

@@ -86,7 +86,16 @@ CASES = [
     # strips of 32 px, four passes
     ("ws64_n8_128", 8, (64,), 64, 128, 128, 2, "ws", "ws"),
     ("ws64_ragged", 16, (64,), 64, 72, 80, 4, "ws", "ws"),
+    # the same two with each build of that kernel forced for both directions (ustrun_debug_flags bit 1: four waves, bit 2: eight
+    # waves; the default takes four waves for the forward -- transform + statistics -- and eight for the input gradient)
+    ("ws64w4_n8_128", 8, (64,), 64, 128, 128, 2, "ws4", "ws4"),
+    ("ws64w4_ragged", 16, (64,), 64, 72, 80, 4, "ws4", "ws4"),
+    ("ws64w8_n8_128", 8, (64,), 64, 128, 128, 2, "ws8", "ws8"),
+    ("ws64w8_ragged", 16, (64,), 64, 72, 80, 4, "ws8", "ws8"),
+    # single pass, odd strip count, a last segment of one step, N not a multiple of anything
+    ("ws64_odd", 9, (64,), 64, 88, 104, 1, "ws", "ws"),
 ]
+WS_CODE = {"ws4": 0x57530000, "ws8": 0x57530100}      # four waves / eight waves (round 3, two per SIMD)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -94,6 +103,14 @@ def test_production_tile_exact(case):
     name, n, cs, co, h, w, G, vf, vd = case
     l = L()
     lib = l.lib()
+    old_flags = lib.ustrun_debug_flags({"ws4": 2, "ws8": 4}.get(vf, 0))
+    try:
+        _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd)
+    finally:
+        lib.ustrun_debug_flags(old_flags)
+
+
+def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):
     g = torch.Generator().manual_seed(len(name) * 131 + n)
     ri = lambda lo, hi, *s: torch.randint(lo, hi + 1, s, generator=g).float()
     ci = sum(cs)
@@ -138,7 +155,7 @@ def test_production_tile_exact(case):
     l.check(lib.ustrun_conv3x3_fwd_rows(sarr, len(srcs), wf.data_ptr(), n, h, w, co, out.data_ptr(), stat.data_ptr(),
                                         C.byref(rows), 1, None), "fwd")
     got = lib.ustrun_debug_last_conv_variant()
-    assert got == (0x57530001 if vf == "ws" else variant(*vf, False, True)), f"forward ran {vstr(got)}"
+    assert got == (WS_CODE["ws4" if vf == "ws" else vf] | 1 if vf in ("ws", "ws4", "ws8") else variant(*vf, False, True)), f"forward ran {vstr(got)}"
     yc = from_nhwc(out.float())
     assert rel(yc, r16(ref.detach())) < 1e-6
     # statistics rows: per pass, sums of the STORED (bf16-rounded) outputs
@@ -154,7 +171,7 @@ def test_production_tile_exact(case):
     da = torch.empty(n, h, w, ci, device="cuda", dtype=torch.bfloat16)
     l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 1, None), "dgrad")
     got = lib.ustrun_debug_last_conv_variant()
-    assert got == (0x57530000 if vd == "ws" else variant(*vd, False, False)), f"input gradient ran {vstr(got)}"
+    assert got == (WS_CODE["ws8" if vd == "ws" else vd] if vd in ("ws", "ws4", "ws8") else variant(*vd, False, False)), f"input gradient ran {vstr(got)}"
     assert rel(from_nhwc(da.float()), r16(a.grad)) < 1e-6
     if len(cs) == 2:
         d0 = torch.empty(n, h, w, cs[0], device="cuda", dtype=torch.bfloat16)

@@ -57,42 +57,46 @@ def main():
         src = l.nhwc_src(x.data_ptr(), ci, h, w, scale=sc.data_ptr(), shift=sh.data_ptr(), relu=1)
         fwd = lambda: l.check(lib.ustrun_conv3x3_fwd(C.byref(src), 1, wf.data_ptr(), n, h, w, co, y.data_ptr(), stat.data_ptr(), 1, None))
         dgr = lambda: l.check(lib.ustrun_conv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 1, None))
-        res = {(f, op): [] for f in (1, 0) for op in ("fwd", "dgrad")}
+        res = {(f, op): [] for f in (1, 2, 4) for op in ("fwd", "dgrad")}
         outs = {}
         for r in range(a.rounds):
-            for f in (1, 0):
+            for f in (1, 2, 4):
                 lib.ustrun_debug_flags(f)
                 res[(f, "fwd")].append(timed(fwd, a.reps))
                 res[(f, "dgrad")].append(timed(dgr, a.reps))
                 if r == 0:
                     outs[f] = (y.clone(), da.clone(), stat[:, :, :].sum(0).clone())
         lib.ustrun_debug_flags(0)
-        same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        same = all(torch.equal(outs[4][0], outs[f][0]) and torch.equal(outs[4][1], outs[f][1]) for f in (1, 2))
         fl = 2.0 * 9 * ci * co * n * h * w
         by = 2.0 * (2 * n * h * w * 64) + 2.0 * 9 * 64 * 64
         for op in ("fwd", "dgrad"):
-            t1, t0 = float(np.median(res[(1, op)])), float(np.median(res[(0, op)]))
-            print(f"N={n:3d} {h}x{w} {op:5s}: tiled {t1:.4f} ms {fl / t1 / 1e9:6.0f} TF/s {by / t1 / 1e6:6.0f} GB/s | streaming {t0:.4f} ms "
-                  f"{fl / t0 / 1e9:6.0f} TF/s {by / t0 / 1e6:6.0f} GB/s ({by / t0 / 1e6 / 8000:.3f} of 8 TB/s) | x{t1 / t0:.2f}   min {min(res[(0, op)]):.4f}", flush=True)
+            t1, t2, t0 = float(np.median(res[(1, op)])), float(np.median(res[(2, op)])), float(np.median(res[(4, op)]))
+            print(f"N={n:3d} {h}x{w} {op:5s}: tiled {t1:.4f} ms {fl / t1 / 1e9:6.0f} TF/s | streaming, 4 waves {t2:.4f} ms {fl / t2 / 1e9:6.0f} TF/s "
+                  f"{by / t2 / 1e6:6.0f} GB/s ({by / t2 / 1e6 / 8000:.3f}) | streaming, 8 waves {t0:.4f} ms "
+                  f"{fl / t0 / 1e9:6.0f} TF/s {by / t0 / 1e6:6.0f} GB/s ({by / t0 / 1e6 / 8000:.3f} of 8 TB/s) | x{t1 / t0:.2f}   min {min(res[(4, op)]):.4f}", flush=True)
         if a.diag:
-            dbg = torch.zeros(256 * 4 * 8, dtype=torch.int64, device=dev)
+            dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
             lib.ustrun_debug_buffer(dbg.data_ptr())
+            lib.ustrun_debug_flags(4)
             for name, fn in (("fwd", fwd), ("dgrad", dgr)):
                 dbg.zero_()
                 fn()
                 torch.cuda.synchronize()
                 t_diag = timed(fn, 5)                      # wall time of the stamped build itself -> the in-kernel clock
-                d = dbg.view(256, 4, 8).double()
+                d = dbg.view(256, 8, 8).double()
                 it = d[..., 5].clamp(min=1)
                 ph = [float((d[..., k] / it).mean()) for k in range(5)]
-                print(f"       diag {name}: cycles per steady iteration: half 0 (72 MFMAs + owed epilogue + offsets) {ph[1]:.0f} | half 1 (72 MFMAs + "
-                      f"epilogue + transform/ring writes/fetches) {ph[2]:.0f} | barrier {ph[4]:.0f} | sum {sum(ph):.0f} (MFMA floor 4608); "
-                      f"fast iterations per wave {float(it.mean()):.1f}; stamped launch {t_diag:.4f} ms -> in-kernel clock "
-                      f"{float((d[..., 1] + d[..., 2] + d[..., 4]).max()) / (t_diag * 1e-3) / 1e9:.2f} GHz (a lower bound: the slowest wave's "
-                      f"stamped cycles, which leave out the non-steady iterations, / wall)", flush=True)
+                tot = d[..., 1] + d[..., 2] + d[..., 4]
+                print(f"       diag {name} (8 waves): cycles per iteration: MFMA groups + staging {ph[1]:.0f} | epilogue (stores, statistics) {ph[2]:.0f} | "
+                      f"lgkmcnt + barrier {ph[4]:.0f} | sum {sum(ph):.0f} (MFMA floor at two waves per SIMD 4608); iterations per wave {float(it.mean()):.1f}; "
+                      f"stamped launch {t_diag:.4f} ms -> in-kernel clock >= {float(tot.max()) / (t_diag * 1e-3) / 1e9:.2f} GHz; "
+                      f"per wave half (0-3 / 4-7): groups {float((d[:, :4, 1] / it[:, :4]).mean()):.0f} / {float((d[:, 4:, 1] / it[:, 4:]).mean()):.0f}, "
+                      f"barrier {float((d[:, :4, 4] / it[:, :4]).mean()):.0f} / {float((d[:, 4:, 4] / it[:, 4:]).mean()):.0f}", flush=True)
             lib.ustrun_debug_buffer(None)
-        print(f"       outputs bit-identical between the two kernels: {same}; stat sums rel diff "
-              f"{float((outs[0][2] - outs[1][2]).abs().max() / outs[1][2].abs().max()):.2e}", flush=True)
+            lib.ustrun_debug_flags(0)
+        print(f"       outputs bit-identical between the three kernels: {same}; stat sums rel diff "
+              f"{float((outs[4][2] - outs[1][2]).abs().max() / outs[1][2].abs().max()):.2e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -422,6 +422,301 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
     }
 }
 
+
+// ======================================================================================================================
+// Round 3: the same streaming structure on EIGHT waves (two per SIMD) -- conv3x3_ws64x8_kernel.
+//
+// What limited the four-wave kernel above: one wave per SIMD (its 144 weight registers leave
+// no room for a second) issues ~750 instructions per 144 MFMAs, a lone wave pays >= 4 cycles per instruction of any kind, and
+// the instructions bunch around the ring writes and stores: the matrix pipe was 62 % busy.  Here each wave owns SIXTEEN output
+// channels on v_mfma_f32_16x16x32_bf16 (A = weights: 9 taps x 2 k-steps x 4 registers = 72 per wave), so a 512-thread block
+// puts two waves on every SIMD and one wave's address arithmetic, transform, ring write or store runs in the other's MFMA
+// shadow.  Wave w: channel group cg = w & 3 (16 channels), row half wm = w >> 2 (4 of the step's 8 output rows); SIMD partners
+// (w, w + 4) share cg and differ in wm.  Per step and wave: 8 pixel tiles (4 rows x 2 halves of the 32-px strip) x 9 taps x 2
+// k-steps = 144 MFMAs of 16 cycles; the three taps of a kernel column still share their input fragments (6 reads -> 12 MFMAs).
+//   * ring pixel pitch 160 B: the 16x16x32 B-operand read (lane l: pixel l & 15, 16-byte channel chunk l >> 4) is
+//     conflict-free for ds_read_b128's four lane groups at that pitch (144 B, the pitch of the 32x32x16 kernel, is 2-way);
+//   * the product is D[channel][pixel] again; a lane holds 4 consecutive channels of ONE pixel per accumulator, so the
+//     epilogue needs no LDS at all: 2 cvt_pk + one 8-byte buffer store per tile (a pixel's 32 bytes from 4 lanes, 16 pixels
+//     per instruction; the four channel groups' 32-byte pieces of a 128-byte line meet in L2), statistics from the rounded
+//     values in registers (4 channels per lane, 16 lanes per channel reduced by DPP-able shuffles at the item's end);
+//   * no deferred half-epilogue: with a partner wave to cover it the step is one run of 12 read/MFMA groups, then the
+//     staging of the next group and the stores.  Still ONE straight-line iteration body, everything irregular switched off
+//     through the buffer range check or selects.
+constexpr int PITCH8 = 160;
+constexpr int ROWB8 = HW * PITCH8;               // 5440
+constexpr int BANKB8 = 8 * ROWB8;                // 43520
+constexpr int RINGB8 = 3 * BANKB8;               // 130560
+constexpr int NR8 = (GITEMS + 511) / 512;        // staging rounds per group with 512 threads: 5 (the last one: threads 0..127)
+constexpr int DUMMYB8 = 384 * 16;                // where threads 128..511 "write" the fifth staging item
+constexpr int LDSB8 = RINGB8 + DUMMYB8;          // 136704
+
+template <bool XF, bool STAT, bool DIAG = false>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws64x8_kernel(const IgemmArgs a, const WsPlan p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, wm = wave >> 2;
+    const int lp = lane & 15, lq = lane >> 4;
+    const SrcDev S = a.src[0];
+    const __bf16* srcp = (const __bf16*)S.ptr;
+    const int H = a.Hb, W = a.Wb;
+    const int sH = (int)S.sH, sW = (int)S.sW;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)srcp, 0, (int)min((long)a.N * S.sN * 2, 0x7fffffffL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out0, 0, (int)min((long)a.N * H * W * 128, 0x7fffffffL), 0x00020000);
+    const int img_bytes = (int)(S.sN * 2), out_bytes = H * W * 128;
+
+    // ---- the wave's weights: A fragments of v_mfma_f32_16x16x32_bf16, row = output channel 16 cg + lp, k = 8 lq + j of the
+    // 32-channel step ks; packed layout [tap][Cin/8][Cout][8] -> one 16-byte load each (input gradient: taps backwards over
+    // the [tap][Cout/8][Cin][8] pack) ----
+    bf16x8 Wr[9][2];
+    {
+        const __bf16* Wp = (const __bf16*)a.W;
+        const bool wflip = a.dstep < 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int wt = wflip ? 8 - tap : tap;
+                Wr[tap][ks] = *(const bf16x8*)(Wp + (((long)wt * 8 + 4 * ks + lq) * 64 + 16 * cg + lp) * 8);
+            }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(Wr[tap][ks]));       // (loaded before the loop, not pending at its head)
+    }
+
+    // ---- staging geometry: item q = tid + 512 i of the group's [8 rows][34 px][8 octets] ----
+    int goffb[NR8], rp[NR8];
+#pragma unroll
+    for (int i = 0; i < NR8; ++i) {
+        const int q = tid + 512 * i, hp = q >> 3, r = hp / HW, px = hp - r * HW;
+        goffb[i] = (r * sH + px * sW + (tid & 7) * 8) * 2;
+        rp[i] = r << 8 | px;
+    }
+    const int loff0 = (tid >> 3) * PITCH8 + (tid & 7) * 16;      // ring offset of item i: loff0 + i * 64 * PITCH8
+    const int afrag0 = lp * PITCH8 + lq * 16;
+    const int wd4_dummy = RINGB8 + (tid >= 128 ? (tid - 128) * 16 : 0);
+    const int st_lane = lp * 128 + 32 * cg + 8 * lq;             // output byte offset of the lane's 4 channels inside a 16-px run
+
+    const int it0 = blockIdx.x * p.ipb, it1 = min(it0 + p.ipb, p.items);
+    auto decode = [&](int item, int k) __attribute__((always_inline)) {
+        Cur c;
+        c.valid = item < it1; c.k = k;
+        item = min(item, it1 - 1);
+        c.item = item;
+        const int per = p.sx * p.sy;
+        c.img = item / per;
+        const int rem = item - c.img * per;
+        const int ys = rem / p.sx;
+        c.x0 = (rem - ys * p.sx) * TW;
+        c.ybeg = ys * p.seg;
+        const int rows = min(p.seg, H - c.ybeg);
+        c.S = (rows + 7) >> 3;
+        return c;
+    };
+    auto advance = [&](const Cur& c) __attribute__((always_inline)) {
+        if (!c.valid) return c;
+        if (c.k < c.S) { Cur n = c; n.k = c.k + 1; return n; }
+        return decode(c.item + 1, 0);
+    };
+    Cur cl = decode(it0, 0);
+    Cur cw = cl, cc = cl;                // write / step cursors, nothing there yet
+    cw.valid = cc.valid = 0;
+
+    u32x4 stg[NR8];
+    unsigned okmW = 0;
+#pragma unroll
+    for (int i = 0; i < NR8; ++i) stg[i] = (u32x4){0u, 0u, 0u, 0u};
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+    const float a_floor = S.relu ? 0.f : -__builtin_inff();
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+
+    unsigned offL[NR8], okmL = 0;
+    unsigned xokm = 0;
+    int xok_x0 = -(1 << 20);
+    auto offsets_one = [&](const Cur& c, int i) __attribute__((always_inline)) {
+        const int y0g = c.ybeg - 1 + 8 * c.k;
+        const int nrows = !c.valid ? 0 : (c.k == c.S ? 2 : 8);
+        const int lo = max(0, -y0g), hi = min(nrows, H - y0g);
+        const unsigned ymask = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+        const int gbase = (y0g * sH + (c.x0 - 1) * sW) * 2;
+        const unsigned ok = (ymask >> (rp[i] >> 8)) & (xokm >> i) & 1u;
+        offL[i] = (unsigned)(gbase + goffb[i]) | ((ok ^ 1u) << 31);
+        okmL = (okmL & ~(1u << i)) | (ok << i);
+    };
+    auto xok_update = [&](const Cur& c) __attribute__((always_inline)) {
+        if (c.x0 != xok_x0) {
+            xok_x0 = c.x0;
+            xokm = 0;
+#pragma unroll
+            for (int i = 0; i < NR8; ++i)
+                xokm |= ((unsigned)(i < NR8 - 1 || tid < 128) & (unsigned)((unsigned)(c.x0 - 1 + (rp[i] & 255)) < (unsigned)W)) << i;
+        }
+    };
+    auto xform = [&](u32x4 raw, bool ok) __attribute__((always_inline)) {
+        if constexpr (!XF) return raw;
+        const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+        f32x4 lo = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]} * sc0 + sh0;
+        f32x4 hi = (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]} * sc1 + sh1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = __builtin_amdgcn_fmed3f(lo[e], a_floor, __builtin_inff());
+            hi[e] = __builtin_amdgcn_fmed3f(hi[e], a_floor, __builtin_inff());
+        }
+        bf16x8 h;
+        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+        u32x4 u = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = ok ? u[e] : 0u;
+        return u;
+    };
+    auto load_consts = [&](const Cur& c) __attribute__((always_inline)) {
+        if constexpr (XF) {
+            if (S.scale) {
+                const long go = S.gN > 0 ? (long)(c.img / S.gN) * S.gstride : 0;
+                const float* scp = S.scale + go + 8 * (tid & 7);
+                const float* shp = S.shift + go + 8 * (tid & 7);
+                sc0 = *(const f32x4*)scp; sc1 = *(const f32x4*)(scp + 4);
+                sh0 = *(const f32x4*)shp; sh1 = *(const f32x4*)(shp + 4);
+            }
+        }
+    };
+
+    f32x4 acc[4][2];                     // [output row of the wave][pixel half]: 16 channels x 16 pixels each
+    int rowaddr[6];
+    // fragments of patch rows q = 0..5 for kernel column dx, channel step ks, pixel half ph (constants at every call site) ...
+    auto frag_read = [&](int dx, int ks, int ph, bf16x8* pf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) pf[q] = *(const bf16x8*)(ring + rowaddr[q] + (16 * ph + dx) * PITCH8 + ks * 64);
+    };
+    // ... and the 12 MFMAs they feed: the wave's 4 output rows x the three taps of the column
+    auto mma12 = [&](int dx, int ks, int ph, const bf16x8* pf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+                acc[i][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wr[dy * 3 + dx][ks], pf[i + dy], acc[i][ph], 0, 0, 0);
+    };
+    // epilogue of tile (row i, pixel half ph): 4 channels of one pixel per lane -> 8 bytes; statistics of the stored values
+    auto epi = [&](int i, int ph, const Cur& c, bool live) __attribute__((always_inline)) {
+        const int y = c.ybeg + 8 * (c.k - 1) + 4 * wm + i;
+        const int ylim = min(c.ybeg + p.seg, H);
+        bf16x4 h;
+        h[0] = (__bf16)acc[i][ph][0]; h[1] = (__bf16)acc[i][ph][1]; h[2] = (__bf16)acc[i][ph][2]; h[3] = (__bf16)acc[i][ph][3];
+        u32x2 u = __builtin_bit_cast(u32x2, h);
+        const bool inimg = live & (y < ylim) & (c.x0 + 16 * ph + lp < W);
+        const unsigned voff = (unsigned)(st_lane + ph * 2048) | (inimg ? 0u : 0x80000000u);
+        __builtin_amdgcn_raw_buffer_store_b64(u, ro, voff, __builtin_amdgcn_readfirstlane(c.img * out_bytes + (y * W + c.x0) * 128), 0);
+        if constexpr (STAT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float f = inimg ? (float)h[e] : 0.f;
+                s1[e] += f;
+                s2[e] += f * f;
+            }
+        }
+    };
+    auto stat_flush = [&](const Cur& c) __attribute__((always_inline)) {       // one partial row per (item, wm), this wave's 16 channels
+        if constexpr (STAT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    s1[e] += __shfl_xor(s1[e], d);
+                    s2[e] += __shfl_xor(s2[e], d);
+                }
+            }
+            if (lp == 0) {
+                float* row = a.stat + ((long)(c.item * 2 + wm) * 2) * 64 + 16 * cg + 4 * lq;
+                *(f32x4*)row = (f32x4){s1[0], s1[1], s1[2], s1[3]};
+                *(f32x4*)(row + 64) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+        }
+    };
+
+    unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0, dt1 = 0;
+    load_consts(cl);
+    const int frA = afrag0 + 4 * wm * ROWB8;                      // + bank A * BANKB8 + q * ROWB8          (q < 4 or wm == 0)
+    const int frB = afrag0 + (4 * wm - 8) * ROWB8;                // + bank B * BANKB8 + q * ROWB8          (q >= 4 and wm == 1)
+    const bool hiB = wm == 1;
+    auto iteration = [&](auto m_c) __attribute__((always_inline)) {
+        constexpr int bA = decltype(m_c)::value, bB = bA == 2 ? 0 : bA + 1, bW = bA == 0 ? 2 : bA - 1;
+        const bool live = cc.valid && cc.k >= 1;
+        rowaddr[0] = frA + bA * BANKB8; rowaddr[1] = rowaddr[0] + ROWB8; rowaddr[2] = rowaddr[0] + 2 * ROWB8; rowaddr[3] = rowaddr[0] + 3 * ROWB8;
+        rowaddr[4] = hiB ? frB + bB * BANKB8 + 4 * ROWB8 : frA + bA * BANKB8 + 4 * ROWB8;
+        rowaddr[5] = rowaddr[4] + ROWB8;
+        char* wdst = ring + bW * BANKB8 + loff0;
+        char* wd4 = tid < 128 ? wdst + 4 * (64 * PITCH8) : smem + wd4_dummy;
+        const Cur cn = advance(cl);
+        xok_update(cl);
+        const int in_soff = __builtin_amdgcn_readfirstlane(cl.img * img_bytes);
+        bf16x8 pf[2][6];
+        auto stage = [&](int i) __attribute__((always_inline)) {
+            *(u32x4*)(i < NR8 - 1 ? wdst + i * (64 * PITCH8) : wd4) = xform(stg[i], (okmW >> i) & 1u);
+            stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, offL[i], in_soff, 0);
+        };
+        // 12 groups (ks, dx, ph) of 6 fragment reads + 12 MFMAs; the reads run one group (192 MFMA cycles) ahead of their MFMAs
+        // -- the partner wave covers what that leaves of the LDS latency, and a third fragment set spills at 256 registers
+        auto read_group = [&](int gg) __attribute__((always_inline)) {
+            if (gg < 12) frag_read((gg >> 1) % 3, gg / 6, gg & 1, pf[gg & 1]);
+        };
+        if constexpr (DIAG) dt0 = stamp();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) acc[i][ph] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        read_group(0);
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            read_group(g + 1);
+            mma12((g >> 1) % 3, g / 6, g & 1, pf[g & 1]);
+            if (g == 1) offsets_one(cl, 0);
+            if (g == 2) offsets_one(cl, 1);
+            if (g == 3) offsets_one(cl, 2);
+            if (g == 4) offsets_one(cl, 3);
+            if (g == 5) offsets_one(cl, 4);
+            if (g == 6) stage(0);
+            if (g == 7) stage(1);
+            if (g == 8) stage(2);
+            if (g == 9) stage(3);
+            if (g == 10) stage(4);
+        }
+        okmW = okmL;
+        load_consts(cl);
+        if constexpr (DIAG) { dt1 = stamp(); dsum[1] += dt1 - dt0; dt0 = dt1; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) epi(i, ph, cc, live);
+        if (live && cc.k == cc.S) stat_flush(cc);
+        if constexpr (DIAG) { dt1 = stamp(); dsum[2] += dt1 - dt0; dt0 = dt1; dsum[5] += 1; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (DIAG) { dt1 = stamp(); dsum[4] += dt1 - dt0; }
+        cc = cw; cw = cl; cl = cn;
+    };
+    while (true) {
+        if (!(cl.valid | cw.valid | cc.valid)) break;
+        iteration(ic<0>{});
+        if (!(cl.valid | cw.valid | cc.valid)) break;
+        iteration(ic<1>{});
+        if (!(cl.valid | cw.valid | cc.valid)) break;
+        iteration(ic<2>{});
+    }
+    if constexpr (DIAG) {
+        if (lane == 0 && p.dbg) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p.dbg[((long)blockIdx.x * 8 + wave) * 8 + k] = dsum[k];
+        }
+    }
+}
+
 // segments per strip: whole waves of blocks over the 256 CUs, few bubbles (one staging-only iteration per item)
 WsPlan ws_plan(const IgemmArgs& a) {
     WsPlan p;
@@ -475,6 +770,32 @@ int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64_kernel<false, true>, LDSB, "conv3x3_ws64_bf16"));
     USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64_kernel<false, false>, LDSB, "conv3x3_ws64_bf16"));
     const bool stat = a.stat != nullptr;
+    // Which build (measured in one process, N = 64 images of 256^2, profiles/r03_ab_ws64_8waves.log): the eight-wave kernel wins on the
+    // plain-source launches (input gradients: 0.320 vs 0.333 ms) and loses where the loader transforms and statistics are taken
+    // (forward: 0.394 vs 0.339 ms) -- its per-wave address / cursor / wait instructions double per SIMD while a 16x16x32 MFMA
+    // hides half as many of them.  debug flag bit 1 forces four waves everywhere, bit 2 eight waves everywhere.
+    const bool eight = (g_debug_flags & 4) ? true : (g_debug_flags & 2) ? false : !(xf || a.stat);
+    if (eight && p.dbg) {                        // stamped build of the eight-wave kernel: [block][wave 0..7][8] u64
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64x8_kernel<true, true, true>, LDSB8, "conv3x3_ws64x8_bf16 (diag)"));
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64x8_kernel<false, false, true>, LDSB8, "conv3x3_ws64x8_bf16 (diag)"));
+        if (xf) hipLaunchKernelGGL((conv3x3_ws64x8_kernel<true, true, true>), dim3(grid), dim3(512), LDSB8, st, a, p);
+        else hipLaunchKernelGGL((conv3x3_ws64x8_kernel<false, false, true>), dim3(grid), dim3(512), LDSB8, st, a, p);
+        USTRUN_LAUNCH_CHECK("conv3x3_ws64x8_bf16 (diag)");
+        return 0;
+    }
+    if (eight) {                                 // round 3: eight waves, two per SIMD
+        set_last_variant(0x57530000 | 0x100 | (xf ? 1 : 0));       // 'WS' | 8 waves | XF
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64x8_kernel<true, true>, LDSB8, "conv3x3_ws64x8_bf16"));
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64x8_kernel<true, false>, LDSB8, "conv3x3_ws64x8_bf16"));
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64x8_kernel<false, true>, LDSB8, "conv3x3_ws64x8_bf16"));
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64x8_kernel<false, false>, LDSB8, "conv3x3_ws64x8_bf16"));
+        if (xf && stat) hipLaunchKernelGGL((conv3x3_ws64x8_kernel<true, true>), dim3(grid), dim3(512), LDSB8, st, a, p);
+        else if (xf) hipLaunchKernelGGL((conv3x3_ws64x8_kernel<true, false>), dim3(grid), dim3(512), LDSB8, st, a, p);
+        else if (stat) hipLaunchKernelGGL((conv3x3_ws64x8_kernel<false, true>), dim3(grid), dim3(512), LDSB8, st, a, p);
+        else hipLaunchKernelGGL((conv3x3_ws64x8_kernel<false, false>), dim3(grid), dim3(512), LDSB8, st, a, p);
+        USTRUN_LAUNCH_CHECK("conv3x3_ws64x8_bf16");
+        return 0;
+    }
     if (p.dbg) {
         USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64_kernel<true, true, true>, LDSB, "conv3x3_ws64_bf16 (diag)"));
         USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64_kernel<false, false, true>, LDSB, "conv3x3_ws64_bf16 (diag)"));

@@ -323,6 +323,143 @@ int stream_blocks(long work_items) {
     return (int)b;
 }
 
+// ---- DiceLossWithMask.forward in EVERY mode combination (utils/losses.py:236-268): the two the step uses run fused with their
+// CE / BCE terms above; this pair serves the rest of the reference signature (class weights, sigmoid per class, softmax + multi,
+// raw inputs).  One lane per pixel, all K classes of the pixel in registers.
+//   act: 0 none, 1 softmax over classes, 2 sigmoid          multi: one global Dice over [N,K,HW] instead of per class
+//   per class: t_k = (target == k) from a class-index map [N,HW] (int64 or f32), m_k = 1 for k = 0, (mask == 1) for k >= 1 (Q4)
+//   multi:     t, m elementwise f32 [N,K,HW], or [N,HW] broadcast over the classes (tper / mper = 1)
+struct DiceCfg { int N, K, HW, act, multi, t_i64, tper, mper; float w[KMAX]; };
+
+__device__ __forceinline__ void dice_pixel(const DiceCfg& c, const float* __restrict__ logits, const void* __restrict__ target,
+                                           const float* __restrict__ mask, long n, long hw, long p, float* pk, float* tk, float* mk) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) if (k < c.K) { pk[k] = logits[(n * c.K + k) * c.HW + hw]; mx = fmaxf(mx, pk[k]); }
+    if (c.act == 1) {
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < c.K) { pk[k] = expf(pk[k] - mx); se += pk[k]; }
+        const float inv = 1.f / se;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < c.K) pk[k] *= inv;
+    } else if (c.act == 2) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < c.K) {
+                const float ea = expf(-fabsf(pk[k]));
+                pk[k] = pk[k] >= 0.f ? 1.f / (1.f + ea) : ea / (1.f + ea);
+            }
+    }
+    if (!c.multi) {
+        const float tv = c.t_i64 ? (float)((const long long*)target)[p] : ((const float*)target)[p];
+        const float m1 = mask ? (mask[p] == 1.f ? 1.f : 0.f) : 1.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) if (k < c.K) { tk[k] = tv == (float)k ? 1.f : 0.f; mk[k] = k == 0 ? 1.f : m1; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < c.K) {
+                tk[k] = c.tper ? ((const float*)target)[p] : ((const float*)target)[(n * c.K + k) * c.HW + hw];
+                mk[k] = !mask ? 1.f : (c.mper ? mask[p] : mask[(n * c.K + k) * c.HW + hw]);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void dice_fwd_kernel(const DiceCfg c, const float* __restrict__ logits, const void* __restrict__ target,
+                                                      const float* __restrict__ mask, float* __restrict__ partials) {
+    __shared__ float red[4][NS];
+    float acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] = 0.f;
+    const long npix = (long)c.N * c.HW;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const long n = (unsigned)p / (unsigned)c.HW, hw = p - n * c.HW;
+        float pk[KMAX], tk[KMAX], mk[KMAX];
+        dice_pixel(c, logits, target, mask, n, hw, p, pk, tk, mk);
+        // sum(target * target * mask) runs over the BROADCAST shape of target and mask only (losses.py:229): a per-pixel target with
+        // a per-pixel (or no) mask is counted once, not once per class
+        const bool yonce = c.multi && c.tper && (c.mper || !mask);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < c.K) {
+                acc[1 + k] += pk[k] * tk[k] * mk[k];
+                acc[1 + KMAX + k] += pk[k] * pk[k] * mk[k];
+                acc[1 + 2 * KMAX + k] += (yonce && k > 0) ? 0.f : tk[k] * tk[k] * mk[k];
+            }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { const float v = wave_sum(acc[i]); if (lane == 0) red[wave][i] = v; }
+    __syncthreads();
+    if (threadIdx.x < NS)
+        partials[(long)blockIdx.x * NS + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[0] = loss; out[1+k] = I_k, out[1+K+k] = Z_k, out[1+2K+k] = Y_k (multi: the totals in k = 0, zeros behind)
+__global__ void dice_finalize_kernel(const DiceCfg c, const float* __restrict__ partials, int rows, float* __restrict__ out) {
+    __shared__ double tot[NS];
+    if (threadIdx.x < NS) {
+        double t = 0.0;
+        for (int r = 0; r < rows; ++r) t += (double)partials[(long)r * NS + threadIdx.x];      // fixed order
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double loss = 0.0;
+        if (c.multi) {
+            double I = 0, Z = 0, Y = 0;
+            for (int k = 0; k < c.K; ++k) { I += tot[1 + k]; Z += tot[1 + KMAX + k]; Y += tot[1 + 2 * KMAX + k]; }
+            loss = 1.0 - (2.0 * I + (double)SMOOTH) / (Z + Y + (double)SMOOTH);
+            for (int k = 0; k < c.K; ++k) { out[1 + k] = k ? 0.f : (float)I; out[1 + c.K + k] = k ? 0.f : (float)Z; out[1 + 2 * c.K + k] = k ? 0.f : (float)Y; }
+        } else {
+            for (int k = 0; k < c.K; ++k) {
+                const double I = tot[1 + k], Z = tot[1 + KMAX + k], Y = tot[1 + 2 * KMAX + k];
+                loss += (double)c.w[k] * (1.0 - (2.0 * I + (double)SMOOTH) / (Z + Y + (double)SMOOTH));
+                out[1 + k] = (float)I; out[1 + c.K + k] = (float)Z; out[1 + 2 * c.K + k] = (float)Y;
+            }
+            loss /= c.K;
+        }
+        out[0] = (float)loss;
+    }
+}
+
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const DiceCfg c, const float* __restrict__ logits, const void* __restrict__ target,
+                                                      const float* __restrict__ mask, const float* __restrict__ sums,
+                                                      const float* __restrict__ gdev, float gscale, float* __restrict__ dlogits) {
+    const float gs = gscale * (gdev ? gdev[0] : 1.f);
+    float A[KMAX], Bc[KMAX];       // dLoss/dp_k = (A[k] t_k + Bc[k] p_k) m_k
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < c.K) {
+            const int kk = c.multi ? 0 : k;
+            const float I = sums[1 + kk], D = sums[1 + c.K + kk] + sums[1 + 2 * c.K + kk] + SMOOTH;
+            const float wk = c.multi ? 1.f : c.w[k] / c.K;
+            A[k] = -2.f / D * wk;
+            Bc[k] = 2.f * (2.f * I + SMOOTH) / (D * D) * wk;
+        }
+    const long npix = (long)c.N * c.HW;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const long n = (unsigned)p / (unsigned)c.HW, hw = p - n * c.HW;
+        float pk[KMAX], tk[KMAX], mk[KMAX], G[KMAX], gp = 0.f;
+        dice_pixel(c, logits, target, mask, n, hw, p, pk, tk, mk);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < c.K) {
+                G[k] = (A[k] * tk[k] + Bc[k] * pk[k]) * mk[k];
+                gp += G[k] * pk[k];
+            }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < c.K) {
+                const float d = c.act == 1 ? pk[k] * (G[k] - gp) : c.act == 2 ? G[k] * pk[k] * (1.f - pk[k]) : G[k];
+                dlogits[(n * c.K + k) * c.HW + hw] = gs * d;
+            }
+    }
+}
+
+
 }  // namespace
 }  // namespace ustrun
 
@@ -359,6 +496,45 @@ extern "C" int ustrun_seg_loss_bwd(const float* logits, const void* target, cons
     hipLaunchKernelGGL(seg_loss_bwd_kernel, dim3(stream_blocks(items)), dim3(256), 0, (hipStream_t)s, logits, target,
                        mask, N, K, HW, mode, sums, gscale_dev, gscale, ce_weight, dice_weight, dlogits);
     USTRUN_LAUNCH_CHECK("seg_loss_bwd");
+    return 0;
+}
+
+
+static int dice_cfg(DiceCfg* c, const char* who, const void* logits, const void* target, int N, int K, int HW, int act, int multi,
+                    int target_is_i64, int target_per_pixel, int mask_per_pixel, const float* weight_host) {
+    USTRUN_CHECK(logits && target, "%s: null pointer", who);
+    USTRUN_CHECK(K >= 1 && K <= KMAX && N > 0 && HW > 0 && (long)N * HW < (1L << 32), "%s: bad shape N=%d K=%d HW=%d", who, N, K, HW);
+    USTRUN_CHECK(act >= 0 && act <= 2, "%s: activation %d (0 none, 1 softmax, 2 sigmoid)", who, act);
+    USTRUN_CHECK(multi || target_per_pixel, "%s: the per-class form takes a class-index target [N,HW]", who);
+    USTRUN_CHECK(!multi || !target_is_i64, "%s: the multi form takes float targets", who);
+    c->N = N; c->K = K; c->HW = HW; c->act = act; c->multi = multi; c->t_i64 = target_is_i64; c->tper = target_per_pixel; c->mper = mask_per_pixel;
+    for (int k = 0; k < KMAX; ++k) c->w[k] = (weight_host && k < K) ? weight_host[k] : 1.f;
+    return 0;
+}
+
+extern "C" int ustrun_dice_fwd(const float* logits, const void* target, int target_is_i64, int target_per_pixel, const float* mask,
+                               int mask_per_pixel, int N, int K, int HW, int act, int multi, const float* weight_host, float* out,
+                               float* partials, int64_t partials_bytes, ustrun_stream_t s) {
+    DiceCfg c;
+    USTRUN_TRY(dice_cfg(&c, "dice_fwd", logits, target, N, K, HW, act, multi, target_is_i64, target_per_pixel, mask_per_pixel, weight_host));
+    USTRUN_CHECK(out && partials && partials_bytes >= ustrun_loss_partials_bytes(N, K, HW), "dice_fwd: partials too small");
+    const int blocks = stream_blocks((long)N * HW);
+    hipLaunchKernelGGL(dice_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, c, logits, target, mask, partials);
+    USTRUN_LAUNCH_CHECK("dice_fwd");
+    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, c, partials, blocks, out);
+    USTRUN_LAUNCH_CHECK("dice_finalize");
+    return 0;
+}
+
+extern "C" int ustrun_dice_bwd(const float* logits, const void* target, int target_is_i64, int target_per_pixel, const float* mask,
+                               int mask_per_pixel, int N, int K, int HW, int act, int multi, const float* weight_host, const float* sums,
+                               const float* gscale_dev, float gscale, float* dlogits, ustrun_stream_t s) {
+    DiceCfg c;
+    USTRUN_TRY(dice_cfg(&c, "dice_bwd", logits, target, N, K, HW, act, multi, target_is_i64, target_per_pixel, mask_per_pixel, weight_host));
+    USTRUN_CHECK(sums && dlogits, "dice_bwd: null pointer");
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3(stream_blocks((long)N * HW)), dim3(256), 0, (hipStream_t)s, c, logits, target, mask, sums,
+                       gscale_dev, gscale, dlogits);
+    USTRUN_LAUNCH_CHECK("dice_bwd");
     return 0;
 }
 

@@ -95,6 +95,8 @@ SIGNATURES = {
     "ustrun_conv2d_wgrad": (i32, [PSrc, i32, vp, i32, i32, i32, i32, i32, i32, i32, fp, i32, fp, i64, i32, vp]),
     "ustrun_conv_rowwin_wgrad": (i32, [PSrc, vp, i32, i32, i32, i32, i32, i32, fp, i32, fp, i64, i32, vp]),
     "ustrun_debug_last_conv_variant": (i32, []),
+    "ustrun_dice_fwd": (i32, [fp, vp, i32, i32, fp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), fp, fp, i64, vp]),
+    "ustrun_dice_bwd": (i32, [fp, vp, i32, i32, fp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), fp, fp, f32, fp, vp]),
     "ustrun_debug_conv_stat_rows": (i32, [i32] * 10),
     "ustrun_debug_last_wgrad_variant": (i32, []),
     "ustrun_debug_flags": (i32, [i32]),

@@ -89,6 +89,60 @@ def seg_loss(logits, target, mask, mode, ce_weight=1.0, dice_weight=1.0):
     return out[0], out[1]
 
 
+_ACT = {"none": 0, "softmax": 1, "sigmoid": 2}
+
+
+class _DiceFn(torch.autograd.Function):
+    """DiceLossWithMask.forward in any mode combination (utils/losses.py:236-268) through ustrun_dice_fwd/_bwd."""
+
+    @staticmethod
+    def forward(ctx, logits, target, mask, act, multi, weight):
+        import ctypes as C
+        lib = L.lib()
+        logits = _f32c(logits, "inputs")
+        N, K, HW = _shape(logits)
+        if multi:
+            target = _f32c(target.float() if target.dtype != torch.float32 else target, "target")
+        else:
+            target = target.contiguous() if target.dtype == torch.int64 else _f32c(target.float(), "target")
+        mask = None if mask is None else _f32c(mask.float() if mask.dtype != torch.float32 else mask, "mask")
+        if target.numel() not in ((N * HW,) if not multi else (N * HW, N * K * HW)):
+            raise AssertionError("predict & target shape do not match")          # losses.py:253
+        if mask is not None and mask.numel() not in ((N * HW,) if not multi else (N * HW, N * K * HW)):
+            raise RuntimeError(f"mask of {tuple(mask.shape)} does not match inputs {tuple(logits.shape)}")
+        tper = int(target.numel() != N * K * HW or not multi)              # one value per pixel (class index, or broadcast over classes)
+        mper = int(mask is not None and (mask.numel() != N * K * HW or not multi))
+        w = None if weight is None else (C.c_float * K)(*[float(v) for v in weight])
+        out = torch.empty(1 + 3 * K, dtype=torch.float32, device=logits.device)
+        nb = lib.ustrun_loss_partials_bytes(N, K, HW)
+        part = torch.empty(nb // 4, dtype=torch.float32, device=logits.device)
+        cfg = (int(target.dtype == torch.int64), tper, mper, N, K, HW, _ACT[act], int(multi))
+        L.check(lib.ustrun_dice_fwd(logits.data_ptr(), target.data_ptr(), cfg[0], cfg[1], L.ptr(mask), cfg[2], N, K, HW, cfg[6], cfg[7], w,
+                                    out.data_ptr(), part.data_ptr(), nb, stream_ptr()), "ustrun_dice_fwd")
+        ctx.save_for_backward(logits, target, out) if mask is None else ctx.save_for_backward(logits, target, out, mask)
+        ctx.cfg, ctx.w = cfg, w
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.lib()
+        saved = ctx.saved_tensors
+        logits, target, out = saved[:3]
+        mask = saved[3] if len(saved) > 3 else None
+        t64, tper, mper, N, K, HW, act, multi = ctx.cfg
+        g = g.contiguous().float().reshape(1)
+        dl = torch.empty_like(logits)
+        L.check(lib.ustrun_dice_bwd(logits.data_ptr(), target.data_ptr(), t64, tper, L.ptr(mask), mper, N, K, HW, act, multi, ctx.w,
+                                    out.data_ptr(), g.data_ptr(), 1.0, dl.data_ptr(), stream_ptr()), "ustrun_dice_bwd")
+        return dl, None, None, None, None, None
+
+
+def dice_general(logits, target, mask=None, act="none", multi=False, weight=None):
+    """One DiceLossWithMask value, differentiable w.r.t. logits.  per class (multi False): target = class indices with N*H*W
+    elements; multi: target / mask with N*K*H*W elements or N*H*W (broadcast over the classes)."""
+    return _DiceFn.apply(logits, target, mask, act, bool(multi), weight)
+
+
 def pseudo_label(logits, threshold, mode):
     """train.py:648-667.  softmax -> (label int64 [N,H,W], mask f32 [N,1,H,W]); sigmoid -> f32 [N,K,H,W] x2."""
     lib = L.lib()
