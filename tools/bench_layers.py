@@ -106,14 +106,57 @@ def convT_layer(lib, n, ci, co, h, w, reps):
     return fl, t_f, t_d, t_w
 
 
+def ab_flags(a, lib):
+    """the conv3x3 layers under each debug-flag value, interleaved (rule 24): median of --rounds rounds per (layer, flag)"""
+    import numpy as np
+    flags = [int(v) for v in a.flags.split(",")]
+    S = a.hw
+    layers = [("inc.2   64->64", 64, 64, S, False, False)]
+    c, s = 64, S
+    for i in range(4):
+        s //= 2
+        layers.append((f"down{i+1}.1 {c}->{2*c} pool", c, 2 * c, s, True, False))
+        layers.append((f"down{i+1}.2 {2*c}->{2*c}", 2 * c, 2 * c, s, False, False))
+        c *= 2
+    for i in range(4):
+        s *= 2
+        layers.append((f"up{i+1}.1 cat {c}->{c//2}", c, c // 2, s, False, True))
+        layers.append((f"up{i+1}.2 {c//2}->{c//2}", c // 2, c // 2, s, False, False))
+        c //= 2
+    tot = {f: [0.0, 0.0, 0.0] for f in flags}
+    print("layer".ljust(28) + " | " + " | ".join(f"flags={f}: fwd / dgrad / wgrad ms (TF/s)" for f in flags))
+    for name, ci, co, hw, pool, cat in layers:
+        if a.only and a.only not in name:
+            continue
+        res = {f: [] for f in flags}
+        for r in range(3):
+            for f in flags:
+                lib.ustrun_debug_flags(f)
+                res[f].append(conv_layer(lib, a.n, ci, co, hw, hw, pool, cat, a.reps))
+        lib.ustrun_debug_flags(0)
+        cells = []
+        for f in flags:
+            fl = res[f][0][0]
+            med = [float(np.median([x[k] for x in res[f]])) for k in (1, 2, 3)]
+            for k in range(3):
+                tot[f][k] += med[k]
+            cells.append(" / ".join(f"{m:.3f} ({fl / m / 1e9:4.0f})" for m in med))
+        print(name.ljust(28) + " | " + " | ".join(cells), flush=True)
+    print("total ms".ljust(28) + " | " + " | ".join(" / ".join(f"{v:.3f}" for v in tot[f]) for f in flags))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=16)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--hw", type=int, default=256)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--flags", type=str, default="", help="comma-separated ustrun_debug_flags values: A/B the builds they select, "
+                    "interleaved per layer inside this process (e.g. 8,0)")
     a = ap.parse_args()
     lib = l.lib()
+    if a.flags:
+        return ab_flags(a, lib)
     S = a.hw
     layers = [("inc.2   64->64", 64, 64, S, False, False)]
     c, s = 64, S

@@ -51,10 +51,16 @@ template <int V> using ic = std::integral_constant<int, V>;
 // cycles outside the 512 MFMA cycles, more than the SIMD's other wave can cover.
 // DIL: dilation of the 3x3 taps (1 everywhere in the U-Net; 2 and 4 for the dilated bottlenecks of DeepLabV2-ResNet, reference
 // networks/backbone/resnet.py:8-10,193-200): the halo is DIL pixels wide and tap (ty, tx) reads DIL * (ty, tx) into the patch.
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1>
+// BREG (round 3): the weight fragments do not pass through LDS.  Each wave loads the B fragments of the NEXT tap straight into
+// registers (one 16-byte buffer load per fragment: the packed layout [tap][K/8][N][8] IS the fragment layout, 32 columns x 16 B
+// contiguous per half-wave) one stage ahead of their MFMAs.  That removes the two weight LDS-DMAs and the four B-fragment LDS
+// reads of a stage -- and, with nothing shared between the waves inside a chunk any more, the per-tap workgroup barrier: the
+// waves meet once per K chunk (when the patch buffers swap) instead of nine times, and drift apart in between.
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
     static_assert(BK == 32, "80-byte patch rows hold one 32-channel chunk");
+    static_assert(!BREG || NT <= 2, "register-fed weights: 16 registers per tap and set");
     constexpr int HW2 = TW + 2 * DIL;
     constexpr int SR = 32 / TW;                 // tile rows per 32-pixel sub-tile (2 or 1)
     constexpr int WM = TH / (SR * MI), WN = 4 / WM;
@@ -75,13 +81,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     constexpr int RAWB = XF ? BATCH * NP * 4096 : 0;   // a raw slot: BATCH x NP x 16 B per thread
     // SKEW: the items a stage fetches are transformed under the NEXT stage's MFMAs (two raw slots, by stage parity) --
     // where a second slot still leaves room for two blocks per CU; otherwise after the stage's own MFMAs
-    constexpr bool SKEW = XF && 2 * ABYTES + 2 * NT * BCH * 16 + 2 * RAWB + 512 <= 81920;
+    constexpr int BBYTES = BREG ? 0 : 2 * NT * BCH * 16;
+    constexpr bool SKEW = XF && 2 * ABYTES + BBYTES + 2 * RAWB + 512 <= 81920;
     constexpr int NRAW = SKEW ? 2 : 1;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                            // 2 x patch [HP][80 B] (current / being staged)
-    char* Bs = smem + 2 * ABYTES;               // 2 x NT x [BK/8][BN][8] bf16
-    char* Raw = Bs + 2 * NT * (BCH * 16);       // NRAW x raw slot
+    char* Bs = smem + 2 * ABYTES;               // 2 x NT x [BK/8][BN][8] bf16 (none with BREG)
+    char* Raw = Bs + BBYTES;                    // NRAW x raw slot
     char* Cst = Raw + NRAW * RAWB;              // 2 x {32 scales, 32 shifts} f32 of a chunk (kept out of vmcnt's way)
 
     const int mt_total = a.N * tiles_y * tiles_x;
@@ -242,6 +249,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             __builtin_amdgcn_global_load_lds((gptr_t*)(wthr[i] + woff), (lptr_t*)(dst + (wave * 64 + 256 * i) * 16), 16, 0, 0);
     };
 
+    // BREG: the fragments of (chunk c, tap) for this wave's 64 columns, k half lh: [ks][column half].  The loads are inline
+    // asm: beside an LDS-DMA in flight hipcc waits vmcnt(0) for any load it knows about (every other stage drained the
+    // B loads it had just issued AND the patch transfer); hidden from it, they are counted by hand below.
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (int)min((long)9 * K8 * a.Cout * 16, 0x7fffffffL), 0x00020000);
+    const int bvoff0 = (lh * a.Cout + n0 + wn * 64 + l31) * 16, bvoff1 = bvoff0 + 2 * a.Cout * 16;      // ks = 0, 1; + 512: columns 32..63
+    bf16x8 bnx[NT][BK / 16][2];
+    auto load_B = [&](int c, int tap, int k) {       // k: slot of the stage (folds to a constant)
+        const int wt = wflip ? 8 - tap : tap;
+        const int soff = __builtin_amdgcn_readfirstlane((int)(((long)wt * K8 + c * (BK / 8)) * a.Cout * 16));
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %4, %6, %7 offen\n\tbuffer_load_dwordx4 %1, %4, %6, %7 offen offset:512\n\t"
+                     "buffer_load_dwordx4 %2, %5, %6, %7 offen\n\tbuffer_load_dwordx4 %3, %5, %6, %7 offen offset:512"
+                     : "=&v"(bnx[k][0][0]), "=&v"(bnx[k][0][1]), "=&v"(bnx[k][1][0]), "=&v"(bnx[k][1][1])
+                     : "v"(bvoff0), "v"(bvoff1), "s"(wrs), "s"(soff) : "memory");
+    };
+
     f32x16 acc[MI][2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -256,8 +278,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     const int nstage = nchunk * NSTG;
 
     // ---- prologue: the first stage's weight tiles and the whole first patch, all transfers in flight together ----
+    if constexpr (BREG) {
 #pragma unroll
-    for (int k = 0; k < NT; ++k) dma_B(0, k, k);
+        for (int k = 0; k < NT; ++k) load_B(0, k, k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) dma_B(0, k, k);
+    }
     if (nchunk > 1) dma_consts(1);
     stage_begin(0, false);                        // one memory round trip for constants, patch and weights together
     if constexpr (XF) {
@@ -283,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    int ni_prev = 0;                              // BREG: patch pieces the previous stage issued (still in flight at its end)
     for (int c = 0; c < nchunk; ++c) {
         const char* Afrag = As + (c & 1) * ABYTES + afrag0;
         char* Anext = As + ((c + 1) & 1) * ABYTES;
@@ -294,7 +322,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             constexpr int jn = (j + 1) % NSTG, tn0 = jn * NT, nn = (9 - tn0 < NT) ? 9 - tn0 : NT;
             const int s = c * NSTG + j;
             // top: next stage's weights, one item of the next patch
-            if (s + 1 < nstage) {
+            bf16x8 bcur[NT][BK / 16][2];
+            const int nb_new = (BREG && s + 1 < nstage) ? 4 * nn : 0;  // B loads this stage issues (wave-uniform)
+            if constexpr (BREG) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+#pragma unroll
+                    for (int ks = 0; ks < BK / 16; ++ks) { bcur[k][ks][0] = bnx[k][ks][0]; bcur[k][ks][1] = bnx[k][ks][1]; }
+                if (s + 1 < nstage) {
+#pragma unroll
+                    for (int k = 0; k < nn; ++k) load_B(jn == 0 ? c + 1 : c, tn0 + k, k);
+                }
+            } else if (s + 1 < nstage) {
 #pragma unroll
                 for (int k = 0; k < nn; ++k) dma_B(jn == 0 ? c + 1 : c, tn0 + k, ((s + 1) & 1) * NT + k);
             }
@@ -312,6 +351,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (BREG) {
+                // this stage's fragments were loaded a stage ago; younger than them: that stage's patch pieces (XF: consumed by
+                // this stage's raw reads, so they must have landed too), then this stage's B loads and patch pieces
+                const int younger = nb_new + ni + (XF ? 0 : ni_prev);
+                switch (younger < 12 ? younger : 12) {
+                    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+                    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                }
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+#pragma unroll
+                    for (int ks = 0; ks < BK / 16; ++ks) asm volatile("" : "+v"(bcur[k][ks][0]), "+v"(bcur[k][ks][1]));   // (no MFMA above the wait)
+                __builtin_amdgcn_sched_barrier(0);
+                ni_prev = ni;
+            }
             // middle: every fragment is base + immediate
             const char* Bp = Bs + (s & 1) * NT * (BCH * 16) + bfrag0;
             bf16x8 bf[NT][BK / 16][2], af[NT][BK / 16][MI];
@@ -321,8 +386,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                 const int tap = t0 + k;
 #pragma unroll
                 for (int ks = 0; ks < BK / 16; ++ks) {
-                    bf[k][ks][0] = *(const bf16x8*)(Bp + k * (BCH * 16) + (2 * ks * BN) * 16);
-                    bf[k][ks][1] = *(const bf16x8*)(Bp + k * (BCH * 16) + (2 * ks * BN + 32) * 16);
+                    if constexpr (BREG) { bf[k][ks][0] = bcur[k][ks][0]; bf[k][ks][1] = bcur[k][ks][1]; }
+                    else {
+                        bf[k][ks][0] = *(const bf16x8*)(Bp + k * (BCH * 16) + (2 * ks * BN) * 16);
+                        bf[k][ks][1] = *(const bf16x8*)(Bp + k * (BCH * 16) + (2 * ks * BN + 32) * 16);
+                    }
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
                         af[k][ks][i] = *(const bf16x8*)(Afrag + ((DIL * (tap / 3) + SR * i) * HW2 + DIL * (tap % 3)) * PITCH + ks * 32);
@@ -352,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                 for (int b = 0; b < nitem; ++b) xform_store(jx * BATCH + b, rr[b], Anext, more, rawR);
                 // scheduling: every LDS read up front (the compiler otherwise fetches fragments pair by pair, each behind
                 // a full wait), then the MFMAs with the transform's VALU work in their shadow, the writes last
-                constexpr int nread = nt * (BK / 16) * (2 + MI) + nitem * NP;
+                constexpr int nread = nt * (BK / 16) * ((BREG ? 0 : 2) + MI) + nitem * NP;
                 constexpr int nmfma = nt * (BK / 16) * MI * 2;
                 constexpr int vpm = (nitem * (NP * 26 + 14) + nmfma - 1) / nmfma;
                 __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);
@@ -366,7 +434,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             // bottom: this top's transfers have landed.  (The scheduling barrier keeps the wait BEHIND the MFMAs: an asm
             // statement only orders against memory operations, and hipcc otherwise hoists it above fifteen of them.)
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!XF && j < NSTG - 1) {
+            if constexpr (BREG && j < NSTG - 1 && (!XF || SKEW)) {
+                // nothing to wait for here: the next stage's own counted wait covers its fragments and raw pieces
+                // (without SKEW the raw pieces are transformed right below: the full wait of the last branch stays)
+            } else if constexpr (!XF && j < NSTG - 1) {
                 // plain source: the patch items go straight into the next chunk's buffer, which nobody reads before the
                 // chunk's last stage -- and they come from HBM, not L2 like the weights.  They were issued after the
                 // weights, so "all but the newest ni" = the weights of the next stage and every earlier item: an item
@@ -388,8 +459,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                     }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!BREG || j == NSTG - 1) {            // BREG: the waves only share the patch, which swaps once per chunk
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             asm volatile("" ::: "memory");
         };
         stage(ic<0>{}); stage(ic<1>{}); stage(ic<2>{}); stage(ic<3>{}); stage(ic<4>{});
@@ -503,19 +576,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
 
 int g_last_variant = 0;    // TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF of the last launch (tests: ustrun_debug_last_conv_variant)
 
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1>
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false>
 int launch_xf(const IgemmArgs& a, hipStream_t st) {
     g_last_variant = TH << 24 | TW << 16 | BN << 8 | MI << 4 | NT << 2 | (POOL ? 2 : 0) | (XF ? 1 : 0);
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
     constexpr int DSLOTS = ((TH + 2 * DIL) * (TW + 2 * DIL) * 5 + 63) / 64 * 64;
     constexpr int AIT = (DSLOTS + 255) / 256, NSTG = (9 + NT - 1) / NT, BATCH = (AIT + NSTG - 2) / (NSTG - 1);
     const size_t rawb = XF ? (size_t)BATCH * (POOL ? 4 : 1) * 4096 : 0;
-    const size_t fixed = 2 * (size_t)DSLOTS * 16 + 2 * NT * (size_t)(BK / 8) * BN * 16 + 512;
+    const size_t fixed = 2 * (size_t)DSLOTS * 16 + (BREG ? 0 : 2 * NT * (size_t)(BK / 8) * BN * 16) + 512;
     const size_t lds = fixed + (XF && fixed + 2 * rawb <= 81920 ? 2 : 1) * rawb;
     dim3 grid(a.N * ty * tx * nt), block(256);
     if constexpr (DIL > 1)         // (up to 93 KB for the dilation-4 patch pair: one block per CU, above the 64 KB default)
-        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL>, 160 * 1024, "conv3x3_halo_bf16"));
-    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL>), grid, block, lds, st, a, tx, ty, nt);
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG>, 160 * 1024, "conv3x3_halo_bf16"));
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;
 }
@@ -527,7 +600,13 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     bool xf = POOL;
     for (int i = 0; i < a.nsrc; ++i) xf |= a.src[i].scale != nullptr || a.src[i].relu != 0;
     if constexpr (POOL) return launch_xf<TH, TW, BN, BK, MI, POOL, NT, true>(a, st);
-    else return xf ? launch_xf<TH, TW, BN, BK, MI, POOL, NT, true>(a, st) : launch_xf<TH, TW, BN, BK, MI, POOL, NT, false>(a, st);
+    else {
+        {                                              // weights through registers, one barrier per chunk (debug flag bit 3: off)
+            if (!(g_debug_flags & 8))
+                return xf ? launch_xf<TH, TW, BN, BK, MI, POOL, NT, true, 1, true>(a, st) : launch_xf<TH, TW, BN, BK, MI, POOL, NT, false, 1, true>(a, st);
+        }
+        return xf ? launch_xf<TH, TW, BN, BK, MI, POOL, NT, true>(a, st) : launch_xf<TH, TW, BN, BK, MI, POOL, NT, false>(a, st);
+    }
 }
 
 }  // namespace
@@ -584,15 +663,20 @@ template <int DIL>
 static int launch_dilated(const IgemmArgs& a, hipStream_t st) {
     bool xf = false;
     for (int i = 0; i < a.nsrc; ++i) xf |= a.src[i].scale != nullptr || a.src[i].relu != 0;
+    const bool breg = !(g_debug_flags & 8);          // weights through registers, one barrier per chunk (round 3)
     if (a.Cout % 128 == 0) {
         // rate 4: the (8 + 8) x (16 + 8) patch of an 8 x 16 tile is three times its output and its pair of buffers leaves room
         // for ONE block per CU anyway -- a 16 x 16 tile (24 x 24 patch: 2.25 x) with the 4 x 2 wave tile does twice the MFMA
         // work per stage in that one block: 0.49 -> 0.39 ms on layer4's 512 -> 512 convolutions (627 -> 786 TF/s).  Rate 2
         // keeps the small tile (two blocks per CU; the large one measured 0.089 -> 0.108 ms there).
-        if (DIL == 4)
+        if (DIL == 4) {
+            if (breg) return xf ? launch_xf<16, 16, 128, 32, 4, false, 1, true, DIL, true>(a, st) : launch_xf<16, 16, 128, 32, 4, false, 1, false, DIL, true>(a, st);
             return xf ? launch_xf<16, 16, 128, 32, 4, false, 1, true, DIL>(a, st) : launch_xf<16, 16, 128, 32, 4, false, 1, false, DIL>(a, st);
+        }
+        if (breg) return xf ? launch_xf<8, 16, 128, 32, 2, false, 2, true, DIL, true>(a, st) : launch_xf<8, 16, 128, 32, 2, false, 2, false, DIL, true>(a, st);
         return xf ? launch_xf<8, 16, 128, 32, 2, false, 2, true, DIL>(a, st) : launch_xf<8, 16, 128, 32, 2, false, 2, false, DIL>(a, st);
     }
+    if (breg) return xf ? launch_xf<8, 16, 64, 32, 1, false, 2, true, DIL, true>(a, st) : launch_xf<8, 16, 64, 32, 1, false, 2, false, DIL, true>(a, st);
     return xf ? launch_xf<8, 16, 64, 32, 1, false, 2, true, DIL>(a, st) : launch_xf<8, 16, 64, 32, 1, false, 2, false, DIL>(a, st);
 }
 

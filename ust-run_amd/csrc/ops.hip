@@ -2,6 +2,7 @@
 // implicit-GEMM / weight-gradient kernels, plus the weight packing kernels.
 #include "common.h"
 #include "loader.h"
+#include <stdlib.h>
 
 namespace ustrun {
 namespace {
@@ -141,7 +142,8 @@ static ustrun_src_t src_slice(const ustrun_src_t& s, int g, int gN, int dtype) {
 
 extern "C" int ustrun_debug_last_conv_variant(void) { return halo_last_variant(); }
 extern "C" int ustrun_debug_last_wgrad_variant(void) { return wgrad_last_variant(); }
-namespace ustrun { int g_debug_flags = 0; }
+// (USTRUN_DEBUG_FLAGS in the environment presets the flags: A/B runs of whole programs on one box)
+namespace ustrun { int g_debug_flags = getenv("USTRUN_DEBUG_FLAGS") ? atoi(getenv("USTRUN_DEBUG_FLAGS")) : 0; }
 extern "C" int ustrun_debug_buffer(void* device_u64) { ws64_set_debug_buffer(device_u64); return 0; }
 extern "C" int ustrun_debug_flags(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
 
