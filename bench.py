@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--fft", default="device", choices=["host", "device"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event roofline leg")
+    ap.add_argument("--dump-layers", default="", help="write every tagged launch class (layer, op, images) of the sampled steps to this JSON file")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` entries (the other BASELINE.json shapes, the f32 parity path, DeepLabV2-ResNet101 @512^2)")
     return ap.parse_args()
@@ -356,6 +357,8 @@ def main():
                              "time_share_of_step": round(ms2.value * 1e-3 / (dt * nprof / a.steps), 3)}
         # the north_star's HBM target is defined on the 64-channel full-resolution DoubleConv layers:
         # per-layer rows of the largest launches (the student's four batched passes), both roofs, binding roof named
+        if a.dump_layers and rank == 0:
+            json.dump(layers, open(a.dump_layers, "w"), indent=0)
         big = max((r["images"] for r in layers), default=0)
         roof["layers"] = [r for r in layers if r["images"] == big and r["op"] == "fwd"]
         roof["layers_bwd"] = [r for r in layers if r["images"] == big and r["op"] != "fwd" and

@@ -26,6 +26,8 @@ typedef __attribute__((address_space(3))) void lptr_t;
 __device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};   // source of padding pixels
 
 template <int V> using ic = std::integral_constant<int, V>;
+template <class T> struct more_value { static constexpr bool value = true; };      // runtime bool: not used as a constant
+template <bool B> struct more_value<std::integral_constant<bool, B>> { static constexpr bool value = B; };
 
 // MI = 32-pixel MFMA sub-tiles per wave along M.  TW = 16: a sub-tile is 2 rows x 16 px (wave tile 2*MI rows x 16 px);
 // TW = 32: a sub-tile is one row of 32 consecutive pixels (wave tile MI rows x 32 px).
@@ -74,7 +76,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     constexpr int BATCH = (AIT + NSTG - 2) / (NSTG - 1);   // patch items per stage; the chunk's last stage carries the constants
     static_assert(BATCH * (NSTG - 1) >= AIT, "staging fits the chunk");
     constexpr int NP = POOL ? 4 : 1;
-    constexpr int ABYTES = DSLOTS * 16;
+    // BREG: every wave issues every staging step (its transfer counts are then compile-time constants, see the counted wait):
+    // the slots past the patch image are a few hundred bytes of trash behind it
+    constexpr int ABYTES = (BREG ? AIT * 256 : DSLOTS) * 16;
     constexpr int BCH = (BK / 8) * BN;          // 16-byte chunks per B tile
     constexpr int BIT = BCH / 256;
     static_assert(BCH % 256 == 0, "B tile must be a whole number of wave-instructions per wave");
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         }
     };
     // does this wave own a slot of staging step i?  (wave-uniform: the counted waits depend on it)
-    auto wave_has = [&](int i) { return 256 * i + wave * 64 < (XF ? XSLOTS : DSLOTS); };
+    auto wave_has = [&](int i) { return BREG || 256 * i + wave * 64 < (XF ? XSLOTS : DSLOTS); };
     // item i of the chunk, b-th item of its stage (both fold to constants: the callers are fully unrolled)
     auto issue_one = [&](int i, int b, char* Adst, char* raw) {
         const bool ok = (aokm >> i) & 1u;
@@ -310,11 +314,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int ni_prev = 0;                              // BREG: patch pieces the previous stage issued (still in flight at its end)
-    for (int c = 0; c < nchunk; ++c) {
+    bf16x8 acar[MI];                              // BREG, plain source: the A fragments of the next half-stage (read under this one's MFMAs)
+    constexpr bool PEEL = BREG && !XF;
+    // (pipelining the fragment reads of the transforming variants the same way measured flat on the forward layers -- 5.86 vs
+    // 5.74 ms over the U-Net's layers at N = 64, one box -- their stage is paced by the transform's VALU work: plain sources only)
+    constexpr bool APIPE = BREG && !XF;
+    int ni_prev = 0;                              // BREG without PEEL: patch pieces the previous stage issued (runtime count)
+    // one K chunk.  PEEL: `more` (a successor exists) is a compile-time constant -- the last chunk is a second copy of the
+    // body -- so that every transfer count is known when the waits are written and a stage stays ONE basic block (the
+    // transforming variants sit at the 256-register limit: two copies of their body spill, they keep the runtime form)
+    auto chunk = [&](const int c, auto more_c) __attribute__((always_inline)) {
+        const bool more = more_c;
+        constexpr bool morec = more_value<decltype(more_c)>::value;       // meaningful with PEEL only
         const char* Afrag = As + (c & 1) * ABYTES + afrag0;
         char* Anext = As + ((c + 1) & 1) * ABYTES;
-        const bool more = c + 1 < nchunk;
         if (more) stage_begin(c + 1);
         auto stage = [&](auto ic_j) {
             constexpr int j = decltype(ic_j)::value;          // stage of the chunk: taps j*NT .. j*NT + nt - 1
@@ -323,13 +336,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             const int s = c * NSTG + j;
             // top: next stage's weights, one item of the next patch
             bf16x8 bcur[NT][BK / 16][2];
-            const int nb_new = (BREG && s + 1 < nstage) ? 4 * nn : 0;  // B loads this stage issues (wave-uniform)
+            const bool has_next = PEEL ? (morec || j < NSTG - 1) : (s + 1 < nstage);        // a stage follows
+            const int nb_new = (BREG && has_next) ? 4 * nn : 0;        // B loads this stage issues (wave-uniform)
             if constexpr (BREG) {
 #pragma unroll
                 for (int k = 0; k < NT; ++k)
 #pragma unroll
                     for (int ks = 0; ks < BK / 16; ++ks) { bcur[k][ks][0] = bnx[k][ks][0]; bcur[k][ks][1] = bnx[k][ks][1]; }
-                if (s + 1 < nstage) {
+                if (has_next) {
 #pragma unroll
                     for (int k = 0; k < nn; ++k) load_B(jn == 0 ? c + 1 : c, tn0 + k, k);
                 }
@@ -354,32 +368,83 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             if constexpr (BREG) {
                 // this stage's fragments were loaded a stage ago; younger than them: that stage's patch pieces (XF: consumed by
                 // this stage's raw reads, so they must have landed too), then this stage's B loads and patch pieces
-                const int younger = nb_new + ni + (XF ? 0 : ni_prev);
-                switch (younger < 12 ? younger : 12) {
-                    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-                    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-                    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-                    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-                    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                if constexpr (PEEL) {        // all compile-time: every wave issues every staging step, `more` is a template value
+                    constexpr auto pieces = [](int jj) constexpr {
+                        int n = 0;
+                        if (morec && jj >= 0 && jj < NSTG - 1)
+                            for (int b = 0; b < BATCH; ++b) n += (jj * BATCH + b < AIT) ? NP : 0;
+                        return n;
+                    };
+                    constexpr int younger = ((morec || j < NSTG - 1) ? 4 * nn : 0) + pieces(j) + pieces(j - 1);
+                    static_assert(younger < 64, "vmcnt is a 6-bit counter");
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(younger) : "memory");
+                } else {
+                    const int younger = nb_new + ni + (XF ? 0 : ni_prev);
+                    switch (younger < 12 ? younger : 12) {
+                        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+                        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    }
+                    ni_prev = ni;
                 }
 #pragma unroll
                 for (int k = 0; k < NT; ++k)
 #pragma unroll
                     for (int ks = 0; ks < BK / 16; ++ks) asm volatile("" : "+v"(bcur[k][ks][0]), "+v"(bcur[k][ks][1]));   // (no MFMA above the wait)
                 __builtin_amdgcn_sched_barrier(0);
-                ni_prev = ni;
             }
             // middle: every fragment is base + immediate
+            auto afrag = [&](int tap, int ks, int i) __attribute__((always_inline)) {
+                return *(const bf16x8*)(Afrag + ((DIL * (tap / 3) + SR * i) * HW2 + DIL * (tap % 3)) * PITCH + ks * 32);
+            };
+            if constexpr (APIPE) {
+                // register-fed weights: nothing is shared between the waves inside a chunk, so the A fragments
+                // of the NEXT half-stage (8 or 4 MFMAs ahead, same patch buffer) are read under this half-stage's MFMAs:
+                // same 2 x MI fragment registers as reading a whole stage up front, and the LDS latency leaves the
+                // critical path everywhere but at a chunk's first half-stage
+                if constexpr (j == 0) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acar[i] = afrag(t0, 0, i);
+                }
+#pragma unroll
+                for (int k = 0; k < nt; ++k)
+#pragma unroll
+                    for (int ks = 0; ks < BK / 16; ++ks) {
+                        bf16x8 anx[MI];
+                        constexpr int dummy = 0; (void)dummy;
+                        const int hn = (k * (BK / 16) + ks + 1);                 // next half-stage of this stage, if any
+                        const bool in_stage = hn < nt * (BK / 16);
+                        if (in_stage) {
+#pragma unroll
+                            for (int i = 0; i < MI; ++i) anx[i] = afrag(t0 + hn / (BK / 16), hn % (BK / 16), i);
+                        } else if (j < NSTG - 1) {                               // first half-stage of the next stage (same chunk)
+#pragma unroll
+                            for (int i = 0; i < MI; ++i) anx[i] = afrag(t0 + nt, 0, i);
+                        }
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) {
+                            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acar[i], bcur[k][ks][0], acc[i][0], 0, 0, 0);
+                            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acar[i], bcur[k][ks][1], acc[i][1], 0, 0, 0);
+                        }
+                        if (in_stage || j < NSTG - 1) {
+#pragma unroll
+                            for (int i = 0; i < MI; ++i) acar[i] = anx[i];
+                        }
+                    }
+            }
             const char* Bp = Bs + (s & 1) * NT * (BCH * 16) + bfrag0;
             bf16x8 bf[NT][BK / 16][2], af[NT][BK / 16][MI];
+            if constexpr (!APIPE) {
 #pragma unroll
             for (int k = 0; k < nt; ++k) {
                 constexpr int dummy = 0; (void)dummy;
@@ -392,9 +457,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                         bf[k][ks][1] = *(const bf16x8*)(Bp + k * (BCH * 16) + (2 * ks * BN + 32) * 16);
                     }
 #pragma unroll
-                    for (int i = 0; i < MI; ++i)
-                        af[k][ks][i] = *(const bf16x8*)(Afrag + ((DIL * (tap / 3) + SR * i) * HW2 + DIL * (tap % 3)) * PITCH + ks * 32);
+                    for (int i = 0; i < MI; ++i) af[k][ks][i] = afrag(tap, ks, i);
                 }
+            }
             }
             // SKEW: the items the previous stage fetched (landed: that stage ended on vmcnt(0)), transformed under the MFMAs
             constexpr int jx = SKEW ? j - 1 : j;              // the stage whose items are transformed here
@@ -405,7 +470,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
 #pragma unroll
                 for (int b = 0; b < nitem; ++b) raw_read(b, rawR, rr[b]);
             }
-            if constexpr (!SKEW) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!SKEW && !APIPE) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!APIPE) {
 #pragma unroll
             for (int k = 0; k < nt; ++k)
 #pragma unroll
@@ -415,14 +481,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][ks][i], bf[k][ks][0], acc[i][0], 0, 0, 0);
                         acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][ks][i], bf[k][ks][1], acc[i][1], 0, 0, 0);
                     }
+            }
             if constexpr (SKEW) {
 #pragma unroll
                 for (int b = 0; b < nitem; ++b) xform_store(jx * BATCH + b, rr[b], Anext, more, rawR);
+            }
+            constexpr int nmfma = nt * (BK / 16) * MI * 2;
+            constexpr int vpm = !SKEW ? 0 : (nitem * (NP * 26 + 14) + nmfma - 1) / nmfma;
+            if constexpr (APIPE) {
+                // pinned (left alone, hipcc re-fetches each fragment just in time into ONE register set: read -> wait -> 2 MFMAs):
+                // the raw items (and a chunk's first fragments) up front; per half-stage two MFMAs, the next half-stage's reads,
+                // the other MFMAs -- its fragments are 2 MI - 2 MFMAs old when a half-stage starts; the transform's VALU work in
+                // the MFMAs' shadow, its writes last
+                if constexpr ((j == 0 ? MI : 0) + nitem * NP > 0) __builtin_amdgcn_sched_group_barrier(0x100, (j == 0 ? MI : 0) + nitem * NP, 0);
+#pragma unroll
+                for (int h = 0; h < nt * (BK / 16); ++h) {
+                    const bool next_read = h + 1 < nt * (BK / 16) || j < NSTG - 1;
+#pragma unroll
+                    for (int m = 0; m < 2 * MI; ++m) {
+                        if (m == 2 && next_read) __builtin_amdgcn_sched_group_barrier(0x100, MI, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if constexpr (vpm > 0) __builtin_amdgcn_sched_group_barrier(0x002, vpm, 0);
+                    }
+                }
+                if constexpr (nitem > 0) __builtin_amdgcn_sched_group_barrier(0x200, nitem, 0);
+            } else if constexpr (SKEW) {
                 // scheduling: every LDS read up front (the compiler otherwise fetches fragments pair by pair, each behind
                 // a full wait), then the MFMAs with the transform's VALU work in their shadow, the writes last
                 constexpr int nread = nt * (BK / 16) * ((BREG ? 0 : 2) + MI) + nitem * NP;
-                constexpr int nmfma = nt * (BK / 16) * MI * 2;
-                constexpr int vpm = (nitem * (NP * 26 + 14) + nmfma - 1) / nmfma;
                 __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);
 #pragma unroll
                 for (int m = 0; m < nmfma; ++m) {
@@ -467,6 +553,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         };
         stage(ic<0>{}); stage(ic<1>{}); stage(ic<2>{}); stage(ic<3>{}); stage(ic<4>{});
         if constexpr (NSTG > 5) { stage(ic<5>{}); stage(ic<6>{}); stage(ic<7>{}); stage(ic<8>{}); }
+    };
+    if constexpr (PEEL) {
+        for (int c = 0; c + 1 < nchunk; ++c) chunk(c, std::true_type{});
+        chunk(nchunk - 1, std::false_type{});
+    } else {
+        for (int c = 0; c < nchunk; ++c) chunk(c, c + 1 < nchunk);
     }
 
     // ---- epilogue: bf16 outputs (NHWC), optional two-destination split, BN-statistics partials.
@@ -583,7 +675,7 @@ int launch_xf(const IgemmArgs& a, hipStream_t st) {
     constexpr int DSLOTS = ((TH + 2 * DIL) * (TW + 2 * DIL) * 5 + 63) / 64 * 64;
     constexpr int AIT = (DSLOTS + 255) / 256, NSTG = (9 + NT - 1) / NT, BATCH = (AIT + NSTG - 2) / (NSTG - 1);
     const size_t rawb = XF ? (size_t)BATCH * (POOL ? 4 : 1) * 4096 : 0;
-    const size_t fixed = 2 * (size_t)DSLOTS * 16 + (BREG ? 0 : 2 * NT * (size_t)(BK / 8) * BN * 16) + 512;
+    const size_t fixed = 2 * (size_t)(BREG ? AIT * 256 : DSLOTS) * 16 + (BREG ? 0 : 2 * NT * (size_t)(BK / 8) * BN * 16) + 512;
     const size_t lds = fixed + (XF && fixed + 2 * rawb <= 81920 ? 2 : 1) * rawb;
     dim3 grid(a.N * ty * tx * nt), block(256);
     if constexpr (DIL > 1)         // (up to 93 KB for the dilation-4 patch pair: one block per CU, above the 64 KB default)
