@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     // does this wave own a slot of staging step i?  (wave-uniform: the counted waits depend on it)
     auto wave_has = [&](int i) { return BREG || 256 * i + wave * 64 < (XF ? XSLOTS : DSLOTS); };
     // item i of the chunk, b-th item of its stage (both fold to constants: the callers are fully unrolled)
-    auto issue_one = [&](int i, int b, char* Adst, char* raw) {
-        const bool ok = (aokm >> i) & 1u;
+    auto issue_one = [&](int i, int b, char* Adst, char* raw, bool live = true) {
+        const bool ok = live && ((aokm >> i) & 1u);
         const __bf16* src = ok ? aptr + aoff[i] : zsrc;
         if constexpr (XF) {
 #pragma unroll
@@ -316,6 +316,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
 
     bf16x8 acar[MI];                              // BREG, plain source: the A fragments of the next half-stage (read under this one's MFMAs)
     constexpr bool PEEL = BREG && !XF;
+    // CT (transforming variants with register-fed weights): the transfer counts are made compile-time WITHOUT a second copy of the
+    // body -- in the last chunk the staging steps and the last stage's weight loads are still issued, as dummies (the 16 zero
+    // bytes of g_zero16 into the raw slot nobody transforms into a patch; the same weights again) -- so the counted wait is one
+    // instruction instead of a ladder of scalar branches and a stage is one basic block
+    constexpr bool CT = BREG && XF && SKEW;
     // (pipelining the fragment reads of the transforming variants the same way measured flat on the forward layers -- 5.86 vs
     // 5.74 ms over the U-Net's layers at N = 64, one box -- their stage is paced by the transform's VALU work: plain sources only)
     constexpr bool APIPE = BREG && !XF;
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             const int s = c * NSTG + j;
             // top: next stage's weights, one item of the next patch
             bf16x8 bcur[NT][BK / 16][2];
-            const bool has_next = PEEL ? (morec || j < NSTG - 1) : (s + 1 < nstage);        // a stage follows
+            const bool has_next = PEEL ? (morec || j < NSTG - 1) : (CT || s + 1 < nstage);  // a stage follows (CT: or a dummy reload)
             const int nb_new = (BREG && has_next) ? 4 * nn : 0;        // B loads this stage issues (wave-uniform)
             if constexpr (BREG) {
 #pragma unroll
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
                     for (int ks = 0; ks < BK / 16; ++ks) { bcur[k][ks][0] = bnx[k][ks][0]; bcur[k][ks][1] = bnx[k][ks][1]; }
                 if (has_next) {
 #pragma unroll
-                    for (int k = 0; k < nn; ++k) load_B(jn == 0 ? c + 1 : c, tn0 + k, k);
+                    for (int k = 0; k < nn; ++k) load_B(jn == 0 ? (CT && !more ? c : c + 1) : c, tn0 + k, k);
                 }
             } else if (s + 1 < nstage) {
 #pragma unroll
@@ -356,11 +361,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             const char* rawR = Raw + (SKEW ? ((s & 1) ^ 1) * RAWB : 0);
             int ni = 0;                                       // patch transfers this wave issues in this stage (wave-uniform)
             if constexpr (j < NSTG - 1) {
-                if (more) {
+                if (CT || more) {
 #pragma unroll
                     for (int b = 0; b < BATCH; ++b) {
                         constexpr int dummy = 0; (void)dummy;
-                        if (j * BATCH + b < AIT && wave_has(j * BATCH + b)) { issue_one(j * BATCH + b, b, Anext, rawW); ni += NP; }
+                        if (j * BATCH + b < AIT && wave_has(j * BATCH + b)) { issue_one(j * BATCH + b, b, Anext, rawW, more); ni += NP; }
                     }
                 }
             }
@@ -368,14 +373,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             if constexpr (BREG) {
                 // this stage's fragments were loaded a stage ago; younger than them: that stage's patch pieces (XF: consumed by
                 // this stage's raw reads, so they must have landed too), then this stage's B loads and patch pieces
-                if constexpr (PEEL) {        // all compile-time: every wave issues every staging step, `more` is a template value
+                if constexpr (PEEL || CT) {  // all compile-time: every wave issues every staging step; `more` is a template value (PEEL)
+                                             // or does not change the counts (CT)
                     constexpr auto pieces = [](int jj) constexpr {
                         int n = 0;
-                        if (morec && jj >= 0 && jj < NSTG - 1)
+                        if ((CT || morec) && jj >= 0 && jj < NSTG - 1)
                             for (int b = 0; b < BATCH; ++b) n += (jj * BATCH + b < AIT) ? NP : 0;
                         return n;
                     };
-                    constexpr int younger = ((morec || j < NSTG - 1) ? 4 * nn : 0) + pieces(j) + pieces(j - 1);
+                    constexpr int younger = ((CT || morec || j < NSTG - 1) ? 4 * nn : 0) + pieces(j) + (XF ? 0 : pieces(j - 1));
                     static_assert(younger < 64, "vmcnt is a 6-bit counter");
                     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(younger) : "memory");
                 } else {
