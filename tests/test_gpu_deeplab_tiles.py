@@ -198,7 +198,7 @@ def test_streaming_kernel_statistics_stay_inside_the_published_rows(n, h, w):
     used = C.c_int(0)
     l.check(lib.ustrun_conv2d_fwd(C.byref(src), 1, wf.data_ptr(), None, n, h, w, 64, 3, 1, 1, out.data_ptr(), 0, stat.data_ptr(), C.byref(used), 1,
                                   None))
-    assert lib.ustrun_debug_last_conv_variant() == 0x57530001, hex(lib.ustrun_debug_last_conv_variant())     # 'WS' | four waves | XF
+    assert lib.ustrun_debug_last_conv_variant() == 0x57530201, hex(lib.ustrun_debug_last_conv_variant())     # 'WS' | consumer/producer waves | XF
     assert used.value == lib.ustrun_debug_conv_stat_rows(n, h, w, 64, 64, 3, 1, 1, 0, 1) <= rows
     assert guards_intact(sflat, stat.numel(), 7.0) and guards_intact(oflat, out.numel(), 7.0)
     stored = ref.bfloat16().float()

@@ -86,8 +86,8 @@ CASES = [
     # strips of 32 px, four passes
     ("ws64_n8_128", 8, (64,), 64, 128, 128, 2, "ws", "ws"),
     ("ws64_ragged", 16, (64,), 64, 72, 80, 4, "ws", "ws"),
-    # the same two with each build of that kernel forced for both directions (ustrun_debug_flags bit 1: four waves, bit 2: eight
-    # waves; the default takes four waves for the forward -- transform + statistics -- and eight for the input gradient)
+    # the same two with the other builds of that kernel forced (ustrun_debug_flags bit 1: four waves, bit 2: eight waves; the
+    # default is the consumer / producer build)
     ("ws64w4_n8_128", 8, (64,), 64, 128, 128, 2, "ws4", "ws4"),
     ("ws64w4_ragged", 16, (64,), 64, 72, 80, 4, "ws4", "ws4"),
     ("ws64w8_n8_128", 8, (64,), 64, 128, 128, 2, "ws8", "ws8"),
@@ -95,7 +95,7 @@ CASES = [
     # single pass, odd strip count, a last segment of one step, N not a multiple of anything
     ("ws64_odd", 9, (64,), 64, 88, 104, 1, "ws", "ws"),
 ]
-WS_CODE = {"ws4": 0x57530000, "ws8": 0x57530100}      # four waves / eight waves (round 3, two per SIMD)
+WS_CODE = {"ws4": 0x57530000, "ws8": 0x57530100, "ws": 0x57530200}      # four waves / eight waves / consumer + producer waves (default)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -155,7 +155,7 @@ def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):
     l.check(lib.ustrun_conv3x3_fwd_rows(sarr, len(srcs), wf.data_ptr(), n, h, w, co, out.data_ptr(), stat.data_ptr(),
                                         C.byref(rows), 1, None), "fwd")
     got = lib.ustrun_debug_last_conv_variant()
-    assert got == (WS_CODE["ws4" if vf == "ws" else vf] | 1 if vf in ("ws", "ws4", "ws8") else variant(*vf, False, True)), f"forward ran {vstr(got)}"
+    assert got == (WS_CODE[vf] | 1 if vf in WS_CODE else variant(*vf, False, True)), f"forward ran {vstr(got)}"
     yc = from_nhwc(out.float())
     assert rel(yc, r16(ref.detach())) < 1e-6
     # statistics rows: per pass, sums of the STORED (bf16-rounded) outputs
@@ -171,7 +171,7 @@ def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):
     da = torch.empty(n, h, w, ci, device="cuda", dtype=torch.bfloat16)
     l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 1, None), "dgrad")
     got = lib.ustrun_debug_last_conv_variant()
-    assert got == (WS_CODE["ws8" if vd == "ws" else vd] if vd in ("ws", "ws4", "ws8") else variant(*vd, False, False)), f"input gradient ran {vstr(got)}"
+    assert got == (WS_CODE[vd] if vd in WS_CODE else variant(*vd, False, False)), f"input gradient ran {vstr(got)}"
     assert rel(from_nhwc(da.float()), r16(a.grad)) < 1e-6
     if len(cs) == 2:
         d0 = torch.empty(n, h, w, cs[0], device="cuda", dtype=torch.bfloat16)

@@ -57,17 +57,17 @@ def main():
         src = l.nhwc_src(x.data_ptr(), ci, h, w, scale=sc.data_ptr(), shift=sh.data_ptr(), relu=1)
         fwd = lambda: l.check(lib.ustrun_conv3x3_fwd(C.byref(src), 1, wf.data_ptr(), n, h, w, co, y.data_ptr(), stat.data_ptr(), 1, None))
         dgr = lambda: l.check(lib.ustrun_conv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 1, None))
-        res = {(f, op): [] for f in (1, 2, 4) for op in ("fwd", "dgrad")}
+        res = {(f, op): [] for f in (1, 2, 4, 32) for op in ("fwd", "dgrad")}
         outs = {}
         for r in range(a.rounds):
-            for f in (1, 2, 4):
+            for f in (1, 2, 4, 32):
                 lib.ustrun_debug_flags(f)
                 res[(f, "fwd")].append(timed(fwd, a.reps))
                 res[(f, "dgrad")].append(timed(dgr, a.reps))
                 if r == 0:
                     outs[f] = (y.clone(), da.clone(), stat[:, :, :].sum(0).clone())
         lib.ustrun_debug_flags(0)
-        same = all(torch.equal(outs[4][0], outs[f][0]) and torch.equal(outs[4][1], outs[f][1]) for f in (1, 2))
+        same = all(torch.equal(outs[32][0], outs[f][0]) and torch.equal(outs[32][1], outs[f][1]) for f in (1, 2))
         fl = 2.0 * 9 * ci * co * n * h * w
         by = 2.0 * (2 * n * h * w * 64) + 2.0 * 9 * 64 * 64
         for op in ("fwd", "dgrad"):
@@ -75,6 +75,9 @@ def main():
             print(f"N={n:3d} {h}x{w} {op:5s}: tiled {t1:.4f} ms {fl / t1 / 1e9:6.0f} TF/s | streaming, 4 waves {t2:.4f} ms {fl / t2 / 1e9:6.0f} TF/s "
                   f"{by / t2 / 1e6:6.0f} GB/s ({by / t2 / 1e6 / 8000:.3f}) | streaming, 8 waves {t0:.4f} ms "
                   f"{fl / t0 / 1e9:6.0f} TF/s {by / t0 / 1e6:6.0f} GB/s ({by / t0 / 1e6 / 8000:.3f} of 8 TB/s) | x{t1 / t0:.2f}   min {min(res[(4, op)]):.4f}", flush=True)
+            tc = float(np.median(res[(32, op)]))
+            print(f"       {op:5s}: consumer / producer waves {tc:.4f} ms {fl / tc / 1e9:6.0f} TF/s {by / tc / 1e6:6.0f} GB/s ({by / tc / 1e6 / 8000:.3f} of 8 TB/s)   "
+                  f"min {min(res[(32, op)]):.4f}   x{t2 / tc:.2f} over four waves", flush=True)
         if a.diag:
             dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
             lib.ustrun_debug_buffer(dbg.data_ptr())
@@ -93,10 +96,21 @@ def main():
                       f"stamped launch {t_diag:.4f} ms -> in-kernel clock >= {float(tot.max()) / (t_diag * 1e-3) / 1e9:.2f} GHz; "
                       f"per wave half (0-3 / 4-7): groups {float((d[:, :4, 1] / it[:, :4]).mean()):.0f} / {float((d[:, 4:, 1] / it[:, 4:]).mean()):.0f}, "
                       f"barrier {float((d[:, :4, 4] / it[:, :4]).mean()):.0f} / {float((d[:, 4:, 4] / it[:, 4:]).mean()):.0f}", flush=True)
+            lib.ustrun_debug_flags(32)
+            for name, fn in (("fwd", fwd), ("dgrad", dgr)):
+                dbg.zero_()
+                fn()
+                torch.cuda.synchronize()
+                d = dbg.view(256, 8, 8).double()
+                it = d[..., 5].clamp(min=1)
+                f = lambda lo, hi, k: float((d[:, lo:hi, k] / it[:, lo:hi]).mean())
+                print(f"       diag {name} (consumer / producer waves), cycles per iteration -- consumers: half 0 {f(0, 4, 0):.0f}, wait B1 {f(0, 4, 1):.0f}, "
+                      f"half 1 {f(0, 4, 2):.0f}, wait B2 {f(0, 4, 3):.0f} | producers: segment A {f(4, 8, 0):.0f}, wait B1 {f(4, 8, 1):.0f}, segment B "
+                      f"{f(4, 8, 2):.0f}, wait B2 {f(4, 8, 3):.0f} (MFMA floor per half 2304)", flush=True)
             lib.ustrun_debug_buffer(None)
             lib.ustrun_debug_flags(0)
         print(f"       outputs bit-identical between the three kernels: {same}; stat sums rel diff "
-              f"{float((outs[4][2] - outs[1][2]).abs().max() / outs[1][2].abs().max()):.2e}", flush=True)
+              f"{float((outs[32][2] - outs[1][2]).abs().max() / outs[1][2].abs().max()):.2e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -717,6 +717,349 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64x8_kernel(const IgemmArgs 
     }
 }
 
+
+// ======================================================================================================================
+// Round 3, second form: CONSUMER and PRODUCER waves -- conv3x3_ws64cp_kernel.
+//
+// The counters of the two kernels above say the same thing: the matrix pipe is ~53 % busy because each wave issues ~4 other
+// instructions per MFMA (fetch offsets, transform, ring writes, stores, statistics, cursors), a SIMD issues roughly one
+// instruction per 4 cycles whoever it comes from, and splitting the TILE over more waves multiplies that work.  Here the WORK
+// KINDS are split instead (the ring-gemm arrangement of the programming guide): a 512-thread block, waves 0-3 multiply, waves
+// 4-7 do everything else; partner waves (w, w + 4) share a SIMD.
+//   consumers (one per SIMD): the four-wave kernel's multiply -- 32 output channels x 4 rows x 32 px per step on
+//     v_mfma_f32_32x32x16_bf16, the wave's 3x3x64x32 weights in 144 registers -- and nothing else: per half-step 12 groups of
+//     4 fragment reads + 6 MFMAs, then 16 cvt_pk + 8 ds_write_b64 that park the half's bf16 results in the wave's scratch.
+//     ~2.3 other instructions per MFMA instead of ~4.2.  Accumulators: ONE half-step (32 registers): with the parked results
+//     handed over at a barrier nothing has to survive a half-step.
+//   producers: the row fetch one iteration ahead (buffer loads, range-checked), BatchNorm affine + ReLU, ring writes, the
+//     cursor arithmetic -- and the consumers' epilogue: 16-byte-per-lane stores of the parked rows and the BatchNorm
+//     statistics of the stored values (fixed order: half 0 then half 1 of a step, one partial row per (item, wave row)).
+//   Two workgroup barriers per step: B1 after half 0 (its parked rows -> producers; they store them during half 1), B2 after
+//     half 1 (those rows are stored during the next step's half 0; the ring bank written this step becomes readable).
+// Same ring (3 banks x 8 rows x 34 px x 144 B), same per-wave scratch (4 rows x 32 px x 80 B), same work decomposition and
+// statistics rows as the four-wave kernel: results are bit-identical to it.
+constexpr int LDSBCP = RINGB + 4 * EWAVE + DUMMYB;
+
+template <bool XF, bool STAT, bool DIAG = false>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs a, const WsPlan p) {
+    unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt0 = 0, dt1 = 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave8 >= 4;
+    const int wave = wave8 & 3;                      // consumer w parks into scratch w; producer w + 4 stores scratch w
+    const int tp = tid & 255;                        // thread index inside the role
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    char* Ew = smem + RINGB + wave * EWAVE;
+    const SrcDev S = a.src[0];
+    const __bf16* srcp = (const __bf16*)S.ptr;
+    const int H = a.Hb, W = a.Wb;
+    const int sH = (int)S.sH, sW = (int)S.sW;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)srcp, 0, (int)min((long)a.N * S.sN * 2, 0x7fffffffL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out0, 0, (int)min((long)a.N * H * W * 128, 0x7fffffffL), 0x00020000);
+    const int img_bytes = (int)(S.sN * 2), out_bytes = H * W * 128;
+
+    // ---- cursors over the block's sequence of groups (all eight waves keep them: the trip count must agree) ----
+    const int it0 = blockIdx.x * p.ipb, it1 = min(it0 + p.ipb, p.items);
+    auto decode = [&](int item, int k) __attribute__((always_inline)) {
+        Cur c;
+        c.valid = item < it1; c.k = k;
+        item = min(item, it1 - 1);
+        c.item = item;
+        const int per = p.sx * p.sy;
+        c.img = item / per;
+        const int rem = item - c.img * per;
+        const int ys = rem / p.sx;
+        c.x0 = (rem - ys * p.sx) * TW;
+        c.ybeg = ys * p.seg;
+        const int rows = min(p.seg, H - c.ybeg);
+        c.S = (rows + 7) >> 3;
+        return c;
+    };
+    auto advance = [&](const Cur& c) __attribute__((always_inline)) {
+        if (!c.valid) return c;
+        if (c.k < c.S) { Cur n = c; n.k = c.k + 1; return n; }
+        return decode(c.item + 1, 0);
+    };
+    Cur cl = decode(it0, 0);
+    Cur cw = cl, cc = cl, cp = cl;
+    cw.valid = cc.valid = cp.valid = 0;
+    bool pend = false;
+
+    const int frA = l31 * PITCH + lh * 16 + 4 * wm * ROWB;
+    const int frB = l31 * PITCH + lh * 16 + (4 * wm - 8) * ROWB;
+    const bool hiB = wm == 1;
+
+    if (!producer) {
+        // =================================== consumer ===================================
+        bf16x8 Wr[9][4];
+        {
+            const __bf16* Wp = (const __bf16*)a.W;
+            const bool wflip = a.dstep < 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int wt = wflip ? 8 - tap : tap;
+                    Wr[tap][ks] = *(const bf16x8*)(Wp + (((long)wt * 8 + 2 * ks + lh) * 64 + 32 * wn + l31) * 8);
+                }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(Wr[tap][ks]));
+        }
+        int rowaddr[6];
+        f32x16 acc[2];
+        // (reading the next half-step's first two fragment groups across the barrier -- legal: they only touch ring rows complete
+        // at the last B2 -- shortened the stamped half-steps by 2-5 % and LENGTHENED the un-stamped launch by 8 %: not kept)
+        auto half = [&](auto half_c) __attribute__((always_inline)) {
+            constexpr int HF = decltype(half_c)::value;
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            bf16x8 pf[3][4];
+            auto read_group = [&](int gg) __attribute__((always_inline)) {      // (dx, ks) = (gg / 4, gg % 4)
+                if (gg < 12) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pf[gg % 3][q] = *(const bf16x8*)(ring + rowaddr[2 * HF + q] + (gg / 4) * PITCH + (gg % 4) * 32);
+                }
+            };
+            // the reads run two groups (384 MFMA cycles) ahead: one group is less than an LDS round trip under this load
+            read_group(0); read_group(1);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                read_group(g + 2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)       // (the first product of an accumulator takes the constant 0 as C: no zeroing pass)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[dy * 3 + g / 4][g % 4], pf[g % 3][i + dy], (g == 0 && dy == 0) ? zero16 : acc[i], 0, 0, 0);
+            }
+            // park the half's rows (bf16) in the wave's scratch: lane = pixel, 4 consecutive channels per register quad
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * HF + ii;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 h;
+                    h[0] = (__bf16)acc[ii][4 * g]; h[1] = (__bf16)acc[ii][4 * g + 1];
+                    h[2] = (__bf16)acc[ii][4 * g + 2]; h[3] = (__bf16)acc[ii][4 * g + 3];
+                    *(bf16x4*)(Ew + (i * 32 + l31) * EPITCH + (8 * g + 4 * lh) * 2) = h;
+                }
+            }
+        };
+        auto iteration = [&](auto m_c) __attribute__((always_inline)) {
+            constexpr int bA = decltype(m_c)::value, bB = bA == 2 ? 0 : bA + 1;
+            rowaddr[0] = frA + bA * BANKB; rowaddr[1] = rowaddr[0] + ROWB; rowaddr[2] = rowaddr[0] + 2 * ROWB; rowaddr[3] = rowaddr[0] + 3 * ROWB;
+            rowaddr[4] = hiB ? frB + bB * BANKB + 4 * ROWB : frA + bA * BANKB + 4 * ROWB;
+            rowaddr[5] = rowaddr[4] + ROWB;
+            const Cur cn = advance(cl);
+            if constexpr (DIAG) dt0 = stamp();
+            half(ic<0>{});
+            if constexpr (DIAG) { dt1 = stamp(); dsum[0] += dt1 - dt0; dt0 = dt1; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // B1
+            asm volatile("" ::: "memory");
+            if constexpr (DIAG) { dt1 = stamp(); dsum[1] += dt1 - dt0; dt0 = dt1; }
+            half(ic<1>{});
+            if constexpr (DIAG) { dt1 = stamp(); dsum[2] += dt1 - dt0; dt0 = dt1; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // B2
+            asm volatile("" ::: "memory");
+            if constexpr (DIAG) { dt1 = stamp(); dsum[3] += dt1 - dt0; dsum[5] += 1; }
+            cp = cc; pend = cc.valid && cc.k >= 1;
+            cc = cw; cw = cl; cl = cn;
+        };
+        while (true) {
+            if (!(cl.valid | cw.valid | cc.valid | (int)pend)) break;
+            iteration(ic<0>{});
+            if (!(cl.valid | cw.valid | cc.valid | (int)pend)) break;
+            iteration(ic<1>{});
+            if (!(cl.valid | cw.valid | cc.valid | (int)pend)) break;
+            iteration(ic<2>{});
+        }
+        if constexpr (DIAG) {
+            if (lane == 0 && p.dbg) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p.dbg[((long)blockIdx.x * 8 + wave8) * 8 + k] = dsum[k];
+            }
+        }
+        return;
+    }
+
+    // =================================== producer ===================================
+    int goffb[NR], rp[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int q = tp + 256 * i, hp = q >> 3, r = hp / HW, px = hp - r * HW;
+        goffb[i] = (r * sH + px * sW + (tp & 7) * 8) * 2;
+        rp[i] = r << 8 | px;
+    }
+    const int loff0 = (tp >> 3) * PITCH + (tp & 7) * 16;
+    const int wd8_dummy = RINGB + 4 * EWAVE + (tp & 127) * 16;
+    const int pp = lane >> 2, o = lane & 3;
+    const int st_lane = (pp * 64 + 32 * wn + 8 * o) * 2;
+    u32x4 stg[NR];
+    unsigned okmW = 0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) stg[i] = (u32x4){0u, 0u, 0u, 0u};
+    f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+    const float a_floor = S.relu ? 0.f : -__builtin_inff();
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    unsigned offL[NR], okmL = 0;
+    unsigned xokm = 0;
+    int xok_x0 = -(1 << 20);
+    auto offsets_one = [&](const Cur& c, int i) __attribute__((always_inline)) {
+        const int y0g = c.ybeg - 1 + 8 * c.k;
+        const int nrows = !c.valid ? 0 : (c.k == c.S ? 2 : 8);
+        const int lo = max(0, -y0g), hi = min(nrows, H - y0g);
+        const unsigned ymask = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+        const int gbase = (y0g * sH + (c.x0 - 1) * sW) * 2;
+        const unsigned ok = (ymask >> (rp[i] >> 8)) & (xokm >> i) & 1u;
+        offL[i] = (unsigned)(gbase + goffb[i]) | ((ok ^ 1u) << 31);
+        okmL = (okmL & ~(1u << i)) | (ok << i);
+    };
+    auto xok_update = [&](const Cur& c) __attribute__((always_inline)) {
+        if (c.x0 != xok_x0) {
+            xok_x0 = c.x0;
+            xokm = 0;
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+                xokm |= ((unsigned)(i < NR - 1 || tp < 128) & (unsigned)((unsigned)(c.x0 - 1 + (rp[i] & 255)) < (unsigned)W)) << i;
+        }
+    };
+    auto xform = [&](u32x4 raw, bool ok) __attribute__((always_inline)) {
+        if constexpr (!XF) return raw;
+        const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+        f32x4 lo = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]} * sc0 + sh0;
+        f32x4 hi = (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]} * sc1 + sh1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = __builtin_amdgcn_fmed3f(lo[e], a_floor, __builtin_inff());
+            hi[e] = __builtin_amdgcn_fmed3f(hi[e], a_floor, __builtin_inff());
+        }
+        bf16x8 h;
+        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+        u32x4 u = __builtin_bit_cast(u32x4, h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = ok ? u[e] : 0u;
+        return u;
+    };
+    auto load_consts = [&](const Cur& c) __attribute__((always_inline)) {
+        if constexpr (XF) {
+            if (S.scale) {
+                const long go = S.gN > 0 ? (long)(c.img / S.gN) * S.gstride : 0;
+                const float* scp = S.scale + go + 8 * (tp & 7);
+                const float* shp = S.shift + go + 8 * (tp & 7);
+                sc0 = *(const f32x4*)scp; sc1 = *(const f32x4*)(scp + 4);
+                sh0 = *(const f32x4*)shp; sh1 = *(const f32x4*)(shp + 4);
+            }
+        }
+    };
+    // the parked rows of a half -> global (16 px x 64 B per store instruction) + statistics of the stored values
+    auto epi_B = [&](int HF, int tt, const Cur& c, bool live) __attribute__((always_inline)) {
+        const int i = 2 * HF + (tt >> 1), px = 16 * (tt & 1) + pp;
+        const int y = c.ybeg + 8 * (c.k - 1) + 4 * wm + i;
+        const int ylim = min(c.ybeg + p.seg, H);
+        u32x4 u = *(const u32x4*)(Ew + (i * 32 + px) * EPITCH + o * 16);
+        const bool inimg = live & (y < ylim) & (c.x0 + px < W);
+        const unsigned voff = (unsigned)(st_lane + (tt & 1) * 2048) | (inimg ? 0u : 0x80000000u);
+        __builtin_amdgcn_raw_buffer_store_b128(u, ro, voff, __builtin_amdgcn_readfirstlane(c.img * out_bytes + (y * W + c.x0) * 128), 0);
+        if constexpr (STAT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = inimg ? u[e] : 0u;
+            const bf16x8 v = __builtin_bit_cast(bf16x8, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s1[e] += f;
+                s2[e] += f * f;
+            }
+        }
+    };
+    auto stat_flush = [&](const Cur& c) __attribute__((always_inline)) {
+        if constexpr (STAT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int d = 4; d < 64; d <<= 1) {
+                    s1[e] += __shfl_xor(s1[e], d);
+                    s2[e] += __shfl_xor(s2[e], d);
+                }
+            }
+            if (lane < 4) {
+                float* row = a.stat + ((long)(c.item * 2 + wm) * 2) * 64 + 32 * wn + 8 * lane;
+                *(f32x4*)row = (f32x4){s1[0], s1[1], s1[2], s1[3]};
+                *(f32x4*)(row + 4) = (f32x4){s1[4], s1[5], s1[6], s1[7]};
+                *(f32x4*)(row + 64) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
+                *(f32x4*)(row + 68) = (f32x4){s2[4], s2[5], s2[6], s2[7]};
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+        }
+    };
+
+    load_consts(cl);
+    auto iteration = [&](auto m_c) __attribute__((always_inline)) {
+        constexpr int bA = decltype(m_c)::value, bW = bA == 0 ? 2 : bA - 1;
+        const bool live = cc.valid && cc.k >= 1;
+        char* wdst = ring + bW * BANKB + loff0;
+        char* wd8 = tp < 128 ? wdst + 8 * (32 * PITCH) : smem + wd8_dummy;
+        const Cur cn = advance(cl);
+        xok_update(cl);
+        const int in_soff = __builtin_amdgcn_readfirstlane(cl.img * img_bytes);
+        auto stage = [&](int i) __attribute__((always_inline)) {
+            *(u32x4*)(i < NR - 1 ? wdst + i * (32 * PITCH) : wd8) = xform(stg[i], (okmW >> i) & 1u);
+            stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, offL[i], in_soff, 0);
+        };
+        // ---- consumers' half 0: the owed stores of the previous step's half 1, then the staging of the next group ----
+        if constexpr (DIAG) dt0 = stamp();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) epi_B(1, tt, cp, pend);
+        if (pend && cp.k == cp.S) stat_flush(cp);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) offsets_one(cl, i);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) stage(i);
+        if constexpr (DIAG) { dt1 = stamp(); dsum[0] += dt1 - dt0; dt0 = dt1; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // B1: half 0 of this step is parked
+        asm volatile("" ::: "memory");
+        if constexpr (DIAG) { dt1 = stamp(); dsum[1] += dt1 - dt0; dt0 = dt1; }
+        // ---- consumers' half 1: the stores of half 0, the rest of the staging ----
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) epi_B(0, tt, cc, live);
+#pragma unroll
+        for (int i = 5; i < NR; ++i) stage(i);
+        okmW = okmL;
+        load_consts(cl);
+        if constexpr (DIAG) { dt1 = stamp(); dsum[2] += dt1 - dt0; dt0 = dt1; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // B2: half 1 parked; the ring bank written above is complete
+        asm volatile("" ::: "memory");
+        if constexpr (DIAG) { dt1 = stamp(); dsum[3] += dt1 - dt0; dsum[5] += 1; }
+        cp = cc; pend = live;
+        cc = cw; cw = cl; cl = cn;
+    };
+    while (true) {
+        if (!(cl.valid | cw.valid | cc.valid | (int)pend)) break;
+        iteration(ic<0>{});
+        if (!(cl.valid | cw.valid | cc.valid | (int)pend)) break;
+        iteration(ic<1>{});
+        if (!(cl.valid | cw.valid | cc.valid | (int)pend)) break;
+        iteration(ic<2>{});
+    }
+    if constexpr (DIAG) {
+        if (lane == 0 && p.dbg) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p.dbg[((long)blockIdx.x * 8 + wave8) * 8 + k] = dsum[k];
+        }
+    }
+}
+
 // segments per strip: whole waves of blocks over the 256 CUs, few bubbles (one staging-only iteration per item)
 WsPlan ws_plan(const IgemmArgs& a) {
     WsPlan p;
@@ -775,6 +1118,30 @@ int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     // (forward: 0.394 vs 0.339 ms) -- its per-wave address / cursor / wait instructions double per SIMD while a 16x16x32 MFMA
     // hides half as many of them.  debug flag bit 1 forces four waves everywhere, bit 2 eight waves everywhere.
     const bool eight = (g_debug_flags & 4) ? true : (g_debug_flags & 2) ? false : !(xf || a.stat);
+    // consumer / producer waves (round 3, second form): debug flag bit 4 forces it off, bit 5 on everywhere
+    const bool cpw = (g_debug_flags & 32) ? true : (g_debug_flags & (16 | 4 | 2)) ? false : true;
+    if (cpw && p.dbg) {          // stamped build: [block][wave 0..7][8] u64 (0/2: work of the two segments, 1/3: waits at B1 / B2, 5: iterations)
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<true, true, true>, LDSBCP, "conv3x3_ws64cp_bf16 (diag)"));
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<false, false, true>, LDSBCP, "conv3x3_ws64cp_bf16 (diag)"));
+        if (xf) hipLaunchKernelGGL((conv3x3_ws64cp_kernel<true, true, true>), dim3(grid), dim3(512), LDSBCP, st, a, p);
+        else hipLaunchKernelGGL((conv3x3_ws64cp_kernel<false, false, true>), dim3(grid), dim3(512), LDSBCP, st, a, p);
+        USTRUN_LAUNCH_CHECK("conv3x3_ws64cp_bf16 (diag)");
+        return 0;
+    }
+    if (cpw && !p.dbg) {
+        set_last_variant(0x57530000 | 0x200 | (xf ? 1 : 0));       // 'WS' | consumer/producer | XF
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<true, true>, LDSBCP, "conv3x3_ws64cp_bf16"));
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<true, false>, LDSBCP, "conv3x3_ws64cp_bf16"));
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<false, true>, LDSBCP, "conv3x3_ws64cp_bf16"));
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<false, false>, LDSBCP, "conv3x3_ws64cp_bf16"));
+        const bool stat_ = a.stat != nullptr;
+        if (xf && stat_) hipLaunchKernelGGL((conv3x3_ws64cp_kernel<true, true>), dim3(grid), dim3(512), LDSBCP, st, a, p);
+        else if (xf) hipLaunchKernelGGL((conv3x3_ws64cp_kernel<true, false>), dim3(grid), dim3(512), LDSBCP, st, a, p);
+        else if (stat_) hipLaunchKernelGGL((conv3x3_ws64cp_kernel<false, true>), dim3(grid), dim3(512), LDSBCP, st, a, p);
+        else hipLaunchKernelGGL((conv3x3_ws64cp_kernel<false, false>), dim3(grid), dim3(512), LDSBCP, st, a, p);
+        USTRUN_LAUNCH_CHECK("conv3x3_ws64cp_bf16");
+        return 0;
+    }
     if (eight && p.dbg) {                        // stamped build of the eight-wave kernel: [block][wave 0..7][8] u64
         USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64x8_kernel<true, true, true>, LDSB8, "conv3x3_ws64x8_bf16 (diag)"));
         USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64x8_kernel<false, false, true>, LDSB8, "conv3x3_ws64x8_bf16 (diag)"));
