@@ -778,10 +778,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
         c.S = (rows + 7) >> 3;
         return c;
     };
+    // the next group: same item, or the next item by counting (strip, segment, image) up -- no divisions on the producers'
+    // path between two barriers (the division-based decode runs once, for the block's first item)
     auto advance = [&](const Cur& c) __attribute__((always_inline)) {
-        if (!c.valid) return c;
-        if (c.k < c.S) { Cur n = c; n.k = c.k + 1; return n; }
-        return decode(c.item + 1, 0);
+        Cur n = c;
+        const bool same = c.k < c.S;
+        const int item = min(c.item + 1, it1 - 1);
+        const bool has = c.item + 1 < it1;
+        int x0 = c.x0 + TW, ybeg = c.ybeg, img = c.img;
+        const bool wrapx = x0 >= p.sx * TW;
+        x0 = wrapx ? 0 : x0;
+        ybeg = wrapx ? ybeg + p.seg : ybeg;
+        const bool wrapy = ybeg >= p.sy * p.seg;
+        ybeg = wrapy ? 0 : ybeg;
+        img = wrapy ? img + 1 : img;
+        const int rows = min(p.seg, H - ybeg);
+        if (same) n.k = c.k + 1;
+        else if (has) { n.item = item; n.img = img; n.x0 = x0; n.ybeg = ybeg; n.S = (rows + 7) >> 3; n.k = 0; }
+        else { n.valid = 0; n.k = 0; }
+        return c.valid ? n : c;
     };
     Cur cl = decode(it0, 0);
     Cur cw = cl, cc = cl, cp = cl;
@@ -1002,10 +1017,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
         }
     };
 
-    load_consts(cl);
     auto iteration = [&](auto m_c) __attribute__((always_inline)) {
         constexpr int bA = decltype(m_c)::value, bW = bA == 0 ? 2 : bA - 1;
         const bool live = cc.valid && cc.k >= 1;
+        // the pass constants of the group whose rows sit in stg (fetched last iteration): loaded HERE and used below, inside one
+        // iteration.  Loaded at the end of the previous iteration (as the four-wave kernel does) they are loop-carried registers,
+        // and the copies hipcc places at the loop's back edge wait vmcnt(0) -- for the row fetches just issued: ~2000 cycles per
+        // iteration that no stamp inside the segments showed
+        load_consts(cw);
         char* wdst = ring + bW * BANKB + loff0;
         char* wd8 = tp < 128 ? wdst + 8 * (32 * PITCH) : smem + wd8_dummy;
         const Cur cn = advance(cl);
@@ -1035,7 +1054,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
 #pragma unroll
         for (int i = 5; i < NR; ++i) stage(i);
         okmW = okmL;
-        load_consts(cl);
         if constexpr (DIAG) { dt1 = stamp(); dsum[2] += dt1 - dt0; dt0 = dt1; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // B2: half 1 parked; the ring bank written above is complete
