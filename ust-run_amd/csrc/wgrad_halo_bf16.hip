@@ -501,6 +501,276 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
     }
 }
 
+
+// ---- round 3: the same tiles with buffer-addressed LDS-DMA ---------------------------------------------------------
+// The kernel above spends 463 of its 833 loop instructions per tile (72 MFMAs) on the ten transfers' addresses: 64-bit
+// pointer arithmetic, per-item bounds tests behind exec-mask branches and the zero page.  Here the tile's two base
+// addresses are wave-uniform (a cursor in SGPRs, no divisions) and go into two buffer resources; an item is a per-lane
+// CONSTANT byte offset (tile-invariant), padding is the buffer's own range check (offset bit 31 set -> the transfer
+// writes zeros), and tiles whose halo lies inside the image -- most of them -- skip the per-item tests altogether.
+// The activation pass drops its masks on such tiles too, and takes ReLU on the rounded bf16 pairs (v_pk_max_i16 against
+// zero: the same values as max in f32 before rounding, half the instructions).
+__device__ __forceinline__ void dma16_buf(int voff, __amdgpu_buffer_rsrc_t rs, const char* lds_wave_base) {
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rs), "s"(m) : "memory", "m0");
+}
+
+template <int T3>
+__global__ __launch_bounds__(256, 2) void wgrad_halo4_bf16_kernel(const WgradArgs a, const int ntn, const int tiles_x,
+                                                                  const int tiles_y, const int tiles_per) {
+    typedef H3<T3> G;
+    constexpr int A3IT = G::AIT, D3IT = G::DIT, D3SLOTS = G::DSLOTS, A3TILE = G::ATILE, STAGE3 = G::STAGE, NBUF = G::NBUF;
+    constexpr int HPX = G::HPX;
+    constexpr int OOB = (int)0x80000000;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF x {activation tile [T3*16 px][128 B], dY patch [HPX px][128 B]}
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int nblk = gridDim.x, pairs = nblk / a.ksplit;          // XCD-contiguous slices, as above
+    int lin;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int slice = lin / pairs, pair = lin - slice * pairs;
+    const int mtile = pair / ntn, ntile = pair % ntn;
+    const int ci0 = mtile * 64, co0 = ntile * 64;
+    const int ttotal = a.N * tiles_y * tiles_x;
+    const int tbeg = slice * tiles_per;
+    const int tend = min(ttotal, tbeg + tiles_per);
+
+    // the 64 input channels of a block come from ONE source (source widths are multiples of 64)
+    const bool second = (a.nsrc == 2 && ci0 >= a.src[0].C);
+    const SrcDev S = pick_src(a.src[0], a.src[1], second);
+    const int cl0 = ci0 - (second ? a.src[0].C : 0);
+    const bool aff = S.scale != nullptr;
+    const bool xf = aff || S.relu;
+    const int apx = tid >> 3;
+    const int agl = (tid & 7) ^ (((apx >> 1) & 1) << 2);
+    f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
+    int cur_grp = -1;
+    auto load_consts = [&](int img) {
+        const int grp = S.gN > 0 ? img / S.gN : 0;
+        if (aff && grp != cur_grp) {
+            const long o = (long)grp * (S.gN > 0 ? S.gstride : 0) + cl0 + 8 * agl;
+            asc0 = *(const f32x4*)(S.scale + o); asc1 = *(const f32x4*)(S.scale + o + 4);
+            ash0 = *(const f32x4*)(S.shift + o); ash1 = *(const f32x4*)(S.shift + o + 4);
+            cur_grp = grp;
+        }
+    };
+    // tile-invariant per-lane byte offsets from the tile's base: activation item i = pixel apx + 32 i (row 2 i + (apx >> 4),
+    // column apx & 15), channel group agl; dY item i = slot tid + 256 i of the patch
+    const int sH2 = (int)S.sH * 2, sW2 = (int)S.sW * 2;
+    int aoff[A3IT];
+#pragma unroll
+    for (int i = 0; i < A3IT; ++i) aoff[i] = (2 * i + (apx >> 4)) * sH2 + (apx & 15) * sW2 + (cl0 + 8 * agl) * 2;
+    int droff[D3IT], dhyx[D3IT];
+#pragma unroll
+    for (int i = 0; i < D3IT; ++i) {
+        const int slot = tid + 256 * i, hp = slot >> 3;
+        const int gl = (slot & 7) ^ (((hp >> 1) & 1) << 2);
+        const int hy = hp / HW2, hx = hp - hy * HW2;
+        const bool v = hp < HPX;
+        droff[i] = v ? ((hy * a.dyW + hx) * a.Cout + 8 * gl) * 2 : OOB;
+        dhyx[i] = v ? ((hy << 8) | hx) : 0xffff;
+    }
+    const bool w4 = 256 * (D3IT - 1) + wave * 64 < D3SLOTS;       // does this wave issue the last dY piece?
+    const char* const sbytes = (const char*)S.ptr;
+    const char* const dbytes = (const char*)a.dy + 2 * co0;
+    const long sN2 = S.sN * 2, dN2 = (long)a.dyH * a.dyW * a.Cout * 2;
+    const int dW2 = a.dyW * a.Cout * 2, dP2 = a.Cout * 2;
+
+    // cursor of the next tile to issue (wave-uniform)
+    int q_img, q_y0, q_x0;
+    {
+        q_img = tbeg / (tiles_y * tiles_x);
+        const int rem = tbeg - q_img * tiles_y * tiles_x;
+        q_y0 = (rem / tiles_x) * T3; q_x0 = (rem % tiles_x) * TW;
+    }
+    // all transfers of the cursor's tile -> stage buffer; bit i of the result: activation item i lies in the source; bit 8: the
+    // whole activation tile does (no masks needed); bits 16..: the tile's image
+    auto issue_tile = [&](char* stage) {
+        const int img = q_img, y0 = q_y0, x0 = q_x0;
+        {
+            const char* dbase = dbytes + (long)img * dN2 + ((y0 - 1) * dW2 + (x0 - 1) * dP2);
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, 0x7fffffff, 0x00020000);
+            const bool inner = y0 >= 1 && y0 + T3 + 1 <= a.dyH && x0 >= 1 && x0 + TW + 1 <= a.dyW;
+            if (inner) {
+#pragma unroll
+                for (int i = 0; i < D3IT; ++i)
+                    if (i < D3IT - 1 || w4) dma16_buf(droff[i], rd, stage + A3TILE + (256 * i + wave * 64) * 16);
+            } else {
+#pragma unroll
+                for (int i = 0; i < D3IT; ++i) {
+                    if (i < D3IT - 1 || w4) {
+                        const unsigned ly = (unsigned)(y0 - 1 + (dhyx[i] >> 8)), lx = (unsigned)(x0 - 1 + (dhyx[i] & 0xff));
+                        const bool ok = ly < (unsigned)a.dyH && lx < (unsigned)a.dyW;      // slots beyond the patch: droff is OOB already
+                        dma16_buf(ok ? droff[i] : OOB, rd, stage + A3TILE + (256 * i + wave * 64) * 16);
+                    }
+                }
+            }
+        }
+        unsigned ok2;
+        {
+            const int ty = y0 - S.off_y, tx = x0 - S.off_x;
+            const char* abase = sbytes + (long)img * sN2 + (ty * sH2 + tx * sW2);
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, 0x7fffffff, 0x00020000);
+            const bool inner = ty >= 0 && ty + T3 <= S.LH && tx >= 0 && tx + TW <= S.LW;
+            if (inner) {
+                ok2 = 0x100u | ((1u << A3IT) - 1u);
+#pragma unroll
+                for (int i = 0; i < A3IT; ++i) dma16_buf(aoff[i], ra, stage + (256 * i + wave * 64) * 16);
+            } else {
+                ok2 = 0;
+#pragma unroll
+                for (int i = 0; i < A3IT; ++i) {
+                    const unsigned ly = (unsigned)(ty + 2 * i + (apx >> 4)), lx = (unsigned)(tx + (apx & 15));
+                    const bool ok = ly < (unsigned)S.LH && lx < (unsigned)S.LW;
+                    ok2 |= (ok ? 1u : 0u) << i;
+                    dma16_buf(ok ? aoff[i] : OOB, ra, stage + (256 * i + wave * 64) * 16);
+                }
+            }
+        }
+        ok2 |= (unsigned)img << 16;
+        q_x0 += TW;
+        if (q_x0 >= tiles_x * TW) {
+            q_x0 = 0; q_y0 += T3;
+            if (q_y0 >= tiles_y * T3) { q_y0 = 0; ++q_img; }
+        }
+        return ok2;
+    };
+    // BatchNorm affine + ReLU of this thread's items, in place (items outside the source stay zero)
+    auto act_item = [&](u32x4 r, bool relu) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, r);
+        const f32x4 lo = (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]} * asc0 + ash0;
+        const f32x4 hi = (f32x4){(float)b[4], (float)b[5], (float)b[6], (float)b[7]} * asc1 + ash1;
+        bf16x8 h;
+        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+        if (relu) {
+            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, h), z));
+        }
+        return __builtin_bit_cast(u32x4, h);
+    };
+    auto activate = [&](char* stage, unsigned ok2) {
+        if (!xf) return;
+        const bool inner = (ok2 >> 8) & 1u;
+#pragma unroll
+        for (int i0 = 0; i0 < A3IT; i0 += 2) {              // two items per LDS round trip (four would spill)
+            u32x4 r[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r[i] = *(const u32x4*)(stage + (tid + 256 * (i0 + i)) * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                u32x4 u = S.relu ? act_item(r[i], true) : act_item(r[i], false);
+                if (!inner) {
+                    const bool ok = (ok2 >> (i0 + i)) & 1u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) u[q] = ok ? u[q] : 0u;
+                }
+                *(u32x4*)(stage + (tid + 256 * (i0 + i)) * 16) = u;
+            }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int lrow = 8 * (lane >> 5) + ((lane & 15) >> 2), lcolb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    int abase, dbase4[4];
+    abase = lrow * RB3 + ((wi * 64 + lcolb) ^ (((lrow >> 1) & 1) << 6));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbase4[c] = A3TILE + lrow * RB3 + ((wj * 64 + lcolb) ^ ((((c + lrow) >> 1) & 1) << 6));
+
+    auto wait_all_but_one_tile = [&]() {
+        if (w4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + A3IT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT - 1 + A3IT) : "memory");
+    };
+    unsigned ok_q[3] = {0, 0, 0};
+    char* st[3] = {smem, smem + STAGE3, smem + (NBUF - 1) * STAGE3};
+    constexpr int PD = NBUF - 1;
+    if (tbeg < tend) {
+        ok_q[0] = issue_tile(st[0]);
+        load_consts(ok_q[0] >> 16);
+        if (PD == 2 && tbeg + 1 < tend) {
+            ok_q[1] = issue_tile(st[1]);
+            wait_all_but_one_tile();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        activate(st[0], ok_q[0]);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = tbeg; t < tend; ++t) {
+        const bool issue = t + PD < tend;
+        if (issue) ok_q[PD] = issue_tile(st[PD]);
+#pragma unroll
+        for (int h = 0; h < T3 / 4; ++h) {
+            const char* Ab = st[0] + abase;
+            bf16x8 af[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) af[r] = tr_frag3(Ab, (4 * h + r) * TW);
+            bf16x8 bq[2][3];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int k0 = 4 * h * HW2 + 2 - kw;
+                bq[0][kw] = tr_frag3(st[0] + dbase4[k0 & 3], k0);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                if (pr + 1 < 6) {
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int k0 = (4 * h + pr + 1) * HW2 + 2 - kw;
+                        bq[(pr + 1) & 1][kw] = tr_frag3(st[0] + dbase4[k0 & 3], k0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int r = pr + kh - 2;
+                        if (r >= 0 && r < 4)
+                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < tend) {
+            if (PD == 2 && issue) wait_all_but_one_tile();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            load_consts(ok_q[1] >> 16);
+            activate(st[1], ok_q[1]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (NBUF == 3) { char* tmp = st[0]; st[0] = st[1]; st[1] = st[2]; st[2] = tmp; ok_q[0] = ok_q[1]; ok_q[1] = ok_q[2]; }
+        else { char* tmp = st[0]; st[0] = st[1]; st[1] = tmp; st[2] = st[1]; ok_q[0] = ok_q[1]; }
+    }
+
+    float* slab = a.partials + (long)slice * 9 * a.Cin * a.Cout;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ci = ci0 + wi * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float* o = slab + ((long)co * a.Cin + ci) * 9;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) o[tap] = acc[tap][r];
+    }
+}
+
 }  // namespace
 
 bool wgrad_halo_supported(const WgradArgs& a) {
@@ -537,12 +807,25 @@ int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStr
     } else {
         WgradArgs b = a;
         b.ksplit = ksplit;
-        if (halo3_rows(a) == 8)
-            hipLaunchKernelGGL(wgrad_halo3_bf16_kernel<8>, dim3(grid.x * ksplit), block, H3<8>::NBUF * H3<8>::STAGE, st, b, a.Cout / 64,
-                               cdiv(a.Wb, TW), cdiv(a.Hb, 8), tiles_per);
-        else
-            hipLaunchKernelGGL(wgrad_halo3_bf16_kernel<4>, dim3(grid.x * ksplit), block, H3<4>::NBUF * H3<4>::STAGE, st, b, a.Cout / 64,
-                               cdiv(a.Wb, TW), cdiv(a.Hb, 4), tiles_per);
+        // buffer-addressed transfers (round 3) need 32-bit byte offsets inside one image of either operand
+        bool buf = !(g_debug_flags & 64) && (long)a.dyH * a.dyW * a.Cout * 2 < (1L << 31);
+        for (int i = 0; i < a.nsrc; ++i) buf = buf && a.src[i].sN * 2 < (1L << 31) && a.src[i].sH * 2 * 16 < (1L << 31);
+        if (buf) set_last_wgrad_variant(0x48100000 | (ksplit & 0xfff));
+        if (halo3_rows(a) == 8) {
+            if (buf)
+                hipLaunchKernelGGL(wgrad_halo4_bf16_kernel<8>, dim3(grid.x * ksplit), block, H3<8>::NBUF * H3<8>::STAGE, st, b, a.Cout / 64,
+                                   cdiv(a.Wb, TW), cdiv(a.Hb, 8), tiles_per);
+            else
+                hipLaunchKernelGGL(wgrad_halo3_bf16_kernel<8>, dim3(grid.x * ksplit), block, H3<8>::NBUF * H3<8>::STAGE, st, b, a.Cout / 64,
+                                   cdiv(a.Wb, TW), cdiv(a.Hb, 8), tiles_per);
+        } else {
+            if (buf)
+                hipLaunchKernelGGL(wgrad_halo4_bf16_kernel<4>, dim3(grid.x * ksplit), block, H3<4>::NBUF * H3<4>::STAGE, st, b, a.Cout / 64,
+                                   cdiv(a.Wb, TW), cdiv(a.Hb, 4), tiles_per);
+            else
+                hipLaunchKernelGGL(wgrad_halo3_bf16_kernel<4>, dim3(grid.x * ksplit), block, H3<4>::NBUF * H3<4>::STAGE, st, b, a.Cout / 64,
+                                   cdiv(a.Wb, TW), cdiv(a.Hb, 4), tiles_per);
+        }
     }
     USTRUN_LAUNCH_CHECK("wgrad_halo_bf16");
     return 0;
