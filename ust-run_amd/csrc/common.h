@@ -105,6 +105,7 @@ bool ws64_supported(const IgemmArgs& a);
 int ws64_stat_rows(const IgemmArgs& a);
 int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st);
 void ws64_set_debug_buffer(void* p);
+extern void* g_ws64_dbg;             // ustrun_debug_buffer: development builds with phase stamps write here
 extern int g_debug_flags;                  // ustrun_debug_flags: bit 0 = keep the 64 -> 64 layers on the tiled kernel
 bool convT_fwd_supported(const IgemmArgs& a);
 bool convT_dgrad_supported(const IgemmArgs& a);

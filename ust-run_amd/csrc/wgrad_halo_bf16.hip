@@ -771,6 +771,309 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo4_bf16_kernel(const WgradArg
     }
 }
 
+
+// ---- round 3: two wave groups in opposite phases ("ping-pong") ------------------------------------------------------
+// Two 256-thread blocks per CU run the kernel above in step with each other: both multiply at the same time (sharing
+// the matrix pipe), both compute addresses / activate at the same time (pipe idle) -- one block per CU alone reaches
+// 79 % of the pair's rate (profiles/r03_wgrad_occupancy.log).  Here ONE 512-thread block per CU holds two groups of
+// four waves, each with its own accumulators, its own two stage buffers and every other tile of the block's range;
+// block-wide barriers separate PHASES, and in every phase one group multiplies its current tile (72 MFMAs per wave)
+// while the other issues the transfers of its tile after next, waits for its next tile (issued two phases = one whole
+// period earlier) and activates it.  The matrix pipe of a SIMD is fed by one wave at a time, the other wave's VALU /
+// SALU / waiting hides behind it.  The groups' accumulators are summed through LDS at the end (group 0 + group 1, a
+// fixed order): half as many slabs as before for the same tiles per wave.
+__device__ __forceinline__ unsigned long long stamp_pp() {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+// DIAG: phase stamps per wave into dbg[block][wave 0..7][8] (0: multiplying, 1: barrier wait after it, 2: preparing, 3: barrier
+// wait after it, 4: phases without work, 5: tiles multiplied, 6: of 2, the wait for the
+// tile's transfers, 7: of 2, issuing the next tile's transfers); a development build, never launched by the product
+template <bool DIAG>
+__global__ __launch_bounds__(512, 1) void wgrad_halo_pp_bf16_kernel(const WgradArgs a, const int ntn, const int tiles_x,
+                                                                    const int tiles_y, const int tiles_per,
+                                                                    unsigned long long* __restrict__ dbg) {
+    constexpr int T3 = 8;
+    typedef H3<T3> G;
+    constexpr int A3IT = G::AIT, D3IT = G::DIT, D3SLOTS = G::DSLOTS, A3TILE = G::ATILE, STAGE3 = G::STAGE;
+    constexpr int HPX = G::HPX;
+    constexpr int OOB = (int)0x80000000;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 groups x 2 x {activation tile, dY patch}
+    const int lane = threadIdx.x & 63, gt = threadIdx.x & 255;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave8 >> 2, wave = wave8 & 3;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int nblk = gridDim.x, pairs = nblk / a.ksplit;
+    int lin;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int slice = lin / pairs, pair = lin - slice * pairs;
+    const int mtile = pair / ntn, ntile = pair % ntn;
+    const int ci0 = mtile * 64, co0 = ntile * 64;
+    const int ttotal = a.N * tiles_y * tiles_x;
+    const int tbeg = slice * tiles_per;
+    const int tend = min(ttotal, tbeg + tiles_per);
+    const int ntl = max(tend - tbeg, 0);
+    const int nk = (ntl + 1 - grp) >> 1;                            // this group's tiles: tbeg + grp + 2 k
+    const int pend = max(2 * (((ntl + 1) >> 1) - 1), 2 * ((ntl >> 1) - 1) + 1);     // last phase with a multiplication
+
+    const bool second = (a.nsrc == 2 && ci0 >= a.src[0].C);
+    const SrcDev S = pick_src(a.src[0], a.src[1], second);
+    const int cl0 = ci0 - (second ? a.src[0].C : 0);
+    const bool aff = S.scale != nullptr;
+    const bool xf = aff || S.relu;
+    const int apx = gt >> 3;
+    const int agl = (gt & 7) ^ (((apx >> 1) & 1) << 2);
+    f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
+    int cur_grp = -1;
+    auto load_consts = [&](int img) {
+        const int g = S.gN > 0 ? img / S.gN : 0;
+        if (aff && g != cur_grp) {
+            const long o = (long)g * (S.gN > 0 ? S.gstride : 0) + cl0 + 8 * agl;
+            asc0 = *(const f32x4*)(S.scale + o); asc1 = *(const f32x4*)(S.scale + o + 4);
+            ash0 = *(const f32x4*)(S.shift + o); ash1 = *(const f32x4*)(S.shift + o + 4);
+            cur_grp = g;
+        }
+    };
+    const int sH2 = (int)S.sH * 2, sW2 = (int)S.sW * 2;
+    int aoff[A3IT];
+#pragma unroll
+    for (int i = 0; i < A3IT; ++i) aoff[i] = (2 * i + (apx >> 4)) * sH2 + (apx & 15) * sW2 + (cl0 + 8 * agl) * 2;
+    int droff[D3IT], dhyx[D3IT];
+#pragma unroll
+    for (int i = 0; i < D3IT; ++i) {
+        const int slot = gt + 256 * i, hp = slot >> 3;
+        const int gl = (slot & 7) ^ (((hp >> 1) & 1) << 2);
+        const int hy = hp / HW2, hx = hp - hy * HW2;
+        const bool v = hp < HPX;
+        droff[i] = v ? ((hy * a.dyW + hx) * a.Cout + 8 * gl) * 2 : OOB;
+        dhyx[i] = v ? ((hy << 8) | hx) : 0xffff;
+    }
+    const bool w4 = 256 * (D3IT - 1) + wave * 64 < D3SLOTS;
+    const char* const sbytes = (const char*)S.ptr;
+    const char* const dbytes = (const char*)a.dy + 2 * co0;
+    const long sN2 = S.sN * 2, dN2 = (long)a.dyH * a.dyW * a.Cout * 2;
+    const int dW2 = a.dyW * a.Cout * 2, dP2 = a.Cout * 2;
+
+    int q_img, q_y0, q_x0;                                          // cursor of the group's next tile to issue
+    {
+        const int t0 = tbeg + grp;
+        q_img = t0 / (tiles_y * tiles_x);
+        const int rem = t0 - q_img * tiles_y * tiles_x;
+        q_y0 = (rem / tiles_x) * T3; q_x0 = (rem % tiles_x) * TW;
+    }
+    auto issue_tile = [&](char* stage) {
+        const int img = q_img, y0 = q_y0, x0 = q_x0;
+        {
+            const char* dbase = dbytes + (long)img * dN2 + ((y0 - 1) * dW2 + (x0 - 1) * dP2);
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, 0x7fffffff, 0x00020000);
+            const bool inner = y0 >= 1 && y0 + T3 + 1 <= a.dyH && x0 >= 1 && x0 + TW + 1 <= a.dyW;
+            if (inner) {
+#pragma unroll
+                for (int i = 0; i < D3IT; ++i)
+                    if (i < D3IT - 1 || w4) dma16_buf(droff[i], rd, stage + A3TILE + (256 * i + wave * 64) * 16);
+            } else {
+#pragma unroll
+                for (int i = 0; i < D3IT; ++i) {
+                    if (i < D3IT - 1 || w4) {
+                        const unsigned ly = (unsigned)(y0 - 1 + (dhyx[i] >> 8)), lx = (unsigned)(x0 - 1 + (dhyx[i] & 0xff));
+                        const bool ok = ly < (unsigned)a.dyH && lx < (unsigned)a.dyW;
+                        dma16_buf(ok ? droff[i] : OOB, rd, stage + A3TILE + (256 * i + wave * 64) * 16);
+                    }
+                }
+            }
+        }
+        unsigned ok2;
+        {
+            const int ty = y0 - S.off_y, tx = x0 - S.off_x;
+            const char* abase = sbytes + (long)img * sN2 + (ty * sH2 + tx * sW2);
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, 0x7fffffff, 0x00020000);
+            const bool inner = ty >= 0 && ty + T3 <= S.LH && tx >= 0 && tx + TW <= S.LW;
+            if (inner) {
+                ok2 = 0x100u | ((1u << A3IT) - 1u);
+#pragma unroll
+                for (int i = 0; i < A3IT; ++i) dma16_buf(aoff[i], ra, stage + (256 * i + wave * 64) * 16);
+            } else {
+                ok2 = 0;
+#pragma unroll
+                for (int i = 0; i < A3IT; ++i) {
+                    const unsigned ly = (unsigned)(ty + 2 * i + (apx >> 4)), lx = (unsigned)(tx + (apx & 15));
+                    const bool ok = ly < (unsigned)S.LH && lx < (unsigned)S.LW;
+                    ok2 |= (ok ? 1u : 0u) << i;
+                    dma16_buf(ok ? aoff[i] : OOB, ra, stage + (256 * i + wave * 64) * 16);
+                }
+            }
+        }
+        ok2 |= (unsigned)img << 16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                               // the group's next tile is two tiles on
+            q_x0 += TW;
+            if (q_x0 >= tiles_x * TW) {
+                q_x0 = 0; q_y0 += T3;
+                if (q_y0 >= tiles_y * T3) { q_y0 = 0; ++q_img; }
+            }
+        }
+        return ok2;
+    };
+    auto act_item = [&](u32x4 r, bool relu) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, r);
+        const f32x4 lo = (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]} * asc0 + ash0;
+        const f32x4 hi = (f32x4){(float)b[4], (float)b[5], (float)b[6], (float)b[7]} * asc1 + ash1;
+        bf16x8 h;
+        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
+        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+        if (relu) {
+            const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, h), z));
+        }
+        return __builtin_bit_cast(u32x4, h);
+    };
+    auto activate = [&](char* stage, unsigned ok2) {
+        if (!xf) return;
+        const bool inner = (ok2 >> 8) & 1u;
+        u32x4 r[A3IT];
+#pragma unroll
+        for (int i = 0; i < A3IT; ++i) r[i] = *(const u32x4*)(stage + (gt + 256 * i) * 16);       // one LDS round trip
+#pragma unroll
+        for (int i = 0; i < A3IT; ++i) {
+            u32x4 u = S.relu ? act_item(r[i], true) : act_item(r[i], false);
+            if (!inner) {
+                const bool ok = (ok2 >> i) & 1u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) u[q] = ok ? u[q] : 0u;
+            }
+            *(u32x4*)(stage + (gt + 256 * i) * 16) = u;
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int lrow = 8 * (lane >> 5) + ((lane & 15) >> 2), lcolb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    int abase, dbase4[4];
+    abase = lrow * RB3 + ((wi * 64 + lcolb) ^ (((lrow >> 1) & 1) << 6));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbase4[c] = A3TILE + lrow * RB3 + ((wj * 64 + lcolb) ^ ((((c + lrow) >> 1) & 1) << 6));
+
+    auto multiply_tile = [&](const char* stage) {
+#pragma unroll
+        for (int h = 0; h < T3 / 4; ++h) {
+            const char* Ab = stage + abase;
+            bf16x8 af[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) af[r] = tr_frag3(Ab, (4 * h + r) * TW);
+            bf16x8 bq[2][3];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int k0 = 4 * h * HW2 + 2 - kw;
+                bq[0][kw] = tr_frag3(stage + dbase4[k0 & 3], k0);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                if (pr + 1 < 6) {
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int k0 = (4 * h + pr + 1) * HW2 + 2 - kw;
+                        bq[(pr + 1) & 1][kw] = tr_frag3(stage + dbase4[k0 & 3], k0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int r = pr + kh - 2;
+                        if (r >= 0 && r < 4)
+                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto wait_all_but_one_tile = [&]() {
+        if (w4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT + A3IT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D3IT - 1 + A3IT) : "memory");
+    };
+
+    char* stC = smem + grp * 2 * STAGE3;           // the group's current tile (being activated, then multiplied)
+    char* stN = stC + STAGE3;                      // the tile after it (in flight)
+    unsigned okC = 0, okN = 0;
+    if (nk > 0) okC = issue_tile(stC);
+    unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, dt0 = 0, dt1 = 0, dsum6 = 0, dsum7 = 0;
+#pragma unroll 1
+    for (int p = -1; p <= pend; ++p) {
+        int role = 4;
+        if constexpr (DIAG) dt0 = stamp_pp();
+        if ((p & 1) == grp) {
+            const int k = p >> 1;
+            if (k >= 0 && k < nk) {
+                multiply_tile(stC);
+                char* tmp = stC; stC = stN; stN = tmp;
+                okC = okN;
+                role = 0;
+                if constexpr (DIAG) ++dsum[5];
+            }
+        } else {
+            const int k = (p + 1) >> 1;            // prepare the group's tile k for the next phase
+            if (k < nk) {
+                const bool more = k + 1 < nk;
+                unsigned long long ta = 0, tb = 0;
+                if (more) okN = issue_tile(stN);
+                if constexpr (DIAG) ta = stamp_pp();
+                if (more) wait_all_but_one_tile();
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (DIAG) tb = stamp_pp();
+                load_consts(okC >> 16);
+                activate(stC, okC);
+                role = 2;
+                if constexpr (DIAG) { dsum6 += tb - ta; dsum7 += ta - dt0; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (DIAG) { dt1 = stamp_pp(); dsum[role] += dt1 - dt0; }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (DIAG) { if (role != 4) dsum[role + 1] += stamp_pp() - dt1; }
+    }
+    if constexpr (DIAG) {
+        if (lane == 0 && dbg)
+            for (int k = 0; k < 8; ++k) dbg[((long)blockIdx.x * 8 + wave8) * 8 + k] = k < 6 ? dsum[k] : k == 6 ? dsum6 : dsum7;
+    }
+
+    // group 1's accumulators -> LDS, group 0 adds them to its own and writes the slab
+    float* red = (float*)smem;
+    if (grp == 1) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((tap * 16 + r) * 4 + wave) * 64 + lane] = acc[tap][r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+        float* slab = a.partials + (long)slice * 9 * a.Cin * a.Cout;
+        const int l31 = lane & 31, lh = lane >> 5;
+        const int ci = ci0 + wi * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float* o = slab + ((long)co * a.Cin + ci) * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) o[tap] = acc[tap][r] + red[((tap * 16 + r) * 4 + wave) * 64 + lane];
+        }
+    }
+}
+
 }  // namespace
 
 bool wgrad_halo_supported(const WgradArgs& a) {
@@ -785,14 +1088,29 @@ bool wgrad_halo_supported(const WgradArgs& a) {
 // tile rows of the non-pooled kernel: 8 (two buffers) once the extent has eight rows, else 4 (three buffers)
 static int halo3_rows(const WgradArgs& a) { return (!a.src[0].pool && a.Hb >= 8) ? 8 : 4; }
 
+// buffer-addressed transfers (round 3) need 32-bit byte offsets inside one image of either operand
+static bool halo_buf_ok(const WgradArgs& a) {
+    bool buf = !(g_debug_flags & 64) && (long)a.dyH * a.dyW * a.Cout * 2 < (1L << 31);
+    for (int i = 0; i < a.nsrc; ++i) buf = buf && a.src[i].sN * 2 < (1L << 31) && a.src[i].sH * 2 * 16 < (1L << 31);
+    return buf;
+}
+// the two-group kernel: eight-row tiles, at least eight of them per block
+static bool halo_pp_ok(const WgradArgs& a) {
+    if ((g_debug_flags & 256) || halo3_rows(a) != 8 || !halo_buf_ok(a)) return false;
+    return (long)a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, TW) >= 8;
+}
+
 // split-K plan of the halo kernel: slabs == ksplit
 int wgrad_halo_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
     const int ttotal = a.N * cdiv(a.Hb, halo3_rows(a)) * cdiv(a.Wb, TW);
     const long pairs = (long)(a.Cin / 64) * (a.Cout / 64);
-    // one resident wave of blocks (2 per CU): every extra block costs a 147 KB f32 slab written and read back --
-    // at 1024 blocks the slab traffic exceeded the layer's own input bytes (measured 527 -> 641 TFLOP/s at 512)
-    long ks = (512 + pairs - 1) / pairs;
-    if (ks > ttotal / 4) ks = ttotal / 4;          // at least four tiles per block
+    const bool pp = halo_pp_ok(a);
+    // one resident wave of blocks (2 per CU; the two-group kernel: 1 per CU): every extra block costs a 147 KB f32 slab
+    // written and read back -- at 1024 blocks the slab traffic exceeded the layer's own input bytes (measured 527 -> 641
+    // TFLOP/s at 512)
+    const int resident = pp ? 256 : 512, min_tiles = pp ? 8 : 4;
+    long ks = (resident + pairs - 1) / pairs;
+    if (ks > ttotal / min_tiles) ks = ttotal / min_tiles;          // at least four tiles per wave group
     if (ks < 1) ks = 1;
     const int per = cdiv(ttotal, ks);
     *tiles_per = per; *ksplit = cdiv(ttotal, per);
@@ -807,13 +1125,28 @@ int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStr
     } else {
         WgradArgs b = a;
         b.ksplit = ksplit;
-        // buffer-addressed transfers (round 3) need 32-bit byte offsets inside one image of either operand
-        bool buf = !(g_debug_flags & 64) && (long)a.dyH * a.dyW * a.Cout * 2 < (1L << 31);
-        for (int i = 0; i < a.nsrc; ++i) buf = buf && a.src[i].sN * 2 < (1L << 31) && a.src[i].sH * 2 * 16 < (1L << 31);
+        const bool buf = halo_buf_ok(a);
+        if (halo_pp_ok(a)) {
+            constexpr int lds = 4 * H3<8>::STAGE;
+            set_last_wgrad_variant(0x48200000 | (ksplit & 0xfff));
+            if (g_ws64_dbg) {              // ustrun_debug_buffer set: the stamped build
+                if (int rc = ensure_dynamic_lds((const void*)wgrad_halo_pp_bf16_kernel<true>, lds, "wgrad_halo")) return rc;
+                hipLaunchKernelGGL(wgrad_halo_pp_bf16_kernel<true>, dim3(grid.x * ksplit), dim3(512), lds, st, b, a.Cout / 64, cdiv(a.Wb, TW),
+                                   cdiv(a.Hb, 8), tiles_per, (unsigned long long*)g_ws64_dbg);
+            } else {
+                if (int rc = ensure_dynamic_lds((const void*)wgrad_halo_pp_bf16_kernel<false>, lds, "wgrad_halo")) return rc;
+                hipLaunchKernelGGL(wgrad_halo_pp_bf16_kernel<false>, dim3(grid.x * ksplit), dim3(512), lds, st, b, a.Cout / 64, cdiv(a.Wb, TW),
+                                   cdiv(a.Hb, 8), tiles_per, (unsigned long long*)nullptr);
+            }
+            USTRUN_LAUNCH_CHECK("wgrad_halo_bf16");
+            return 0;
+        }
         if (buf) set_last_wgrad_variant(0x48100000 | (ksplit & 0xfff));
         if (halo3_rows(a) == 8) {
+            if (buf && (g_debug_flags & 128))
+                if (int rc = ensure_dynamic_lds((const void*)wgrad_halo4_bf16_kernel<8>, H3<8>::NBUF * H3<8>::STAGE + 16384, "wgrad_halo")) return rc;
             if (buf)
-                hipLaunchKernelGGL(wgrad_halo4_bf16_kernel<8>, dim3(grid.x * ksplit), block, H3<8>::NBUF * H3<8>::STAGE, st, b, a.Cout / 64,
+                hipLaunchKernelGGL(wgrad_halo4_bf16_kernel<8>, dim3(grid.x * ksplit), block, H3<8>::NBUF * H3<8>::STAGE + ((g_debug_flags & 128) ? 16384 : 0), st, b, a.Cout / 64,
                                    cdiv(a.Wb, TW), cdiv(a.Hb, 8), tiles_per);
             else
                 hipLaunchKernelGGL(wgrad_halo3_bf16_kernel<8>, dim3(grid.x * ksplit), block, H3<8>::NBUF * H3<8>::STAGE, st, b, a.Cout / 64,
