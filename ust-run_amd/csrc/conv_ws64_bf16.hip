@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
 #pragma unroll
     for (int i = 0; i < NR; ++i) stg[i] = (u32x4){0u, 0u, 0u, 0u};
     f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
-    const float a_floor = S.relu ? 0.f : -__builtin_inff();
+    const short a_floor16 = S.relu ? (short)0 : (short)0x8000;     // ReLU on the rounded bf16 pairs (act8_bf16)
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -199,18 +199,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
     // BatchNorm affine + ReLU in f32, back to bf16, zero padding applied after the activation
     auto xform = [&](u32x4 raw, bool ok) __attribute__((always_inline)) {
         if constexpr (!XF) return raw;
-        const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
-        f32x4 lo = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]} * sc0 + sh0;
-        f32x4 hi = (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]} * sc1 + sh1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            lo[e] = __builtin_amdgcn_fmed3f(lo[e], a_floor, __builtin_inff());
-            hi[e] = __builtin_amdgcn_fmed3f(hi[e], a_floor, __builtin_inff());
-        }
-        bf16x8 h;
-        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
-        u32x4 u = __builtin_bit_cast(u32x4, h);
+        u32x4 u = act8_bf16(raw, sc0, sc1, sh0, sh1, a_floor16);
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] = ok ? u[e] : 0u;
         return u;
@@ -293,8 +282,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = (float)v[e];           // statistics see the stored values
-                s1[e] += f;
-                s2[e] += f * f;
+                s1[e] = add_scalar(s1[e], f);
+                s2[e] = fma_scalar(f, f, s2[e]);
             }
         }
     };
@@ -530,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64x8_kernel(const IgemmArgs 
 #pragma unroll
     for (int i = 0; i < NR8; ++i) stg[i] = (u32x4){0u, 0u, 0u, 0u};
     f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
-    const float a_floor = S.relu ? 0.f : -__builtin_inff();
+    const short a_floor16 = S.relu ? (short)0 : (short)0x8000;     // ReLU on the rounded bf16 pairs (act8_bf16)
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 
     unsigned offL[NR8], okmL = 0;
@@ -557,18 +546,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64x8_kernel(const IgemmArgs 
     };
     auto xform = [&](u32x4 raw, bool ok) __attribute__((always_inline)) {
         if constexpr (!XF) return raw;
-        const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
-        f32x4 lo = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]} * sc0 + sh0;
-        f32x4 hi = (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]} * sc1 + sh1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            lo[e] = __builtin_amdgcn_fmed3f(lo[e], a_floor, __builtin_inff());
-            hi[e] = __builtin_amdgcn_fmed3f(hi[e], a_floor, __builtin_inff());
-        }
-        bf16x8 h;
-        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
-        u32x4 u = __builtin_bit_cast(u32x4, h);
+        u32x4 u = act8_bf16(raw, sc0, sc1, sh0, sh1, a_floor16);
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] = ok ? u[e] : 0u;
         return u;
@@ -614,8 +592,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64x8_kernel(const IgemmArgs 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float f = inimg ? (float)h[e] : 0.f;
-                s1[e] += f;
-                s2[e] += f * f;
+                s1[e] = add_scalar(s1[e], f);
+                s2[e] = fma_scalar(f, f, s2[e]);
             }
         }
     };
@@ -919,7 +897,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
 #pragma unroll
     for (int i = 0; i < NR; ++i) stg[i] = (u32x4){0u, 0u, 0u, 0u};
     f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
-    const float a_floor = S.relu ? 0.f : -__builtin_inff();
+    const short a_floor16 = S.relu ? (short)0 : (short)0x8000;     // ReLU on the rounded bf16 pairs (act8_bf16)
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -947,18 +925,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
     };
     auto xform = [&](u32x4 raw, bool ok) __attribute__((always_inline)) {
         if constexpr (!XF) return raw;
-        const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
-        f32x4 lo = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]} * sc0 + sh0;
-        f32x4 hi = (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]} * sc1 + sh1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            lo[e] = __builtin_amdgcn_fmed3f(lo[e], a_floor, __builtin_inff());
-            hi[e] = __builtin_amdgcn_fmed3f(hi[e], a_floor, __builtin_inff());
-        }
-        bf16x8 h;
-        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
-        u32x4 u = __builtin_bit_cast(u32x4, h);
+        u32x4 u = act8_bf16(raw, sc0, sc1, sh0, sh1, a_floor16);
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] = ok ? u[e] : 0u;
         return u;
@@ -990,8 +957,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = (float)v[e];
-                s1[e] += f;
-                s2[e] += f * f;
+                s1[e] = add_scalar(s1[e], f);
+                s2[e] = fma_scalar(f, f, s2[e]);
             }
         }
     };

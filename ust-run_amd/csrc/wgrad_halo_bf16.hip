@@ -644,8 +644,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo4_bf16_kernel(const WgradArg
     // BatchNorm affine + ReLU of this thread's items, in place (items outside the source stay zero)
     auto act_item = [&](u32x4 r, bool relu) {
         const bf16x8 b = __builtin_bit_cast(bf16x8, r);
-        const f32x4 lo = (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]} * asc0 + ash0;
-        const f32x4 hi = (f32x4){(float)b[4], (float)b[5], (float)b[6], (float)b[7]} * asc1 + ash1;
+        f32x4 lo, hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {              // scalar FMAs on purpose: beside another wave's MFMAs a v_pk_fma_f32 costs more than two v_fma_f32
+            lo[q] = fma_scalar((float)b[q], asc0[q], ash0[q]);
+            hi[q] = fma_scalar((float)b[4 + q], asc1[q], ash1[q]);
+        }
         bf16x8 h;
         h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
         h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
@@ -924,8 +928,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo_pp_bf16_kernel(const WgradA
     };
     auto act_item = [&](u32x4 r, bool relu) {
         const bf16x8 b = __builtin_bit_cast(bf16x8, r);
-        const f32x4 lo = (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]} * asc0 + ash0;
-        const f32x4 hi = (f32x4){(float)b[4], (float)b[5], (float)b[6], (float)b[7]} * asc1 + ash1;
+        f32x4 lo, hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {              // scalar FMAs on purpose: beside another wave's MFMAs a v_pk_fma_f32 costs more than two v_fma_f32
+            lo[q] = fma_scalar((float)b[q], asc0[q], ash0[q]);
+            hi[q] = fma_scalar((float)b[4 + q], asc1[q], ash1[q]);
+        }
         bf16x8 h;
         h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
         h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
