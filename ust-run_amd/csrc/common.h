@@ -53,6 +53,15 @@ __device__ __forceinline__ float add_scalar(float x, float y) {
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
+// One LDS-DMA piece (64 lanes x 16 B) addressed through a buffer resource: lane address = base + soff + voff, an offset with
+// bit 31 set (beyond num_records) writes zeros.  Inline asm: hipcc does not see it -- the kernels count vmcnt by hand.
+__device__ __forceinline__ void dma16_buf_s(int voff, __amdgpu_buffer_rsrc_t rs, int soff, const char* lds_wave_base) {
+    // (a generic pointer into LDS is aperture base (high half) | LDS byte offset (low half): no address-space cast, whose null
+    // test hipcc mis-selects on gfx950 when the pointer comes out of a select)
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+    const int so = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(voff), "s"(rs), "s"(m), "s"(so) : "memory", "m0");
+}
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;

@@ -123,9 +123,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     //   direct   : item i = LDS slot q = tid + 256 i of the patch image: pixel q / 5, 16-byte group q % 5 (4 = pad)
     //   transform: item i = (pixel (tid + 256 i) / 4, channel group tid % 4): the thread keeps one group, its
     //              scale/shift stay in registers
-    // aoff[i] = element offset of the item from the chunk base, bit i of aokm = the item reads the image. ----
+    // aoff[i] = BYTE offset of the item from the chunk base (image base of the source + first channel of the chunk), bit 31
+    // set when the item does not read the image: the buffer-addressed transfer below then writes zeros by its own range
+    // check (no zero page, no 64-bit pointer arithmetic per item and chunk: that was 12 VALU instructions x 7 items of
+    // the 195 a chunk carried beside its 144 MFMAs); bit i of aokm = the item reads the image. ----
+    constexpr int OOB = (int)0x80000000;
     int aoff[AIT];
     unsigned aokm = 0;
+    __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)g_zero16, 0, 0, 0x00020000);     // current source, this image
+    int asoff = 0;                              // byte offset of the chunk's first channel
     int cur_src = -1;
     float a_floor = 0.f;                        // ReLU as max(x, floor): 0, or -inf for a source without ReLU
     const __bf16* aptr = nullptr;               // chunk base: source + image + first channel of the chunk
@@ -145,9 +151,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
             const int hy = hp / HW2, hx = hp - hy * HW2;
             const int ly = by + hy, lx = bx + hx;
             const bool ok = hp < HP && g < 4 && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
-            aoff[i] = ok ? (int)((POOL ? 2 : 1) * ((long)ly * S.sH + (long)lx * S.sW)) + 8 * g : 0;
+            aoff[i] = ok ? 2 * ((int)((POOL ? 2 : 1) * ((long)ly * S.sH + (long)lx * S.sW)) + 8 * g) : OOB;
             aokm |= (ok ? 1u : 0u) << i;
         }
+        ars = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (long)img * S.sN * 2), 0, 0x7fffffff, 0x00020000);
     };
     auto stage_begin = [&](int c, bool from_lds = true) {   // per-chunk state, set one chunk ahead of its use
         const int cg = c * BK;
@@ -155,7 +162,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
         const SrcDev S = pick_src(a.src[0], a.src[1], second != 0);
         const int cl = cg - (second ? a.src[0].C : 0);
         if (second != cur_src) { src_setup(S); cur_src = second; }
-        aptr = (const __bf16*)S.ptr + (img * S.sN + cl);
+        aptr = (const __bf16*)S.ptr + (img * S.sN + cl);      // (the prologue of the transforming variants loads through it)
+        asoff = 2 * cl;
         asc0 = asc1 = (f32x4){1.f, 1.f, 1.f, 1.f}; ash0 = ash1 = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (S.scale && !from_lds) {                  // prologue: straight from memory, in flight with the patch loads
             const long goff = S.gN > 0 ? (long)(img / S.gN) * S.gstride : 0;
@@ -186,16 +194,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     auto wave_has = [&](int i) { return BREG || 256 * i + wave * 64 < (XF ? XSLOTS : DSLOTS); };
     // item i of the chunk, b-th item of its stage (both fold to constants: the callers are fully unrolled)
     auto issue_one = [&](int i, int b, char* Adst, char* raw, bool live = true) {
-        const bool ok = live && ((aokm >> i) & 1u);
-        const __bf16* src = ok ? aptr + aoff[i] : zsrc;
+        const int vo = live ? aoff[i] : OOB;
         if constexpr (XF) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const long d = ok ? (q & 1 ? dq1 : 0) + (q & 2 ? dq2 : 0) : 0;
-                __builtin_amdgcn_global_load_lds((gptr_t*)(src + d), (lptr_t*)(raw + ((b * NP + q) * 256 + wave * 64) * 16), 16, 0, 0);
+                const int d = 2 * (int)((q & 1 ? dq1 : 0) + (q & 2 ? dq2 : 0));       // wave-uniform: rides in the scalar offset
+                dma16_buf_s(vo, ars, asoff + d, raw + ((b * NP + q) * 256 + wave * 64) * 16);
             }
         } else {
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Adst + (256 * i + wave * 64) * 16), 16, 0, 0);
+            dma16_buf_s(vo, ars, asoff, Adst + (256 * i + wave * 64) * 16);
         }
     };
     auto act8 = [&](bf16x8 r, f32x4& lo, f32x4& hi) {     // bf16 raw -> activated f32
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             const bool ok = (aokm >> i) & 1u;
-            const __bf16* src = ok ? aptr + aoff[i] : zsrc;
+            const __bf16* src = ok ? (const __bf16*)((const char*)aptr + aoff[i]) : zsrc;
 #pragma unroll
             for (int q = 0; q < NP; ++q) pv[i][q] = *(const bf16x8*)(src + (ok ? (q & 1 ? dq1 : 0) + (q & 2 ? dq2 : 0) : 0));
         }

@@ -1105,6 +1105,9 @@ static bool halo_buf_ok(const WgradArgs& a) {
 // the two-group kernel: eight-row tiles, at least eight of them per block
 static bool halo_pp_ok(const WgradArgs& a) {
     if ((g_debug_flags & 256) || halo3_rows(a) != 8 || !halo_buf_ok(a)) return false;
+    // measured (profiles/r03_ab_wgrad_pp_layers.log): ahead by 3-4 % from 256 channels on, behind by 2-3 % on the 64- and 128-channel
+    // layers, whose blocks share no operand tiles through L2
+    if ((long)(a.Cin / 64) * (a.Cout / 64) < 16) return false;
     return (long)a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, TW) >= 8;
 }
 
