@@ -230,3 +230,70 @@ def test_convT_bf16_batched_passes_exact():
     da = torch.empty(n, h, w, ci, device="cuda", dtype=torch.bfloat16)
     l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), 1, None))
     assert rel(from_nhwc(da.float()), r16(ar.grad)) < 1e-6
+
+
+# 3x3 weight gradient, the three builds of the all-taps kernel (wgrad_halo_bf16.hip): 0x482 = two wave groups in opposite phases
+# (>= 256 channels: 16 (ci, co) pairs), 0x481 = buffer-addressed transfers, 256-thread blocks, 0x480 = the round-2 kernel (kept for
+# operands beyond 2 GB per image; forced here with ustrun_debug_flags 64).  Exact (integer data), ragged extents, a source placed at
+# an offset (zero padding through the buffer range check), batched passes with per-pass BatchNorm constants, odd tile counts (the
+# two groups get unequal shares), every output between sentinel zones.
+WGRAD_CASES = [
+    # (id, N, source channels, Cout, H, W, groups, flags, expected variant family)
+    ("pp_512", 6, (512,), 512, 24, 40, 2, 0, 0x482),
+    ("pp_cat_256_256", 4, (256, 256), 256, 16, 24, 1, 0, 0x482),
+    ("pp_odd_tiles", 3, (256,), 256, 24, 16, 1, 0, 0x482),
+    ("pp_off_512", 6, (512,), 512, 24, 40, 2, 256, 0x481),
+    ("buf_128", 4, (128,), 128, 40, 56, 2, 0, 0x481),
+    ("buf_cat_64_64", 4, (64, 64), 64, 24, 40, 1, 0, 0x481),
+    ("buf_rows4", 5, (128,), 64, 4, 24, 1, 0, 0x481),
+    ("old_512", 6, (512,), 512, 24, 40, 2, 64, 0x480),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_wgrad_all_taps_builds_exact(case):
+    name, n, cs, co, h, w, G, flags, fam = case
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(len(name) * 17 + n)
+    ri = lambda lo, hi, *s: torch.randint(lo, hi + 1, s, generator=g).float()
+    ci, gn = sum(cs), n // G
+    y0 = ri(-3, 3, n, cs[0], h, w)
+    sc = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (G, cs[0]), generator=g)]
+    sh = ri(-1, 1, G, cs[0])
+    a0 = torch.relu(y0 * sc.repeat_interleave(gn, 0)[:, :, None, None] + sh.repeat_interleave(gn, 0)[:, :, None, None])
+    aff = torch.zeros(G, 4, cs[0])
+    aff[:, 0], aff[:, 1] = sc, sh
+    affg, y0g = aff.cuda(), nhwc16(y0)
+    srcs = [l.nhwc_src(y0g.data_ptr(), cs[0], h, w, affg.data_ptr(), affg.data_ptr() + 4 * cs[0], relu=1, gN=gn if G > 1 else 0,
+                       gstride=4 * cs[0])]
+    acts, keep = [a0], [affg, y0g]
+    if len(cs) == 2:
+        uh, uw, oy, ox = h - 3, w - 5, 2, 3
+        u = ri(-3, 3, n, cs[1], uh, uw)
+        acts.append(F.pad(u, [ox, w - uw - ox, oy, h - uh - oy]))
+        ug = nhwc16(u)
+        keep.append(ug)
+        srcs.append(l.nhwc_src(ug.data_ptr(), cs[1], uh, uw, off=(oy, ox)))
+    a = torch.cat(acts, 1)
+    dy = ri(-2, 2, n, co, h, w)
+    wr = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    F.conv2d(a, wr, None, 1, 1).backward(dy)
+    assert float(wr.grad.abs().max()) < 2 ** 24
+    sarr = (l.Src * len(srcs))(*srcs)
+    dyg = nhwc16(dy)
+    nb = lib.ustrun_wgrad_partials_bytes(9, ci, co, n * h * w)
+    part = torch.empty(nb // 4, device="cuda")
+    Z = 4096
+    buf = torch.full((Z + co * ci * 9 + Z,), 7.0, device="cuda")
+    dw = buf[Z:Z + co * ci * 9]
+    old = lib.ustrun_debug_flags(flags)
+    try:
+        l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 0, part.data_ptr(), nb, 1, None), "wgrad")
+        v = lib.ustrun_debug_last_wgrad_variant()
+        l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 1, part.data_ptr(), nb, 1, None), "wgrad acc")
+    finally:
+        lib.ustrun_debug_flags(old)
+    assert (v >> 20) == fam, f"weight gradient ran variant {v:#x}"
+    assert torch.equal(dw.view(co, ci, 3, 3).cpu(), 2 * wr.grad)
+    assert bool((buf[:Z] == 7.0).all()) and bool((buf[-Z:] == 7.0).all())

@@ -583,11 +583,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo4_bf16_kernel(const WgradArg
     const int dW2 = a.dyW * a.Cout * 2, dP2 = a.Cout * 2;
 
     // cursor of the next tile to issue (wave-uniform)
+    // tiles of an image are walked DOWN its columns (y fastest): the two dY halo rows a tile shares with the next one are in L2
+    // when that tile asks for them (walking along x left them a whole tile row = MBs of other blocks' traffic apart, and every
+    // halo row came from memory twice: 25 % on top of dY; the halo columns now re-read instead are 12.5 %)
     int q_img, q_y0, q_x0;
     {
         q_img = tbeg / (tiles_y * tiles_x);
         const int rem = tbeg - q_img * tiles_y * tiles_x;
-        q_y0 = (rem / tiles_x) * T3; q_x0 = (rem % tiles_x) * TW;
+        q_x0 = (rem / tiles_y) * TW; q_y0 = (rem % tiles_y) * T3;
     }
     // all transfers of the cursor's tile -> stage buffer; bit i of the result: activation item i lies in the source; bit 8: the
     // whole activation tile does (no masks needed); bits 16..: the tile's image
@@ -634,10 +637,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo4_bf16_kernel(const WgradArg
             }
         }
         ok2 |= (unsigned)img << 16;
-        q_x0 += TW;
-        if (q_x0 >= tiles_x * TW) {
-            q_x0 = 0; q_y0 += T3;
-            if (q_y0 >= tiles_y * T3) { q_y0 = 0; ++q_img; }
+        q_y0 += T3;
+        if (q_y0 >= tiles_y * T3) {
+            q_y0 = 0; q_x0 += TW;
+            if (q_x0 >= tiles_x * TW) { q_x0 = 0; ++q_img; }
         }
         return ok2;
     };
@@ -868,10 +871,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo_pp_bf16_kernel(const WgradA
 
     int q_img, q_y0, q_x0;                                          // cursor of the group's next tile to issue
     {
-        const int t0 = tbeg + grp;
+        const int t0 = tbeg + grp;                                  // (y fastest, as in the kernel above)
         q_img = t0 / (tiles_y * tiles_x);
         const int rem = t0 - q_img * tiles_y * tiles_x;
-        q_y0 = (rem / tiles_x) * T3; q_x0 = (rem % tiles_x) * TW;
+        q_x0 = (rem / tiles_y) * TW; q_y0 = (rem % tiles_y) * T3;
     }
     auto issue_tile = [&](char* stage) {
         const int img = q_img, y0 = q_y0, x0 = q_x0;
@@ -918,10 +921,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo_pp_bf16_kernel(const WgradA
         ok2 |= (unsigned)img << 16;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                               // the group's next tile is two tiles on
-            q_x0 += TW;
-            if (q_x0 >= tiles_x * TW) {
-                q_x0 = 0; q_y0 += T3;
-                if (q_y0 >= tiles_y * T3) { q_y0 = 0; ++q_img; }
+            q_y0 += T3;
+            if (q_y0 >= tiles_y * T3) {
+                q_y0 = 0; q_x0 += TW;
+                if (q_x0 >= tiles_x * TW) { q_x0 = 0; ++q_img; }
             }
         }
         return ok2;
