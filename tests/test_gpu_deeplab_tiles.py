@@ -58,13 +58,25 @@ def guards_intact(flat, n, poison):
     return bool((lo == poison).all()) and bool((hi == poison).all())
 
 
-def ct_variant(bn, bk, mode):
-    return 0x43540000 | (bn // 32) << 8 | (bk // 32) << 4 | mode
+def ct_variant(bn, bk, mode, breg=False):
+    return 0x43540000 | (0x1000 if breg else 0) | (bn // 32) << 8 | (bk // 32) << 4 | mode
 
 
-@pytest.mark.parametrize("ci,co,want", [(256, 1024, ct_variant(256, 32, 2)), (1024, 256, ct_variant(128, 64, 2)),
-                                        (64, 64, ct_variant(64, 64, 2)), (256, 64, ct_variant(64, 64, 2))])
-def test_conv1x1_production_tiles(ci, co, want):
+# round 3: weights through registers (0x1000; the default), 64-channel chunks everywhere; ustrun_debug_flags bit 9 = the round-2 builds
+@pytest.mark.parametrize("ci,co,flags,want", [(256, 1024, 0, ct_variant(256, 64, 2, True)), (1024, 256, 0, ct_variant(128, 64, 2, True)),
+                                              (64, 64, 0, ct_variant(64, 64, 2, True)), (256, 64, 0, ct_variant(64, 64, 2, True)),
+                                              (256, 1024, 512, ct_variant(256, 32, 2)), (1024, 256, 512, ct_variant(128, 64, 2)),
+                                              (64, 64, 512, ct_variant(64, 64, 2))])
+def test_conv1x1_production_tiles(ci, co, flags, want):
+    lib = L().lib()
+    old = lib.ustrun_debug_flags(flags)
+    try:
+        _conv1x1_production_tiles(ci, co, want)
+    finally:
+        lib.ustrun_debug_flags(old)
+
+
+def _conv1x1_production_tiles(ci, co, want):
     """The bottleneck GEMMs at the shapes DeepLabV2 @512^2 runs them (N = 2, 64 x 64 maps: M = 8192 pixels): BatchNorm affine +
     ReLU on load, bf16 outputs, statistics rows of the stored values; 256 -> 1024 reaches the 256-column tile (18.9 % of the
     forward + backward kernel time in profiles/r02_deeplab_fwdbwd_n8_kernel_stats.csv), 1024 -> 256 the 128-column one."""

@@ -36,9 +36,14 @@ __device__ __forceinline__ int fastmod(int v, int d, float inv) {      // v mod 
 //         12-13,66,70): [M x Cin] x [Cin x Cout] with the forward's loader (producer's BatchNorm + ReLU on load), the
 //         dgrad's plain epilogue, optional bias, and BatchNorm-statistics partials (one row per 128-pixel tile) of the
 //         rounded outputs
-template <int BN, int BK, int MODE>
+// BREG (round 3, as in conv_halo_bf16.hip): the packed weight layout [K/8][N][8] IS the B-fragment layout, so each wave loads the
+// fragments of its 64 columns straight from L2 into registers one stage (two k-steps = 4 MI MFMAs) ahead -- no weight
+// tile in LDS, no LDS-DMA beside the compiler-visible activation loads (which made hipcc drain vmcnt(0) at every chunk) -- and the
+// waves share only the activation tile: one barrier per 64-channel chunk.
+template <int BN, int BK, int MODE, bool BREG>
 __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, const int mt_total, const int nt_total) {
     constexpr bool DG = MODE == 1, PLAIN = MODE == 2;
+    static_assert(!BREG || BK == 64, "register-fed weights: two stages of two k-steps per chunk");
     constexpr int BM = 128;
     constexpr int WN = BN / 64, WM = 4 / WN, MI = BM / (32 * WM);
     constexpr int CPR = BK / 8;                 // 16-byte groups per pixel per chunk
@@ -162,6 +167,27 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
         }
     };
 
+    // BREG: fragments (k-step ks of the stage, column half j) of this wave's 64 columns: K-row c*CPR + 2 ks + lh, column
+    // colw + 32 j + l31.  Inline asm (hipcc must not fold them into its own vmcnt bookkeeping); counted by hand below.
+    bf16x8 bnx[2][2];
+    int bvoff = 0;
+    __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, 0x7fffffff, 0x00020000);
+    if constexpr (BREG) {
+        const int n = n0 + wn * 64 + l31;
+        long bc;
+        if (DG || PLAIN) bc = (long)n * 8;
+        else { const int tp = n / a.Cout, co = n - tp * a.Cout; bc = ((long)tp * (a.Cin / 8) * a.Cout + co) * 8; }
+        bvoff = (int)((bc + (long)lh * brow) * 2);
+    }
+    auto load_Breg = [&](int c, int stg) {       // stage stg (k-steps 2 stg, 2 stg + 1) of chunk c -> bnx
+        const int s0 = __builtin_amdgcn_readfirstlane((int)(((long)(c * CPR + 4 * stg) * brow) * 2));
+        const int s1 = __builtin_amdgcn_readfirstlane((int)(((long)(c * CPR + 4 * stg + 2) * brow) * 2));
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %4, %5, %6 offen\n\tbuffer_load_dwordx4 %1, %4, %5, %6 offen offset:512\n\t"
+                     "buffer_load_dwordx4 %2, %4, %5, %7 offen\n\tbuffer_load_dwordx4 %3, %4, %5, %7 offen offset:512"
+                     : "=&v"(bnx[0][0]), "=&v"(bnx[0][1]), "=&v"(bnx[1][0]), "=&v"(bnx[1][1])
+                     : "v"(bvoff), "s"(wrs), "s"(s0), "s"(s1) : "memory");
+    };
+
     f32x16 acc[MI][2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -170,14 +196,56 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    dma_B(0, 0);
+    if constexpr (BREG) load_Breg(0, 0); else dma_B(0, 0);
     load_A(0);
     write_A(As);
+    if constexpr (BREG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     const int prow0 = wm * 32 * MI + l31;        // this lane's A row in sub-tile 0
+    if constexpr (BREG) {
 #pragma unroll 1
-    for (int c = 0; c < nchunk; ++c) {
+        for (int c = 0; c < nchunk; ++c) {
+            const bool more = c + 1 < nchunk;
+            const char* Acur = As + buf * ABYTES;
+#pragma unroll
+            for (int stg = 0; stg < 2; ++stg) {
+                bf16x8 bcur[2][2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) { bcur[ks][0] = bnx[ks][0]; bcur[ks][1] = bnx[ks][1]; }
+                // top: the next stage's weights (stage 1 of this chunk, or stage 0 of the next one); behind them, in stage 0, the next
+                // chunk's activation items -- so that the wait for THIS stage's weights never covers a load from HBM
+                if (stg == 0) { load_Breg(c, 1); if (more) load_A(c + 1); }
+                else if (more) load_Breg(c + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // this stage's fragments were issued one stage ago; younger than them: stage 0: the 4 loads just issued + the AIT
+                // activation loads; stage 1: the activation loads issued in stage 0 + the 4 loads just issued
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + AIT) : "memory");
+                else if (stg == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(bcur[ks][0]), "+v"(bcur[ks][1]));      // (no MFMA above the wait)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int ch = 2 * (2 * stg + ks) + lh;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int p = prow0 + 32 * i;
+                        const bf16x8 af = *(const bf16x8*)(Acur + p * ROWB + ((ch ^ swz(p)) * 16));
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bcur[ks][0], acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bcur[ks][1], acc[i][1], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) write_A(As + (buf ^ 1) * ABYTES);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+#pragma unroll 1
+    for (int c = 0; c < (BREG ? 0 : nchunk); ++c) {
         const bool more = c + 1 < nchunk;
         if (more) { dma_B(c + 1, buf ^ 1); load_A(c + 1); }
         const char* Acur = As + buf * ABYTES;
@@ -271,14 +339,15 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     }
 }
 
-template <int BN, int BK, int MODE>
+template <int BN, int BK, int MODE, bool BREG = false>
 int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const int ncols = MODE == 0 ? 4 * a.Cout : a.Cout;
     const int mt = cdiv(a.M, 128), nt = ncols / BN;
-    const size_t lds = 2 * (size_t)128 * BK * 2 + 2 * (size_t)(BK / 8) * BN * 16;
+    const size_t lds_a = 2 * (size_t)128 * BK * 2, lds_ep = 4 * 32 * 144;
+    const size_t lds = BREG ? (lds_a > lds_ep ? lds_a : lds_ep) : lds_a + 2 * (size_t)(BK / 8) * BN * 16;
     dim3 grid(mt * nt), block(256);
-    set_last_variant(0x43540000 | (BN / 32) << 8 | (BK / 32) << 4 | MODE);       // 'CT' | BN/32 | BK/32 | MODE (tests)
-    hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, MODE>), grid, block, lds, st, a, mt, nt);
+    set_last_variant(0x43540000 | (BREG ? 0x1000 : 0) | (BN / 32) << 8 | (BK / 32) << 4 | MODE);   // 'CT' | register-fed weights | BN/32 | BK/32 | MODE (tests)
+    hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, MODE, BREG>), grid, block, lds, st, a, mt, nt);
     USTRUN_LAUNCH_CHECK("convT_bf16");
     return 0;
 }
@@ -312,8 +381,10 @@ bool convT_dgrad_supported(const IgemmArgs& a) {
     return a.Cin % 64 == 0 && a.Cout % 128 == 0 && a.C0 == a.Cout;
 }
 
+// (ustrun_debug_flags bit 9 = 512: the round-2 builds with weight tiles in LDS, for A/B runs and the tests that pin them)
 int convT_fwd_launch_bf16(const IgemmArgs& a, hipStream_t st) {
-    return launch_cfg<256, 32, 0>(a, st);
+    if (g_debug_flags & 512) return launch_cfg<256, 32, 0>(a, st);
+    return launch_cfg<256, 64, 0, true>(a, st);
 }
 // a 1x1 convolution at stride 1 over one bf16 NHWC source (ustrun_conv2d_fwd, k = 1)
 bool conv1x1_supported(const IgemmArgs& a) {
@@ -324,13 +395,15 @@ bool conv1x1_supported(const IgemmArgs& a) {
     return a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.C0 == a.Cout && a.Ho == a.Hb && a.Wo == a.Wb;
 }
 int conv1x1_launch_bf16(const IgemmArgs& a, hipStream_t st) {
-    if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 256) return launch_cfg<256, 32, 2>(a, st);
-    if (a.Cout % 128 == 0) return launch_cfg<128, 64, 2>(a, st);
-    return launch_cfg<64, 64, 2>(a, st);
+    const bool old = g_debug_flags & 512;
+    if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 256) return old ? launch_cfg<256, 32, 2>(a, st) : launch_cfg<256, 64, 2, true>(a, st);
+    if (a.Cout % 128 == 0) return old ? launch_cfg<128, 64, 2>(a, st) : launch_cfg<128, 64, 2, true>(a, st);
+    return old ? launch_cfg<64, 64, 2>(a, st) : launch_cfg<64, 64, 2, true>(a, st);
 }
 int convT_dgrad_launch_bf16(const IgemmArgs& a, hipStream_t st) {
-    if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 512) return launch_cfg<256, 32, 1>(a, st);
-    return launch_cfg<128, 64, 1>(a, st);
+    const bool old = g_debug_flags & 512;
+    if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 512) return old ? launch_cfg<256, 32, 1>(a, st) : launch_cfg<256, 64, 1, true>(a, st);
+    return old ? launch_cfg<128, 64, 1>(a, st) : launch_cfg<128, 64, 1, true>(a, st);
 }
 
 }  // namespace ustrun
