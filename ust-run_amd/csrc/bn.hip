@@ -246,7 +246,11 @@ struct Win {
     static constexpr int NPX = POOL ? 4 : 1;
 };
 
-template <bool POOL, int ESZ>
+// EVEN (pooled windows of an even-sized map: every U-Net level): all four pixels and the pooled cell exist, so the validity
+// selects (3 per element), the clamped addresses and the integer arg-max index go away -- the routing is three compares per channel
+// and mask logic.  The general form below costs 360 VALU instructions per window for 72 loaded bytes: the pooled reduce was issue
+// bound at 3.3 TB/s (profiles/r03_bench_bn_bwd.log).
+template <bool POOL, int ESZ, bool EVEN = false>
 __device__ __forceinline__ void window_dz(const float* da, const float* __restrict__ dp,
                                           const float* __restrict__ y, f32x4 sc, f32x4 sh, long w, int WH, int WW,
                                           int H, int W, int C, int c, f32x4 (&yv)[Win<POOL>::NPX],
@@ -254,6 +258,39 @@ __device__ __forceinline__ void window_dz(const float* da, const float* __restri
     constexpr int NPX = Win<POOL>::NPX;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 av[NPX];
+    if constexpr (POOL && EVEN) {
+        const unsigned uw = (unsigned)w, per = (unsigned)(WH * WW);
+        const unsigned n = uw / per, rem = uw - n * per, wy = rem / (unsigned)WW, wx = rem - wy * (unsigned)WW;
+        const long off0 = (((long)n * H + 2 * wy) * W + 2 * wx) * C + c;
+        const long rowo = (long)W * C;
+        yv[0] = ld4t<ESZ>(y, off0); yv[1] = ld4t<ESZ>(y, off0 + C); yv[2] = ld4t<ESZ>(y, off0 + rowo); yv[3] = ld4t<ESZ>(y, off0 + rowo + C);
+        if (da) {
+            dz[0] = ld4t<ESZ>(da, off0); dz[1] = ld4t<ESZ>(da, off0 + C); dz[2] = ld4t<ESZ>(da, off0 + rowo); dz[3] = ld4t<ESZ>(da, off0 + rowo + C);
+        } else {
+            dz[0] = dz[1] = dz[2] = dz[3] = zero;
+        }
+        const f32x4 g4 = dp ? ld4t<ESZ>(dp, (long)w * C + c) : zero;       // the pooled map's cell IS window w
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ok[q] = true; av[q] = yv[q] * sc + sh; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // first arg-max of relu(a) in the order (0,0) (0,1) (1,0) (1,1): strict > keeps the first
+            const float a0 = fmaxf(av[0][j], 0.f), a1 = fmaxf(av[1][j], 0.f), a2 = fmaxf(av[2][j], 0.f), a3 = fmaxf(av[3][j], 0.f);
+            const bool m1 = a1 > a0;
+            const float b1 = fmaxf(a0, a1);
+            const bool m2 = a2 > b1;
+            const float b2 = fmaxf(b1, a2);
+            const bool m3 = a3 > b2;
+            const float g = g4[j];
+            const bool e3 = m3, e2 = m2 && !m3, e1 = m1 && !m2 && !m3, e0 = !(m1 || m2 || m3);
+            dz[0][j] += e0 ? g : 0.f; dz[1][j] += e1 ? g : 0.f; dz[2][j] += e2 ? g : 0.f; dz[3][j] += e3 ? g : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dz[q][j] = (av[q][j] > 0.f) ? dz[q][j] : 0.f;
+        return;
+    }
     // plain: the window IS the pixel, its offset is linear (no division: these kernels were instruction bound on the
     // 64-bit divides, not memory bound); pooled: 32-bit divides (windows per pass < 2^31)
     int n = 0, wy = 0, wx = 0;
@@ -318,7 +355,7 @@ __device__ __forceinline__ void window_dz(const float* da, const float* __restri
 // blockIdx.y = forward pass (batched passes: each has its own slice of every tensor, constants and partial rows)
 struct PassOff { long act, pool, aff, part, coef; };   // element strides between passes (bytes are esz * act for tensors)
 
-template <bool POOL, int ESZ>
+template <bool POOL, int ESZ, bool EVEN = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ dp,
                                                            const float* __restrict__ y, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int N, int H, int W, int C,
@@ -351,7 +388,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             for (; w + (U - 1) * stride < nwin; w += U * stride) {
                 f32x4 yv[U][NPX], dz[U][NPX]; bool ok[U][NPX];
 #pragma unroll
-                for (int u = 0; u < U; ++u) window_dz<POOL, ESZ>(da, dp, y, sc, sh, w + u * stride, WH, WW, H, W, C, c, yv[u], dz[u], ok[u]);
+                for (int u = 0; u < U; ++u) window_dz<POOL, ESZ, EVEN>(da, dp, y, sc, sh, w + u * stride, WH, WW, H, W, C, c, yv[u], dz[u], ok[u]);
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -359,7 +396,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             }
             for (; w < nwin; w += stride) {
                 f32x4 yv[NPX], dz[NPX]; bool ok[NPX];
-                window_dz<POOL, ESZ>(da, dp, y, sc, sh, w, WH, WW, H, W, C, c, yv, dz, ok);
+                window_dz<POOL, ESZ, EVEN>(da, dp, y, sc, sh, w, WH, WW, H, W, C, c, yv, dz, ok);
 #pragma unroll
                 for (int q = 0; q < NPX; ++q) { s1 += dz[q]; s2 += dz[q] * yv[q]; }
             }
@@ -423,7 +460,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int r
     if (rg == 0 && c < C && dgamma) { dgamma[c] = dg_run; dbeta[c] = db_run; }
 }
 
-template <bool POOL, int ESZ>
+template <bool POOL, int ESZ, bool EVEN = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* da, const float* __restrict__ dp,
                                                           const float* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ coef,
@@ -451,7 +488,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* da, cons
         long w = (long)blockIdx.x * PL + pl;
         for (; w < nwin; w += stride) {
             f32x4 yv[NPX], dz[NPX]; bool ok[NPX];
-            window_dz<POOL, ESZ>(da, dp, y, sc, sh, w, WH, WW, H, W, C, c, yv, dz, ok);
+            window_dz<POOL, ESZ, EVEN>(da, dp, y, sc, sh, w, WH, WW, H, W, C, c, yv, dz, ok);
             long base = w * C + c;                       // plain: the pixel itself
             if (POOL) {
                 const unsigned uw = (unsigned)w, per = (unsigned)(WH * WW);
@@ -628,11 +665,12 @@ int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const fl
     int blocks = reduce_blocks(nwin, G);
     if (blocks > 1024 / passes) blocks = 1024 / passes;          // all passes' rows share the 1024-row table
     const PassOff po = {act_elems, pool_elems, aff_stride, (long)blocks * 2 * C, 3L * C};
-#define USTRUN_BN_REDUCE(P, E)                                                                                         \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<P, E>), dim3(blocks, passes), dim3(256), 0, s, (const float*)da,         \
+#define USTRUN_BN_REDUCE(P, E, V)                                                                                      \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<P, E, V>), dim3(blocks, passes), dim3(256), 0, s, (const float*)da,      \
                        (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials, po)
-    if (dtype == USTRUN_BF16) { if (pool) USTRUN_BN_REDUCE(true, 2); else USTRUN_BN_REDUCE(false, 2); }
-    else { if (pool) USTRUN_BN_REDUCE(true, 4); else USTRUN_BN_REDUCE(false, 4); }
+    const bool even = pool && !(H & 1) && !(W & 1);
+    if (dtype == USTRUN_BF16) { if (even) USTRUN_BN_REDUCE(true, 2, true); else if (pool) USTRUN_BN_REDUCE(true, 2, false); else USTRUN_BN_REDUCE(false, 2, false); }
+    else { if (even) USTRUN_BN_REDUCE(true, 4, true); else if (pool) USTRUN_BN_REDUCE(true, 4, false); else USTRUN_BN_REDUCE(false, 4, false); }
 #undef USTRUN_BN_REDUCE
     USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, blocks, C, (double)N * H * W, gamma,
@@ -655,11 +693,12 @@ int bn_bwd_apply_passes(const void* da, const void* dp, const void* y, const flo
     long blocks = (nwin + (long)PL * 4 - 1) / ((long)PL * 4);
     if (blocks > 4096) blocks = 4096;
     const PassOff po = {act_elems, pool_elems, aff_stride, 0, 3L * C};
-#define USTRUN_BN_APPLY(P, E)                                                                                               \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<P, E>), dim3((int)blocks, passes), dim3(256), 0, s, (const float*)da,          \
+#define USTRUN_BN_APPLY(P, E, V)                                                                                            \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<P, E, V>), dim3((int)blocks, passes), dim3(256), 0, s, (const float*)da,       \
                        (const float*)dp, (const float*)y, scale, shift, coef, N, H, W, C, G, (float*)dy, po)
-    if (dtype == USTRUN_BF16) { if (pool) USTRUN_BN_APPLY(true, 2); else USTRUN_BN_APPLY(false, 2); }
-    else { if (pool) USTRUN_BN_APPLY(true, 4); else USTRUN_BN_APPLY(false, 4); }
+    const bool even = pool && !(H & 1) && !(W & 1);
+    if (dtype == USTRUN_BF16) { if (even) USTRUN_BN_APPLY(true, 2, true); else if (pool) USTRUN_BN_APPLY(true, 2, false); else USTRUN_BN_APPLY(false, 2, false); }
+    else { if (even) USTRUN_BN_APPLY(true, 4, true); else if (pool) USTRUN_BN_APPLY(true, 4, false); else USTRUN_BN_APPLY(false, 4, false); }
 #undef USTRUN_BN_APPLY
     USTRUN_LAUNCH_CHECK("bn_bwd_apply");
     return 0;
