@@ -345,7 +345,10 @@ int ustrun_debug_last_conv_variant(void);
  * (MODE 0 ConvTranspose forward, 1 its input gradient, 2 a 1x1 convolution).
  * Same for the last weight-gradient launch: the one-tap-per-block kernel (wgrad_tap_bf16.hip) reports
  * 0x54000000 | (TM / 64) << 20 | (TN / 64) << 16 | loader << 12 | ksplit (loader 2 = pixel-linear 1x1, 1 = one shifted tap,
- * 0 = k x k taps); the all-taps halo kernel 0x48000000 | ksplit; 0 before any / for the generic kernels         */
+ * 0 = k x k taps); the all-taps halo kernel 0x48000000 | build << 20 | ksplit (build 0 = round-2 kernel, 1 = buffer-addressed
+ * transfers, 2 = two wave groups in opposite phases); 0 before any / for the generic kernels.
+ * ustrun_debug_last_conv_variant of the ConvTranspose / 1x1 GEMM kernel: 0x43540000 | (weights through registers ? 0x1000 : 0) |
+ * (BN / 32) << 8 | (BK / 32) << 4 | mode (0 forward, 1 input gradient, 2 plain 1x1)                              */
 int ustrun_debug_last_wgrad_variant(void);
 /* test aid, host only (no launch, no device access): the number of BatchNorm-statistics rows the kernel that would serve a
  * k x k convolution of a dense NHWC source [N, Cin] -> [N, Ho, Wo, Cout] writes.  tests/test_host_logic.py sweeps shapes
@@ -354,8 +357,14 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
 /* test / tuning aid: process-wide kernel-selection flags, returns the previous value.  bit 0: run the 64 -> 64 channel
  * full-resolution convolutions on the halo-tiled kernel instead of the weight-stationary row-streaming one (A/B timing
  * inside one process); bit 1: the four-wave build of the streaming kernel for every launch, bit 2: the eight-wave build for every
- * launch (default: eight waves for plain sources without statistics -- the input gradients --, four waves otherwise).
- * The last-variant code of the streaming kernel is 0x57530000 | (eight waves ? 0x100 : 0) | XF                  */
+ * launch; bit 4 (16): no consumer / producer build (then eight waves for plain sources without statistics, four waves otherwise),
+ * bit 5 (32): the consumer / producer build for every launch -- it is the default since round 3.
+ * bit 3 (8): halo-tiled kernel with weight tiles in LDS (round 2) instead of weights through registers;
+ * bit 6 (64): all-taps weight gradient with per-item pointers (round 2) instead of buffer-addressed transfers;
+ * bit 7 (128): that kernel with extra LDS so that one block fits a CU (occupancy experiment);
+ * bit 8 (256): no two-group weight-gradient kernel; bit 9 (512): ConvTranspose / 1x1 GEMM with weight tiles in LDS (round 2).
+ * The last-variant code of the streaming kernel is 0x57530000 | (eight waves ? 0x100 : consumer / producer ? 0x200 : 0) | XF.
+ * The environment variable USTRUN_DEBUG_FLAGS presets the value at load time.                                   */
 int ustrun_debug_flags(int flags);
 /* development aid: while a device buffer of >= 32 * blocks u64 is set here, the streaming kernel runs its phase-stamping
  * diagnostic build and writes per-wave cycle sums there (tools/ab_ws64.py --diag); NULL restores the product kernel */

@@ -109,7 +109,8 @@ def main():
                       f"{f(4, 8, 2):.0f}, wait B2 {f(4, 8, 3):.0f} (MFMA floor per half 2304)", flush=True)
             lib.ustrun_debug_buffer(None)
             lib.ustrun_debug_flags(0)
-        print(f"       outputs bit-identical between the three kernels: {same}; stat sums rel diff "
+        print(f"       outputs bit-identical between the kernels on this random float data (different summation orders; the exact-integer "
+              f"tests are tests/test_gpu_production_tiles.py): {same}; stat sums rel diff "
               f"{float((outs[32][2] - outs[1][2]).abs().max() / outs[1][2].abs().max()):.2e}", flush=True)
 
 
