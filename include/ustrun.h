@@ -363,6 +363,7 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  * bit 6 (64): all-taps weight gradient with per-item pointers (round 2) instead of buffer-addressed transfers;
  * bit 7 (128): that kernel with extra LDS so that one block fits a CU (occupancy experiment);
  * bit 8 (256): no two-group weight-gradient kernel; bit 9 (512): ConvTranspose / 1x1 GEMM with weight tiles in LDS (round 2).
+ * bits 10-11: force the halo kernel's tile in the 128-column case (1: 8 x 32 px, 2: 16 x 16, 3: 8 x 16; 0: chosen by padding).
  * The last-variant code of the streaming kernel is 0x57530000 | (eight waves ? 0x100 : consumer / producer ? 0x200 : 0) | XF.
  * The environment variable USTRUN_DEBUG_FLAGS presets the value at load time.                                   */
 int ustrun_debug_flags(int flags);

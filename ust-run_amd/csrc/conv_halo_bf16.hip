@@ -748,6 +748,26 @@ bool halo_tall_tile(const IgemmArgs& a) {
     return (long)a.N * cdiv(a.Hb, 16) * cdiv(a.Wb, 16) * (a.Cout / 128) >= 512;
 }
 
+// Tile of the 128-column, un-pooled, un-dilated case: 0 = 8 x 32 px (MI 4), 1 = 16 x 16 px (MI 4), 2 = 8 x 16 px (MI 2, 128 columns),
+// 3 = 8 x 16 px, 64 columns (less than one block per CU).  ustrun_debug_flags bits 10-11 force 0..2 (+1) for A/B runs.
+int halo_tile128(const IgemmArgs& a) {
+    const int force = (g_debug_flags >> 10) & 3;
+    const bool wide = a.Wb >= 32;
+    if (force) return (force == 1 && !wide) ? 1 : force - 1;
+    if (halo_tall_tile(a)) {
+        // enough blocks for any tile: the one that wastes the fewest MFMAs on padding, weighted by the tiles' measured relative
+        // rates on full tiles (8 x 32: 1, 16 x 16: 0.93, 8 x 16 with two sub-tiles per wave: 0.80 -- profiles/r03_ab_halo_tiles.log:
+        // 512 -> 512 at 48 x 48: 0.346 -> 0.290 ms on 16 x 16 tiles; 1024 -> 1024 at 18 x 18 and 24 x 24: -9 % on 8 x 16).  Maps
+        // whose sides are multiples of 32 (every level of the 256 x 256 workloads) keep the 8 x 32 tile.
+        const double h8 = cdiv(a.Hb, 8) * 8.0, h16 = cdiv(a.Hb, 16) * 16.0, w16 = cdiv(a.Wb, 16) * 16.0, w32 = cdiv(a.Wb, 32) * 32.0;
+        const double s0 = wide ? 1.0 / (h8 * w32) : 0.0, s1 = 0.93 / (h16 * w16), s2 = 0.80 / (h8 * w16);
+        return (s0 >= s1 && s0 >= s2) ? 0 : (s1 >= s2 ? 1 : 2);
+    }
+    static const int small_thr = getenv("USTRUN_HALO_SMALL_THR") ? atoi(getenv("USTRUN_HALO_SMALL_THR")) : 256;
+    if ((long)a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16) * (a.Cout / 128) < small_thr) return 3;
+    return 2;
+}
+
 // BatchNorm-statistics rows written by the configuration conv3x3_halo_launch_bf16 picks
 int halo_stat_rows_used(const IgemmArgs& a) {
     if (halo_dilation(a) == 4 && a.Cout % 128 == 0) return a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16);       // 16 x 16 tiles, two rows each
@@ -757,8 +777,8 @@ int halo_stat_rows_used(const IgemmArgs& a) {
     const bool wide = a.Wb >= 32;
     if (pool) return a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
     if (a.Cout % 128 == 0) {
-        if (halo_tall_tile(a)) return wide ? a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 32) : a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16);
-        return a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
+        const int t = halo_tile128(a);
+        return t == 0 ? a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 32) : t == 1 ? a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16) : a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
     }
     return wide ? a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 32) : a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16);
 }
@@ -794,14 +814,15 @@ int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     // MI = 2 tiles run two taps per barrier (16 MFMAs per wave and stage, like the MI = 4 tiles)
     if (pool) return launch_cfg<8, 16, 128, 32, 2, true, 2>(a, st);
     if (a.Cout % 128 == 0) {
-        if (halo_tall_tile(a))                    // 256 px x 128 ch per block, wave tile 128 px x 64 ch
-            return wide ? launch_cfg<8, 32, 128, 32, 4, false>(a, st) : launch_cfg<16, 16, 128, 32, 4, false>(a, st);
-        // less than one block per CU (the batch-1 forward, validation at test_bs 1): twice the blocks at 64 channels each
-        // (20-25 % faster per layer at batch 1; USTRUN_HALO_SMALL_THR is the tuning knob)
-        static const int small_thr = getenv("USTRUN_HALO_SMALL_THR") ? atoi(getenv("USTRUN_HALO_SMALL_THR")) : 256;
-        if ((long)a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16) * (a.Cout / 128) < small_thr)
-            return launch_cfg<8, 16, 64, 32, 1, false, 2>(a, st);
-        return launch_cfg<8, 16, 128, 32, 2, false, 2>(a, st);
+        // 256 px x 128 ch per block, wave tile 128 px x 64 ch (tiles 0, 1); less than one block per CU (the batch-1 forward,
+        // validation at test_bs 1): twice the blocks at 64 channels each (tile 3: 20-25 % faster per layer at batch 1;
+        // USTRUN_HALO_SMALL_THR is the tuning knob)
+        switch (halo_tile128(a)) {
+            case 0: return launch_cfg<8, 32, 128, 32, 4, false>(a, st);
+            case 1: return launch_cfg<16, 16, 128, 32, 4, false>(a, st);
+            case 3: return launch_cfg<8, 16, 64, 32, 1, false, 2>(a, st);
+            default: return launch_cfg<8, 16, 128, 32, 2, false, 2>(a, st);
+        }
     }
     if (wide) return launch_cfg<8, 32, 64, 32, 2, false, 2>(a, st);
     return launch_cfg<16, 16, 64, 32, 2, false, 2>(a, st);
