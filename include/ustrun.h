@@ -364,6 +364,7 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  * bit 7 (128): that kernel with extra LDS so that one block fits a CU (occupancy experiment);
  * bit 8 (256): no two-group weight-gradient kernel; bit 9 (512): ConvTranspose / 1x1 GEMM with weight tiles in LDS (round 2).
  * bits 10-11: force the halo kernel's tile in the 128-column case (1: 8 x 32 px, 2: 16 x 16, 3: 8 x 16; 0: chosen by padding).
+ * bit 12 (4096): BatchNorm backward (plain, bf16) on the 4-channel-per-lane kernels instead of the 8-channel ones.
  * The last-variant code of the streaming kernel is 0x57530000 | (eight waves ? 0x100 : consumer / producer ? 0x200 : 0) | XF.
  * The environment variable USTRUN_DEBUG_FLAGS presets the value at load time.                                   */
 int ustrun_debug_flags(int flags);

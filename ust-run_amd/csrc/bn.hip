@@ -504,6 +504,113 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* da, cons
     }
 }
 
+// ---- plain (un-pooled) bf16 passes with 8 channels = 16 bytes per lane (round 3) --------------------------------------------
+// The 4-channel kernels above keep 16 bytes per thread in flight (two 8-byte loads, one pixel per trip in the apply pass): at
+// their occupancy that is about half of what 8 TB/s x the memory latency asks of a CU, and the plain apply pass ran at
+// 4.8-5.1 TB/s where the pooled one (nine loads per thread) reaches 5.5.  Here a lane owns 8 channels of a pixel: thread =
+// (octet tid % G8, pixel lane tid / G8), G8 = C / 8 a power of two <= 256; the arithmetic is the same per element.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_bn;
+struct F8 { f32x4 lo, hi; };
+__device__ __forceinline__ F8 up8(bf16x8_bn v) {
+    return F8{(f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]}};
+}
+__device__ __forceinline__ F8 ld8f(const float* p) { return F8{*(const f32x4*)p, *(const f32x4*)(p + 4)}; }
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_x8_kernel(const __bf16* __restrict__ da, const __bf16* __restrict__ y,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ coef, long npix, int C, int G8,
+                                                             __bf16* __restrict__ dy, const PassOff po) {
+    {
+        const long g = blockIdx.y;
+        da += g * po.act; y += g * po.act; dy += g * po.act;
+        scale += g * po.aff; shift += g * po.aff; coef += g * po.coef;
+    }
+    const int PL = 256 / G8;
+    const int c = 8 * (threadIdx.x % G8), pl = threadIdx.x / G8;
+    const F8 sc = ld8f(scale + c), sh = ld8f(shift + c), k0 = ld8f(coef + c), k1 = ld8f(coef + C + c), k2 = ld8f(coef + 2 * C + c);
+    const long stride = (long)gridDim.x * PL;
+    constexpr int U = 2;
+    long w = (long)blockIdx.x * PL + pl;
+    auto one = [&](bf16x8_bn yb, bf16x8_bn db) {
+        const F8 yv = up8(yb), dv = up8(db);
+        bf16x8_bn o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float al = yv.lo[j] * sc.lo[j] + sh.lo[j], ah = yv.hi[j] * sc.hi[j] + sh.hi[j];
+            const float zl = al > 0.f ? dv.lo[j] : 0.f, zh = ah > 0.f ? dv.hi[j] : 0.f;
+            o[j] = (__bf16)(k0.lo[j] * zl + k1.lo[j] * yv.lo[j] + k2.lo[j]);
+            o[4 + j] = (__bf16)(k0.hi[j] * zh + k1.hi[j] * yv.hi[j] + k2.hi[j]);
+        }
+        return o;
+    };
+    for (; w + (U - 1) * stride < npix; w += U * stride) {
+        bf16x8_bn yb[U], db[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { yb[u] = *(const bf16x8_bn*)(y + (w + u * stride) * C + c); db[u] = *(const bf16x8_bn*)(da + (w + u * stride) * C + c); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) *(bf16x8_bn*)(dy + (w + u * stride) * C + c) = one(yb[u], db[u]);
+    }
+    for (; w < npix; w += stride)
+        *(bf16x8_bn*)(dy + w * C + c) = one(*(const bf16x8_bn*)(y + w * C + c), *(const bf16x8_bn*)(da + w * C + c));
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_x8_kernel(const __bf16* __restrict__ da, const __bf16* __restrict__ y,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              long npix, int C, int G8, float* __restrict__ partials,
+                                                              const PassOff po) {
+    {
+        const long g = blockIdx.y;
+        da += g * po.act; y += g * po.act;
+        scale += g * po.aff; shift += g * po.aff; partials += g * po.part;
+    }
+    __shared__ f32x4 red[4][256];
+    const int PL = 256 / G8;
+    const int g8 = threadIdx.x % G8, c = 8 * g8, pl = threadIdx.x / G8;
+    const F8 sc = ld8f(scale + c), sh = ld8f(shift + c);
+    F8 s1 = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, s2 = s1;
+    const long stride = (long)gridDim.x * PL;
+    constexpr int U = 4;
+    long w = (long)blockIdx.x * PL + pl;
+    auto acc1 = [&](bf16x8_bn yb, bf16x8_bn db) {
+        const F8 yv = up8(yb), dv = up8(db);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float al = yv.lo[j] * sc.lo[j] + sh.lo[j], ah = yv.hi[j] * sc.hi[j] + sh.hi[j];
+            const float zl = al > 0.f ? dv.lo[j] : 0.f, zh = ah > 0.f ? dv.hi[j] : 0.f;
+            s1.lo[j] += zl; s1.hi[j] += zh;
+            s2.lo[j] += zl * yv.lo[j]; s2.hi[j] += zh * yv.hi[j];
+        }
+    };
+    for (; w + (U - 1) * stride < npix; w += U * stride) {       // four pixels' loads in flight, sums in ascending pixel order
+        bf16x8_bn yb[U], db[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { yb[u] = *(const bf16x8_bn*)(y + (w + u * stride) * C + c); db[u] = *(const bf16x8_bn*)(da + (w + u * stride) * C + c); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc1(yb[u], db[u]);
+    }
+    for (; w < npix; w += stride) acc1(*(const bf16x8_bn*)(y + w * C + c), *(const bf16x8_bn*)(da + w * C + c));
+    red[0][threadIdx.x] = s1.lo; red[1][threadIdx.x] = s1.hi; red[2][threadIdx.x] = s2.lo; red[3][threadIdx.x] = s2.hi;
+    __syncthreads();
+    if (pl == 0) {                                              // fixed order over the block's pixel lanes
+        for (int k = 1; k < PL; ++k) {
+            s1.lo += red[0][k * G8 + g8]; s1.hi += red[1][k * G8 + g8];
+            s2.lo += red[2][k * G8 + g8]; s2.hi += red[3][k * G8 + g8];
+        }
+        float* r0 = partials + ((long)blockIdx.x * 2 + 0) * C + c;
+        float* r1 = partials + ((long)blockIdx.x * 2 + 1) * C + c;
+        *(f32x4*)r0 = s1.lo; *(f32x4*)(r0 + 4) = s1.hi;
+        *(f32x4*)r1 = s2.lo; *(f32x4*)(r1 + 4) = s2.hi;
+    }
+}
+
+// 8-channel kernels: bf16, no pooling, C / 8 a power of two <= 256 (every layer of the U-Net and of ResNet-50/101);
+// ustrun_debug_flags bit 12 (4096) keeps the 4-channel kernels (A/B runs)
+static bool x8_ok(int C, bool pool, int dtype) {
+    if (g_debug_flags & 4096) return false;
+    const int g8 = C / 8;
+    return dtype == USTRUN_BF16 && !pool && C % 8 == 0 && g8 >= 1 && g8 <= 256 && (g8 & (g8 - 1)) == 0;
+}
+
 int group_size(int C4) { int g = 1; while (g < C4 && g < 256) g <<= 1; return g; }
 
 int reduce_blocks(long nwin, int G) {
@@ -658,13 +765,23 @@ int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const fl
     USTRUN_CHECK((da || dp) && y && scale && shift && mean && rstd && gamma && coef && partials, "bn_bwd_reduce: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0 && passes >= 1 && passes <= 64, "bn_bwd_reduce: C=%d must be a multiple of 4", C);
     USTRUN_CHECK(partials_bytes >= ustrun_bn_bwd_partials_bytes((int64_t)N * H * W, C), "bn_bwd_reduce: partials too small");
-    const int G = group_size(C / 4);
     const bool pool = dp != nullptr;
+    const bool x8 = x8_ok(C, pool, dtype) && da;
+    const int G = x8 ? C / 8 : group_size(C / 4);
     const long nwin = pool ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long)N * H * W;
     USTRUN_CHECK(nwin < (1L << 31), "bn_bwd_reduce: %ld windows per pass", nwin);
     int blocks = reduce_blocks(nwin, G);
     if (blocks > 1024 / passes) blocks = 1024 / passes;          // all passes' rows share the 1024-row table
     const PassOff po = {act_elems, pool_elems, aff_stride, (long)blocks * 2 * C, 3L * C};
+    if (x8) {
+        hipLaunchKernelGGL(bn_bwd_reduce_x8_kernel, dim3(blocks, passes), dim3(256), 0, s, (const __bf16*)da, (const __bf16*)y, scale, shift,
+                           nwin, C, G, partials, po);
+        USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, blocks, C, (double)N * H * W, gamma,
+                           mean, rstd, dgamma, dbeta, accumulate, coef, passes, po);
+        USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
+        return 0;
+    }
 #define USTRUN_BN_REDUCE(P, E, V)                                                                                      \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<P, E, V>), dim3(blocks, passes), dim3(256), 0, s, (const float*)da,      \
                        (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials, po)
@@ -685,14 +802,21 @@ int bn_bwd_apply_passes(const void* da, const void* dp, const void* y, const flo
     USTRUN_CHECK(dtype_ok(dtype), "bn_bwd_apply: dtype %d not built", dtype);
     USTRUN_CHECK((da || dp) && y && scale && shift && coef && dy, "bn_bwd_apply: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0, "bn_bwd_apply: C=%d must be a multiple of 4", C);
-    const int G = group_size(C / 4);
     const bool pool = dp != nullptr;
+    const bool x8 = x8_ok(C, pool, dtype) && da;
+    const int G = x8 ? C / 8 : group_size(C / 4);
     const long nwin = pool ? (long)N * ((H + 1) / 2) * ((W + 1) / 2) : (long)N * H * W;
     USTRUN_CHECK(nwin < (1L << 31), "bn_bwd_apply: %ld windows per pass", nwin);
     const int PL = 256 / G;
     long blocks = (nwin + (long)PL * 4 - 1) / ((long)PL * 4);
     if (blocks > 4096) blocks = 4096;
     const PassOff po = {act_elems, pool_elems, aff_stride, 0, 3L * C};
+    if (x8) {
+        hipLaunchKernelGGL(bn_bwd_apply_x8_kernel, dim3((int)blocks, passes), dim3(256), 0, s, (const __bf16*)da, (const __bf16*)y, scale, shift,
+                           coef, nwin, C, G, (__bf16*)dy, po);
+        USTRUN_LAUNCH_CHECK("bn_bwd_apply");
+        return 0;
+    }
 #define USTRUN_BN_APPLY(P, E, V)                                                                                            \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<P, E, V>), dim3((int)blocks, passes), dim3(256), 0, s, (const float*)da,       \
                        (const float*)dp, (const float*)y, scale, shift, coef, N, H, W, C, G, (float*)dy, po)
