@@ -438,3 +438,55 @@ def test_bf16_storage_bn_head_backward():
     assert rel(outs[1][0], outs[0][0]) < 1e-5 and rel(outs[1][1], outs[0][1]) < 1e-5
     assert rel(outs[1][2], outs[0][2].bfloat16().float()) < 1e-5
     assert rel(outs[1][3], outs[0][3]) < 1e-6
+
+
+@pytest.mark.parametrize("n,c,h,w,pool,flags", [
+    (2, 64, 12, 16, False, 0),        # plain, 8 channels per lane (G8 = 8)
+    (3, 8, 9, 7, False, 0),           # plain, one octet (G8 = 1), odd extent
+    (2, 1024, 6, 10, False, 0),       # plain, G8 = 128
+    (2, 2048, 3, 5, False, 0),        # plain, G8 = 256 (ResNet layer4)
+    (2, 96, 8, 8, False, 0),          # 12 octets: not a power of two -> the 4-channel kernels
+    (2, 64, 12, 16, False, 4096),     # ... which bit 12 selects for any C
+    (2, 64, 12, 16, True, 0),         # pooled windows of an even-sized map (no validity selects)
+    (2, 128, 10, 14, True, 0),
+    (2, 64, 11, 15, True, 0),         # odd-sized map: the general pooled form
+])
+def test_bn_backward_bf16_builds(n, c, h, w, pool, flags):
+    """Every build of the BatchNorm + ReLU (+ MaxPool routing) backward on bf16 tensors against the f32 kernels run on the same
+    (bf16-rounded) inputs: coefficient sums to 1e-5, the applied gradient to one bf16 rounding."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(c + h + w)
+    y = (torch.randn(n, c, h, w, generator=g) * 2 + 0.5).bfloat16().float()
+    da = torch.randn(n, c, h, w, generator=g).bfloat16().float()
+    dp = torch.randn(n, c, h // 2, w // 2, generator=g).bfloat16().float()
+    var, mean = torch.var_mean(y, dim=(0, 2, 3), unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    gamma, beta = 1 + 0.3 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    t = [v.cuda() for v in (gamma * rstd, beta - mean * gamma * rstd, mean, rstd, gamma)]
+    nb = lib.ustrun_bn_bwd_partials_bytes(n * h * w, c)
+    part = torch.empty(nb // 4, device="cuda")
+    outs = {}
+    old = lib.ustrun_debug_flags(flags)
+    try:
+        for dt, cast in ((0, lambda v: v), (1, lambda v: v.bfloat16())):
+            yg, dag, dpg = cast(nhwc(y)), cast(nhwc(da)), cast(nhwc(dp))
+            dpp = dpg.data_ptr() if pool else None
+            dgam, dbet, coef = torch.empty(c, device="cuda"), torch.empty(c, device="cuda"), torch.empty(3 * c, device="cuda")
+            l.check(lib.ustrun_bn_bwd_reduce(dag.data_ptr(), dpp, yg.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                             t[3].data_ptr(), t[4].data_ptr(), n, h, w, c, dgam.data_ptr(), dbet.data_ptr(), 0,
+                                             coef.data_ptr(), part.data_ptr(), nb, dt, None))
+            buf = torch.full((4096 + yg.numel() + 4096,), 7.0, device="cuda", dtype=yg.dtype)
+            dy = buf[4096:4096 + yg.numel()].view_as(yg)
+            l.check(lib.ustrun_bn_bwd_apply(dag.data_ptr(), dpp, yg.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), coef.data_ptr(),
+                                            n, h, w, c, dy.data_ptr(), dt, None))
+            assert bool((buf[:4096] == 7.0).all()) and bool((buf[-4096:] == 7.0).all())
+            outs[dt] = (dgam.cpu(), dbet.cpu(), dy.float().cpu(), coef.cpu())
+    finally:
+        lib.ustrun_debug_flags(old)
+    assert rel(outs[1][0], outs[0][0]) < 1e-5 and rel(outs[1][1], outs[0][1]) < 1e-5 and rel(outs[1][3], outs[0][3]) < 1e-5
+    # the bf16 pass rounds once; its f32 value may differ from the f32 kernel's by the coefficient error above -> one bf16 ulp
+    want = outs[0][2]
+    err = (outs[1][2] - want).abs()
+    assert bool((err <= want.abs() * 2 ** -7 + 1e-6).all()), float((err / (want.abs() + 1e-6)).max())
+    assert rel(outs[1][2], want.bfloat16().float()) < 2e-3
