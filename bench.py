@@ -363,6 +363,18 @@ def main():
         roof["layers"] = [r for r in layers if r["images"] == big and r["op"] == "fwd"]
         roof["layers_bwd"] = [r for r in layers if r["images"] == big and r["op"] != "fwd" and
                               r["layer"] in ("inc.conv2", "down1.conv2", "down2.conv2", "up4.conv1", "up4.conv2", "up4.up")]
+        # ... and the two DoubleConv BLOCKS that target names (inc, up4.conv), forward: both convolutions' algorithmic bytes
+        # (read x, write y1, read y1, write y2) over both launches' time, against the HBM roof
+        dc = []
+        for blk, names in (("inc", ("inc.conv1", "inc.conv2")), ("up4.conv", ("up4.conv1", "up4.conv2"))):
+            rows = [r for r in roof["layers"] if r["layer"] in names]
+            if len(rows) == 2:
+                ms = sum(r["ms"] for r in rows)
+                by, fl = sum(r["alg_bytes"] for r in rows), sum(r["alg_flops"] for r in rows)
+                dc.append({"block": blk, "op": "fwd", "images": big, "ms": round(ms, 4), "alg_bytes": by, "alg_flops": fl,
+                           "gbps": round(by / ms / 1e6, 1), "frac_hbm": round(by / ms / 1e6 / HBM_PEAK, 4),
+                           "tflops": round(fl / ms / 1e9, 1), "frac_mfma": round(fl / ms / 1e9 / peak, 4)})
+        roof["doubleconv"] = dc
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), measured offline with
         # rocprofv3 --pmc on this same command and committed under profiles/ (bench.py cannot run under two profilers)
         tpath = os.path.join(ROOT, "profiles", f"traffic_{a.dtype}.json")
