@@ -196,7 +196,10 @@ extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const
         }
     }
     if (first) {     // C <= 4 input channels: direct f32 stencil, HBM-bound on its output
-        prof_begin(0, 2.0 * a.M * Cout * 9 * a.Cin, 4.0 * ((double)a.M * (a.Cin + Cout) + 9.0 * a.Cin * Cout), (hipStream_t)s);
+        // algorithmic bytes: the f32 image in, the activation out at ITS element size (bf16 storage: 2 bytes -- this used to count
+        // 4, which overstated the layer's GB/s by 1.9x), the weights
+        prof_begin(0, 2.0 * a.M * Cout * 9 * a.Cin,
+                   (double)a.M * a.Cin * (srcs[0].f32 ? 4.0 : act_esz(dtype)) + (double)a.M * Cout * act_esz(dtype) + 36.0 * a.Cin * Cout, (hipStream_t)s);
         const int rc = conv_first_fwd(srcs[0], w_fwd, dtype, N, y, stat, (hipStream_t)s);
         prof_end((hipStream_t)s);
         return rc;
