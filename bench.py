@@ -176,11 +176,13 @@ def secondary_unet(dev, dataset, lb, dtype, steps, warmup, lib):
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for s in range(steps):
-        if s == steps - 1:
-            lib.ustrun_profile_enable(1)
         tr.step(*batches[(warmup + s) % 2])
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
+    # the per-launch HIP events cost time: the profiled step runs AFTER the clock has stopped
+    lib.ustrun_profile_enable(1)
+    tr.step(*batches[(warmup + steps) % 2])
+    torch.cuda.synchronize(dev)
     lib.ustrun_profile_enable(0)
     peak = 157.3 if dtype == "f32" else 2500.0
     return {"workload": f"{dataset} {H}x{H}, {K}-class U-Net, SSL step, batch={lb}+{lb}", "dtype": dtype, "steps": steps,
@@ -220,11 +222,12 @@ def secondary_deeplab(dev, n, hw, dtype, lib, ssl, steps):
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(steps):
-        if i == steps - 1:
-            lib.ustrun_profile_enable(1)
         step(i)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
+    lib.ustrun_profile_enable(1)             # profiled step outside the timed window
+    step(steps)
+    torch.cuda.synchronize(dev)
     lib.ustrun_profile_enable(0)
     return {"workload": f"BUSI {hw}x{hw}, 2-class DeepLabV2-ResNet101, {what}", "dtype": dtype, "steps": steps,
             "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(imgs / dt, 2), "roofline": _class_roofline(lib, 2500.0, 1),

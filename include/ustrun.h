@@ -350,6 +350,10 @@ int ustrun_debug_last_conv_variant(void);
  * ustrun_debug_last_conv_variant of the ConvTranspose / 1x1 GEMM kernel: 0x43540000 | (weights through registers ? 0x1000 : 0) |
  * (BN / 32) << 8 | (BK / 32) << 4 | mode (0 forward, 1 input gradient, 2 plain 1x1)                              */
 int ustrun_debug_last_wgrad_variant(void);
+/* the last BatchNorm-backward launch (ustrun_bn_bwd_reduce / _apply and the whole-network backward):
+ * 0x424E0000 | pass << 8 (0 reduce, 1 apply) | element bytes << 4 | even-sized pooled windows << 2 | pooled << 1 |
+ * eight channels (16 bytes) per lane; 0 before any                                                              */
+int ustrun_debug_last_bn_variant(void);
 /* test aid, host only (no launch, no device access): the number of BatchNorm-statistics rows the kernel that would serve a
  * k x k convolution of a dense NHWC source [N, Cin] -> [N, Ho, Wo, Cout] writes.  tests/test_host_logic.py sweeps shapes
  * with it: the count must never exceed ustrun_conv_mtiles(N, Ho, Wo, Cout), which is what callers allocate           */
@@ -366,11 +370,18 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  * bits 10-11: force the halo kernel's tile in the 128-column case (1: 8 x 32 px, 2: 16 x 16, 3: 8 x 16; 0: chosen by padding).
  * bit 12 (4096): BatchNorm backward (plain, bf16) on the 4-channel-per-lane kernels instead of the 8-channel ones.
  * The last-variant code of the streaming kernel is 0x57530000 | (eight waves ? 0x100 : consumer / producer ? 0x200 : 0) | XF.
- * The environment variable USTRUN_DEBUG_FLAGS presets the value at load time.                                   */
+ * bit 13 (8192): 64-output-channel 3x3 layers on >= 32-wide maps on the 16 x 32-pixel tile (one block per CU; A/B runs).
+ * The value is PER CALLING THREAD (as are the last-variant codes and the stamp buffer below): a thread that sets it changes
+ * kernel selection for the launches it issues itself and for nobody else, so the library keeps no process-wide mutable
+ * state.  Every thread starts from the value the environment variable USTRUN_DEBUG_FLAGS had when the library was loaded
+ * (read once at load, never on a launch path).                                                                    */
 int ustrun_debug_flags(int flags);
-/* development aid: while a device buffer of >= 32 * blocks u64 is set here, the streaming kernel runs its phase-stamping
- * diagnostic build and writes per-wave cycle sums there (tools/ab_ws64.py --diag); NULL restores the product kernel */
-int ustrun_debug_buffer(void* device_u64);
+/* development aid: while a device buffer is set here (per calling thread), the 64 -> 64 streaming kernel and the two-group
+ * all-taps weight gradient run their phase-stamping diagnostic builds and write per-wave cycle sums there as
+ * [workgroup][8 waves][8] u64 = 64 u64 per workgroup (tools/ab_ws64.py --diag, tools/diag_wgrad.py).  n_u64 = the buffer's
+ * length: a launch whose grid needs more (grid x 64) fails with an error instead of writing past the end.  NULL restores
+ * the product kernels                                                                                              */
+int ustrun_debug_buffer(void* device_u64, int64_t n_u64);
 
 /* ---- optional launch profiler (bench.py): HIP events recorded on the launch stream around every
  * implicit-GEMM (kind 0) / weight-gradient (kind 1) launch while enabled; collect synchronises on

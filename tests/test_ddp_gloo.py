@@ -123,6 +123,45 @@ def test_two_piece_reducer_world2():
     assert res[0] == res[1]
 
 
+def _worker_wait(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "ust-run_amd")]
+    from ustrun import ddp
+    ddp.init("gloo", wait_timeout_s=60)
+    assert ddp._WAIT[0] is not None             # the side group exists before any epoch end
+    t0 = time.time()
+    if rank == 0:
+        time.sleep(3.0)                         # "validation": rank 0 arrives late
+    ddp.wait_for_rank0(timeout_s=60)
+    waited = time.time() - t0
+    # the epoch-end wait must not break the data path: a collective on the main group right after it
+    x = torch.full((5,), float(rank + 1))
+    dist.all_reduce(x)
+    q.put((rank, waited, float(x[0])))
+    dist.destroy_process_group()
+
+
+def test_epoch_end_wait_with_rank0_delayed_world2():
+    """`wait_for_rank0` (train.py's epoch-end wait) on the gloo side group that `ddp.init` creates up front: rank 1 parks
+    until the late rank 0 arrives, nobody times out, the main group still works afterwards."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_wait, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = {r: (w, s) for r, w, s in (q.get() for _ in range(2))}
+    assert res[1][0] >= 2.5                      # rank 1 really waited for rank 0's three seconds
+    assert res[0][1] == 3.0 and res[1][1] == 3.0
+
+
 def test_single_process_needs_no_collective():
     from ustrun import ddp
     assert ddp.make_grad_allreduce(1) is None

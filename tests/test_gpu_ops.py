@@ -452,8 +452,10 @@ def test_bf16_storage_bn_head_backward():
     (2, 64, 11, 15, True, 0),         # odd-sized map: the general pooled form
 ])
 def test_bn_backward_bf16_builds(n, c, h, w, pool, flags):
-    """Every build of the BatchNorm + ReLU (+ MaxPool routing) backward on bf16 tensors against the f32 kernels run on the same
-    (bf16-rounded) inputs: coefficient sums to 1e-5, the applied gradient to one bf16 rounding."""
+    """Every build of the BatchNorm + ReLU (+ MaxPool routing) backward on bf16 tensors: against torch autograd in float64 through
+    `F.batch_norm -> relu (-> max_pool2d)` on the same (bf16-rounded) inputs (reference networks/unet_parts.py:17-18,34), and
+    against the f32 kernels; the build each launch ran is asserted (`ustrun_debug_last_bn_variant`)."""
+    import torch.nn.functional as F
     l = L()
     lib = l.lib()
     g = torch.Generator().manual_seed(c + h + w)
@@ -466,6 +468,13 @@ def test_bn_backward_bf16_builds(n, c, h, w, pool, flags):
     t = [v.cuda() for v in (gamma * rstd, beta - mean * gamma * rstd, mean, rstd, gamma)]
     nb = lib.ustrun_bn_bwd_partials_bytes(n * h * w, c)
     part = torch.empty(nb // 4, device="cuda")
+    # expectation: autograd in float64 (batch statistics of y itself = the mean / rstd handed to the kernels)
+    yd, gd, bd = y.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    act = torch.relu(F.batch_norm(yd, None, None, gd, bd, True, 0.0, 1e-5))
+    obj = (act * da.double()).sum()
+    if pool:
+        obj = obj + (F.max_pool2d(act, 2) * dp.double()).sum()
+    obj.backward()
     outs = {}
     old = lib.ustrun_debug_flags(flags)
     try:
@@ -476,14 +485,23 @@ def test_bn_backward_bf16_builds(n, c, h, w, pool, flags):
             l.check(lib.ustrun_bn_bwd_reduce(dag.data_ptr(), dpp, yg.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
                                              t[3].data_ptr(), t[4].data_ptr(), n, h, w, c, dgam.data_ptr(), dbet.data_ptr(), 0,
                                              coef.data_ptr(), part.data_ptr(), nb, dt, None))
+            g8 = c // 8
+            x8 = dt == 1 and not pool and not (flags & 4096) and c % 8 == 0 and g8 <= 256 and (g8 & (g8 - 1)) == 0
+            code = 0x424E0000 | (2 if dt else 4) << 4 | (4 if pool and h % 2 == 0 and w % 2 == 0 else 0) | (2 if pool else 0) | (1 if x8 else 0)
+            assert lib.ustrun_debug_last_bn_variant() == code, hex(lib.ustrun_debug_last_bn_variant())
             buf = torch.full((4096 + yg.numel() + 4096,), 7.0, device="cuda", dtype=yg.dtype)
             dy = buf[4096:4096 + yg.numel()].view_as(yg)
             l.check(lib.ustrun_bn_bwd_apply(dag.data_ptr(), dpp, yg.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), coef.data_ptr(),
                                             n, h, w, c, dy.data_ptr(), dt, None))
+            assert lib.ustrun_debug_last_bn_variant() == code | 1 << 8, hex(lib.ustrun_debug_last_bn_variant())
             assert bool((buf[:4096] == 7.0).all()) and bool((buf[-4096:] == 7.0).all())
             outs[dt] = (dgam.cpu(), dbet.cpu(), dy.float().cpu(), coef.cpu())
     finally:
         lib.ustrun_debug_flags(old)
+    from_nhwc = lambda v: v.permute(0, 3, 1, 2)
+    for dt in (0, 1):                       # both dtypes against autograd: parameter gradients 2e-5, dy to the stored precision
+        assert rel(outs[dt][0], gd.grad) < 2e-5 and rel(outs[dt][1], bd.grad) < 2e-5, dt
+        assert rel(from_nhwc(outs[dt][2]), yd.grad) < (2e-5 if dt == 0 else 4e-3), dt
     assert rel(outs[1][0], outs[0][0]) < 1e-5 and rel(outs[1][1], outs[0][1]) < 1e-5 and rel(outs[1][3], outs[0][3]) < 1e-5
     # the bf16 pass rounds once; its f32 value may differ from the f32 kernel's by the coefficient error above -> one bf16 ulp
     want = outs[0][2]

@@ -79,15 +79,15 @@ def main():
             print(f"       {op:5s}: consumer / producer waves {tc:.4f} ms {fl / tc / 1e9:6.0f} TF/s {by / tc / 1e6:6.0f} GB/s ({by / tc / 1e6 / 8000:.3f} of 8 TB/s)   "
                   f"min {min(res[(32, op)]):.4f}   x{t2 / tc:.2f} over four waves", flush=True)
         if a.diag:
-            dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
-            lib.ustrun_debug_buffer(dbg.data_ptr())
+            dbg = torch.zeros(2048 * 64, dtype=torch.int64, device=dev)      # 64 u64 per workgroup; the library refuses grids beyond the buffer
+            l.check(lib.ustrun_debug_buffer(dbg.data_ptr(), dbg.numel()))
             lib.ustrun_debug_flags(4)
             for name, fn in (("fwd", fwd), ("dgrad", dgr)):
                 dbg.zero_()
                 fn()
                 torch.cuda.synchronize()
                 t_diag = timed(fn, 5)                      # wall time of the stamped build itself -> the in-kernel clock
-                d = dbg.view(256, 8, 8).double()
+                d = dbg[:256 * 64].view(256, 8, 8).double()
                 it = d[..., 5].clamp(min=1)
                 ph = [float((d[..., k] / it).mean()) for k in range(5)]
                 tot = d[..., 1] + d[..., 2] + d[..., 4]
@@ -101,13 +101,13 @@ def main():
                 dbg.zero_()
                 fn()
                 torch.cuda.synchronize()
-                d = dbg.view(256, 8, 8).double()
+                d = dbg[:256 * 64].view(256, 8, 8).double()
                 it = d[..., 5].clamp(min=1)
                 f = lambda lo, hi, k: float((d[:, lo:hi, k] / it[:, lo:hi]).mean())
                 print(f"       diag {name} (consumer / producer waves), cycles per iteration -- consumers: half 0 {f(0, 4, 0):.0f}, wait B1 {f(0, 4, 1):.0f}, "
                       f"half 1 {f(0, 4, 2):.0f}, wait B2 {f(0, 4, 3):.0f} | producers: segment A {f(4, 8, 0):.0f}, wait B1 {f(4, 8, 1):.0f}, segment B "
                       f"{f(4, 8, 2):.0f}, wait B2 {f(4, 8, 3):.0f} (MFMA floor per half 2304)", flush=True)
-            lib.ustrun_debug_buffer(None)
+            lib.ustrun_debug_buffer(None, 0)
             lib.ustrun_debug_flags(0)
         print(f"       outputs bit-identical between the kernels on this random float data (different summation orders; the exact-integer "
               f"tests are tests/test_gpu_production_tiles.py): {same}; stat sums rel diff "

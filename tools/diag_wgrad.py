@@ -43,13 +43,13 @@ def main():
     t = timed()
     fl = 2.0 * 9 * ci * co * n * hw * hw
     print(f"{ci}->{co} {hw}x{hw} N={n}: {t:.4f} ms {fl / t / 1e9:.0f} TF/s (kernel + slab reduce), variant {lib.ustrun_debug_last_wgrad_variant():#x}")
-    dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
-    lib.ustrun_debug_buffer(dbg.data_ptr())
+    dbg = torch.zeros(2048 * 64, dtype=torch.int64, device=dev)      # 64 u64 per workgroup; the library refuses grids beyond the buffer
+    l.check(lib.ustrun_debug_buffer(dbg.data_ptr(), dbg.numel()))
     run()
     torch.cuda.synchronize()
     td = timed(5)
-    lib.ustrun_debug_buffer(None)
-    d = dbg.view(256, 8, 8).double()
+    lib.ustrun_debug_buffer(None, 0)
+    d = dbg[:256 * 64].view(256, 8, 8).double()
     tiles = d[..., 5].clamp(min=1)
     f = lambda k: float((d[..., k] / tiles).mean())
     tot = d[..., 0] + d[..., 1] + d[..., 2] + d[..., 3] + d[..., 4]

@@ -611,6 +611,13 @@ static bool x8_ok(int C, bool pool, int dtype) {
     return dtype == USTRUN_BF16 && !pool && C % 8 == 0 && g8 >= 1 && g8 <= 256 && (g8 & (g8 - 1)) == 0;
 }
 
+// ustrun_debug_last_bn_variant: 0x424E0000 ('BN') | pass (0 reduce, 1 apply) << 8 | element bytes << 4 | even windows << 2 |
+// pooled << 1 | eight channels per lane; per calling thread
+thread_local int g_last_bn_variant = 0;
+void note_bn_variant(int pass, int esz, bool even, bool pool, bool x8) {
+    g_last_bn_variant = 0x424E0000 | pass << 8 | esz << 4 | (even ? 4 : 0) | (pool ? 2 : 0) | (x8 ? 1 : 0);
+}
+
 int group_size(int C4) { int g = 1; while (g < C4 && g < 256) g <<= 1; return g; }
 
 int reduce_blocks(long nwin, int G) {
@@ -773,6 +780,7 @@ int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const fl
     int blocks = reduce_blocks(nwin, G);
     if (blocks > 1024 / passes) blocks = 1024 / passes;          // all passes' rows share the 1024-row table
     const PassOff po = {act_elems, pool_elems, aff_stride, (long)blocks * 2 * C, 3L * C};
+    note_bn_variant(0, act_esz(dtype), pool && !(H & 1) && !(W & 1), pool, x8);
     if (x8) {
         hipLaunchKernelGGL(bn_bwd_reduce_x8_kernel, dim3(blocks, passes), dim3(256), 0, s, (const __bf16*)da, (const __bf16*)y, scale, shift,
                            nwin, C, G, partials, po);
@@ -811,6 +819,7 @@ int bn_bwd_apply_passes(const void* da, const void* dp, const void* y, const flo
     long blocks = (nwin + (long)PL * 4 - 1) / ((long)PL * 4);
     if (blocks > 4096) blocks = 4096;
     const PassOff po = {act_elems, pool_elems, aff_stride, 0, 3L * C};
+    note_bn_variant(1, act_esz(dtype), pool && !(H & 1) && !(W & 1), pool, x8);
     if (x8) {
         hipLaunchKernelGGL(bn_bwd_apply_x8_kernel, dim3((int)blocks, passes), dim3(256), 0, s, (const __bf16*)da, (const __bf16*)y, scale, shift,
                            coef, nwin, C, G, (__bf16*)dy, po);
@@ -843,3 +852,5 @@ extern "C" int ustrun_bn_bwd_apply(const void* da, const void* dp, const void* y
                                    int dtype, ustrun_stream_t s) {
     return bn_bwd_apply_passes(da, dp, y, scale, shift, coef, N, H, W, C, dy, dtype, 1, 0, 0, 0, (hipStream_t)s);
 }
+
+extern "C" int ustrun_debug_last_bn_variant(void) { return g_last_bn_variant; }

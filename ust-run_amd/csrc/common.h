@@ -147,9 +147,14 @@ void set_last_variant(int v);
 bool ws64_supported(const IgemmArgs& a);
 int ws64_stat_rows(const IgemmArgs& a);
 int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st);
-void ws64_set_debug_buffer(void* p);
-extern void* g_ws64_dbg;             // ustrun_debug_buffer: development builds with phase stamps write here
-extern int g_debug_flags;                  // ustrun_debug_flags: bit 0 = keep the 64 -> 64 layers on the tiled kernel
+// Test / tuning state is PER CALLING THREAD (the header promises a library without process-wide mutable state): a thread that
+// sets flags or a stamp buffer changes kernel selection for its own launches only; every thread starts from the value the
+// environment variable USTRUN_DEBUG_FLAGS had when the library was loaded (read once, never on a launch path).
+extern thread_local int g_debug_flags;     // ustrun_debug_flags: bit 0 = keep the 64 -> 64 layers on the tiled kernel ...
+struct DebugBuf { unsigned long long* p; long n_u64; };
+extern thread_local DebugBuf g_dbg;        // ustrun_debug_buffer: development builds with phase stamps write [block][8 waves][8] u64 here
+// the stamp buffer for a launch of `blocks` workgroups: null when none is set; error (rc != 0) when the one set is too small
+int debug_buffer_for(long blocks, const char* who, unsigned long long** out);
 bool convT_fwd_supported(const IgemmArgs& a);
 bool convT_dgrad_supported(const IgemmArgs& a);
 bool conv1x1_supported(const IgemmArgs& a);

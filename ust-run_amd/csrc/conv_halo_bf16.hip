@@ -59,7 +59,7 @@ template <bool B> struct more_value<std::integral_constant<bool, B>> { static co
 // reads of a stage -- and, with nothing shared between the waves inside a chunk any more, the per-tap workgroup barrier: the
 // waves meet once per K chunk (when the patch buffers swap) instead of nine times, and drift apart in between.
 template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
+__global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
     static_assert(BK == 32, "80-byte patch rows hold one 32-channel chunk");
     static_assert(!BREG || NT <= 2, "register-fed weights: 16 registers per tap and set");
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const IgemmAr
     }
 }
 
-int g_last_variant = 0;    // TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF of the last launch (tests: ustrun_debug_last_conv_variant)
+thread_local int g_last_variant = 0;    // (per calling thread) TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF of the last launch (tests: ustrun_debug_last_conv_variant)
 
 template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false>
 int launch_xf(const IgemmArgs& a, hipStream_t st) {
@@ -691,8 +691,10 @@ int launch_xf(const IgemmArgs& a, hipStream_t st) {
     const size_t fixed = 2 * (size_t)(BREG ? AIT * 256 : DSLOTS) * 16 + (BREG ? 0 : 2 * NT * (size_t)(BK / 8) * BN * 16) + 512;
     const size_t lds = fixed + (XF && fixed + 2 * rawb <= 81920 ? 2 : 1) * rawb;
     dim3 grid(a.N * ty * tx * nt), block(256);
-    if constexpr (DIL > 1)         // (up to 93 KB for the dilation-4 patch pair: one block per CU, above the 64 KB default)
-        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG>, 160 * 1024, "conv3x3_halo_bf16"));
+    // above the 64 KB default (the dilation-4 patch pair: 93 KB; the 16 x 16 x 128 transforming tile: 66 KB): raise the limit
+    // whatever the dilation is (the un-dilated 16 x 16 tile used to launch without the attribute)
+    if (lds > 64 * 1024)
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG>, (int)lds, "conv3x3_halo_bf16"));
     hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;
@@ -763,8 +765,7 @@ int halo_tile128(const IgemmArgs& a) {
         const double s0 = wide ? 1.0 / (h8 * w32) : 0.0, s1 = 0.93 / (h16 * w16), s2 = 0.80 / (h8 * w16);
         return (s0 >= s1 && s0 >= s2) ? 0 : (s1 >= s2 ? 1 : 2);
     }
-    static const int small_thr = getenv("USTRUN_HALO_SMALL_THR") ? atoi(getenv("USTRUN_HALO_SMALL_THR")) : 256;
-    if ((long)a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16) * (a.Cout / 128) < small_thr) return 3;
+    if ((long)a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16) * (a.Cout / 128) < 256) return 3;      // less than one block per CU
     return 2;
 }
 
@@ -780,6 +781,7 @@ int halo_stat_rows_used(const IgemmArgs& a) {
         const int t = halo_tile128(a);
         return t == 0 ? a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 32) : t == 1 ? a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16) : a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
     }
+    if (wide && (g_debug_flags & 8192) && a.Hb >= 16) return a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 32);
     return wide ? a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 32) : a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16);
 }
 
@@ -815,8 +817,7 @@ int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     if (pool) return launch_cfg<8, 16, 128, 32, 2, true, 2>(a, st);
     if (a.Cout % 128 == 0) {
         // 256 px x 128 ch per block, wave tile 128 px x 64 ch (tiles 0, 1); less than one block per CU (the batch-1 forward,
-        // validation at test_bs 1): twice the blocks at 64 channels each (tile 3: 20-25 % faster per layer at batch 1;
-        // USTRUN_HALO_SMALL_THR is the tuning knob)
+        // validation at test_bs 1): twice the blocks at 64 channels each (tile 3: 20-25 % faster per layer at batch 1)
         switch (halo_tile128(a)) {
             case 0: return launch_cfg<8, 32, 128, 32, 4, false>(a, st);
             case 1: return launch_cfg<16, 16, 128, 32, 4, false>(a, st);
@@ -824,6 +825,8 @@ int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st) {
             default: return launch_cfg<8, 16, 128, 32, 2, false, 2>(a, st);
         }
     }
+    // (ustrun_debug_flags bit 13 = 8192: the 512-pixel x 64-channel tile, wave tile 128 px x 64 ch, one block per CU -- A/B runs)
+    if (wide && (g_debug_flags & 8192) && a.Hb >= 16) return launch_cfg<16, 32, 64, 32, 4, false, 1>(a, st);
     if (wide) return launch_cfg<8, 32, 64, 32, 2, false, 2>(a, st);
     return launch_cfg<16, 16, 64, 32, 2, false, 2>(a, st);
 }

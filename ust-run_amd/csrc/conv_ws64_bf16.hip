@@ -1069,8 +1069,6 @@ WsPlan ws_plan(const IgemmArgs& a) {
 
 }  // namespace
 
-void* g_ws64_dbg = nullptr;       // ustrun_debug_buffer: when set, the DIAG build runs and writes [block][wave][8] u64 there
-void ws64_set_debug_buffer(void* p) { g_ws64_dbg = p; }
 
 bool ws64_supported(const IgemmArgs& a) {
     if (a.nseg != 9 || a.nz != 1 || a.s_in != 1 || a.s_out != 1 || a.segw != 3 || a.nsrc != 1) return false;
@@ -1088,8 +1086,8 @@ int ws64_stat_rows(const IgemmArgs& a) { return ws_plan(a).items * 2; }
 
 int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     WsPlan p = ws_plan(a);
-    p.dbg = (unsigned long long*)g_ws64_dbg;
     const int grid = cdiv(p.items, p.ipb);
+    USTRUN_TRY(debug_buffer_for(grid, "conv3x3_ws64_bf16", &p.dbg));     // set: the DIAG build runs and writes [block][wave][8] u64 there
     bool xf = false;
     set_last_variant(0x57530000 | ((a.src[0].scale != nullptr || a.src[0].relu != 0) ? 1 : 0));     // 'WS' | XF
     xf |= a.src[0].scale != nullptr || a.src[0].relu != 0;

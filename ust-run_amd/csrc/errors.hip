@@ -7,24 +7,28 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 }
-// ---- dynamic LDS above the 64 KB default: the attribute is per kernel AND per device; set it once for each pair and
-// report a failed set here instead of as an opaque launch error later ----
+// ---- dynamic LDS above the 64 KB default: the attribute is per kernel AND per device.  The largest size asked for so far is
+// kept per (kernel, device) and the attribute is only ever RAISED (a later, smaller request must not lower the limit a
+// larger launch of the same kernel still needs: ADVICE r3); a failed set is reported here instead of as an opaque launch
+// error later ----
+#include <map>
 #include <mutex>
-#include <set>
 #include <utility>
 namespace ustrun {
 int ensure_dynamic_lds(const void* fn, int bytes, const char* who) {
     static std::mutex mu;
-    static std::set<std::pair<const void*, long>> done;      // (kernel, device << 24 | bytes rounded up to KB)
+    static std::map<std::pair<const void*, int>, int> granted;      // (kernel, device) -> bytes the attribute stands at
+    if (bytes <= 64 * 1024) return 0;                                 // the default limit covers it
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     USTRUN_CHECK(e == hipSuccess, "%s: hipGetDevice failed: %s", who, hipGetErrorString(e));
-    const std::pair<const void*, long> key(fn, (long)dev << 24 | (long)((bytes + 1023) >> 10));
+    const std::pair<const void*, int> key(fn, dev);
     std::lock_guard<std::mutex> lk(mu);
-    if (done.count(key)) return 0;
+    auto it = granted.find(key);
+    if (it != granted.end() && it->second >= bytes) return 0;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     USTRUN_CHECK(e == hipSuccess, "%s: cannot raise the dynamic LDS limit to %d bytes on device %d: %s", who, bytes, dev, hipGetErrorString(e));
-    done.insert(key);
+    granted[key] = bytes;
     return 0;
 }
 }

@@ -143,8 +143,24 @@ static ustrun_src_t src_slice(const ustrun_src_t& s, int g, int gN, int dtype) {
 extern "C" int ustrun_debug_last_conv_variant(void) { return halo_last_variant(); }
 extern "C" int ustrun_debug_last_wgrad_variant(void) { return wgrad_last_variant(); }
 // (USTRUN_DEBUG_FLAGS in the environment presets the flags: A/B runs of whole programs on one box)
-namespace ustrun { int g_debug_flags = getenv("USTRUN_DEBUG_FLAGS") ? atoi(getenv("USTRUN_DEBUG_FLAGS")) : 0; }
-extern "C" int ustrun_debug_buffer(void* device_u64) { ws64_set_debug_buffer(device_u64); return 0; }
+namespace ustrun {
+static const int g_env_debug_flags = getenv("USTRUN_DEBUG_FLAGS") ? atoi(getenv("USTRUN_DEBUG_FLAGS")) : 0;     // read once, at load
+thread_local int g_debug_flags = g_env_debug_flags;
+thread_local DebugBuf g_dbg = {nullptr, 0};
+int debug_buffer_for(long blocks, const char* who, unsigned long long** out) {
+    *out = nullptr;
+    if (!g_dbg.p) return 0;
+    USTRUN_CHECK(blocks * 64 <= g_dbg.n_u64, "%s: the stamped build writes 64 u64 per workgroup: %ld workgroups need %ld u64, "
+                 "ustrun_debug_buffer was given %ld", who, blocks, blocks * 64, g_dbg.n_u64);
+    *out = g_dbg.p;
+    return 0;
+}
+}
+extern "C" int ustrun_debug_buffer(void* device_u64, int64_t n_u64) {
+    USTRUN_CHECK(!device_u64 || n_u64 >= 64, "debug_buffer: %ld u64 is smaller than one workgroup's stamps", (long)n_u64);
+    g_dbg.p = (unsigned long long*)device_u64; g_dbg.n_u64 = device_u64 ? (long)n_u64 : 0;
+    return 0;
+}
 extern "C" int ustrun_debug_flags(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
 
 extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W, int Cout,

@@ -1143,10 +1143,12 @@ int wgrad_halo_launch_bf16(const WgradArgs& a, int ksplit, int tiles_per, hipStr
         if (halo_pp_ok(a)) {
             constexpr int lds = 4 * H3<8>::STAGE;
             set_last_wgrad_variant(0x48200000 | (ksplit & 0xfff));
-            if (g_ws64_dbg) {              // ustrun_debug_buffer set: the stamped build
+            unsigned long long* dbg = nullptr;
+            USTRUN_TRY(debug_buffer_for((long)grid.x * ksplit, "wgrad_halo_pp", &dbg));
+            if (dbg) {                     // ustrun_debug_buffer set: the stamped build
                 if (int rc = ensure_dynamic_lds((const void*)wgrad_halo_pp_bf16_kernel<true>, lds, "wgrad_halo")) return rc;
                 hipLaunchKernelGGL(wgrad_halo_pp_bf16_kernel<true>, dim3(grid.x * ksplit), dim3(512), lds, st, b, a.Cout / 64, cdiv(a.Wb, TW),
-                                   cdiv(a.Hb, 8), tiles_per, (unsigned long long*)g_ws64_dbg);
+                                   cdiv(a.Hb, 8), tiles_per, dbg);
             } else {
                 if (int rc = ensure_dynamic_lds((const void*)wgrad_halo_pp_bf16_kernel<false>, lds, "wgrad_halo")) return rc;
                 hipLaunchKernelGGL(wgrad_halo_pp_bf16_kernel<false>, dim3(grid.x * ksplit), dim3(512), lds, st, b, a.Cout / 64, cdiv(a.Wb, TW),

@@ -312,7 +312,7 @@ static int launch_tile(const WgradArgs& a, hipStream_t st) {
     return 0;
 }
 
-int g_last_wgrad_variant = 0;
+thread_local int g_last_wgrad_variant = 0;     // (per calling thread)
 int wgrad_last_variant() { return g_last_wgrad_variant; }
 void set_last_wgrad_variant(int v) { g_last_wgrad_variant = v; }
 

@@ -100,7 +100,8 @@ SIGNATURES = {
     "ustrun_debug_conv_stat_rows": (i32, [i32] * 10),
     "ustrun_debug_last_wgrad_variant": (i32, []),
     "ustrun_debug_flags": (i32, [i32]),
-    "ustrun_debug_buffer": (i32, [vp]),
+    "ustrun_debug_buffer": (i32, [vp, i64]),
+    "ustrun_debug_last_bn_variant": (i32, []),
     "ustrun_profile_enable": (i32, [i32]),
     "ustrun_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ustrun_profile_stream": (i32, [vp, i32]),

@@ -22,28 +22,35 @@ def env_world():
 
 
 _WAIT = [None]
+WAIT_TIMEOUT_S = 6 * 3600
 
 
-def init(backend=None, device=None):
-    """Join the process group described by the torchrun environment (RANK/WORLD_SIZE/MASTER_*)."""
+def init(backend=None, device=None, wait_timeout_s=WAIT_TIMEOUT_S):
+    """Join the process group described by the torchrun environment (RANK/WORLD_SIZE/MASTER_*).  The host-side gloo group
+    behind `wait_for_rank0` is created HERE, while every rank is present and no GPU work is pending: `new_group` is itself a
+    rendezvous of all ranks, and created lazily at the first epoch end it would have met rank 0 minutes late, in the middle
+    of its validation."""
     rank, local, world = env_world()
     if world > 1 and not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")   # "nccl" IS RCCL on ROCm
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
+    if world > 1 and _WAIT[0] is None:
+        import datetime
+        _WAIT[0] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=wait_timeout_s))
     return rank, local, world
 
 
-def wait_for_rank0(timeout_s=6 * 3600):
+def wait_for_rank0(timeout_s=WAIT_TIMEOUT_S):
     """Park the other ranks while rank 0 validates and saves at an epoch end.  A barrier on the RCCL group is itself a
-    collective under that group's watchdog timeout, so a long validation would trip it just the same; the wait runs on a
-    host-side gloo group with its own long timeout instead (created on first use, by every rank)."""
+    collective under that group's watchdog timeout, so a long validation would trip it just the same; the wait runs on the
+    host-side gloo group `init` created, with its own long timeout."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     if _WAIT[0] is None:
-        import datetime
-        _WAIT[0] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s))
-    dist.monitored_barrier(_WAIT[0], timeout=__import__("datetime").timedelta(seconds=timeout_s))
+        raise RuntimeError("ddp.wait_for_rank0: the process group was not set up by ddp.init (its gloo side group is missing)")
+    import datetime
+    dist.monitored_barrier(_WAIT[0], timeout=datetime.timedelta(seconds=timeout_s))
 
 
 class GradReducer:
