@@ -14,9 +14,13 @@
  *   - activations inside the network are NHWC ("pixel-major": channels of one pixel are
  *     contiguous); the network input and the logits are NCHW as in the reference.
  *   - dtype selects the storage type of activations, activation gradients and packed weights:
- *     USTRUN_F32 (exact f32 MFMA, the parity path) or USTRUN_BF16 (bf16 tensors in HBM, bf16 MFMA,
- *     f32 accumulate / BatchNorm statistics / losses / optimizer).  `void*` activation arguments
- *     follow it; the network input, logits, parameters and gradients of parameters are always f32.
+ *     USTRUN_F32 (exact f32 MFMA, the parity path), USTRUN_BF16 (bf16 tensors in HBM, bf16 MFMA,
+ *     f32 accumulate / BatchNorm statistics / losses / optimizer) or USTRUN_F16 (the same kernels
+ *     built for IEEE half: the reference's own mixed-precision type, torch.cuda.amp autocast +
+ *     GradScaler, train.py:30,54,551-552,842-845; activation GRADIENTS in half need the caller's loss
+ *     scale: ustrun_seg_loss_bwd's gscale carries it in, ustrun_sgd_ema_scaled takes it out and skips
+ *     the update when the scaled gradient is not finite).  `void*` activation arguments follow
+ *     dtype; the network input, logits, parameters and gradients of parameters are always f32.
  */
 #ifndef USTRUN_H
 #define USTRUN_H
@@ -27,7 +31,7 @@ extern "C" {
 #endif
 
 #define USTRUN_VERSION 100
-enum { USTRUN_F32 = 0, USTRUN_BF16 = 1 };
+enum { USTRUN_F32 = 0, USTRUN_BF16 = 1, USTRUN_F16 = 2 };
 enum { USTRUN_LOSS_SOFTMAX = 0, USTRUN_LOSS_SIGMOID = 1 };
 
 typedef void* ustrun_stream_t;
@@ -370,6 +374,7 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  * bits 10-11: force the halo kernel's tile in the 128-column case (1: 8 x 32 px, 2: 16 x 16, 3: 8 x 16; 0: chosen by padding).
  * bit 12 (4096): BatchNorm backward (plain, bf16) on the 4-channel-per-lane kernels instead of the 8-channel ones.
  * The last-variant code of the streaming kernel is 0x57530000 | (eight waves ? 0x100 : consumer / producer ? 0x200 : 0) | XF.
+ * bits 16-20: layer + 1 at which ustrun_unet_backward stops early (tests/diag_grad.py; 0: runs through).
  * bit 13 (8192): 64-output-channel 3x3 layers on >= 32-wide maps on the 16 x 32-pixel tile (one block per CU; A/B runs).
  * The value is PER CALLING THREAD (as are the last-variant codes and the stamp buffer below): a thread that sets it changes
  * kernel selection for the launches it issues itself and for nobody else, so the library keeps no process-wide mutable

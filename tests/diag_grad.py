@@ -37,9 +37,8 @@ def patched_empty(*a, **k):
 torch.empty = patched_empty
 keep["arm"] = True
 wsave = logits.grad_fn.ws
-import ctypes
 from ustrun import _lib
-ctypes.c_int.in_dll(_lib.lib(), "ustrun_debug_stop_layer").value = 6
+_lib.lib().ustrun_debug_flags((6 + 1) << 16)        # stop the backward before layer 6 (bits 16-20 = layer + 1)
 logits.square().mean().backward()
 torch.cuda.synchronize()
 sc = keep["scratch"].view(torch.float32)

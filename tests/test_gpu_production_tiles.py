@@ -22,6 +22,19 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+class E:
+    """the 16-bit element type the current test runs on: every test of this file runs for both builds of the kernel sources
+    (bf16, and IEEE half = the reference's torch.cuda.amp autocast type, train.py:551-552); the integer data is exact in both"""
+    t, code = torch.bfloat16, 1
+
+
+@pytest.fixture(autouse=True, params=["bf16", "f16"])
+def elt(request):
+    E.t, E.code = (torch.bfloat16, 1) if request.param == "bf16" else (torch.float16, 2)
+    yield request.param
+    E.t, E.code = torch.bfloat16, 1
+
+
 def L():
     from ustrun import _lib
     return _lib
@@ -33,7 +46,7 @@ def rel(a, b):
 
 
 def nhwc16(t):
-    return t.permute(0, 2, 3, 1).contiguous().cuda().bfloat16()
+    return t.permute(0, 2, 3, 1).contiguous().cuda().to(E.t)
 
 
 def from_nhwc(t):
@@ -41,17 +54,17 @@ def from_nhwc(t):
 
 
 def r16(t):
-    return t.bfloat16().float()
+    return t.to(E.t).float()
 
 
 def pack16(w):
     l = L()
     co, ci = w.shape[:2]
     n = 9 * ((ci + 7) // 8 * 8) * ((co + 7) // 8 * 8)
-    wf = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
-    wd = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    wf = torch.zeros(n, dtype=E.t, device="cuda")
+    wd = torch.zeros(n, dtype=E.t, device="cuda")
     wg = w.contiguous().cuda()
-    l.check(l.lib().ustrun_pack_conv3x3(wg.data_ptr(), co, ci, wf.data_ptr(), wd.data_ptr(), 1, None))
+    l.check(l.lib().ustrun_pack_conv3x3(wg.data_ptr(), co, ci, wf.data_ptr(), wd.data_ptr(), E.code, None))
     return wf, wd
 
 
@@ -163,13 +176,13 @@ def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):
     sarr = (l.Src * len(srcs))(*srcs)
     # output and statistics rows between sentinel zones (nothing outside the tensor / the rows the call reports is written)
     ZO = 8192
-    obuf = torch.full((ZO + n * h * w * co + ZO,), 9.0, device="cuda", dtype=torch.bfloat16)
+    obuf = torch.full((ZO + n * h * w * co + ZO,), 9.0, device="cuda", dtype=E.t)
     out = obuf[ZO:ZO + n * h * w * co].view(n, h, w, co)
     rows_max = lib.ustrun_conv_mtiles(n, h, w, co)
     stat = torch.full((rows_max + 64, 2, co), 5.0, device="cuda")
     rows = C.c_int(0)
     l.check(lib.ustrun_conv3x3_fwd_rows(sarr, len(srcs), wf.data_ptr(), n, h, w, co, out.data_ptr(), stat.data_ptr(),
-                                        C.byref(rows), 1, None), "fwd")
+                                        C.byref(rows), E.code, None), "fwd")
     got = lib.ustrun_debug_last_conv_variant()
     assert got == (WS_CODE[vf] | 1 if vf in WS_CODE else variant(*vf, False, True)), f"forward ran {vstr(got)}"
     yc = from_nhwc(out.float())
@@ -186,18 +199,18 @@ def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):
 
     # input gradient: whole, then split into [source 0 | source 1 window]
     dyg = nhwc16(dy)
-    dbuf = torch.full((ZO + n * h * w * ci + ZO,), 9.0, device="cuda", dtype=torch.bfloat16)
+    dbuf = torch.full((ZO + n * h * w * ci + ZO,), 9.0, device="cuda", dtype=E.t)
     da = dbuf[ZO:ZO + n * h * w * ci].view(n, h, w, ci)
-    l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 1, None), "dgrad")
+    l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, E.code, None), "dgrad")
     got = lib.ustrun_debug_last_conv_variant()
     assert got == (WS_CODE[vd] if vd in WS_CODE else variant(*vd, False, False)), f"input gradient ran {vstr(got)}"
     assert rel(from_nhwc(da.float()), r16(a.grad)) < 1e-6
     assert bool((dbuf[:ZO] == 9.0).all()) and bool((dbuf[-ZO:] == 9.0).all()), "input gradient wrote outside its output"
     if len(cs) == 2:
-        d0 = torch.empty(n, h, w, cs[0], device="cuda", dtype=torch.bfloat16)
-        d1 = torch.full((n, uh, uw, cs[1]), 7.0, device="cuda", dtype=torch.bfloat16)
+        d0 = torch.empty(n, h, w, cs[0], device="cuda", dtype=E.t)
+        d1 = torch.full((n, uh, uw, cs[1]), 7.0, device="cuda", dtype=E.t)
         l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, d0.data_ptr(), cs[0], d1.data_ptr(),
-                                         uh, uw, oy, ox, 1, None), "dgrad split")
+                                         uh, uw, oy, ox, E.code, None), "dgrad split")
         assert lib.ustrun_debug_last_conv_variant() == variant(*vd, False, False)
         assert rel(from_nhwc(d0.float()), r16(a.grad[:, :cs[0]])) < 1e-6
         assert rel(from_nhwc(d1.float()), r16(a.grad[:, cs[0]:, oy:oy + uh, ox:ox + uw])) < 1e-6
@@ -206,9 +219,9 @@ def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):
     nb = lib.ustrun_wgrad_partials_bytes(9, ci, co, n * h * w)
     part = torch.empty(nb // 4, device="cuda")
     dw = torch.empty(co, ci, 3, 3, device="cuda")
-    l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 0, part.data_ptr(), nb, 1, None), "wgrad")
+    l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 0, part.data_ptr(), nb, E.code, None), "wgrad")
     assert rel(dw.cpu(), wr.grad) < 1e-6
-    l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 1, part.data_ptr(), nb, 1, None), "wgrad acc")
+    l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 1, part.data_ptr(), nb, E.code, None), "wgrad acc")
     assert rel(dw.cpu(), 2 * wr.grad) < 1e-6
 
 
@@ -231,24 +244,24 @@ def test_convT_bf16_batched_passes_exact():
     ref = F.conv_transpose2d(ar, wr, br, stride=2)
     ref.backward(du)
     nel = 4 * ci * co
-    wf = torch.zeros(nel, dtype=torch.bfloat16, device="cuda")
-    wd = torch.zeros(nel, dtype=torch.bfloat16, device="cuda")
+    wf = torch.zeros(nel, dtype=E.t, device="cuda")
+    wd = torch.zeros(nel, dtype=E.t, device="cuda")
     wg = wt.cuda()
-    l.check(lib.ustrun_pack_convT2x2(wg.data_ptr(), ci, co, wf.data_ptr(), wd.data_ptr(), 1, None))
+    l.check(lib.ustrun_pack_convT2x2(wg.data_ptr(), ci, co, wf.data_ptr(), wd.data_ptr(), E.code, None))
     aff = torch.zeros(G, 4, ci)
     aff[:, 0], aff[:, 1] = sc, sh
     affg, yg, bg, dug = aff.cuda(), nhwc16(y), b.cuda(), nhwc16(du)
     src = l.nhwc_src(yg.data_ptr(), ci, h, w, affg.data_ptr(), affg.data_ptr() + 4 * ci, relu=1, gN=gn, gstride=4 * ci)
-    u = torch.empty(n, 2 * h, 2 * w, co, device="cuda", dtype=torch.bfloat16)
-    l.check(lib.ustrun_convT2x2_fwd(C.byref(src), wf.data_ptr(), bg.data_ptr(), n, h, w, co, u.data_ptr(), 1, None))
+    u = torch.empty(n, 2 * h, 2 * w, co, device="cuda", dtype=E.t)
+    l.check(lib.ustrun_convT2x2_fwd(C.byref(src), wf.data_ptr(), bg.data_ptr(), n, h, w, co, u.data_ptr(), E.code, None))
     assert rel(from_nhwc(u.float()), r16(ref.detach())) < 1e-6
     nb = max(lib.ustrun_wgrad_partials_bytes(4, ci, co, n * h * w), 512 * co * 4)
     part = torch.empty(nb // 4, device="cuda")
     dw, db = torch.empty(ci, co, 2, 2, device="cuda"), torch.empty(co, device="cuda")
-    l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, 1, None))
+    l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, E.code, None))
     assert rel(dw.cpu(), wr.grad) < 1e-6 and rel(db.cpu(), br.grad) < 1e-6
-    da = torch.empty(n, h, w, ci, device="cuda", dtype=torch.bfloat16)
-    l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), 1, None))
+    da = torch.empty(n, h, w, ci, device="cuda", dtype=E.t)
+    l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), E.code, None))
     assert rel(from_nhwc(da.float()), r16(ar.grad)) < 1e-6
 
 
@@ -309,9 +322,9 @@ def test_wgrad_all_taps_builds_exact(case):
     dw = buf[Z:Z + co * ci * 9]
     old = lib.ustrun_debug_flags(flags)
     try:
-        l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 0, part.data_ptr(), nb, 1, None), "wgrad")
+        l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 0, part.data_ptr(), nb, E.code, None), "wgrad")
         v = lib.ustrun_debug_last_wgrad_variant()
-        l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 1, part.data_ptr(), nb, 1, None), "wgrad acc")
+        l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 1, part.data_ptr(), nb, E.code, None), "wgrad acc")
     finally:
         lib.ustrun_debug_flags(old)
     assert (v >> 20) == fam, f"weight gradient ran variant {v:#x}"

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__
                                                       const float* __restrict__ shift, int relu, int gN, long gstride,
                                                       int N, int H, int W, int C, float* __restrict__ out) {
     constexpr int V = ESZ == 2 ? 8 : 4;             // channels per thread: one 16-byte load per window pixel
-    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+    typedef __attribute__((ext_vector_type(8))) elt_t bf16x8v;
     const int Hp = H / 2, Wp = W / 2, CV = C / V;
     // a thread keeps its channel group (256 % CV == 0 for the power-of-two channel counts; else it re-derives it)
     const long npix = (long)N * Hp * Wp;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__
         if (ESZ == 2) {
             bf16x8v r[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = *(const bf16x8v*)((const __bf16*)y + base + ((q >> 1) * (long)W + (q & 1)) * C);
+            for (int q = 0; q < 4; ++q) r[q] = *(const bf16x8v*)((const elt_t*)y + base + ((q >> 1) * (long)W + (q & 1)) * C);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__
         if (ESZ == 2) {                                     // one 16-byte store
             bf16x8v o8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o8[j] = (__bf16)m[j % V];
-            *(bf16x8v*)((__bf16*)out + ob) = o8;
+            for (int j = 0; j < 8; ++j) o8[j] = (elt_t)m[j % V];
+            *(bf16x8v*)((elt_t*)out + ob) = o8;
         } else {
 #pragma unroll
             for (int h = 0; h < V / 4; ++h) st4t<ESZ>(out, ob + 4 * h, (f32x4){m[4 * h], m[4 * h + 1], m[4 * h + 2], m[4 * h + 3]});
@@ -509,17 +509,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* da, cons
 // their occupancy that is about half of what 8 TB/s x the memory latency asks of a CU, and the plain apply pass ran at
 // 4.8-5.1 TB/s where the pooled one (nine loads per thread) reaches 5.5.  Here a lane owns 8 channels of a pixel: thread =
 // (octet tid % G8, pixel lane tid / G8), G8 = C / 8 a power of two <= 256; the arithmetic is the same per element.
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_bn;
+typedef __attribute__((ext_vector_type(8))) elt_t bf16x8_bn;
 struct F8 { f32x4 lo, hi; };
 __device__ __forceinline__ F8 up8(bf16x8_bn v) {
     return F8{(f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, (f32x4){(float)v[4], (float)v[5], (float)v[6], (float)v[7]}};
 }
 __device__ __forceinline__ F8 ld8f(const float* p) { return F8{*(const f32x4*)p, *(const f32x4*)(p + 4)}; }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_x8_kernel(const __bf16* __restrict__ da, const __bf16* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_apply_x8_kernel(const elt_t* __restrict__ da, const elt_t* __restrict__ y,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ coef, long npix, int C, int G8,
-                                                             __bf16* __restrict__ dy, const PassOff po) {
+                                                             elt_t* __restrict__ dy, const PassOff po) {
     {
         const long g = blockIdx.y;
         da += g * po.act; y += g * po.act; dy += g * po.act;
@@ -538,8 +538,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_x8_kernel(const __bf16* __re
         for (int j = 0; j < 4; ++j) {
             const float al = yv.lo[j] * sc.lo[j] + sh.lo[j], ah = yv.hi[j] * sc.hi[j] + sh.hi[j];
             const float zl = al > 0.f ? dv.lo[j] : 0.f, zh = ah > 0.f ? dv.hi[j] : 0.f;
-            o[j] = (__bf16)(k0.lo[j] * zl + k1.lo[j] * yv.lo[j] + k2.lo[j]);
-            o[4 + j] = (__bf16)(k0.hi[j] * zh + k1.hi[j] * yv.hi[j] + k2.hi[j]);
+            o[j] = (elt_t)(k0.lo[j] * zl + k1.lo[j] * yv.lo[j] + k2.lo[j]);
+            o[4 + j] = (elt_t)(k0.hi[j] * zh + k1.hi[j] * yv.hi[j] + k2.hi[j]);
         }
         return o;
     };
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_x8_kernel(const __bf16* __re
         *(bf16x8_bn*)(dy + w * C + c) = one(*(const bf16x8_bn*)(y + w * C + c), *(const bf16x8_bn*)(da + w * C + c));
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_x8_kernel(const __bf16* __restrict__ da, const __bf16* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_x8_kernel(const elt_t* __restrict__ da, const elt_t* __restrict__ y,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               long npix, int C, int G8, float* __restrict__ partials,
                                                               const PassOff po) {
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_x8_kernel(const __bf16* __r
 static bool x8_ok(int C, bool pool, int dtype) {
     if (g_debug_flags & 4096) return false;
     const int g8 = C / 8;
-    return dtype == USTRUN_BF16 && !pool && C % 8 == 0 && g8 >= 1 && g8 <= 256 && (g8 & (g8 - 1)) == 0;
+    return dtype == USTRUN_D16 && !pool && C % 8 == 0 && g8 >= 1 && g8 <= 256 && (g8 & (g8 - 1)) == 0;
 }
 
 // ustrun_debug_last_bn_variant: 0x424E0000 ('BN') | pass (0 reduce, 1 apply) << 8 | element bytes << 4 | even windows << 2 |
@@ -714,7 +714,7 @@ extern "C" int ustrun_bn_relu_apply(const void* y, const float* scale, const flo
 extern "C" int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dtype, ustrun_stream_t s) {
     USTRUN_CHECK(dtype_ok(dtype), "pool_act: dtype %d not built", dtype);
     USTRUN_CHECK(src && src->ptr && out && N > 0, "pool_act: bad args");
-    const int C = src->C, H = src->H, W = src->W, V = dtype == USTRUN_BF16 ? 8 : 4;
+    const int C = src->C, H = src->H, W = src->W, V = dtype == USTRUN_D16 ? 8 : 4;
     USTRUN_CHECK(C % V == 0 && H >= 2 && W >= 2, "pool_act: C=%d extent %dx%d unsupported", C, H, W);
     USTRUN_CHECK(src->sC == 1 && src->sW == C && src->sH == (int64_t)W * C && src->sN == (int64_t)H * W * C && !src->pool &&
                  !src->off_y && !src->off_x && !src->f32, "pool_act: source must be a plain contiguous NHWC activation");
@@ -728,7 +728,7 @@ extern "C" int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dt
     if (nb < 1) nb = 1;
     const int blocks = (int)nb;
     const int gN = src->scale ? src->gN : 0;
-    if (dtype == USTRUN_BF16)
+    if (dtype == USTRUN_D16)
         hipLaunchKernelGGL(pool_act_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)src->ptr, src->scale,
                            src->shift, src->relu, gN, (long)src->gstride, N, H, W, C, (float*)out);
     else
@@ -745,7 +745,7 @@ extern "C" int ustrun_maxpool_bwd(const void* dp, const void* x, int N, int H, i
     const long total = (long)N * H * W * C;
     long nb = (total + 1023) / 1024;
     if (nb > 8192) nb = 8192;
-    if (dtype == USTRUN_BF16)
+    if (dtype == USTRUN_D16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<2>, dim3((int)nb), dim3(256), 0, (hipStream_t)s, (const float*)dp, (const float*)x, N, H,
                            W, C, (float*)dx);
     else
@@ -782,7 +782,7 @@ int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const fl
     const PassOff po = {act_elems, pool_elems, aff_stride, (long)blocks * 2 * C, 3L * C};
     note_bn_variant(0, act_esz(dtype), pool && !(H & 1) && !(W & 1), pool, x8);
     if (x8) {
-        hipLaunchKernelGGL(bn_bwd_reduce_x8_kernel, dim3(blocks, passes), dim3(256), 0, s, (const __bf16*)da, (const __bf16*)y, scale, shift,
+        hipLaunchKernelGGL(bn_bwd_reduce_x8_kernel, dim3(blocks, passes), dim3(256), 0, s, (const elt_t*)da, (const elt_t*)y, scale, shift,
                            nwin, C, G, partials, po);
         USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, blocks, C, (double)N * H * W, gamma,
@@ -794,7 +794,7 @@ int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const fl
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<P, E, V>), dim3(blocks, passes), dim3(256), 0, s, (const float*)da,      \
                        (const float*)dp, (const float*)y, scale, shift, N, H, W, C, G, partials, po)
     const bool even = pool && !(H & 1) && !(W & 1);
-    if (dtype == USTRUN_BF16) { if (even) USTRUN_BN_REDUCE(true, 2, true); else if (pool) USTRUN_BN_REDUCE(true, 2, false); else USTRUN_BN_REDUCE(false, 2, false); }
+    if (dtype == USTRUN_D16) { if (even) USTRUN_BN_REDUCE(true, 2, true); else if (pool) USTRUN_BN_REDUCE(true, 2, false); else USTRUN_BN_REDUCE(false, 2, false); }
     else { if (even) USTRUN_BN_REDUCE(true, 4, true); else if (pool) USTRUN_BN_REDUCE(true, 4, false); else USTRUN_BN_REDUCE(false, 4, false); }
 #undef USTRUN_BN_REDUCE
     USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
@@ -821,8 +821,8 @@ int bn_bwd_apply_passes(const void* da, const void* dp, const void* y, const flo
     const PassOff po = {act_elems, pool_elems, aff_stride, 0, 3L * C};
     note_bn_variant(1, act_esz(dtype), pool && !(H & 1) && !(W & 1), pool, x8);
     if (x8) {
-        hipLaunchKernelGGL(bn_bwd_apply_x8_kernel, dim3((int)blocks, passes), dim3(256), 0, s, (const __bf16*)da, (const __bf16*)y, scale, shift,
-                           coef, nwin, C, G, (__bf16*)dy, po);
+        hipLaunchKernelGGL(bn_bwd_apply_x8_kernel, dim3((int)blocks, passes), dim3(256), 0, s, (const elt_t*)da, (const elt_t*)y, scale, shift,
+                           coef, nwin, C, G, (elt_t*)dy, po);
         USTRUN_LAUNCH_CHECK("bn_bwd_apply");
         return 0;
     }
@@ -830,7 +830,7 @@ int bn_bwd_apply_passes(const void* da, const void* dp, const void* y, const flo
     hipLaunchKernelGGL((bn_bwd_apply_kernel<P, E, V>), dim3((int)blocks, passes), dim3(256), 0, s, (const float*)da,       \
                        (const float*)dp, (const float*)y, scale, shift, coef, N, H, W, C, G, (float*)dy, po)
     const bool even = pool && !(H & 1) && !(W & 1);
-    if (dtype == USTRUN_BF16) { if (even) USTRUN_BN_APPLY(true, 2, true); else if (pool) USTRUN_BN_APPLY(true, 2, false); else USTRUN_BN_APPLY(false, 2, false); }
+    if (dtype == USTRUN_D16) { if (even) USTRUN_BN_APPLY(true, 2, true); else if (pool) USTRUN_BN_APPLY(true, 2, false); else USTRUN_BN_APPLY(false, 2, false); }
     else { if (even) USTRUN_BN_APPLY(true, 4, true); else if (pool) USTRUN_BN_APPLY(true, 4, false); else USTRUN_BN_APPLY(false, 4, false); }
 #undef USTRUN_BN_APPLY
     USTRUN_LAUNCH_CHECK("bn_bwd_apply");

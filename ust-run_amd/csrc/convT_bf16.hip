@@ -18,7 +18,7 @@
 namespace ustrun {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     const float invW = 1.f / (float)W;
     const int Ktot = DG ? 4 * a.Cin : a.Cin;
     const int nchunk = Ktot / BK;
-    const __bf16* Wp = (const __bf16*)a.W;
-    const __bf16* Ap = (const __bf16*)a.src[0].ptr;
+    const elt_t* Wp = (const elt_t*)a.W;
+    const elt_t* Ap = (const elt_t*)a.src[0].ptr;
     const int x0r = (int)(m0 % W);              // x of the tile's first pixel
 
     // ---- A items: pixel = (tid + 256 i) / CPR, 8-channel group c8 = tid % CPR ------------------------------
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
                 f32x4 lo = (f32x4){(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * asc0 + ash0;
                 f32x4 hi = (f32x4){(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * asc1 + ash1;
                 if (a_relu) { lo = relu4(lo); hi = relu4(hi); }
-                h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-                h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+                h[0] = (elt_t)lo[0]; h[1] = (elt_t)lo[1]; h[2] = (elt_t)lo[2]; h[3] = (elt_t)lo[3];
+                h[4] = (elt_t)hi[0]; h[5] = (elt_t)hi[1]; h[6] = (elt_t)hi[2]; h[7] = (elt_t)hi[3];
             }
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
             u32x4 u = __builtin_bit_cast(u32x4, h);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
 #pragma unroll
         for (int i = 0; i < BIT; ++i) {
             const int o = (tid + 256 * i) / BN;
-            const __bf16* src = Wp + bcol + (long)(c * CPR + o) * brow;
+            const elt_t* src = Wp + bcol + (long)(c * CPR + o) * brow;
             __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + (wave * 64 + 256 * i) * 16), 16, 0, 0);
         }
     };
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
                     for (int i = 0; i < MI; ++i) {
                         const int p = prow0 + 32 * i;
                         const bf16x8 af = *(const bf16x8*)(Acur + p * ROWB + ((ch ^ swz(p)) * 16));
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bcur[ks][0], acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bcur[ks][1], acc[i][1], 0, 0, 0);
+                        acc[i][0] = USTRUN_MFMA_32x32x16(af, bcur[ks][0], acc[i][0], 0, 0, 0);
+                        acc[i][1] = USTRUN_MFMA_32x32x16(af, bcur[ks][1], acc[i][1], 0, 0, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
             for (int i = 0; i < MI; ++i) {
                 const int p = prow0 + 32 * i;
                 const bf16x8 af = *(const bf16x8*)(Acur + p * ROWB + ((ch ^ swz(p)) * 16));
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[i][1], 0, 0, 0);
+                acc[i][0] = USTRUN_MFMA_32x32x16(af, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = USTRUN_MFMA_32x32x16(af, b1, acc[i][1], 0, 0, 0);
             }
         }
         if (more) write_A(As + (buf ^ 1) * ABYTES);
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     if (!DG && !PLAIN) { tap = colw / a.Cout; co0 = colw - tap * a.Cout; }
     float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};          // PLAIN: BatchNorm-statistics partials of this lane's two channels
     const float bias0 = (!DG && a.bias) ? a.bias[co0 + l31] : 0.f, bias1 = (!DG && a.bias) ? a.bias[co0 + 32 + l31] : 0.f;
-    __bf16* outp = (__bf16*)a.out0;
+    elt_t* outp = (elt_t*)a.out0;
     const long tapoff = (long)(tap >> 1) * 2 * W + (tap & 1);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const __bf16 hv = (__bf16)(acc[i][j][r] + (j ? bias1 : bias0));
-                *(__bf16*)(ep + row * EPITCH + (j * 32 + l31) * 2) = hv;
+                const elt_t hv = (elt_t)(acc[i][j][r] + (j ? bias1 : bias0));
+                *(elt_t*)(ep + row * EPITCH + (j * 32 + l31) * 2) = hv;
                 if constexpr (PLAIN) {      // rows past M carry zero activations and 1x1 convs in front of a BatchNorm have no bias
                     const float f = (float)hv;
                     st1[j] += f; st2[j] += f * f;

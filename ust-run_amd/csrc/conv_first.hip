@@ -15,8 +15,8 @@
 namespace ustrun {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) elt_t bf16x4;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 constexpr int FTH = 8, FTW = 16, FHW = FTW + 2, FHP = (FTH + 2) * FHW;   // 10 x 18 patch
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
     }
     for (int t = tid; t < C * 9 * 64; t += 256) {                    // packed forward weights -> [c*9+tap][co]
         const int co = t & 63, k = t >> 6, c = k / 9, tap = k - c * 9;
-        wl[k][co] = wbf16 ? (float)((const __bf16*)w)[(((long)tap * ((C + 7) / 8) + c / 8) * 64 + co) * 8 + (c & 7)]
+        wl[k][co] = wbf16 ? (float)((const elt_t*)w)[(((long)tap * ((C + 7) / 8) + c / 8) * 64 + co) * 8 + (c & 7)]
                           : ((const float*)w)[((long)tap * C + c) * 64 + co];
     }
     __syncthreads();
@@ -107,12 +107,12 @@ constexpr int MTH = 8, MTW = 32, MHW = MTW + 2, MHP = (MTH + 2) * MHW;   // 10 x
 
 template <int KS>
 __global__ __launch_bounds__(256, 4) void conv_first_fwd_mfma_kernel(const float* __restrict__ x, long sN, long sC, long sH, long sW,
-                                                                    int C, int H, int W, const __bf16* __restrict__ w,
-                                                                    __bf16* __restrict__ y, float* __restrict__ stat,
+                                                                    int C, int H, int W, const elt_t* __restrict__ w,
+                                                                    elt_t* __restrict__ y, float* __restrict__ stat,
                                                                     int tiles_x, int tiles_y) {
     constexpr int EPITCH = 144;
     __shared__ float patch[CMAX * MHP + 4];                 // [c][10][34]; the last word stays zero (K padding)
-    __shared__ __attribute__((aligned(16))) __bf16 Bw[KS * 2][64][8];
+    __shared__ __attribute__((aligned(16))) elt_t Bw[KS * 2][64][8];
     __shared__ __attribute__((aligned(16))) char eps[4 * 32 * EPITCH];
     __shared__ float red[4][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_fwd_mfma_kernel(const float
     for (int t = tid; t < KS * 2 * 64 * 8; t += 256) {       // k = c*9 + tap; packed forward weights are [tap][1][64][8 (c)]
         const int j = t & 7, co = (t >> 3) & 63, k8 = t >> 9, k = k8 * 8 + j;
         const int c = k / 9, tap = k - c * 9;
-        Bw[k8][co][j] = k < K ? w[((long)tap * 64 + co) * 8 + c] : (__bf16)0.f;
+        Bw[k8][co][j] = k < K ? w[((long)tap * 64 + co) * 8 + c] : (elt_t)0.f;
     }
     // this lane's K entries: k = 16 ks + 8 lh + j -> patch offset relative to the pixel's (0,0) tap
     int koff[KS][8];
@@ -162,9 +162,9 @@ __global__ __launch_bounds__(256, 4) void conv_first_fwd_mfma_kernel(const float
         for (int ks = 0; ks < KS; ++ks) {
             bf16x8 af;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) af[j] = (__bf16)patch[koff[ks][j] >= 0 ? base + koff[ks][j] : CMAX * MHP];
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[ks][0], acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[ks][1], acc[i][1], 0, 0, 0);
+            for (int j = 0; j < 8; ++j) af[j] = (elt_t)patch[koff[ks][j] >= 0 ? base + koff[ks][j] : CMAX * MHP];
+            acc[i][0] = USTRUN_MFMA_32x32x16(af, bfr[ks][0], acc[i][0], 0, 0, 0);
+            acc[i][1] = USTRUN_MFMA_32x32x16(af, bfr[ks][1], acc[i][1], 0, 0, 0);
         }
     }
     // epilogue
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256, 4) void conv_first_fwd_mfma_kernel(const float
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const __bf16 hv = (__bf16)acc[i][n][r];
-                *(__bf16*)(ep + row * EPITCH + (n * 32 + l31) * 2) = hv;
+                const elt_t hv = (elt_t)acc[i][n][r];
+                *(elt_t*)(ep + row * EPITCH + (n * 32 + l31) * 2) = hv;
                 if (oy < H && x0 + row < W) {
                     const float v = (float)hv;                 // statistics see the stored value
                     s1[n] += v; s2[n] += v * v;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
                                                               float* __restrict__ partials, int tiles_x, int tiles_y,
                                                               int ttotal, int tiles_per) {
     // im2col source: xs[c][kw][hy][16] bf16 = patch shifted by kw so that 8 consecutive pixels are 16-B aligned
-    __shared__ __attribute__((aligned(16))) __bf16 xs[CMAX][3][FTH + 2][FTW];
+    __shared__ __attribute__((aligned(16))) elt_t xs[CMAX][3][FTH + 2][FTW];
     __shared__ __attribute__((aligned(16))) char dys[FTH * FTW * WRB];
     __shared__ float accs[4][32][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             const int d = xdec[i];
-            if (d >= 0) xs[d >> 16][(d >> 12) & 3][(d >> 6) & 63][d & 63] = (__bf16)xr[i];
+            if (d >= 0) xs[d >> 16][(d >> 12) & 3][(d >> 6) & 63][d & 63] = (elt_t)xr[i];
         }
 #pragma unroll
         for (int i = 0; i < DIT; ++i) {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
                 *(f32x4*)(dys + (e >> 3) * WRB + (e & 7) * 16) = dr[i];          // 8 bf16, as stored
             } else {
                 bf16x4 h;
-                h[0] = (__bf16)dr[i][0]; h[1] = (__bf16)dr[i][1]; h[2] = (__bf16)dr[i][2]; h[3] = (__bf16)dr[i][3];
+                h[0] = (elt_t)dr[i][0]; h[1] = (elt_t)dr[i][1]; h[2] = (elt_t)dr[i][2]; h[3] = (elt_t)dr[i][3];
                 *(bf16x4*)(dys + (e >> 4) * WRB + (e & 15) * 8) = h;
             }
         }
@@ -302,16 +302,16 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
             const int r = wave * 2 + rr;                              // tile row = 16 pixels = one MFMA k-step
             bf16x8 a;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] = (__bf16)0.f;
+            for (int q = 0; q < 8; ++q) a[q] = (elt_t)0.f;
             if (ivalid) a = *(const bf16x8*)&xs[ic][ikw][r + ikh][8 * lh];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const char* base = dys + (r * FTW + lrow) * WRB + (j * 32 + lcol) * 2;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)base);
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + 4 * WRB));
+                const bf16x4 lo = USTRUN_DS_READ_TR16((lds_bf16x4*)base);
+                const bf16x4 hi = USTRUN_DS_READ_TR16((lds_bf16x4*)(base + 4 * WRB));
                 bf16x8 b;
                 b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3]; b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                acc[j] = USTRUN_MFMA_32x32x16(a, b, acc[j], 0, 0, 0);
             }
         }
     }
@@ -360,15 +360,15 @@ bool conv_first_supported(const ustrun_src_t& s, int Cout) {
     return s.C <= CMAX && Cout == 64 && !s.pool && !s.scale && !s.relu && s.off_y == 0 && s.off_x == 0;
 }
 int conv_first_stat_rows(int N, int H, int W, int dtype) {
-    return dtype == USTRUN_BF16 ? N * cdiv(H, MTH) * cdiv(W, MTW) : N * cdiv(H, FTH) * cdiv(W, FTW);
+    return dtype == USTRUN_D16 ? N * cdiv(H, MTH) * cdiv(W, MTW) : N * cdiv(H, FTH) * cdiv(W, FTW);
 }
 
 int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, void* y, float* stat, hipStream_t st) {
-    if (dtype == USTRUN_BF16) {            // im2col on the matrix cores
+    if (dtype == USTRUN_D16) {            // im2col on the matrix cores
         const int tx = cdiv(s.W, MTW), ty = cdiv(s.H, MTH), ks = cdiv(9 * s.C, 16);
         dim3 grid(N * ty * tx), block(256);
 #define USTRUN_CF(KS) hipLaunchKernelGGL(conv_first_fwd_mfma_kernel<KS>, grid, block, 0, st, (const float*)s.ptr, (long)s.sN, \
-                                         (long)s.sC, (long)s.sH, (long)s.sW, s.C, s.H, s.W, (const __bf16*)w_fwd, (__bf16*)y, stat, tx, ty)
+                                         (long)s.sC, (long)s.sH, (long)s.sW, s.C, s.H, s.W, (const elt_t*)w_fwd, (elt_t*)y, stat, tx, ty)
         if (ks == 1) USTRUN_CF(1); else if (ks == 2) USTRUN_CF(2); else USTRUN_CF(3);
 #undef USTRUN_CF
         USTRUN_LAUNCH_CHECK("conv_first_fwd_mfma");

@@ -17,8 +17,8 @@
 namespace ustrun {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) elt_t bf16x4;
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
 
     const int nchunk = a.Cin / BK;
     const int K8 = a.Cin / 8;
-    const __bf16* Wp = (const __bf16*)a.W;
-    const __bf16* zsrc = (const __bf16*)g_zero16;
+    const elt_t* Wp = (const elt_t*)a.W;
+    const elt_t* zsrc = (const elt_t*)g_zero16;
     const bool wflip = a.dstep < 0;             // input-gradient: geometric tap g pairs with weight slice 8 - g
 
     // ---- A patch staging.  Tile constants per SOURCE (recomputed when a concat switches source):
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
     int asoff = 0;                              // byte offset of the chunk's first channel
     int cur_src = -1;
     float a_floor = 0.f;                        // ReLU as max(x, floor): 0, or -inf for a source without ReLU
-    const __bf16* aptr = nullptr;               // chunk base: source + image + first channel of the chunk
+    const elt_t* aptr = nullptr;               // chunk base: source + image + first channel of the chunk
     long dq1 = 0, dq2 = 0;                      // pooled source: element offsets of the right / lower neighbour
     f32x4 asc0, asc1, ash0, ash1;
     const int p8 = tid & 3;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
         const SrcDev S = pick_src(a.src[0], a.src[1], second != 0);
         const int cl = cg - (second ? a.src[0].C : 0);
         if (second != cur_src) { src_setup(S); cur_src = second; }
-        aptr = (const __bf16*)S.ptr + (img * S.sN + cl);      // (the prologue of the transforming variants loads through it)
+        aptr = (const elt_t*)S.ptr + (img * S.sN + cl);      // (the prologue of the transforming variants loads through it)
         asoff = 2 * cl;
         asc0 = asc1 = (f32x4){1.f, 1.f, 1.f, 1.f}; ash0 = ash1 = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (S.scale && !from_lds) {                  // prologue: straight from memory, in flight with the patch loads
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
             lo = max4(lo, l2); hi = max4(hi, h2);
         }
         bf16x8 h;
-        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+        h[0] = (elt_t)lo[0]; h[1] = (elt_t)lo[1]; h[2] = (elt_t)lo[2]; h[3] = (elt_t)lo[3];
+        h[4] = (elt_t)hi[0]; h[5] = (elt_t)hi[1]; h[6] = (elt_t)hi[2]; h[7] = (elt_t)hi[3];
         u32x4 u = __builtin_bit_cast(u32x4, h);
 #pragma unroll
         for (int q = 0; q < 4; ++q) u[q] = inimg ? u[q] : 0u;      // padding is applied after the activation
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
         *(bf16x8*)dst = xform8(r, (aokm >> i) & 1u);
     };
     // ---- B tile of (chunk c, geometric tap): LDS-DMA, 16 B per lane, lane-linear destination ----
-    const __bf16* wthr[BIT];
+    const elt_t* wthr[BIT];
 #pragma unroll
     for (int i = 0; i < BIT; ++i) {
         const int idx = tid + 256 * i, o = idx / BN, n = idx % BN;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
             const bool ok = (aokm >> i) & 1u;
-            const __bf16* src = ok ? (const __bf16*)((const char*)aptr + aoff[i]) : zsrc;
+            const elt_t* src = ok ? (const elt_t*)((const char*)aptr + aoff[i]) : zsrc;
 #pragma unroll
             for (int q = 0; q < NP; ++q) pv[i][q] = *(const bf16x8*)(src + (ok ? (q & 1 ? dq1 : 0) + (q & 2 ? dq2 : 0) : 0));
         }
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                         }
 #pragma unroll
                         for (int i = 0; i < MI; ++i) {
-                            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acar[i], bcur[k][ks][0], acc[i][0], 0, 0, 0);
-                            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acar[i], bcur[k][ks][1], acc[i][1], 0, 0, 0);
+                            acc[i][0] = USTRUN_MFMA_32x32x16(acar[i], bcur[k][ks][0], acc[i][0], 0, 0, 0);
+                            acc[i][1] = USTRUN_MFMA_32x32x16(acar[i], bcur[k][ks][1], acc[i][1], 0, 0, 0);
                         }
                         if (in_stage || j < NSTG - 1) {
 #pragma unroll
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                 for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][ks][i], bf[k][ks][0], acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[k][ks][i], bf[k][ks][1], acc[i][1], 0, 0, 0);
+                        acc[i][0] = USTRUN_MFMA_32x32x16(af[k][ks][i], bf[k][ks][0], acc[i][0], 0, 0, 0);
+                        acc[i][1] = USTRUN_MFMA_32x32x16(af[k][ks][i], bf[k][ks][1], acc[i][1], 0, 0, 0);
                     }
             }
             if constexpr (SKEW) {
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
     // banks) and writes 16 bytes per lane, 128 contiguous bytes per pixel.
     const int C1 = a.Cout - a.C0;
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    typedef __attribute__((ext_vector_type(2))) elt_t bf16x2;
     f32x2 s1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2v[2] = {{0.f, 0.f}, {0.f, 0.f}};    // two pixel rows at a time (packed f32 math)
     constexpr int EPITCH = 144;
     char* ep = smem + wave * (32 * EPITCH);         // the A patches are dead after the last barrier
@@ -597,8 +597,8 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
                 const bf16x2 h = __builtin_convertvector(v, bf16x2);
-                *(__bf16*)(ep + row * EPITCH + (j * 32 + l31) * 2) = h[0];
-                *(__bf16*)(ep + (row + 1) * EPITCH + (j * 32 + l31) * 2) = h[1];
+                *(elt_t*)(ep + row * EPITCH + (j * 32 + l31) * 2) = h[0];
+                *(elt_t*)(ep + (row + 1) * EPITCH + (j * 32 + l31) * 2) = h[1];
                 if (!STAT) continue;
                 f32x2 f = __builtin_convertvector(h, f32x2);               // statistics see the stored values
                 if (MASK) {
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
             // interior tile, one destination (wave-uniform): four plain stores off one base -- the general path below costs
             // three nested exec-mask regions and a 64-bit address chain per store
             const int r0 = lane >> 3, ch = lane & 7;
-            __bf16* base = (__bf16*)a.out0 + (((long)img * a.Ho + oyb) * a.Wo + x0) * a.C0 + n0 + wn * 64 + ch * 8;
+            elt_t* base = (elt_t*)a.out0 + (((long)img * a.Ho + oyb) * a.Wo + x0) * a.C0 + n0 + wn * 64 + ch * 8;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = r0 + 8 * t;
@@ -642,11 +642,11 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
             const int col = n0 + wn * 64 + ch * 8;
             if (oy < a.Ho && ox < a.Wo) {
                 if (col < a.C0) {
-                    *(bf16x8*)((__bf16*)a.out0 + (((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col) = v8;
+                    *(bf16x8*)((elt_t*)a.out0 + (((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col) = v8;
                 } else {
                     const int y1 = oy - a.o1y, x1 = ox - a.o1x;
                     if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
-                        *(bf16x8*)((__bf16*)a.out1 + (((long)img * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0)) = v8;
+                        *(bf16x8*)((elt_t*)a.out1 + (((long)img * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0)) = v8;
                 }
             }
         }

@@ -26,8 +26,8 @@
 namespace ustrun {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) elt_t bf16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
     const int l31 = lane & 31, lh = lane >> 5;
     char* Ew = smem + RINGB + wave * EWAVE;
     const SrcDev S = a.src[0];
-    const __bf16* srcp = (const __bf16*)S.ptr;
+    const elt_t* srcp = (const elt_t*)S.ptr;
     const int H = a.Hb, W = a.Wb;
     const int sH = (int)S.sH, sW = (int)S.sW;
     // one buffer descriptor per tensor (ws64_supported keeps them under 2 GiB); the image goes into the scalar offset
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
     // walks the taps backwards (a.dstep < 0) over the [tap][Cout/8][Cin][8] pack. ----
     bf16x8 Wr[9][4];
     {
-        const __bf16* Wp = (const __bf16*)a.W;
+        const elt_t* Wp = (const elt_t*)a.W;
         const bool wflip = a.dstep < 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
         for (int i = 0; i < 2; ++i)                // (alternating the two accumulators instead measured 2-4 % slower)
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
-                acc[2 * HF + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[dy * 3 + dx][ks], pf[i + dy], acc[2 * HF + i], 0, 0, 0);
+                acc[2 * HF + i] = USTRUN_MFMA_32x32x16(Wr[dy * 3 + dx][ks], pf[i + dy], acc[2 * HF + i], 0, 0, 0);
     };
     auto zero_half = [&](auto half_c) __attribute__((always_inline)) {
         constexpr int HF = decltype(half_c)::value;
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 bf16x4 h;
-                h[0] = (__bf16)acc[i][4 * g]; h[1] = (__bf16)acc[i][4 * g + 1];
-                h[2] = (__bf16)acc[i][4 * g + 2]; h[3] = (__bf16)acc[i][4 * g + 3];
+                h[0] = (elt_t)acc[i][4 * g]; h[1] = (elt_t)acc[i][4 * g + 1];
+                h[2] = (elt_t)acc[i][4 * g + 2]; h[3] = (elt_t)acc[i][4 * g + 3];
                 *(bf16x4*)(Ew + (i * 32 + l31) * EPITCH + (8 * g + 4 * lh) * 2) = h;
             }
         }
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64x8_kernel(const IgemmArgs 
     const int cg = wave & 3, wm = wave >> 2;
     const int lp = lane & 15, lq = lane >> 4;
     const SrcDev S = a.src[0];
-    const __bf16* srcp = (const __bf16*)S.ptr;
+    const elt_t* srcp = (const elt_t*)S.ptr;
     const int H = a.Hb, W = a.Wb;
     const int sH = (int)S.sH, sW = (int)S.sW;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)srcp, 0, (int)min((long)a.N * S.sN * 2, 0x7fffffffL), 0x00020000);
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64x8_kernel(const IgemmArgs 
     // the [tap][Cout/8][Cin][8] pack) ----
     bf16x8 Wr[9][2];
     {
-        const __bf16* Wp = (const __bf16*)a.W;
+        const elt_t* Wp = (const elt_t*)a.W;
         const bool wflip = a.dstep < 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
@@ -576,14 +576,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64x8_kernel(const IgemmArgs 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
-                acc[i][ph] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wr[dy * 3 + dx][ks], pf[i + dy], acc[i][ph], 0, 0, 0);
+                acc[i][ph] = USTRUN_MFMA_16x16x32(Wr[dy * 3 + dx][ks], pf[i + dy], acc[i][ph], 0, 0, 0);
     };
     // epilogue of tile (row i, pixel half ph): 4 channels of one pixel per lane -> 8 bytes; statistics of the stored values
     auto epi = [&](int i, int ph, const Cur& c, bool live) __attribute__((always_inline)) {
         const int y = c.ybeg + 8 * (c.k - 1) + 4 * wm + i;
         const int ylim = min(c.ybeg + p.seg, H);
         bf16x4 h;
-        h[0] = (__bf16)acc[i][ph][0]; h[1] = (__bf16)acc[i][ph][1]; h[2] = (__bf16)acc[i][ph][2]; h[3] = (__bf16)acc[i][ph][3];
+        h[0] = (elt_t)acc[i][ph][0]; h[1] = (elt_t)acc[i][ph][1]; h[2] = (elt_t)acc[i][ph][2]; h[3] = (elt_t)acc[i][ph][3];
         u32x2 u = __builtin_bit_cast(u32x2, h);
         const bool inimg = live & (y < ylim) & (c.x0 + 16 * ph + lp < W);
         const unsigned voff = (unsigned)(st_lane + ph * 2048) | (inimg ? 0u : 0x80000000u);
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
     const int l31 = lane & 31, lh = lane >> 5;
     char* Ew = smem + RINGB + wave * EWAVE;
     const SrcDev S = a.src[0];
-    const __bf16* srcp = (const __bf16*)S.ptr;
+    const elt_t* srcp = (const elt_t*)S.ptr;
     const int H = a.Hb, W = a.Wb;
     const int sH = (int)S.sH, sW = (int)S.sW;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)srcp, 0, (int)min((long)a.N * S.sN * 2, 0x7fffffffL), 0x00020000);
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
         // =================================== consumer ===================================
         bf16x8 Wr[9][4];
         {
-            const __bf16* Wp = (const __bf16*)a.W;
+            const elt_t* Wp = (const elt_t*)a.W;
             const bool wflip = a.dstep < 0;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy)       // (the first product of an accumulator takes the constant 0 as C: no zeroing pass)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[dy * 3 + g / 4][g % 4], pf[g % 3][i + dy], (g == 0 && dy == 0) ? zero16 : acc[i], 0, 0, 0);
+                        acc[i] = USTRUN_MFMA_32x32x16(Wr[dy * 3 + g / 4][g % 4], pf[g % 3][i + dy], (g == 0 && dy == 0) ? zero16 : acc[i], 0, 0, 0);
             }
             // park the half's rows (bf16) in the wave's scratch: lane = pixel, 4 consecutive channels per register quad
 #pragma unroll
@@ -835,8 +835,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     bf16x4 h;
-                    h[0] = (__bf16)acc[ii][4 * g]; h[1] = (__bf16)acc[ii][4 * g + 1];
-                    h[2] = (__bf16)acc[ii][4 * g + 2]; h[3] = (__bf16)acc[ii][4 * g + 3];
+                    h[0] = (elt_t)acc[ii][4 * g]; h[1] = (elt_t)acc[ii][4 * g + 1];
+                    h[2] = (elt_t)acc[ii][4 * g + 2]; h[3] = (elt_t)acc[ii][4 * g + 3];
                     *(bf16x4*)(Ew + (i * 32 + l31) * EPITCH + (8 * g + 4 * lh) * 2) = h;
                 }
             }

@@ -57,11 +57,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 // lane's scale/shift/weights live in registers for the whole launch, four pixels in flight per lane; after the
 // butterfly every lane of the group holds the logits and lane k stores class k.
 template <int K>
-__global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const __bf16* __restrict__ y, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const elt_t* __restrict__ y, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, long npix, int HW, int C, int G,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            float* __restrict__ logits) {
-    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+    typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
     const int g = threadIdx.x % G, pl = threadIdx.x / G, PPB = 256 / G;
     float sc[8], sh[8], wk[K][8];
 #pragma unroll
@@ -246,11 +246,11 @@ extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* s
     USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_fwd: C=%d K=%d unsupported", C, K);
     USTRUN_CHECK(npix > 0 && HW > 0 && npix % HW == 0 && npix < (1LL << 32), "head_fwd: bad extent");
     const int G = C / 8;
-    if (dtype == USTRUN_BF16 && C % 8 == 0 && G <= 64 && (G & (G - 1)) == 0 && K >= 1 && K <= 4 && K <= G) {
+    if (dtype == USTRUN_D16 && C % 8 == 0 && G <= 64 && (G & (G - 1)) == 0 && K >= 1 && K <= 4 && K <= G) {
         long nb = (npix + (256 / G) * 8 - 1) / ((256 / G) * 8);      // two rounds of four pixels per lane
         if (nb > 8192) nb = 8192;
         dim3 grid((int)nb), block(256);
-#define USTRUN_HF(KK) hipLaunchKernelGGL(head_fwd_bf16_kernel<KK>, grid, block, 0, (hipStream_t)s, (const __bf16*)y, scale, shift, \
+#define USTRUN_HF(KK) hipLaunchKernelGGL(head_fwd_bf16_kernel<KK>, grid, block, 0, (hipStream_t)s, (const elt_t*)y, scale, shift, \
                                          (long)npix, HW, C, G, w, bias, logits)
         if (K == 1) USTRUN_HF(1); else if (K == 2) USTRUN_HF(2); else if (K == 3) USTRUN_HF(3); else USTRUN_HF(4);
 #undef USTRUN_HF
@@ -260,7 +260,7 @@ extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* s
     const int LPP = lanes_per_pixel(C / 4);
     long blocks = (npix + (256 / LPP) * 4 - 1) / ((256 / LPP) * 4);
     if (blocks > 8192) blocks = 8192;
-    if (dtype == USTRUN_BF16)
+    if (dtype == USTRUN_D16)
         hipLaunchKernelGGL(head_fwd_kernel<2>, dim3((int)blocks), dim3(256), 0, (hipStream_t)s, (const float*)y, scale, shift,
                            (long)npix, HW, C, K, LPP, w, bias, logits);
     else
@@ -288,7 +288,7 @@ int head_bwd_passes(const float* dlogits, const void* y, const float* scale, con
 #define USTRUN_HB(E, KT)                                                                                                     \
     hipLaunchKernelGGL((head_bwd_kernel<E, KT>), dim3(blocks, passes), dim3(256), (1024 + 256) * sizeof(float), s, dlogits,    \
                        (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials, pass_aff)
-    if (dtype == USTRUN_BF16) { if (K == 2) USTRUN_HB(2, 2); else if (K == 4) USTRUN_HB(2, 4); else USTRUN_HB(2, 0); }
+    if (dtype == USTRUN_D16) { if (K == 2) USTRUN_HB(2, 2); else if (K == 4) USTRUN_HB(2, 4); else USTRUN_HB(2, 0); }
     else { if (K == 2) USTRUN_HB(4, 2); else if (K == 4) USTRUN_HB(4, 4); else USTRUN_HB(4, 0); }
 #undef USTRUN_HB
     USTRUN_LAUNCH_CHECK("head_bwd");

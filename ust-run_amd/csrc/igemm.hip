@@ -280,8 +280,8 @@ int igemm_mtiles(int64_t M, int Cout) { (void)Cout; return cdiv(M, 128); }
 
 // stat rows actually written by the kernel igemm_launch will pick
 int igemm_stat_rows_used(const IgemmArgs& a, int dtype) {
-    if (dtype == USTRUN_BF16 && !(g_debug_flags & 1) && ws64_supported(a)) return ws64_stat_rows(a);
-    if (dtype == USTRUN_BF16 && halo_supported(a)) return halo_stat_rows_used(a);
+    if (dtype == USTRUN_D16 && !(g_debug_flags & 1) && ws64_supported(a)) return ws64_stat_rows(a);
+    if (dtype == USTRUN_D16 && halo_supported(a)) return halo_stat_rows_used(a);
     return cdiv(a.M, 128);
 }
 
@@ -300,13 +300,13 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     for (int i = 0; i < a.nsrc; ++i) in_elems += (double)a.N * a.src[i].H * a.src[i].W * a.src[i].C;
     const double out_elems = (double)a.M * a.nz * a.Cout;
     const double w_elems = (double)a.nseg * a.nz * a.Cin * a.Cout;
-    const double aesz = dtype == USTRUN_BF16 ? 2.0 : 4.0;     // stored element size of activations and packed weights
+    const double aesz = dtype == USTRUN_D16 ? 2.0 : 4.0;     // stored element size of activations and packed weights
     prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, aesz * (in_elems + out_elems + w_elems), st);
     int rc;
     bool grouped = false;
     for (int i = 0; i < a.nsrc; ++i) grouped |= a.src[i].gN > 0;
-    USTRUN_CHECK(!grouped || dtype == USTRUN_BF16, "igemm: batched passes reached a kernel without per-pass BatchNorm constants");
-    if (dtype == USTRUN_BF16) {
+    USTRUN_CHECK(!grouped || dtype == USTRUN_D16, "igemm: batched passes reached a kernel without per-pass BatchNorm constants");
+    if (dtype == USTRUN_D16) {
         if (!(g_debug_flags & 1) && ws64_supported(a)) rc = conv3x3_ws64_launch_bf16(a, st);
         else if (halo_supported(a)) rc = conv3x3_halo_launch_bf16(a, st);
         else if (convT_fwd_supported(a)) rc = convT_fwd_launch_bf16(a, st);

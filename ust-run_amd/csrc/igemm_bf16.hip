@@ -9,8 +9,8 @@
 namespace ustrun {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) elt_t bf16x4;
 
 struct RowInfo { int n; int yx; };
 
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IgemmArgs a, c
     const int nchunk = (a.Cin + BK - 1) / BK;
     const int nstage = a.nseg * nchunk;
     const int K8 = (a.Cin + 7) / 8;         // packed K octets per slice
-    const __bf16* Wp = (const __bf16*)a.W;
+    const elt_t* Wp = (const elt_t*)a.W;
 
     f32x4 av[AR][NP];
     f32x4 asc, ash;
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IgemmArgs a, c
             }
         }
         // B tile: packed bf16 weights [slice][K8][Cout][8]
-        const __bf16* wb = Wp + ((long)(seg + z) * K8) * a.Cout * 8;
+        const elt_t* wb = Wp + ((long)(seg + z) * K8) * a.Cout * 8;
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
             const int idx = tid + 256 * i, o = idx / BN, n = idx % BN;
             bf16x8 v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+            for (int j = 0; j < 8; ++j) v[j] = (elt_t)0.f;
             const int ko = c0 / 8 + o;
             if (ko < K8 && n0 + n < a.Cout) v = *(const bf16x8*)(wb + ((long)ko * a.Cout + n0 + n) * 8);
             bv[i] = v;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IgemmArgs a, c
             }
             const int row = a_r0 + RPP * i;
             bf16x4 h;
-            h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+            h[0] = (elt_t)v[0]; h[1] = (elt_t)v[1]; h[2] = (elt_t)v[2]; h[3] = (elt_t)v[3];
             *(bf16x4*)(As + row * ROWB + (((a_c4 >> 1) ^ swz(row)) * 16) + (a_c4 & 1) * 8) = h;
         }
 #pragma unroll
@@ -185,10 +185,10 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const IgemmArgs a, c
             const bf16x8 a1 = *(const bf16x8*)(Ap1 + ((ch ^ sw1) * 16));
             const bf16x8 b0 = *(const bf16x8*)(Bp + (2 * ks * BN) * 16);
             const bf16x8 b1 = *(const bf16x8*)(Bp + (2 * ks * BN + 32) * 16);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            acc[0][0] = USTRUN_MFMA_32x32x16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = USTRUN_MFMA_32x32x16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = USTRUN_MFMA_32x32x16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = USTRUN_MFMA_32x32x16(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -262,7 +262,7 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
 // torch conv weight [Cout][Cin][taps] (taps = 9) or convT weight [Cin][Cout][taps] (taps = 4)
 // -> fwd [tap][ceil(Cin/8)][Cout][8] and dgrad [tap][ceil(Cout/8)][Cin][8], bf16, zero padded
 __global__ void pack_bf16_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int transposed_src,
-                                 __bf16* __restrict__ wf, __bf16* __restrict__ wd) {
+                                 elt_t* __restrict__ wf, elt_t* __restrict__ wd) {
     const int Ki = (Cin + 7) / 8, Ko = (Cout + 7) / 8;
     const long nf = (long)taps * Ki * Cout * 8, nd = (long)taps * Ko * Cin * 8;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nf + nd; e += (long)gridDim.x * blockDim.x) {
@@ -280,7 +280,7 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, int Cout, int Cin,
         float v = 0.f;
         if (ci < Cin && co < Cout)
             v = transposed_src ? w[((long)ci * Cout + co) * taps + tap] : w[((long)co * Cin + ci) * taps + tap];
-        if (e < nf) wf[e] = (__bf16)v; else if (wd) wd[e - nf] = (__bf16)v;
+        if (e < nf) wf[e] = (elt_t)v; else if (wd) wd[e - nf] = (elt_t)v;
     }
 }
 
@@ -300,16 +300,16 @@ int igemm_launch_bf16(const IgemmArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(256) void pack_bf16_multi_kernel(const PackJobs jobs) {
     const PackJob j = jobs.j[blockIdx.y];
     const float* __restrict__ w = j.w;
-    __bf16* wf = (__bf16*)j.wf;
-    __bf16* wd = (__bf16*)j.wd;
+    elt_t* wf = (elt_t*)j.wf;
+    elt_t* wd = (elt_t*)j.wd;
     const int Cin = j.Cin, Cout = j.Cout, taps = j.taps;
     // 3x3 conv weights with whole 64-channel input groups (every layer but the first): a block takes 8 output channels
     // x 64 input channels -- 8 contiguous 2304-byte runs of the source -- through LDS and writes both layouts in
     // 16-byte pieces that add up to whole 128-byte (forward) and 1 KB (input-gradient) runs.  The element-per-thread
     // path below wrote 2-byte pieces 16 bytes apart: 1.3 GB of HBM traffic for 248 MB of weights.
     if (!j.transposed_src && taps == 9 && Cin % 64 == 0 && Cout % 8 == 0 && wd) {
-        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-        __shared__ __bf16 t[8][64 * 9 + 2];                 // [co][ci*9 + tap] (+2: rows start 4 bytes apart in the banks)
+        typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
+        __shared__ elt_t t[8][64 * 9 + 2];                 // [co][ci*9 + tap] (+2: rows start 4 bytes apart in the banks)
         const int Ki = Cin / 8, Ko = Cout / 8, tiles_ci = Cin / 64, ntile = Ko * tiles_ci;
         for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
             const int cog = tile / tiles_ci, ci0 = (tile % tiles_ci) * 64;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void pack_bf16_multi_kernel(const PackJobs job
                 const int co = e / 144, q = e % 144;
                 const f32x4 v = *(const f32x4*)(w + ((long)(cog * 8 + co) * Cin + ci0) * 9 + 4 * q);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[co][4 * q + k] = (__bf16)v[k];
+                for (int k = 0; k < 4; ++k) t[co][4 * q + k] = (elt_t)v[k];
             }
             __syncthreads();
             for (int e = threadIdx.x; e < 9 * 8 * 8; e += 256) {        // forward: (tap, ci group, co) -> 8 ci
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void pack_bf16_multi_kernel(const PackJobs job
         const bool in = ci < Cin && co < Cout;
         const float* src = w + (j.transposed_src ? ((long)ci * Cout + co) : ((long)co * Cin + ci)) * taps;
         for (int tap = 0; tap < taps; ++tap) {
-            const __bf16 v = (__bf16)(in ? src[tap] : 0.f);
+            const elt_t v = (elt_t)(in ? src[tap] : 0.f);
             if (co < Cout) wf[(((long)tap * Ki + ci / 8) * Cout + co) * 8 + (ci & 7)] = v;
             if (wd && ci < Cin) wd[(((long)tap * Ko + co / 8) * Cin + ci) * 8 + (co & 7)] = v;
         }
@@ -365,8 +365,8 @@ int pack_bf16(const float* w, int Cout, int Cin, int taps, int transposed_src, v
     const long total = (long)taps * (((Cin + 7) / 8) * (long)Cout + ((Cout + 7) / 8) * (long)Cin) * 8;
     long b = (total + 1023) / 1024;
     if (b > 4096) b = 4096;
-    hipLaunchKernelGGL(pack_bf16_kernel, dim3((int)b), dim3(256), 0, st, w, Cout, Cin, taps, transposed_src, (__bf16*)wf,
-                       (__bf16*)wd);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((int)b), dim3(256), 0, st, w, Cout, Cin, taps, transposed_src, (elt_t*)wf,
+                       (elt_t*)wd);
     USTRUN_LAUNCH_CHECK("pack_bf16");
     return 0;
 }

@@ -6,35 +6,35 @@
 
 namespace ustrun {
 
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) elt_t bf16x4_t;
 
 // element-type-agnostic accessors: `base` is the tensor base, idx an ELEMENT index, esz 4 (f32) or 2 (bf16)
 __device__ __forceinline__ f32x4 ld4(const float* base, long idx, int esz) {
     if (esz == 4) return *(const f32x4*)(base + idx);
-    const bf16x4_t h = *(const bf16x4_t*)((const __bf16*)base + idx);
+    const bf16x4_t h = *(const bf16x4_t*)((const elt_t*)base + idx);
     return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
 __device__ __forceinline__ float ld1(const float* base, long idx, int esz) {
-    return esz == 4 ? base[idx] : (float)((const __bf16*)base)[idx];
+    return esz == 4 ? base[idx] : (float)((const elt_t*)base)[idx];
 }
 __device__ __forceinline__ void st4(float* base, long idx, f32x4 v, int esz) {
     if (esz == 4) { *(f32x4*)(base + idx) = v; return; }
     bf16x4_t h;
-    h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-    *(bf16x4_t*)((__bf16*)base + idx) = h;
+    h[0] = (elt_t)v[0]; h[1] = (elt_t)v[1]; h[2] = (elt_t)v[2]; h[3] = (elt_t)v[3];
+    *(bf16x4_t*)((elt_t*)base + idx) = h;
 }
 __device__ __forceinline__ void st1(float* base, long idx, float v, int esz) {
-    if (esz == 4) base[idx] = v; else ((__bf16*)base)[idx] = (__bf16)v;
+    if (esz == 4) base[idx] = v; else ((elt_t*)base)[idx] = (elt_t)v;
 }
 // value as it will read back from a tensor of element size esz
-__device__ __forceinline__ float rnd(float v, int esz) { return esz == 4 ? v : (float)(__bf16)v; }
+__device__ __forceinline__ float rnd(float v, int esz) { return esz == 4 ? v : (float)(elt_t)v; }
 
 // compile-time element size: no branch around the memory instruction (a runtime select makes hipcc put
 // every load in its own basic block with its own wait -- cdna_hip_programming.md "Three .s-level traps" (c))
 template <int ESZ> __device__ __forceinline__ f32x4 ld4t(const float* base, long idx) {
     if constexpr (ESZ == 4) return *(const f32x4*)(base + idx);
     else {
-        const bf16x4_t h = *(const bf16x4_t*)((const __bf16*)base + idx);
+        const bf16x4_t h = *(const bf16x4_t*)((const elt_t*)base + idx);
         return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
     }
 }
@@ -42,15 +42,15 @@ template <int ESZ> __device__ __forceinline__ void st4t(float* base, long idx, f
     if constexpr (ESZ == 4) *(f32x4*)(base + idx) = v;
     else {
         bf16x4_t h;
-        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-        *(bf16x4_t*)((__bf16*)base + idx) = h;
+        h[0] = (elt_t)v[0]; h[1] = (elt_t)v[1]; h[2] = (elt_t)v[2]; h[3] = (elt_t)v[3];
+        *(bf16x4_t*)((elt_t*)base + idx) = h;
     }
 }
 template <int ESZ> __device__ __forceinline__ void st1t(float* base, long idx, float v) {
-    if constexpr (ESZ == 4) base[idx] = v; else ((__bf16*)base)[idx] = (__bf16)v;
+    if constexpr (ESZ == 4) base[idx] = v; else ((elt_t*)base)[idx] = (elt_t)v;
 }
 template <int ESZ> __device__ __forceinline__ float rndt(float v) {
-    if constexpr (ESZ == 4) return v; else return (float)(__bf16)v;
+    if constexpr (ESZ == 4) return v; else return (float)(elt_t)v;
 }
 
 // field-wise select between the two kernel-argument sources (a runtime index into a kernarg

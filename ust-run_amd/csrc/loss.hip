@@ -576,6 +576,7 @@ extern "C" int ustrun_box_mix(const float* a, const float* b, const float* box, 
 /* Small host values reach the device inside the kernel-argument block: no copy engine, no host wait, ordered on the
  * stream like any launch.  (A pinned hipMemcpyAsync on a busy stream cost the step 20 ms here; a pageable copy drains
  * the queue.) */
+namespace ustrun { namespace {
 struct RectArgs { int r[USTRUN_MAX_RECTS][4]; };
 __global__ void rect_masks_kernel(RectArgs a, int N, int H, int W, float* __restrict__ box) {
     const long total = (long)N * H * W;
@@ -586,6 +587,7 @@ __global__ void rect_masks_kernel(RectArgs a, int N, int H, int W, float* __rest
         box[i] = (y >= a.r[n][0] && y < a.r[n][1] && x >= a.r[n][2] && x < a.r[n][3]) ? 1.f : 0.f;
     }
 }
+} }
 extern "C" int ustrun_rect_masks(const int32_t* rects_host, int N, int H, int W, float* box, ustrun_stream_t s) {
     USTRUN_CHECK(rects_host && box && H > 0 && W > 0, "rect_masks: bad args");
     USTRUN_CHECK(N > 0 && N <= USTRUN_MAX_RECTS, "rect_masks: 1..USTRUN_MAX_RECTS rectangles per call");
@@ -598,10 +600,12 @@ extern "C" int ustrun_rect_masks(const int32_t* rects_host, int N, int H, int W,
     return 0;
 }
 
+namespace ustrun { namespace {
 struct SmallArgs { uint32_t w[USTRUN_UPLOAD_MAX / 4]; };
 __global__ void upload_small_kernel(SmallArgs a, int words, uint32_t* __restrict__ dst) {
     for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = a.w[i];
 }
+} }
 extern "C" int ustrun_upload_small(void* dst, const void* src_host, int nbytes, ustrun_stream_t s) {
     USTRUN_CHECK(dst && src_host, "upload_small: null pointer");
     USTRUN_CHECK(nbytes > 0 && nbytes <= USTRUN_UPLOAD_MAX && nbytes % 4 == 0 && ((uintptr_t)dst & 3) == 0,

@@ -47,7 +47,7 @@ extern "C" int ustrun_pack_conv3x3(const float* w, int Cout, int Cin, void* w_fw
                                    ustrun_stream_t s) {
     USTRUN_CHECK(dtype_ok(dtype), "pack_conv3x3: dtype %d not built", dtype);
     USTRUN_CHECK(w && w_fwd && Cout > 0 && Cin > 0, "pack_conv3x3: bad args");
-    if (dtype == USTRUN_BF16) return pack_bf16(w, Cout, Cin, 9, 0, w_fwd, w_dgrad, (hipStream_t)s);
+    if (dtype == USTRUN_D16) return pack_bf16(w, Cout, Cin, 9, 0, w_fwd, w_dgrad, (hipStream_t)s);
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(pack_blocks((long)Cout * Cin * 9)), dim3(256), 0, (hipStream_t)s, w, Cout,
                        Cin, (float*)w_fwd, (float*)w_dgrad);
     USTRUN_LAUNCH_CHECK("pack_conv3x3");
@@ -58,7 +58,7 @@ extern "C" int ustrun_pack_convT2x2(const float* w, int Cin, int Cout, void* w_f
                                     ustrun_stream_t s) {
     USTRUN_CHECK(dtype_ok(dtype), "pack_convT2x2: dtype %d not built", dtype);
     USTRUN_CHECK(w && w_fwd && Cout > 0 && Cin > 0, "pack_convT2x2: bad args");
-    if (dtype == USTRUN_BF16) return pack_bf16(w, Cout, Cin, 4, 1, w_fwd, w_dgrad, (hipStream_t)s);
+    if (dtype == USTRUN_D16) return pack_bf16(w, Cout, Cin, 4, 1, w_fwd, w_dgrad, (hipStream_t)s);
     hipLaunchKernelGGL(pack_convT_kernel, dim3(pack_blocks((long)Cout * Cin * 4)), dim3(256), 0, (hipStream_t)s, w, Cin,
                        Cout, (float*)w_fwd, (float*)w_dgrad);
     USTRUN_LAUNCH_CHECK("pack_convT2x2");
@@ -133,7 +133,7 @@ static int src_groups(const ustrun_src_t* srcs, int nsrc, int N, int* gN) {
 }
 static ustrun_src_t src_slice(const ustrun_src_t& s, int g, int gN, int dtype) {
     ustrun_src_t t = s;
-    const int esz = (s.f32 || dtype != USTRUN_BF16) ? 4 : 2;
+    const int esz = (s.f32 || dtype != USTRUN_D16) ? 4 : 2;
     t.ptr = (const char*)s.ptr + (int64_t)g * gN * s.sN * esz;
     if (s.scale && s.gN > 0) { t.scale = s.scale + (int64_t)g * s.gstride; t.shift = s.shift + (int64_t)g * s.gstride; }
     t.gN = 0; t.gstride = 0;
@@ -186,7 +186,7 @@ extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const
     int gN = 0;
     const int G = src_groups(srcs, nsrc, N, &gN);
     USTRUN_CHECK(G >= 1, "conv3x3_fwd: inconsistent pass groups");
-    if (G > 1 && !(dtype == USTRUN_BF16 && halo_supported(a))) {      // one launch per pass
+    if (G > 1 && !(dtype == USTRUN_D16 && halo_supported(a))) {      // one launch per pass
         USTRUN_CHECK(!stat || stat_rows, "conv3x3_fwd: batched passes need ustrun_conv3x3_fwd_rows");
         int total = 0;
         for (int g = 0; g < G; ++g) {
@@ -259,7 +259,7 @@ extern "C" int ustrun_convT2x2_fwd(const ustrun_src_t* src, const void* w_fwd, c
         int gN = 0;
         const int G = src_groups(src, 1, N, &gN);
         USTRUN_CHECK(G >= 1, "convT2x2_fwd: inconsistent pass groups");
-        if (G > 1 && !(dtype == USTRUN_BF16 && convT_fwd_supported(a))) {
+        if (G > 1 && !(dtype == USTRUN_D16 && convT_fwd_supported(a))) {
             for (int g = 0; g < G; ++g) {
                 const ustrun_src_t sl = src_slice(*src, g, gN, dtype);
                 USTRUN_TRY(ustrun_convT2x2_fwd(&sl, w_fwd, bias, gN, H, W, Cout,
@@ -330,7 +330,7 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
         int gN = 0;
         const int G = src_groups(srcs, nsrc, N, &gN);
         USTRUN_CHECK(G >= 1, "conv3x3_wgrad: inconsistent pass groups");
-        if (G > 1 && !(dtype == USTRUN_BF16 && wgrad_halo_supported(a))) {
+        if (G > 1 && !(dtype == USTRUN_D16 && wgrad_halo_supported(a))) {
             for (int g = 0; g < G; ++g) {
                 ustrun_src_t sl[2];
                 for (int i = 0; i < nsrc; ++i) sl[i] = src_slice(srcs[i], g, gN, dtype);
@@ -340,9 +340,9 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
             return 0;
         }
     }
-    if (dtype == USTRUN_BF16 && nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W && srcs[0].f32)
+    if (dtype == USTRUN_D16 && nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W && srcs[0].f32)
         return conv_first_wgrad(srcs[0], dy, act_esz(dtype), N, dw, accumulate, partials, partials_bytes, (hipStream_t)s);
-    if (dtype == USTRUN_BF16 && wgrad_halo_supported(a)) {
+    if (dtype == USTRUN_D16 && wgrad_halo_supported(a)) {
         int per;
         wgrad_halo_plan(a, &slabs, &per);
         USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 9 * a.Cin * Cout * 4, "conv3x3_wgrad: partials too small");
@@ -403,7 +403,7 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
         int gN = 0;
         const int G = src_groups(src, 1, N, &gN);
         USTRUN_CHECK(G >= 1, "convT2x2_wgrad: inconsistent pass groups");
-        if (G > 1 && !(dtype == USTRUN_BF16 && wgradT_supported(a))) {
+        if (G > 1 && !(dtype == USTRUN_D16 && wgradT_supported(a))) {
             for (int g = 0; g < G; ++g) {
                 const ustrun_src_t sl = src_slice(*src, g, gN, dtype);
                 USTRUN_TRY(ustrun_convT2x2_wgrad(&sl, (const char*)du + (int64_t)g * gN * 4 * H * W * Cout * act_esz(dtype), gN, H, W,
@@ -412,7 +412,7 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
             return 0;
         }
     }
-    if (dtype == USTRUN_BF16 && wgradT_supported(a)) {       // all four taps (and the bias) in one GEMM: wgradT_bf16.hip
+    if (dtype == USTRUN_D16 && wgradT_supported(a)) {       // all four taps (and the bias) in one GEMM: wgradT_bf16.hip
         wgradT_plan(a.Cin, Cout, a.M, &a.ksplit, &a.kchunk);
         slabs = a.ksplit;
         const int64_t slab_bytes = (int64_t)slabs * 4 * a.Cin * Cout * 4;
@@ -435,7 +435,7 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
         if (blocks > 512) blocks = 512;
         USTRUN_CHECK(partials_bytes >= (int64_t)blocks * Cout * 4, "convT2x2_wgrad: partials too small for bias");
         USTRUN_CHECK(Cout % 4 == 0, "convT2x2_wgrad: Cout %d must be a multiple of 4", Cout);
-        if (dtype == USTRUN_BF16)
+        if (dtype == USTRUN_D16)
             hipLaunchKernelGGL(bias_grad_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)du, npix, Cout, partials);
         else
             hipLaunchKernelGGL(bias_grad_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)du, npix, Cout, partials);

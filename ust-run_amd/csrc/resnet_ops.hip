@@ -303,7 +303,7 @@ using namespace ustrun;
 extern "C" int ustrun_pack_conv(const float* w, int Cout, int Cin, int taps, void* w_fwd, int dtype, ustrun_stream_t s) {
     USTRUN_CHECK(dtype_ok(dtype), "pack_conv: dtype %d not built", dtype);
     USTRUN_CHECK(w && w_fwd && Cout > 0 && Cin > 0 && taps >= 1 && taps <= 49, "pack_conv: bad args");
-    if (dtype == USTRUN_BF16) return pack_bf16(w, Cout, Cin, taps, 0, w_fwd, nullptr, (hipStream_t)s);
+    if (dtype == USTRUN_D16) return pack_bf16(w, Cout, Cin, taps, 0, w_fwd, nullptr, (hipStream_t)s);
     hipLaunchKernelGGL(pack_conv_f32_kernel, dim3(stream_blocks((long)Cout * Cin * taps)), dim3(256), 0, (hipStream_t)s, w, Cout, Cin,
                        taps, (float*)w_fwd);
     USTRUN_LAUNCH_CHECK("pack_conv");
@@ -366,7 +366,7 @@ extern "C" int ustrun_maxpool3x3s2(const void* y, const float* scale, const floa
     USTRUN_CHECK(y && scale && shift && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && dtype_ok(dtype), "maxpool3x3s2: bad args");
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;             // floor((H + 2 - 3) / 2) + 1
     const long total = (long)N * Ho * Wo * (C / 4);
-    if (dtype == USTRUN_BF16)
+    if (dtype == USTRUN_D16)
         hipLaunchKernelGGL(maxpool3x3s2_kernel<2>, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)s, (const float*)y, scale, shift, N,
                            H, W, C, Ho, Wo, (float*)out);
     else
@@ -381,7 +381,7 @@ extern "C" int ustrun_bn_add_relu(const void* y, const float* scale, const float
     USTRUN_CHECK(y && scale && shift && idn && out && npix > 0 && C > 0 && C % 4 == 0 && dtype_ok(dtype), "bn_add_relu: bad args");
     USTRUN_CHECK((iscale == nullptr) == (ishift == nullptr), "bn_add_relu: iscale/ishift must come together");
     const long total = npix * (C / 4);
-    if (dtype == USTRUN_BF16)
+    if (dtype == USTRUN_D16)
         hipLaunchKernelGGL(bn_add_relu_kernel<2>, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)s, (const float*)y, scale, shift,
                            (const float*)idn, iscale, ishift, (long)npix, C, (float*)out);
     else
@@ -416,7 +416,7 @@ extern "C" int ustrun_aspp_gather(const float* z, int N, int h, int w, int K, in
 // ---- backward entry points --------------------------------------------------------------------------------------------------
 #define USTRUN_BY_DTYPE(KERNEL, BLOCKS, ...)                                                                                    \
     do {                                                                                                                        \
-        if (dtype == USTRUN_BF16) hipLaunchKernelGGL(KERNEL<2>, dim3(BLOCKS), dim3(256), 0, (hipStream_t)s, __VA_ARGS__);       \
+        if (dtype == USTRUN_D16) hipLaunchKernelGGL(KERNEL<2>, dim3(BLOCKS), dim3(256), 0, (hipStream_t)s, __VA_ARGS__);       \
         else hipLaunchKernelGGL(KERNEL<4>, dim3(BLOCKS), dim3(256), 0, (hipStream_t)s, __VA_ARGS__);                            \
     } while (0)
 
@@ -484,7 +484,7 @@ extern "C" int ustrun_conv2d_wgrad(const ustrun_src_t* srcs, int nsrc, const voi
     a.ashift = stride == 2 ? 1 : 0;
     a.partials = partials;
     int slabs;
-    if (dtype == USTRUN_BF16 && wgrad_halo_supported(a)) {
+    if (dtype == USTRUN_D16 && wgrad_halo_supported(a)) {
         int per;
         wgrad_halo_plan(a, &slabs, &per);
         USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 9 * a.Cin * Cout * 4, "conv2d_wgrad: partials too small");
@@ -494,7 +494,7 @@ extern "C" int ustrun_conv2d_wgrad(const ustrun_src_t* srcs, int nsrc, const voi
         USTRUN_TRY(rc);
         return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 2, accumulate, (hipStream_t)s);
     }
-    if (dtype == USTRUN_BF16 && wgrad_tap_supported(a)) {
+    if (dtype == USTRUN_D16 && wgrad_tap_supported(a)) {
         wgrad_tap_plan(a, &a.ksplit, &a.kchunk);
         USTRUN_CHECK(partials_bytes >= (int64_t)a.ksplit * a.nseg * a.Cin * Cout * 4, "conv2d_wgrad: partials too small");
         double in_elems = (double)N * srcs[0].H * srcs[0].W * srcs[0].C;

@@ -178,9 +178,6 @@ int grad_index_conv(int i) {    // index of conv i's weight in model.parameters(
 
 using namespace ustrun;
 
-// debugging aid (not part of the ABI): stop backward before the BatchNorm backward of this layer
-extern "C" int ustrun_debug_stop_layer = -1;
-
 extern "C" int64_t ustrun_unet_packed_bytes(const ustrun_unet_desc_t* d) {
     Plan p; if (make_plan(d, p)) return -1;
     return p.pack_total * 4;
@@ -198,7 +195,7 @@ extern "C" int ustrun_unet_pack(const ustrun_unet_desc_t* d, ustrun_stream_t s) 
     Plan p; USTRUN_TRY(make_plan(d, p));
     USTRUN_CHECK(d->packed, "unet_pack: packed arena missing");
     float* pk = (float*)d->packed;
-    if (d->dtype == USTRUN_BF16) {                 // every layer in one launch
+    if (d->dtype == USTRUN_D16) {                 // every layer in one launch
         PackJobs jobs;
         for (int i = 0; i < 18; ++i) {
             USTRUN_CHECK(d->conv_w[i], "unet_pack: conv weight %d missing", i);
@@ -316,7 +313,8 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
     const int i_hi = which <= 1 ? 17 : (which == 4 ? 7 : 9);
     const int i_lo = which == 1 ? 10 : (which == 3 ? 8 : 0);
     for (int i = i_hi; i >= i_lo; --i) {
-        if (i == ustrun_debug_stop_layer) return 0;
+        if (i == ((g_debug_flags >> 16) & 31) - 1) return 0;      // debugging aid (ustrun_debug_flags bits 16-20 = layer + 1): stop before this layer
+
         const int l = p.lvl[i], H = p.Hs[l], W = p.Ws[l], C = p.cout[i];
         const float* aff = affp(i);
         const int gi = grad_index_conv(i);

@@ -289,9 +289,9 @@ int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
     double in_elems = 0;
     for (int i = 0; i < a.nsrc; ++i) in_elems += (double)a.N * a.src[i].H * a.src[i].W * a.src[i].C;
     prof_begin(1, 2.0 * a.M * a.nseg * a.Cin * a.Cout,
-               (dtype == USTRUN_BF16 ? 2.0 : 4.0) * (in_elems + (double)a.N * a.dyH * a.dyW * a.Cout) + 4.0 * a.nseg * a.Cin * a.Cout, st);
+               (dtype == USTRUN_D16 ? 2.0 : 4.0) * (in_elems + (double)a.N * a.dyH * a.dyW * a.Cout) + 4.0 * a.nseg * a.Cin * a.Cout, st);
     struct End { hipStream_t s; ~End() { prof_end(s); } } end_{st};
-    if (dtype == USTRUN_BF16) return wgrad_launch_bf16(a, st);
+    if (dtype == USTRUN_D16) return wgrad_launch_bf16(a, st);
     if (pool) {
         if (m128 && n128) return launch_cfg<128, 128, true>(a, st);
         if (m128) return launch_cfg<128, 64, true>(a, st);

@@ -19,8 +19,8 @@
 namespace ustrun {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) elt_t bf16x4;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -33,8 +33,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int k0, int col0, in
     const int colb = (col0 + 16 * ((lane >> 4) & 1) + 4 * p) * 2;
     const int r0 = k0 + 8 * (lane >> 5) + q, r1 = r0 + 4;      // r1 & 3 == r0 & 3
     const int off = colb ^ ((r0 & 3) << 6);
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * RB + off));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * RB + off));
+    const bf16x4 lo = USTRUN_DS_READ_TR16((lds_bf16x4*)(tile + r0 * RB + off));
+    const bf16x4 hi = USTRUN_DS_READ_TR16((lds_bf16x4*)(tile + r1 * RB + off));
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -47,8 +47,8 @@ __device__ __forceinline__ bf16x8 tr_frag_du(const char* tile, int k0, int t, in
     const int q = (lane & 15) >> 2, p = lane & 3, g = (lane >> 4) & 1;
     const int r0 = k0 + 8 * (lane >> 5) + q, r1 = r0 + 4;
     const int off = ((p ^ (r0 & 3)) << 6) + 16 * t + 8 * g;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * RB + off));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * RB + off));
+    const bf16x4 lo = USTRUN_DS_READ_TR16((lds_bf16x4*)(tile + r0 * RB + off));
+    const bf16x4 hi = USTRUN_DS_READ_TR16((lds_bf16x4*)(tile + r1 * RB + off));
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_bf16_kernel(const WgradArgs a, 
             cur_grp = grp;
         }
     };
-    const __bf16* sp = (const __bf16*)S.ptr + cl;
+    const elt_t* sp = (const elt_t*)S.ptr + cl;
     const int arow = tid >> 4;
     bf16x8 av[4];
     auto load_A = [&](long k0) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_bf16_kernel(const WgradArgs a, 
         for (int i = 0; i < 4; ++i) {
             const long m = k0 + arow + 16 * i;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) av[i][q] = (__bf16)0.f;
+            for (int q = 0; q < 8; ++q) av[i][q] = (elt_t)0.f;
             if (m < kend) av[i] = *(const bf16x8*)(sp + m * S.sW);
         }
     };
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void wgradT_bf16_kernel(const WgradArgs a, 
                 f32x4 lo = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]} * asc0 + ash0;
                 f32x4 hi = (f32x4){(float)h[4], (float)h[5], (float)h[6], (float)h[7]} * asc1 + ash1;
                 if (S.relu) { lo = relu4(lo); hi = relu4(hi); }
-                h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-                h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+                h[0] = (elt_t)lo[0]; h[1] = (elt_t)lo[1]; h[2] = (elt_t)lo[2]; h[3] = (elt_t)lo[3];
+                h[4] = (elt_t)hi[0]; h[5] = (elt_t)hi[1]; h[6] = (elt_t)hi[2]; h[7] = (elt_t)hi[3];
             }
             *(bf16x8*)(dst + row * RB + ((c8 * 16) ^ ((row & 3) << 6))) = h;
         }
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_bf16_kernel(const WgradArgs a, 
     const int item = ((((pos >> 2) ^ brl) << 2) | (pos & 3));      // (4 wave + brl) & 3 == brl
     const int tap = item >> 2, co = co0 + 8 * (item & 3);          // LDS row = [tap][32 co]
     const long tapoff = (long)(tap >> 1) * 2 * W + (tap & 1);
-    const __bf16* dup = (const __bf16*)a.dy + co;
+    const elt_t* dup = (const elt_t*)a.dy + co;
     int bx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) bx[i] = (int)((kbeg + 16 * i + 4 * wave + brl) % W);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void wgradT_bf16_kernel(const WgradArgs a, 
     f32x16 accb[2];
     bf16x8 ones;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ones[q] = (__bf16)1.f;
+    for (int q = 0; q < 8; ++q) ones[q] = (elt_t)1.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -205,15 +205,15 @@ __global__ __launch_bounds__(256, 2) void wgradT_bf16_kernel(const WgradArgs a, 
                 bf16x8 on = ones;
                 if (rem < 8) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) on[q] = (__bf16)(q < rem ? 1.f : 0.f);
+                    for (int q = 0; q < 8; ++q) on[q] = (elt_t)(q < rem ? 1.f : 0.f);
                 }
-                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(on, b0, accb[0], 0, 0, 0);
-                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(on, b1, accb[1], 0, 0, 0);
+                accb[0] = USTRUN_MFMA_32x32x16(on, b0, accb[0], 0, 0, 0);
+                accb[1] = USTRUN_MFMA_32x32x16(on, b1, accb[1], 0, 0, 0);
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            acc[0][0] = USTRUN_MFMA_32x32x16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = USTRUN_MFMA_32x32x16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = USTRUN_MFMA_32x32x16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = USTRUN_MFMA_32x32x16(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (more) write_A(k0 + KP, As + (buf ^ 1) * (KP * RB));
         __syncthreads();

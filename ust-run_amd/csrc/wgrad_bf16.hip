@@ -9,8 +9,8 @@
 namespace ustrun {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) elt_t bf16x4;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 
@@ -25,8 +25,8 @@ template <int RB> __device__ __forceinline__ bf16x8 tr_frag(const char* tile, in
     const int r0 = k0 + 8 * (lane >> 5) + q, r1 = r0 + 4;
     const char* a0 = tile + r0 * RB + (colb ^ (seg_swz<RB>(r0) << 6));
     const char* a1 = tile + r1 * RB + (colb ^ (seg_swz<RB>(r1) << 6));
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
+    const bf16x4 lo = USTRUN_DS_READ_TR16((lds_bf16x4*)a0);
+    const bf16x4 hi = USTRUN_DS_READ_TR16((lds_bf16x4*)a1);
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, c
 
     auto to_bf16 = [](f32x4 v) {
         bf16x4 h;
-        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        h[0] = (elt_t)v[0]; h[1] = (elt_t)v[1]; h[2] = (elt_t)v[2]; h[3] = (elt_t)v[3];
         return h;
     };
 
@@ -180,10 +180,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradArgs a, c
             const bf16x8 a1 = tr_frag<RBA>(As, kk * 16, wm * 64 + 32, lane);
             const bf16x8 b0 = tr_frag<RBB>(Bs, kk * 16, wn * 64, lane);
             const bf16x8 b1 = tr_frag<RBB>(Bs, kk * 16, wn * 64 + 32, lane);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            acc[0][0] = USTRUN_MFMA_32x32x16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = USTRUN_MFMA_32x32x16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = USTRUN_MFMA_32x32x16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = USTRUN_MFMA_32x32x16(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();
     }

@@ -18,8 +18,8 @@
 namespace ustrun {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) elt_t bf16x4;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -35,8 +35,8 @@ __device__ __attribute__((aligned(16))) const unsigned g_zero16w[4] = {0u, 0u, 0
 
 // lane_base = per-lane byte offset ((8*(l>>5) + q) * RB + column bytes), k0 = first pixel row of the fragment
 __device__ __forceinline__ bf16x8 tr_frag(const char* lane_base, int k0) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lane_base + k0 * RB));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lane_base + (k0 + 4) * RB));
+    const bf16x4 lo = USTRUN_DS_READ_TR16((lds_bf16x4*)(lane_base + k0 * RB));
+    const bf16x4 hi = USTRUN_DS_READ_TR16((lds_bf16x4*)(lane_base + (k0 + 4) * RB));
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
             cur_grp = grp;
         }
     };
-    const __bf16* sp = (const __bf16*)S.ptr + cl;
-    const __bf16* zsrc = (const __bf16*)g_zero16w;
+    const elt_t* sp = (const elt_t*)S.ptr + cl;
+    const elt_t* zsrc = (const elt_t*)g_zero16w;
 
     // ---- dY side: DMA item i = LDS slot tid + 256 i of the patch image: pixel slot / 12, group slot % 12 (>= 8: pad).
     // Tile-invariant: the relative element offset and the patch coordinates (hy << 8 | hx; 0xffff = no data) ----
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
         droff[i] = v ? (hy * a.dyW + hx) * a.Cout + 8 * g : 0;
         dhyx[i] = v ? ((hy << 8) | hx) : 0xffff;
     }
-    const __bf16* dyp = (const __bf16*)a.dy + co0;
+    const elt_t* dyp = (const elt_t*)a.dy + co0;
 
     bf16x8 av[AIT][NP];
     unsigned aok = 0;
@@ -114,13 +114,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
         int img, y0, x0;
         tile_origin(t, img, y0, x0);
         load_consts(img);                          // the items fetched below are transformed at this stage's bottom
-        const __bf16* dbase = dyp + (((long)img * a.dyH + (y0 - 1)) * a.dyW + (x0 - 1)) * a.Cout;
+        const elt_t* dbase = dyp + (((long)img * a.dyH + (y0 - 1)) * a.dyW + (x0 - 1)) * a.Cout;
 #pragma unroll
         for (int i = 0; i < DIT; ++i) {
             if (256 * i + wave * 64 < DSLOTS) {                // wave-uniform
                 const int ly = y0 - 1 + (dhyx[i] >> 8), lx = x0 - 1 + (dhyx[i] & 0xff);
                 const bool ok = dhyx[i] != 0xffff && ly >= 0 && ly < a.dyH && lx >= 0 && lx < a.dyW;
-                const __bf16* src = ok ? dbase + droff[i] : zsrc;
+                const elt_t* src = ok ? dbase + droff[i] : zsrc;
                 __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Dbuf + (256 * i + wave * 64) * 16), 16, 0, 0);
             }
         }
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
             const int px = (tid + 256 * i) >> 3;
             bf16x8 h;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) h[q] = (__bf16)0.f;
+            for (int q = 0; q < 8; ++q) h[q] = (elt_t)0.f;
             if ((aok >> i) & 1u) {                   // outside the source: zero (padding is applied after the activation)
                 if (xf) {
                     f32x4 lo, hi;
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
                         act8(av[i][q], l2, h2);
                         lo = max4(lo, l2); hi = max4(hi, h2);
                     }
-                    h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-                    h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+                    h[0] = (elt_t)lo[0]; h[1] = (elt_t)lo[1]; h[2] = (elt_t)lo[2]; h[3] = (elt_t)lo[3];
+                    h[4] = (elt_t)hi[0]; h[5] = (elt_t)hi[1]; h[6] = (elt_t)hi[2]; h[7] = (elt_t)hi[3];
                 } else {
                     h = av[i][0];
                 }
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_bf16_kernel(const WgradArgs
                 for (int kh = 0; kh < 3; ++kh) {      // tap (kh,kw) pairs pixel row r with dY row r + 2 - kh of the patch
                     const int r = pr + kh - 2;
                     if (r >= 0 && r < TH)
-                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                        acc[kh * 3 + kw] = USTRUN_MFMA_32x32x16(b, af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
                 }
             }
         }
@@ -261,8 +261,8 @@ __device__ __forceinline__ void dma16(const void* gsrc, const char* lds_wave_bas
 }
 
 __device__ __forceinline__ bf16x8 tr_frag3(const char* lane_base, int k0) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lane_base + k0 * RB3));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lane_base + (k0 + 4) * RB3));
+    const bf16x4 lo = USTRUN_DS_READ_TR16((lds_bf16x4*)(lane_base + k0 * RB3));
+    const bf16x4 hi = USTRUN_DS_READ_TR16((lds_bf16x4*)(lane_base + (k0 + 4) * RB3));
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
             cur_grp = grp;
         }
     };
-    const __bf16* sp = (const __bf16*)S.ptr + cl;
-    const __bf16* zsrc = (const __bf16*)g_zero16w;
+    const elt_t* sp = (const elt_t*)S.ptr + cl;
+    const elt_t* zsrc = (const elt_t*)g_zero16w;
 
     // ---- dY side: item i = LDS slot tid + 256 i of the patch: pixel slot >> 3, logical group (slot & 7) ^ swap ----
     int droff[D3IT], dhyx[D3IT];
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
         droff[i] = v ? (hy * a.dyW + hx) * a.Cout + 8 * gl : 0;
         dhyx[i] = v ? ((hy << 8) | hx) : 0xffff;
     }
-    const __bf16* dyp = (const __bf16*)a.dy + co0;
+    const elt_t* dyp = (const elt_t*)a.dy + co0;
     const bool w4 = 256 * (D3IT - 1) + wave * 64 < D3SLOTS;       // does this wave issue the last dY piece?
 
     auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
@@ -343,13 +343,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
     auto issue_tile = [&](int t, char* stage) {
         int img, y0, x0;
         tile_origin(t, img, y0, x0);
-        const __bf16* dbase = dyp + (((long)img * a.dyH + (y0 - 1)) * a.dyW + (x0 - 1)) * a.Cout;
+        const elt_t* dbase = dyp + (((long)img * a.dyH + (y0 - 1)) * a.dyW + (x0 - 1)) * a.Cout;
 #pragma unroll
         for (int i = 0; i < D3IT; ++i) {
             if (i < D3IT - 1 || w4) {
                 const int ly = y0 - 1 + (dhyx[i] >> 8), lx = x0 - 1 + (dhyx[i] & 0xff);
                 const bool ok = dhyx[i] != 0xffff && ly >= 0 && ly < a.dyH && lx >= 0 && lx < a.dyW;
-                const __bf16* src = ok ? dbase + droff[i] : zsrc;
+                const elt_t* src = ok ? dbase + droff[i] : zsrc;
                 dma16(src, stage + A3TILE + (256 * i + wave * 64) * 16);
             }
         }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
             const int ly = y0 + (px >> 4) - S.off_y, lx = x0 + (px & 15) - S.off_x;
             const bool ok = ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
             ok2 |= (ok ? 1u : 0u) << i;
-            const __bf16* src = ok ? sp + sbase + (long)ly * S.sH + (long)lx * S.sW : zsrc;
+            const elt_t* src = ok ? sp + sbase + (long)ly * S.sH + (long)lx * S.sW : zsrc;
             dma16(src, stage + (256 * i + wave * 64) * 16);
         }
         return ok2;
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
                 hi[q] = __builtin_amdgcn_fmed3f(hi[q], floor_, __builtin_inff());
             }
             bf16x8 h;
-            h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-            h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+            h[0] = (elt_t)lo[0]; h[1] = (elt_t)lo[1]; h[2] = (elt_t)lo[2]; h[3] = (elt_t)lo[3];
+            h[4] = (elt_t)hi[0]; h[5] = (elt_t)hi[1]; h[6] = (elt_t)hi[2]; h[7] = (elt_t)hi[3];
             u32x4 u = __builtin_bit_cast(u32x4, h);
             const bool ok = (ok2 >> i) & 1u;
 #pragma unroll
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo3_bf16_kernel(const WgradArg
                     for (int kh = 0; kh < 3; ++kh) {      // tap (kh,kw) pairs tile row r with dY row r + 2 - kh of the patch
                         const int r = pr + kh - 2;
                         if (r >= 0 && r < 4)
-                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                            acc[kh * 3 + kw] = USTRUN_MFMA_32x32x16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -654,8 +654,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo4_bf16_kernel(const WgradArg
             hi[q] = fma_scalar((float)b[4 + q], asc1[q], ash1[q]);
         }
         bf16x8 h;
-        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+        h[0] = (elt_t)lo[0]; h[1] = (elt_t)lo[1]; h[2] = (elt_t)lo[2]; h[3] = (elt_t)lo[3];
+        h[4] = (elt_t)hi[0]; h[5] = (elt_t)hi[1]; h[6] = (elt_t)hi[2]; h[7] = (elt_t)hi[3];
         if (relu) {
             const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, h), z));
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo4_bf16_kernel(const WgradArg
                     for (int kh = 0; kh < 3; ++kh) {
                         const int r = pr + kh - 2;
                         if (r >= 0 && r < 4)
-                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                            acc[kh * 3 + kw] = USTRUN_MFMA_32x32x16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -938,8 +938,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo_pp_bf16_kernel(const WgradA
             hi[q] = fma_scalar((float)b[4 + q], asc1[q], ash1[q]);
         }
         bf16x8 h;
-        h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-        h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+        h[0] = (elt_t)lo[0]; h[1] = (elt_t)lo[1]; h[2] = (elt_t)lo[2]; h[3] = (elt_t)lo[3];
+        h[4] = (elt_t)hi[0]; h[5] = (elt_t)hi[1]; h[6] = (elt_t)hi[2]; h[7] = (elt_t)hi[3];
         if (relu) {
             const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, h), z));
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo_pp_bf16_kernel(const WgradA
                     for (int kh = 0; kh < 3; ++kh) {
                         const int r = pr + kh - 2;
                         if (r >= 0 && r < 4)
-                            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
+                            acc[kh * 3 + kw] = USTRUN_MFMA_32x32x16(bq[pr & 1][kw], af[r], acc[kh * 3 + kw], 0, 0, 0);   // D[co][ci]
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

@@ -17,8 +17,8 @@
 namespace ustrun {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) elt_t bf16x4;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -34,8 +34,8 @@ template <int RB> __device__ __forceinline__ bf16x8 tr_frag(const char* tile, in
     const int q = (lane & 15) >> 2, p = lane & 3;
     const int colb = (col0 + 16 * ((lane >> 4) & 1) + 4 * p) * 2;
     const int r0 = k0 + 8 * (lane >> 5) + q, r1 = r0 + 4;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r0 * RB + (colb ^ (seg_swz<RB>(r0) << 6))));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r1 * RB + (colb ^ (seg_swz<RB>(r1) << 6))));
+    const bf16x4 lo = USTRUN_DS_READ_TR16((lds_bf16x4*)(tile + r0 * RB + (colb ^ (seg_swz<RB>(r0) << 6))));
+    const bf16x4 hi = USTRUN_DS_READ_TR16((lds_bf16x4*)(tile + r1 * RB + (colb ^ (seg_swz<RB>(r1) << 6))));
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
         ash0 = *(const f32x4*)(S.shift + cl); ash1 = *(const f32x4*)(S.shift + cl + 4);
     }
     const float floor_ = S.relu ? 0.f : -__builtin_inff();
-    const __bf16* sp = (const __bf16*)S.ptr + cl;
+    const elt_t* sp = (const elt_t*)S.ptr + cl;
     const int arow = tid / AQ;
     const int sN = (int)S.sN, sH = (int)S.sH, sW = (int)S.sW;        // element offsets fit 31 bits (host check)
     bf16x8 av[AP];
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
                 f32x4 hi = (f32x4){(float)h[4], (float)h[5], (float)h[6], (float)h[7]} * asc1 + ash1;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { lo[q] = __builtin_fmaxf(lo[q], floor_); hi[q] = __builtin_fmaxf(hi[q], floor_); }
-                h[0] = (__bf16)lo[0]; h[1] = (__bf16)lo[1]; h[2] = (__bf16)lo[2]; h[3] = (__bf16)lo[3];
-                h[4] = (__bf16)hi[0]; h[5] = (__bf16)hi[1]; h[6] = (__bf16)hi[2]; h[7] = (__bf16)hi[3];
+                h[0] = (elt_t)lo[0]; h[1] = (elt_t)lo[1]; h[2] = (elt_t)lo[2]; h[3] = (elt_t)lo[3];
+                h[4] = (elt_t)hi[0]; h[5] = (elt_t)hi[1]; h[6] = (elt_t)hi[2]; h[7] = (elt_t)hi[3];
             }
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
             u32x4 bits = __builtin_bit_cast(u32x4, h);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
     // and NOT by LDS-DMA: with a DMA in flight hipcc puts s_waitcnt vmcnt(0) in front of the stage's first ds_read (it cannot
     // tell the two LDS buffers apart), which also drains the activation prefetch before the MFMAs instead of after them.
     const int b8 = tid % BQ, brow = tid / BQ;
-    const __bf16* dyp = (const __bf16*)a.dy + co0 + 8 * b8;
+    const elt_t* dyp = (const elt_t*)a.dy + co0 + 8 * b8;
     const int dyC = a.Cout;
     bf16x8 bv[BP];
     auto load_B = [&](int k0) {
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0)
-                                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SWAP ? USTRUN_MFMA_32x32x16(bf[j], af[i], acc[i][j], 0, 0, 0)
+                                     : USTRUN_MFMA_32x32x16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (more) {
             write_A(As + (buf ^ 1) * (KP * RBA));

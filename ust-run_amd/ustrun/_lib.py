@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libustrun.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 LOSS_SOFTMAX, LOSS_SIGMOID = 0, 1
 
 vp, fp, i32, i64, f32 = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float

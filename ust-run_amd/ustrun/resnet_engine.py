@@ -23,7 +23,7 @@ import torch
 from . import _lib as L
 from .engine import stream_ptr
 
-_DT = {"f32": L.F32, "bf16": L.BF16}
+_DT = {"f32": L.F32, "bf16": L.BF16, "f16": L.F16}
 
 
 class Act:
@@ -41,7 +41,7 @@ class Act:
 
 
 def _tdtype(dt):
-    return torch.bfloat16 if dt == L.BF16 else torch.float32
+    return torch.bfloat16 if dt == L.BF16 else torch.float16 if dt == L.F16 else torch.float32
 
 
 _GEN = [0]
