@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--dataset", default="fundus", choices=["fundus", "prostate", "BUSI", "MNMS"])
     ap.add_argument("--label_bs", type=int, default=16)
     ap.add_argument("--unlabel_bs", type=int, default=16)
-    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "f16"],
                     help="bf16 = bf16 matrix-core operands, f32 accumulate/statistics (configs[1]); f32 = the exact parity path")
     ap.add_argument("--fft", default="device", choices=["host", "device"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,6 +239,8 @@ def secondary_runs(dev, lib):
     Each entry frees its memory before the next; a failing entry is reported, not fatal."""
     import gc
     jobs = [("unet", dict(dataset="fundus", lb=16, dtype="f32", steps=3, warmup=1)),
+            # the reference's own mixed-precision mode (--amp 1: IEEE half + GradScaler) on configs[1]'s shape
+            ("unet", dict(dataset="fundus", lb=16, dtype="f16", steps=10, warmup=3)),
             ("unet", dict(dataset="prostate", lb=8, dtype="bf16", steps=10, warmup=2)),
             ("unet", dict(dataset="MNMS", lb=8, dtype="bf16", steps=10, warmup=2)),
             ("deeplab", dict(n=16, hw=512, dtype="bf16", ssl=False, steps=5)),

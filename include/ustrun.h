@@ -229,6 +229,18 @@ int ustrun_dice_counts(const void* pred, const void* gt, int pred_is_i64, int gt
 
 /* ---- SGD(momentum, weight decay) + EMA teacher over flat buffers: train.py:512,848,87-93 ------
  * g += wd*p; v = first ? g : mu*v + g; p -= lr*v; t = alpha*t + (1-alpha)*p                    */
+/* ---- dynamic loss scale of the IEEE-half path: torch.cuda.amp.GradScaler as train.py:552,842-845 uses it, on the device.
+ * amp_state = 8 floats {scale, scale, growth_tracker, found_inf, steps skipped so far, steps seen so far, 0, 0} (initialise
+ * to {65536, 65536, 0, 0, 0, 0, 0, 0}); its address is what
+ * ustrun_seg_loss_bwd / ustrun_dice_bwd take as gscale_dev, which scales the backward.  Per step, after the gradient
+ * all-reduce: ustrun_amp_check (found_inf = 1 if any element of g is not finite) -> ustrun_sgd_ema_scaled (gradient x
+ * grad_scale / scale; found_inf: parameters and momentum untouched = GradScaler.step skipping optimizer.step, the EMA line
+ * still runs) -> ustrun_amp_update (scale x backoff after a skipped step, x growth after growth_interval clean ones --
+ * GradScaler defaults 2, 0.5, 2000 --, found_inf cleared).  Nothing here waits for the host.                           */
+int ustrun_amp_check(const float* g, int64_t n, float* amp_state, ustrun_stream_t s);
+int ustrun_sgd_ema_scaled(float* p, const float* g, float* v, float* t, int64_t n, float lr, float mu, float wd,
+                          int first, float alpha, float grad_scale, const float* amp_state, ustrun_stream_t s);
+int ustrun_amp_update(float* amp_state, float growth_factor, float backoff_factor, int growth_interval, ustrun_stream_t s);
 int ustrun_sgd_ema(float* p, const float* g, float* v, float* t, int64_t n, float lr, float mu,
                    float wd, int first, float alpha, float grad_scale, ustrun_stream_t s);
 

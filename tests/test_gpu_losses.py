@@ -220,3 +220,52 @@ def test_freq_mix_device_matches_numpy_fft(C, S, LB):
 
 def H_amp(x):
     return H.amp_spectrum(x.astype(np.float64))
+
+
+def test_loss_scale_follows_gradscaler():
+    """The device-side loss scale (ustrun_amp_check / ustrun_sgd_ema_scaled / ustrun_amp_update) against the semantics of
+    torch.cuda.amp.GradScaler around torch.optim.SGD as the reference uses them (train.py:552,842-851): a finite scaled
+    gradient is unscaled and applied; a non-finite one skips optimizer.step (parameters, momentum untouched) while the EMA
+    line still runs and the scale backs off; `growth_interval` clean steps in a row double it.  Expectation: torch.optim.SGD on
+    the CPU driven by the same found_inf decisions (GradScaler itself refuses to run without a CUDA device in this image's
+    CPU build, so its three rules are restated here: step skipped iff inf/nan, scale x0.5 on skip, x2 after `interval`)."""
+    from ustrun import functional as F
+    n, lr, mu, wd, alpha = 10007, 0.03, 0.9, 1e-4, 0.99
+    g0 = torch.Generator().manual_seed(4)
+    p0 = torch.randn(n, generator=g0)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([p_ref], lr=lr, momentum=mu, weight_decay=wd)
+    t_ref = p0.clone() * 0.5
+    p, v, t = p0.clone().cuda(), torch.zeros(n).cuda(), (p0 * 0.5).cuda()
+    ls = F.LossScale("cuda", init_scale=1024.0, growth_interval=3)
+    scale, tracker = 1024.0, 0
+    plan = ["ok", "inf", "ok", "ok", "ok", "nan", "ok"]
+    for step, kind in enumerate(plan):
+        grad = torch.randn(n, generator=g0)                    # the UNSCALED gradient
+        gs = grad * scale                                      # what a backward through scaler.scale(loss) leaves
+        if kind == "inf":
+            gs[n - 2] = float("inf")                           # (in the scalar tail of the 16-byte loop)
+        if kind == "nan":
+            gs[17] = float("nan")
+        gd = gs.cuda()
+        assert float(ls.state[0]) == scale
+        ls.step(p, gd, v, t, lr, mu, wd, step == 0, alpha, grad_scale=0.5)     # grad_scale: the 1 / world of two ranks
+        if kind == "ok":
+            p_ref.grad = grad * 0.5
+            opt.step()
+            tracker += 1
+            if tracker == 3:
+                scale, tracker = scale * 2, 0
+        else:
+            scale, tracker = scale * 0.5, 0
+        t_ref = alpha * t_ref + (1 - alpha) * p_ref.detach()
+        assert float((p.cpu() - p_ref.detach()).abs().max()) <= 2e-6, (step, kind)
+        assert float((t.cpu() - t_ref).abs().max()) <= 2e-6, (step, kind)
+        if step >= 1:
+            vb = opt.state[p_ref]["momentum_buffer"]
+            assert float((v.cpu() - vb).abs().max()) <= 1e-5 * float(vb.abs().max()), (step, kind)
+        st = ls.state.cpu()
+        assert float(st[0]) == scale and float(st[1]) == scale and int(st[2]) == tracker and float(st[3]) == 0.0
+    assert ls.skipped_steps() == (2, len(plan))
+    sd = ls.state_dict()
+    assert sd["scale"] == scale and sd["_growth_tracker"] == tracker and sd["growth_interval"] == 3

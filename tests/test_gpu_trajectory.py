@@ -61,11 +61,17 @@ def _run(dtype, g):
         if (s + 1) % 100 == 0:
             val[s + 1] = (evaluate.validate(T.DATASET, model, loaders, log=None)[0], evaluate.validate(T.DATASET, ema, loaders, log=None)[0])
     norms = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+    if tr.scaler is not None:
+        skipped, seen = tr.scaler.skipped_steps()
+        print(f"[{dtype}] loss scale {tr.scaler.get_scale():.0f}, {skipped} of {seen} steps skipped")
+        assert seen == T.STEPS and skipped == 0
     return np.array(loss), np.array(dice), val, norms
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_200_step_trajectory_lands_on_the_oracle(dtype):
+    """(f16 = `--amp 1` of the reference: IEEE-half kernels + the device-side GradScaler; a skipped step would be a lost update
+    against the f32 oracle, so the run also asserts that the default scale 65536 never overflowed here)"""
     g = load_golden("g9_traj_fundus_200")
     loss, dice, val, norms = _run(dtype, g)
     steps = g["step"].astype(int)

@@ -98,6 +98,17 @@ def test_driver_command_lines_keep_the_reference_flags_and_defaults():
         ("prostate", "debug", "unet", "0", True, 1, 6, 1, False)
 
 
+def test_amp_flag_selects_the_precision_like_the_reference():
+    """train.py:54,551-552,842-847: `--amp 1` (the default) = fp16 autocast + GradScaler, `--amp 0` = fp32.  Here: --amp 1 ->
+    the IEEE-half build with the device-side loss scale, --amp_dtype bf16 -> bfloat16, --amp 0 -> the exact f32 path;
+    --backend_dtype overrides."""
+    T = _load_driver("train")
+    dt = lambda *argv: T.compute_dtype(T.parser.parse_args(list(argv)))
+    assert dt() == "f16" and dt("--amp", "1") == "f16" and dt("--amp", "0") == "f32"
+    assert dt("--amp_dtype", "bf16") == "bf16" and dt("--amp", "0", "--amp_dtype", "bf16") == "f32"
+    assert dt("--backend_dtype", "bf16") == "bf16" and dt("--amp", "0", "--backend_dtype", "f16") == "f16"
+
+
 def test_load_resumes_from_the_runs_own_checkpoint_like_the_reference():
     """train.py:542-546: `--load` restores '../model/{dataset}/{save_name}/checkpoint.pth'; `--load_path` is parsed and never
     read.  The build's train() must form the same path (checked on the source: train() needs a GPU to run)."""

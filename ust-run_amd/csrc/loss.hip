@@ -316,6 +316,66 @@ __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ p, con
     }
 }
 
+// ---- dynamic loss scale for the IEEE-half path = torch.cuda.amp.GradScaler as the reference uses it (train.py:552,842-845:
+// scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()), kept on the device so that no step waits for the host.
+// amp_state = {scale, scale, growth_tracker, found_inf, steps skipped, steps seen, -, -}: the first two floats are what ustrun_seg_loss_bwd / ustrun_dice_bwd read
+// as the upstream gradients of their two outputs (gscale_dev), so the scale enters the backward there.
+__global__ __launch_bounds__(256) void amp_check_kernel(const float* __restrict__ g, long n, float* __restrict__ state) {
+    const long n4 = n / 4;
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)g)[i];
+        // a finite float has an exponent field below 0xff; the sum of four finite values may overflow, so test each
+        bad |= !(__builtin_isfinite(v[0]) && __builtin_isfinite(v[1]) && __builtin_isfinite(v[2]) && __builtin_isfinite(v[3]));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= !__builtin_isfinite(g[n4 * 4 + threadIdx.x]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) state[3] = 1.f;          // idempotent store: no atomics, any order
+}
+
+// the same update as sgd_ema_kernel with the gradient divided by the loss scale; found_inf set: GradScaler.step skips
+// optimizer.step (parameters and momentum stay), the EMA line of the loop still runs (train.py:848-851)
+__global__ __launch_bounds__(256) void sgd_ema_scaled_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
+                                                            float* __restrict__ t, long n, float lr, float mu, float wd, int first,
+                                                            float alpha, float gsc, const float* __restrict__ state) {
+    const bool skip = state[3] != 0.f;
+    gsc = gsc / state[0];
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 pv = ((f32x4*)p)[i];
+        if (!skip) {
+            const f32x4 gv = ((const f32x4*)g)[i] * gsc + wd * pv;
+            const f32x4 vv = first ? gv : mu * ((f32x4*)v)[i] + gv;
+            ((f32x4*)v)[i] = vv;
+            pv = pv - lr * vv;
+            ((f32x4*)p)[i] = pv;
+        }
+        if (t) ((f32x4*)t)[i] = alpha * ((f32x4*)t)[i] + (1.f - alpha) * pv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = n4 * 4 + threadIdx.x;
+        float pv = p[i];
+        if (!skip) {
+            const float gv = g[i] * gsc + wd * pv;
+            const float vv = first ? gv : mu * v[i] + gv;
+            v[i] = vv; pv -= lr * vv; p[i] = pv;
+        }
+        if (t) t[i] = alpha * t[i] + (1.f - alpha) * pv;
+    }
+}
+
+// GradScaler.update(): back off after a skipped step, grow after `interval` clean ones; clears found_inf for the next step
+__global__ void amp_update_kernel(float* __restrict__ state, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float scale = state[0], tracker = state[2];
+    state[5] += 1.f;                                                    // steps seen / steps skipped: logging and tests
+    if (state[3] != 0.f) { scale *= backoff; tracker = 0.f; state[4] += 1.f; }
+    else {
+        tracker += 1.f;
+        if (tracker >= (float)interval) { scale *= growth; tracker = 0.f; }
+    }
+    state[0] = scale; state[1] = scale; state[2] = tracker; state[3] = 0.f;
+}
+
 int stream_blocks(long work_items) {
     long b = (work_items + 256 * 4 - 1) / (256 * 4);
     if (b > 1024) b = 1024;
@@ -641,5 +701,33 @@ extern "C" int ustrun_sgd_ema(float* p, const float* g, float* v, float* t, int6
     hipLaunchKernelGGL(sgd_ema_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)s, p, g, v, t, (long)n,
                        lr, mu, wd, first, alpha, grad_scale);
     USTRUN_LAUNCH_CHECK("sgd_ema");
+    return 0;
+}
+
+extern "C" int ustrun_amp_check(const float* g, int64_t n, float* amp_state, ustrun_stream_t s) {
+    USTRUN_CHECK(g && amp_state && n > 0 && (uintptr_t)g % 16 == 0, "amp_check: bad args");
+    hipLaunchKernelGGL(amp_check_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)s, g, (long)n, amp_state);
+    USTRUN_LAUNCH_CHECK("amp_check");
+    return 0;
+}
+
+extern "C" int ustrun_sgd_ema_scaled(float* p, const float* g, float* v, float* t, int64_t n, float lr, float mu, float wd,
+                                     int first, float alpha, float grad_scale, const float* amp_state, ustrun_stream_t s) {
+    USTRUN_CHECK(p && g && v && amp_state && n > 0, "sgd_ema_scaled: bad args");
+    USTRUN_CHECK(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                     (!t || (uintptr_t)t % 16 == 0), "sgd_ema_scaled: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(sgd_ema_scaled_kernel, dim3(stream_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)s, p, g, v, t, (long)n,
+                       lr, mu, wd, first, alpha, grad_scale, amp_state);
+    USTRUN_LAUNCH_CHECK("sgd_ema_scaled");
+    return 0;
+}
+
+extern "C" int ustrun_amp_update(float* amp_state, float growth_factor, float backoff_factor, int growth_interval,
+                                 ustrun_stream_t s) {
+    USTRUN_CHECK(amp_state && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval >= 1,
+                 "amp_update: bad args");
+    hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, amp_state, growth_factor, backoff_factor,
+                       growth_interval);
+    USTRUN_LAUNCH_CHECK("amp_update");
     return 0;
 }

@@ -61,7 +61,11 @@ parser.add_argument('--increase', default=1.0005, type=float)
 parser.add_argument('--queue_len', default=10, type=int)
 # additive flags of this build
 parser.add_argument('--synthetic', type=int, default=1, help='seeded synthetic batches (SURVEY.md 8d)')
-parser.add_argument('--backend_dtype', default='f32', choices=['f32', 'bf16'])
+parser.add_argument('--amp_dtype', default='fp16', choices=['fp16', 'bf16'],
+                    help="storage / matrix-core type under --amp 1: 'fp16' = the reference's torch.cuda.amp autocast + GradScaler "
+                         "(train.py:30,551-552,842-845: IEEE half, dynamic loss scale on the device), 'bf16' = bfloat16, no loss scale")
+parser.add_argument('--backend_dtype', default='', choices=['', 'f32', 'bf16', 'f16'],
+                    help="explicit override of what --amp / --amp_dtype select ('' = follow them; --amp 0 = f32, the exact path)")
 parser.add_argument('--fft', default='device', choices=['host', 'device'])
 parser.add_argument('--data_root', type=str, default='../../data')
 parser.add_argument('--log_every', type=int, default=50)
@@ -69,6 +73,14 @@ parser.add_argument('--synthetic_pool', type=int, default=8, help='distinct synt
 parser.add_argument('--backbone', default='resnet101', choices=['resnet50', 'resnet101'],
                     help='--model deeplabv2: the dilated ResNet of networks/deeplabv2.py (BASELINE.json configs[4])')
 parser.add_argument('--image_size', type=int, default=0, help='patch extent override (0: the dataset default; configs[4] runs BUSI at 512)')
+
+
+def compute_dtype(args):
+    """--amp / --amp_dtype / --backend_dtype -> the library's dtype name.  The reference's default (--amp 1) trains under fp16
+    autocast with a GradScaler; --amp 0 is its fp32 path (train.py:551-552,842-847)."""
+    if args.backend_dtype:
+        return args.backend_dtype
+    return {"fp16": "f16", "bf16": "bf16"}[args.amp_dtype] if args.amp else "f32"
 
 
 def make_loaders(args, C, H, dev=None):
@@ -112,11 +124,11 @@ def train(args, snapshot_path):
             # (base.py:12); a 1-channel dataset feeds three equal channels.
             from networks.deeplabv2 import DeepLabV2
             ck = "../../checkpoints/pretrained/%s.pth" % args.backbone
-            model = DeepLabV2(args.backbone, K, pretrained=os.path.exists(ck), dtype=args.backend_dtype)
+            model = DeepLabV2(args.backbone, K, pretrained=os.path.exists(ck), dtype=compute_dtype(args))
         elif args.model != 'unet':
             raise SystemExit("--model is 'unet' (the reference's path, train.py:496-503) or 'deeplabv2' (networks/deeplabv2.py)")
         else:
-            model = UNet(n_channels=C, n_classes=K, dtype=args.backend_dtype)
+            model = UNet(n_channels=C, n_classes=K, dtype=compute_dtype(args))
         if ema:
             for p in model.parameters():
                 p.detach_()

@@ -78,6 +78,9 @@ SIGNATURES = {
     "ustrun_seg_loss_bwd": (i32, [fp, vp, fp, i32, i32, i32, i32, fp, fp, f32, f32, f32, fp, vp]),
     "ustrun_dice_counts": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ustrun_sgd_ema": (i32, [fp, fp, fp, fp, i64, f32, f32, f32, i32, f32, f32, vp]),
+    "ustrun_amp_check": (i32, [fp, i64, fp, vp]),
+    "ustrun_sgd_ema_scaled": (i32, [fp, fp, fp, fp, i64, f32, f32, f32, i32, f32, f32, fp, vp]),
+    "ustrun_amp_update": (i32, [fp, f32, f32, i32, vp]),
     "ustrun_pack_conv": (i32, [fp, i32, i32, i32, vp, i32, vp]),
     "ustrun_pack_conv_elems": (i64, [i32, i32, i32]),
     "ustrun_conv2d_fwd": (i32, [PSrc, i32, vp, fp, i32, i32, i32, i32, i32, i32, i32, vp, i32, fp, C.POINTER(C.c_int), i32, vp]),

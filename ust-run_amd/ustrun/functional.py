@@ -253,3 +253,42 @@ def sgd_ema(p, g, v, t, lr, momentum, weight_decay, first, alpha, grad_scale=1.0
     L.check(lib.ustrun_sgd_ema(p.data_ptr(), g.data_ptr(), v.data_ptr(), L.ptr(t), p.numel(), float(lr), float(momentum),
                                float(weight_decay), int(first), float(alpha), float(grad_scale), stream_ptr()),
             "ustrun_sgd_ema")
+
+
+class LossScale:
+    """torch.cuda.amp.GradScaler semantics (train.py:552,842-845) on the device: no step waits for the host.  `state` is the four
+    floats {scale, scale, growth_tracker, found_inf} of include/ustrun.h; pass `state` as `gdev` to `seg_loss_bwd` to scale the
+    backward, then call `step(...)` where the reference calls scaler.step(optimizer); scaler.update()."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.state = torch.tensor([init_scale, init_scale, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+
+    def step(self, p, g, v, t, lr, momentum, weight_decay, first, alpha, grad_scale=1.0):
+        lib = L.lib()
+        st = stream_ptr()
+        L.check(lib.ustrun_amp_check(g.data_ptr(), g.numel(), self.state.data_ptr(), st), "ustrun_amp_check")
+        L.check(lib.ustrun_sgd_ema_scaled(p.data_ptr(), g.data_ptr(), v.data_ptr(), L.ptr(t), p.numel(), float(lr), float(momentum),
+                                          float(weight_decay), int(first), float(alpha), float(grad_scale), self.state.data_ptr(),
+                                          st), "ustrun_sgd_ema_scaled")
+        L.check(lib.ustrun_amp_update(self.state.data_ptr(), float(self.growth_factor), float(self.backoff_factor),
+                                      int(self.growth_interval), st), "ustrun_amp_update")
+
+    def skipped_steps(self):
+        """(host read) -> (steps skipped, steps seen)"""
+        s = self.state.cpu()
+        return int(s[4]), int(s[5])
+
+    def get_scale(self):
+        """(host read: logging / checkpoints only)"""
+        return float(self.state[0])
+
+    def state_dict(self):
+        s = self.state.cpu()
+        return {"scale": float(s[0]), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(s[2])}
+
+    def load_state_dict(self, sd):
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval = int(sd["growth_interval"])
+        self.state.copy_(torch.tensor([sd["scale"], sd["scale"], float(sd.get("_growth_tracker", 0)), 0.0, 0.0, 0.0, 0.0, 0.0]))

@@ -191,6 +191,9 @@ class SSLTrainer:
         # offset of down4's first parameter (index 24): [mid_off, dec_off) is final after the first encoder block's backward
         self.mid_off = sum((p.numel() + 3) // 4 * 4 for p in params[:24]) if len(params) == 64 else 0
         self.flat_v = torch.zeros_like(self.flat_p)
+        # IEEE-half storage (the reference's autocast type) needs the reference's GradScaler around the backward
+        # (train.py:552,842-845): scale on the device, skipped steps and scale updates without a host sync
+        self.scaler = F.LossScale(self.flat_p.device) if getattr(model, "compute_dtype", "f32") == "f16" else None
         model._ustrun_grad_sink = self.grad_views        # backward accumulates straight into flat_g
         engine.invalidate_packed(model)
         engine.invalidate_packed(ema_model)
@@ -423,7 +426,8 @@ class SSLTrainer:
         for lg, tgt, msk, coef in terms:
             out = F.seg_loss_fwd(lg.detach(), tgt, msk, mode)
             outs.append(out)
-            dl = F.seg_loss_bwd(lg.detach(), tgt, msk, mode, out, gscale=coef)
+            dl = F.seg_loss_bwd(lg.detach(), tgt, msk, mode, out, gscale=coef,
+                                gdev=self.scaler.state if self.scaler is not None else None)     # scaler.scale(loss)
             if lg_all is None:
                 lg.backward(dl)
             else:
@@ -453,8 +457,12 @@ class SSLTrainer:
             self._side_busy = False
         # SGD + EMA (train.py:848-851; alpha from the pre-increment iter_num, Q10), poly LR for the NEXT step
         alpha = min(1 - 1 / (self.iter_num + 1), self.ema_decay)
-        F.sgd_ema(self.flat_p, self.flat_g, self.flat_v, self.flat_t, self.lr, self.momentum, self.wd,
-                  self.first_step, alpha, grad_scale=1.0 / self.world_size)
+        if self.scaler is not None:               # scaler.step(optimizer); scaler.update() -- and the EMA line, in one pass
+            self.scaler.step(self.flat_p, self.flat_g, self.flat_v, self.flat_t, self.lr, self.momentum, self.wd,
+                             self.first_step, alpha, grad_scale=1.0 / self.world_size)
+        else:
+            F.sgd_ema(self.flat_p, self.flat_g, self.flat_v, self.flat_t, self.lr, self.momentum, self.wd,
+                      self.first_step, alpha, grad_scale=1.0 / self.world_size)
         self.first_step = False
         engine.invalidate_packed(model)
         engine.invalidate_packed(ema)
