@@ -201,7 +201,7 @@ def _field_stats(got, ref, median=None):
     return worst[0], worst[1], dots / (n1 ** 0.5 * n2 ** 0.5), (n1 / n2) ** 0.5
 
 
-def _hip_grads(sd, dtype, x, R):
+def _hip_grads(sd, dtype, x, R, allow_nonfinite=False):
     from networks.deeplabv2 import DeepLabV2
     m = DeepLabV2("resnet50", R.shape[1], pretrained=False, dtype=dtype)
     m.load_state_dict(sd)
@@ -213,7 +213,7 @@ def _hip_grads(sd, dtype, x, R):
     for k, p in m.named_parameters():
         assert p.grad is not None and p.grad.shape == p.shape, k
         got[k] = p.grad.cpu()
-        assert torch.isfinite(got[k]).all(), k
+        assert allow_nonfinite or torch.isfinite(got[k]).all(), k
     return out.detach().cpu(), got
 
 
@@ -272,6 +272,44 @@ def test_deeplab_backward_vs_oracle_bf16():
           f"cosine {ycos:.4f}")
     assert rel(out, ref_out) < 6e-2
     assert med[0] < 2.5 * ymed[0] and (1 - cos) < 4 * (1 - ycos) and abs(ratio - 1) < 5e-2
+
+
+def test_deeplab_backward_vs_oracle_f16():
+    """The same check for the IEEE-half build -- the reference's own mixed-precision type (torch.cuda.amp autocast,
+    train.py:551-552) -- at the reference's DEFAULT initialisation (every bn3.weight 1: no conditioning help).
+    Eleven significant bits keep the composed backward correlated where eight do not: the f32 path's response to rounding
+    parameters + input to half is the yardstick (median per-tensor rel-L2, 1 - cosine); the f16 path, which also rounds every
+    stored activation and gradient, must stay within 2.5x / 4x of it.  The loss carries a scale that backs off while the scaled
+    gradient is not finite, as the GradScaler does (a sum-reduced loss through fifty default-init residual blocks overflows
+    half's 65504 at scale 64), and the gradients are unscaled."""
+    from oracle import deeplab_ref as D
+    sd = D.make_state_dict("resnet50", 2, 23)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 96, 80, generator=g)
+    R = torch.randn(2, 2, 96, 80, generator=g)
+    ref_out, ref = _oracle_grads(x, sd, "resnet50", R, torch.float64)
+    scale = 64.0
+    for _ in range(10):
+        out, got = _hip_grads(sd, "f16", x, R * scale, allow_nonfinite=True)
+        if all(bool(torch.isfinite(v).all()) for v in got.values()):
+            break
+        scale *= 0.25
+    print(f"loss scale after back-off: {scale}")
+    assert all(bool(torch.isfinite(v).all()) for v in got.values())
+    got = {k: v / scale for k, v in got.items()}
+    sdr = {k: (v.half().float() if v.is_floating_point() and v.dim() == 4 else v) for k, v in sd.items()}
+    _, yard = _hip_grads(sdr, "f32", x.half().float(), R)
+    med, ymed = [], []
+    w, wk, cos, ratio = _field_stats(got, ref, med)
+    yw, ywk, ycos, _ = _field_stats(yard, ref, ymed)
+    print(f"deeplab backward f16 (default init): logits rel {rel(out, ref_out):.2e}; vs f64 oracle: median grad rel-L2 {med[0]:.2e}, worst {w:.2e} "
+          f"({wk}), cosine {cos:.4f}, norm ratio {ratio:.3f}; f32 path on half-rounded parameters + input: median {ymed[0]:.2e}, "
+          f"worst {yw:.2e}, cosine {ycos:.4f}")
+    # measured: logits 6.3e-2 (train mode, batch 2: the bf16 build sits at 0.44 here); median 0.67 vs the yardstick's 0.49, cosine
+    # 0.73 vs 0.86 -- at this init the gradient is chaotic under ANY 11-bit perturbation, and the half build stays in proportion
+    assert rel(out, ref_out) < 0.1
+    assert abs(ratio - 1) < 5e-2
+    assert med[0] < 2.5 * ymed[0] and (1 - cos) < 4 * (1 - ycos)
 
 
 def _ce_batch():

@@ -319,3 +319,14 @@ def test_deeplab_512_reference_golden_and_bf16_eval():
         yard = rel(_bf16_emulation(x.cpu(), sdc, "resnet101", False), ref32)
     print(f"deeplab r101 512^2: train vs reference {e_train:.2e}, eval {e_eval:.2e}, bf16 eval vs f32 {e_bf16:.2e} (torch-CPU bf16-rounding emulation {yard:.2e})")
     assert e_bf16 < 1.3 * yard + 2e-2, (e_bf16, yard)
+    # the reference's own mixed-precision type (fp16 autocast, train.py:551-552) through the same kernels built for IEEE half:
+    # 11 significant bits instead of 8 -- bound 0.12 from f32 (the CPU study measured 0.09 for fp16 rounding)
+    del mb, evb
+    mh = DeepLabV2("resnet101", k, pretrained=False, dtype="f16")
+    mh.load_state_dict(sd)
+    mh = mh.cuda().eval()
+    with torch.no_grad():
+        evh = mh(x)
+    e_f16 = rel(evh, ev)
+    print(f"deeplab r101 512^2: f16 eval vs f32 {e_f16:.2e}")
+    assert e_f16 < 0.12, e_f16
