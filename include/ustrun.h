@@ -386,6 +386,7 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  * bits 10-11: force the halo kernel's tile in the 128-column case (1: 8 x 32 px, 2: 16 x 16, 3: 8 x 16; 0: chosen by padding).
  * bit 12 (4096): BatchNorm backward (plain, bf16) on the 4-channel-per-lane kernels instead of the 8-channel ones.
  * The last-variant code of the streaming kernel is 0x57530000 | (eight waves ? 0x100 : consumer / producer ? 0x200 : 0) | XF.
+ * bit 14 (16384): first convolution (C <= 4 -> 64) on the tile-per-block kernel of rounds 1-3 instead of the streaming one.
  * bits 16-20: layer + 1 at which ustrun_unet_backward stops early (tests/diag_grad.py; 0: runs through).
  * bit 13 (8192): 64-output-channel 3x3 layers on >= 32-wide maps on the 16 x 32-pixel tile (one block per CU; A/B runs).
  * The value is PER CALLING THREAD (as are the last-variant codes and the stamp buffer below): a thread that sets it changes
@@ -399,6 +400,10 @@ int ustrun_debug_flags(int flags);
  * length: a launch whose grid needs more (grid x 64) fails with an error instead of writing past the end.  NULL restores
  * the product kernels                                                                                              */
 int ustrun_debug_buffer(void* device_u64, int64_t n_u64);
+/* measurement aid (tools/clock_probe.py, bench.py): `blocks` workgroups each write 4 u64 {s_memtime (shader-clock ticks),
+ * s_memrealtime (100 MHz ticks), XCC id, HW_ID} to device_u64[blocks][4].  Two probes on one stream around a series of
+ * launches give the shader clock the chip held meanwhile: d(memtime) / d(memrealtime) x 100 MHz, per XCD.          */
+int ustrun_debug_clock_probe(void* device_u64, int blocks, ustrun_stream_t s);
 
 /* ---- optional launch profiler (bench.py): HIP events recorded on the launch stream around every
  * implicit-GEMM (kind 0) / weight-gradient (kind 1) launch while enabled; collect synchronises on

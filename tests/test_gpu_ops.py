@@ -290,28 +290,51 @@ def test_conv3x3_bf16_mfma(n, ci, co, h, w, exact):
     assert rel(dw.cpu(), wr.grad) < tol
 
 
-@pytest.mark.parametrize("n,c,h,w", [(2, 3, 16, 32), (1, 1, 19, 37), (2, 4, 9, 70), (3, 3, 40, 33)])
-def test_conv_first_bf16_mfma_exact(n, c, h, w):
-    """First convolution (NCHW f32 network input, C <= 4 -> 64) on the bf16 matrix cores as an im2col GEMM:
-    small-integer data is exact in bf16, so a slip in the k -> (channel, tap) gather or the ragged-tile masks
-    shows as an O(1) error; BatchNorm-statistics partials must be the sums of the stored outputs."""
+@pytest.mark.parametrize("elt", ["bf16", "f16"])
+@pytest.mark.parametrize("flags", [0, 16384])
+@pytest.mark.parametrize("n,c,h,w", [(2, 3, 16, 32), (1, 1, 19, 37), (2, 4, 9, 70), (3, 3, 40, 33), (4, 3, 136, 96), (16, 1, 72, 100),
+                                     (2, 2, 200, 64)])
+def test_conv_first_bf16_mfma_exact(n, c, h, w, flags, elt):
+    """First convolution (NCHW f32 network input, C <= 4 -> 64) on the 16-bit matrix cores as an im2col GEMM, both builds (the
+    streaming kernel of round 4: a block walks a 32-pixel strip 8 rows per step -- several steps, a ragged last step, ragged
+    strips, segments of 8..64 rows; and, with ustrun_debug_flags bit 14, the tile-per-block kernel of rounds 1-3), both
+    element types: small-integer data is exact, so a slip in the k -> (channel, tap) gather, the patch ring or the ragged
+    masks shows as an O(1) error; BatchNorm-statistics partials must be the sums of the stored outputs PER IMAGE ROW RANGE
+    (rows of one image are contiguous: batched passes split the table by rows); nothing outside the output or beyond the
+    reported row count is written."""
     l = L()
     lib = l.lib()
+    t16, code = (torch.bfloat16, 1) if elt == "bf16" else (torch.float16, 2)
     g = torch.Generator().manual_seed(11 * c + h)
     x = torch.randint(-3, 4, (n, c, h, w), generator=g).float()
     wt = torch.randint(-2, 3, (64, c, 3, 3), generator=g).float()
     y_ref = F.conv2d(x, wt, None, 1, 1)
-    wf, _ = pack_conv_bf16(wt)
+    nel = 9 * 8 * 64
+    wf, wd = torch.zeros(nel, dtype=t16, device="cuda"), torch.zeros(nel, dtype=t16, device="cuda")
+    wg = wt.cuda()
+    l.check(lib.ustrun_pack_conv3x3(wg.data_ptr(), 64, c, wf.data_ptr(), wd.data_ptr(), code, None))
     xg = x.contiguous().cuda()
     src = l.nchw_src(xg.data_ptr(), c, h, w)
-    y = torch.empty(n, h, w, 64, device="cuda", dtype=torch.bfloat16)
-    rows = lib.ustrun_conv_mtiles(n, h, w, 64)
-    stat = torch.full((rows, 2, 64), 7.0, device="cuda")
-    l.check(lib.ustrun_conv3x3_fwd(C.byref(src), 1, wf.data_ptr(), n, h, w, 64, y.data_ptr(), stat.data_ptr(), 1, None))
+    Z = 4096
+    buf = torch.full((Z + n * h * w * 64 + Z,), 9.0, device="cuda", dtype=t16)
+    y = buf[Z:Z + n * h * w * 64].view(n, h, w, 64)
+    rows_max = lib.ustrun_conv_mtiles(n, h, w, 64)
+    stat = torch.full((rows_max + 16, 2, 64), 7.0, device="cuda")
+    rows = C.c_int(0)
+    old = lib.ustrun_debug_flags(flags)
+    try:
+        l.check(lib.ustrun_conv3x3_fwd_rows(C.byref(src), 1, wf.data_ptr(), n, h, w, 64, y.data_ptr(), stat.data_ptr(), C.byref(rows),
+                                            code, None))
+    finally:
+        lib.ustrun_debug_flags(old)
     yc = from_nhwc(y.float())
-    assert rel(yc, r16(y_ref)) < 1e-6
-    np.testing.assert_allclose(stat[:, 0].sum(0).cpu().numpy(), yc.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-2)
-    np.testing.assert_allclose(stat[:, 1].sum(0).cpu().numpy(), (yc * yc).sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-2)
+    assert rel(yc, y_ref.to(t16).float()) < 1e-6
+    assert bool((buf[:Z] == 9.0).all()) and bool((buf[-Z:] == 9.0).all())
+    assert 0 < rows.value <= rows_max and rows.value % n == 0
+    assert bool((stat[rows.value:] == 7.0).all())
+    st = stat[:rows.value].view(n, rows.value // n, 2, 64).sum(1).cpu()            # per image
+    np.testing.assert_allclose(st[:, 0].numpy(), yc.sum((2, 3)).numpy(), rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(st[:, 1].numpy(), (yc * yc).sum((2, 3)).numpy(), rtol=1e-5, atol=1e-2)
 
 
 @pytest.mark.parametrize("n,ci,co,h,w", [(2, 128, 64, 5, 7), (3, 256, 128, 12, 10), (1, 64, 64, 3, 50), (4, 256, 128, 128, 128),

@@ -11,6 +11,7 @@
 //    kw-shifted copies keep the 16-byte fragment reads aligned), dY tiles are read transposed.
 #include "common.h"
 #include "loader.h"
+#include <type_traits>
 
 namespace ustrun {
 namespace {
@@ -354,17 +355,200 @@ __global__ __launch_bounds__(1024) void conv_first_wgrad_reduce_kernel(const flo
     }
 }
 
+// ---- forward, streaming form (round 4) -------------------------------------------------------------------------------------
+// The layer writes 128 B per pixel and reads 12: it is a store stream with a little arithmetic in front.  The tile-per-block
+// kernel above pays its whole setup (weight fragments through LDS, k -> patch offsets with divisions, a patch fill whose loads
+// nothing overlaps) for 256 pixels and then stores through 2-byte LDS writes: 3.0-3.2 TB/s of output where the BatchNorm
+// passes, which move the same kind of bytes, reach 5.4.  Here a block owns a 32-pixel-wide strip of `seg_rows` rows of one
+// image and walks it 8 rows per step: weight fragments (the A operand: rows = output channels) and the k -> patch index
+// tables are built once per block and live in registers; the next step's 10 x 34 x C input patch is fetched into registers
+// under the current step's work and lands in the other LDS buffer; the product is D[channel][pixel], so four consecutive
+// channels of a pixel sit in four consecutive accumulator registers: 2 cvt_pk + ONE ds_write_b64 per group into a per-wave
+// scratch, read back as 16-byte pieces (8 channels of one pixel per lane) that go out as whole 128-byte lines; the BatchNorm
+// statistics are taken from those pieces (8 channels per lane, 16 accumulators) and leave the block ONCE, as one row per block.
+constexpr int SPITCH = 144;          // scratch row: 128 B of channels + 16 B pad (16-byte aligned rows)
+
+template <int C, bool STAT>
+__global__ __launch_bounds__(256, 3) void conv_first_fwd_stream_kernel(const float* __restrict__ x, long sN, int sC, int sH, int sW,
+                                                                      int H, int W, const elt_t* __restrict__ w,
+                                                                      elt_t* __restrict__ y, float* __restrict__ stat,
+                                                                      int strips, int segs, int seg_rows, int img_bytes) {
+    constexpr int KS = (9 * C + 15) / 16;
+    constexpr int PROWS = MTH + 2;                          // patch rows of a step
+    // one patch buffer (floats): [c][10][34], then a ZERO AREA that padded k entries read: a lane's k -> patch index table is
+    // built for its first row of a step and the second row is the same table + one patch row (an immediate offset), so a
+    // padded entry reads ZIDX and ZIDX + MHW
+    constexpr int ZIDX = CMAX * MHP;
+    constexpr int PSZ = ZIDX + MHW + 6;
+    __shared__ float patch[2 * PSZ];
+    __shared__ __attribute__((aligned(16))) char scr[4 * 32 * SPITCH];
+    __shared__ float red[4][2][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the stores' row offset is a scalar operand
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int item = blockIdx.x;
+    const int sx = item % strips, sy = (item / strips) % segs, img = item / (strips * segs);
+    const int x0 = sx * MTW, r0 = sy * seg_rows, r1 = min(H, r0 + seg_rows);
+    const int nsteps = (r1 - r0 + MTH - 1) / MTH;
+    constexpr int K = 9 * C;
+    // every access to the image and to the output goes through a buffer resource of ONE image: an offset with bit 31 set fails
+    // the range check (loads return 0, stores are dropped), so padding and ragged edges need no branch around a memory
+    // instruction (hipcc turns a select around a load into a branch with its own wait: the prefetch would serialise)
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + img * sN), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (long)img * H * W * 64), 0, H * W * 128, 0x00020000);
+    // weight fragments, A operand of D[co][px] = W[co][k] P[k][px]: lane (row = co, half lh) holds k = 16 ks + 8 lh + j;
+    // packed forward weights are [tap][1][64][8 (c)]
+    bf16x8 wf[KS][2];
+    int kidx[KS][8];                                       // BYTE offset into a patch buffer of k's entry for (row 2 wave, pixel l31)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * lh + j, c = k / 9, tap = k - c * 9;
+            const bool kv = k < K;
+            wf[ks][0][j] = kv ? w[((long)tap * 64 + l31) * 8 + c] : (elt_t)0.f;
+            wf[ks][1][j] = kv ? w[((long)tap * 64 + 32 + l31) * 8 + c] : (elt_t)0.f;
+            kidx[ks][j] = (kv ? c * MHP + (tap / 3 + 2 * wave) * MHW + tap % 3 + l31 : ZIDX) * 4;
+        }
+    // patch fetch: thread t < 34 C owns patch column (c, px) = (t / 34, t % 34) and fetches its 10 rows -- the row part of the
+    // address and its validity are wave-uniform, the column part is a per-thread constant
+    const bool loader = tid < C * MHW;
+    const int lc = tid / MHW, lpx = tid - lc * MHW, lix = x0 - 1 + lpx;
+    const int coloff = (loader && lix >= 0 && lix < W) ? (lc * sC + lix * sW) * 4 : OOB;
+    const int lds_col = (lc * MHP + lpx) * 4;
+    float pre[PROWS];
+    auto load = [&](int s) {
+        const int yb = r0 + MTH * s - 1;
+#pragma unroll
+        for (int i = 0; i < PROWS; ++i) {
+            const int iy = yb + i;                          // (uniform)
+            const int voff = (iy >= 0 && iy < H) ? coloff : OOB;
+            pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff, iy * sH * 4, 0));
+        }
+    };
+    for (int t = tid; t < MHW + 6; t += 256) { patch[ZIDX + t] = 0.f; patch[PSZ + ZIDX + t] = 0.f; }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    char* ep = scr + wave * (32 * SPITCH);
+    if (loader) load(0);
+    auto step = [&](int s, auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        const char* P = (const char*)(patch + buf * PSZ);
+        if (loader) {
+#pragma unroll
+            for (int i = 0; i < PROWS; ++i) *(float*)((char*)(patch + buf * PSZ) + lds_col + i * MHW * 4) = pre[i];
+        }
+        __syncthreads();                                  // (also: every wave is done with the buffer the NEXT step fills)
+        if (loader && s + 1 < nsteps) load(s + 1);        // in flight under this step's work
+        const int yb = r0 + MTH * s;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = yb + 2 * wave + i;
+            f32x16 acc[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (elt_t) * (const float*)(P + kidx[ks][j] + i * MHW * 4);
+                acc[0] = USTRUN_MFMA_32x32x16(wf[ks][0], pf, acc[0], 0, 0, 0);
+                acc[1] = USTRUN_MFMA_32x32x16(wf[ks][1], pf, acc[1], 0, 0, 0);
+            }
+            // D row (channel) = (r & 3) + 8 (r >> 2) + 4 lh, column (pixel) = l31: registers 4g .. 4g + 3 = channels 8g + 4lh + 0..3
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 h4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h4[q] = (elt_t)acc[n][4 * g + q];
+                    *(bf16x4*)(ep + l31 * SPITCH + (n * 32 + 8 * g + 4 * lh) * 2) = h4;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool rowok = oy < r1;                    // (uniform)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int idx = lane + 64 * t, pr = idx >> 3, ch = idx & 7;        // ch == lane & 7 for every t
+                const bf16x8 v8 = *(const bf16x8*)(ep + pr * SPITCH + ch * 16);
+                const int ox = x0 + pr;
+                const bool ok = rowok && ox < W;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v8), ry, ok ? (ox * 64 + ch * 8) * 2 : OOB, oy * W * 128, 0);
+                if constexpr (STAT) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = ok ? (float)v8[j] : 0.f;             // statistics see the stored value
+                        s1[j] += v; s2[j] += v * v;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        step(s, std::integral_constant<int, 0>{});
+        if (s + 1 < nsteps) step(s + 1, std::integral_constant<int, 1>{});
+    }
+    if constexpr (STAT) {                                  // lanes with equal lane & 7 hold the same 8 channels
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
+            if (lane < 8) { red[wave][0][lane * 8 + j] = s1[j]; red[wave][1][lane * 8 + j] = s2[j]; }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int q = tid >> 6, c = tid & 63;
+            stat[((long)item * 2 + q) * 64 + c] = red[0][q][c] + red[1][q][c] + red[2][q][c] + red[3][q][c];
+        }
+    }
+}
+
+// rows per block of the streaming forward: 64 where that still gives every CU four blocks, else shorter segments
+int stream_seg_rows(int N, int H, int W) {
+    int seg = 64;
+    while (seg > MTH && (long)N * cdiv(W, MTW) * cdiv(H, seg) < 1024) seg >>= 1;
+    return seg;
+}
+
 }  // namespace
 
 bool conv_first_supported(const ustrun_src_t& s, int Cout) {
     return s.C <= CMAX && Cout == 64 && !s.pool && !s.scale && !s.relu && s.off_y == 0 && s.off_x == 0;
 }
 int conv_first_stat_rows(int N, int H, int W, int dtype) {
-    return dtype == USTRUN_D16 ? N * cdiv(H, MTH) * cdiv(W, MTW) : N * cdiv(H, FTH) * cdiv(W, FTW);
+    if (dtype == USTRUN_D16 && (g_debug_flags & 16384)) return N * cdiv(H, MTH) * cdiv(W, MTW);
+    return dtype == USTRUN_D16 ? N * cdiv(H, stream_seg_rows(N, H, W)) * cdiv(W, MTW) : N * cdiv(H, FTH) * cdiv(W, FTW);
 }
 
 int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, void* y, float* stat, hipStream_t st) {
-    if (dtype == USTRUN_D16) {            // im2col on the matrix cores
+    if (dtype == USTRUN_D16 && !(g_debug_flags & 16384)) {       // im2col on the matrix cores, streaming form (round 4)
+        const int seg = stream_seg_rows(N, s.H, s.W), strips = cdiv(s.W, MTW), segs = cdiv(s.H, seg);
+        USTRUN_CHECK(s.C >= 1 && s.C <= CMAX, "conv_first_fwd: C=%d", s.C);
+        const long img_elems = (long)(s.C - 1) * s.sC + (long)(s.H - 1) * s.sH + (long)(s.W - 1) * s.sW + 1;
+        USTRUN_CHECK(img_elems * 4 < (1L << 31) && (long)s.H * s.W * 128 < (1L << 31), "conv_first_fwd: an image beyond 2^31 bytes");
+        dim3 grid(N * segs * strips), block(256);
+#define USTRUN_CFS(CC)                                                                                                              \
+    do {                                                                                                                            \
+        if (stat) hipLaunchKernelGGL((conv_first_fwd_stream_kernel<CC, true>), grid, block, 0, st, (const float*)s.ptr, (long)s.sN, (int)s.sC, \
+                                     (int)s.sH, (int)s.sW, s.H, s.W, (const elt_t*)w_fwd, (elt_t*)y, stat, strips, segs, seg, (int)(img_elems * 4)); \
+        else hipLaunchKernelGGL((conv_first_fwd_stream_kernel<CC, false>), grid, block, 0, st, (const float*)s.ptr, (long)s.sN, (int)s.sC,   \
+                                (int)s.sH, (int)s.sW, s.H, s.W, (const elt_t*)w_fwd, (elt_t*)y, stat, strips, segs, seg, (int)(img_elems * 4));     \
+    } while (0)
+        if (s.C == 1) USTRUN_CFS(1); else if (s.C == 2) USTRUN_CFS(2); else if (s.C == 3) USTRUN_CFS(3); else USTRUN_CFS(4);
+#undef USTRUN_CFS
+        USTRUN_LAUNCH_CHECK("conv_first_fwd_stream");
+        return 0;
+    }
+    if (dtype == USTRUN_D16) {            // the round-1..3 tile-per-block kernel (ustrun_debug_flags bit 14: A/B runs)
         const int tx = cdiv(s.W, MTW), ty = cdiv(s.H, MTH), ks = cdiv(9 * s.C, 16);
         dim3 grid(N * ty * tx), block(256);
 #define USTRUN_CF(KS) hipLaunchKernelGGL(conv_first_fwd_mfma_kernel<KS>, grid, block, 0, st, (const float*)s.ptr, (long)s.sN, \

@@ -163,6 +163,29 @@ extern "C" int ustrun_debug_buffer(void* device_u64, int64_t n_u64) {
 }
 extern "C" int ustrun_debug_flags(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
 
+// ---- clock probe (tools/clock_probe.py; MI355X_MICROARCH.md "DVFS give-back" item 6): every workgroup records the shader-clock
+// counter (s_memtime: one tick per shader cycle) and the constant 100 MHz counter (s_memrealtime) together with where it ran.
+// Two probes on one stream around a long series of back-to-back launches of a kernel give the clock the chip HELD while it ran
+// them: d(memtime) / d(memrealtime) x 100 MHz per XCD -- without a stamped build of that kernel.
+namespace ustrun { namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out) {
+    unsigned long long t, r;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r) :: "memory");
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc), "=s"(hw));
+    if (threadIdx.x == 0) {
+        unsigned long long* o = out + (long)blockIdx.x * 4;
+        o[0] = t; o[1] = r; o[2] = xcc & 0xf; o[3] = hw;
+    }
+}
+} }
+extern "C" int ustrun_debug_clock_probe(void* device_u64, int blocks, ustrun_stream_t s) {
+    USTRUN_CHECK(device_u64 && blocks > 0 && blocks <= 65536, "debug_clock_probe: bad args");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)s, (unsigned long long*)device_u64);
+    USTRUN_LAUNCH_CHECK("debug_clock_probe");
+    return 0;
+}
+
 extern "C" int ustrun_conv3x3_fwd(const ustrun_src_t* srcs, int nsrc, const void* w_fwd, int N, int H, int W, int Cout,
                                   void* y, float* stat, int dtype, ustrun_stream_t s) {
     return ustrun_conv3x3_fwd_rows(srcs, nsrc, w_fwd, N, H, W, Cout, y, stat, nullptr, dtype, s);

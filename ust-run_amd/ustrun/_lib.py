@@ -105,6 +105,7 @@ SIGNATURES = {
     "ustrun_debug_flags": (i32, [i32]),
     "ustrun_debug_buffer": (i32, [vp, i64]),
     "ustrun_debug_last_bn_variant": (i32, []),
+    "ustrun_debug_clock_probe": (i32, [vp, i32, vp]),
     "ustrun_profile_enable": (i32, [i32]),
     "ustrun_profile_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     "ustrun_profile_stream": (i32, [vp, i32]),
