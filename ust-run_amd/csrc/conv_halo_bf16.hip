@@ -58,10 +58,17 @@ template <bool B> struct more_value<std::integral_constant<bool, B>> { static co
 // contiguous per half-wave) one stage ahead of their MFMAs.  That removes the two weight LDS-DMAs and the four B-fragment LDS
 // reads of a stage -- and, with nothing shared between the waves inside a chunk any more, the per-tap workgroup barrier: the
 // waves meet once per K chunk (when the patch buffers swap) instead of nine times, and drift apart in between.
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false>
+// M16 (round 4, plain sources with register-fed weights only): the same tile on v_mfma_f32_16x16x32 instead of 32x32x16 -- one
+// instruction spans the whole 32-channel chunk; a 32-pixel sub-tile is two 16-pixel halves, the wave's 64 columns four groups of
+// 16; operands swapped (A = weights, B = pixels) so that the product is D[channel][pixel]: four consecutive channels of a pixel
+// in the four registers of a tile -> 2 cvt_pk + one ds_write_b64 in the epilogue instead of four 2-byte writes.  Same fragment
+// bytes from LDS, same weight loads, same accumulator count; what differs is the clock the chip holds (MI355X_MICROARCH.md,
+// "DVFS give-back" item 7).
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false, bool M16 = false>
 __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
     static_assert(BK == 32, "80-byte patch rows hold one 32-channel chunk");
+    static_assert(!M16 || BREG, "the 16x16x32 build takes its weights through registers");
     static_assert(!BREG || NT <= 2, "register-fed weights: 16 registers per tap and set");
     constexpr int HW2 = TW + 2 * DIL;
     constexpr int SR = 32 / TW;                 // tile rows per 32-pixel sub-tile (2 or 1)
@@ -265,26 +272,42 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
     // B loads it had just issued AND the patch transfer); hidden from it, they are counted by hand below.
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (int)min((long)9 * K8 * a.Cout * 16, 0x7fffffffL), 0x00020000);
     const int bvoff0 = (lh * a.Cout + n0 + wn * 64 + l31) * 16, bvoff1 = bvoff0 + 2 * a.Cout * 16;      // ks = 0, 1; + 512: columns 32..63
-    bf16x8 bnx[NT][BK / 16][2];
+    // M16: lane (column l & 15, k group l >> 4) of column group g: the 16-byte item [tap][4 c + (l >> 4)][n0 + 64 wn + 16 g + (l & 15)]
+    const int bvoff16 = ((lane >> 4) * a.Cout + n0 + wn * 64 + (lane & 15)) * 16;
+    bf16x8 bnx[NT][BK / 16][2];                       // (M16: the four column groups, [g >> 1][g & 1])
     auto load_B = [&](int c, int tap, int k) {       // k: slot of the stage (folds to a constant)
         const int wt = wflip ? 8 - tap : tap;
         const int soff = __builtin_amdgcn_readfirstlane((int)(((long)wt * K8 + c * (BK / 8)) * a.Cout * 16));
+        if constexpr (M16)
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %4, %5, %6 offen\n\tbuffer_load_dwordx4 %1, %4, %5, %6 offen offset:256\n\t"
+                         "buffer_load_dwordx4 %2, %4, %5, %6 offen offset:512\n\tbuffer_load_dwordx4 %3, %4, %5, %6 offen offset:768"
+                         : "=&v"(bnx[k][0][0]), "=&v"(bnx[k][0][1]), "=&v"(bnx[k][1][0]), "=&v"(bnx[k][1][1])
+                         : "v"(bvoff16), "s"(wrs), "s"(soff) : "memory");
+        else
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %4, %6, %7 offen\n\tbuffer_load_dwordx4 %1, %4, %6, %7 offen offset:512\n\t"
                      "buffer_load_dwordx4 %2, %5, %6, %7 offen\n\tbuffer_load_dwordx4 %3, %5, %6, %7 offen offset:512"
                      : "=&v"(bnx[k][0][0]), "=&v"(bnx[k][0][1]), "=&v"(bnx[k][1][0]), "=&v"(bnx[k][1][1])
                      : "v"(bvoff0), "v"(bvoff1), "s"(wrs), "s"(soff) : "memory");
     };
 
-    f32x16 acc[MI][2];
+    f32x16 acc[M16 ? 1 : MI][2];
+    f32x4 acc16[M16 ? MI : 1][2][4];                  // [sub-tile][16-pixel half][column group]: D[channel][pixel]
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < (M16 ? 1 : MI); ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (M16 ? MI : 1); ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc16[i][h][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // this lane's fragment bases: patch pixel of sub-tile 0 at tap (0,0), K half lh; weight column wn*64 + l31
-    const int afrag0 = ((wm * SR * MI + (TW == 16 ? (l31 >> 4) : 0)) * HW2 + (l31 & (TW - 1))) * PITCH + lh * 16;
+    const int afrag0 = M16 ? ((wm * SR * MI) * HW2 + (lane & 15)) * PITCH + (lane >> 4) * 16      // pixel l & 15 of a half, k group l >> 4
+                           : ((wm * SR * MI + (TW == 16 ? (l31 >> 4) : 0)) * HW2 + (l31 & (TW - 1))) * PITCH + lh * 16;
     const int bfrag0 = (lh * BN + wn * 64 + l31) * 16;
     const int nstage = nchunk * NSTG;
 
@@ -418,6 +441,9 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
             }
             // middle: every fragment is base + immediate
             auto afrag = [&](int tap, int ks, int i) __attribute__((always_inline)) {
+                if constexpr (M16)       // ks = the 16-pixel half: the right half of a 32-pixel row, or the second row of a 2 x 16 sub-tile
+                    return *(const bf16x8*)(Afrag + ((DIL * (tap / 3) + SR * i + (TW == 16 ? ks : 0)) * HW2 + DIL * (tap % 3) + (TW == 16 ? 0 : 16 * ks)) * PITCH);
+                else
                 return *(const bf16x8*)(Afrag + ((DIL * (tap / 3) + SR * i) * HW2 + DIL * (tap % 3)) * PITCH + ks * 32);
             };
             if constexpr (APIPE) {
@@ -446,8 +472,14 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                         }
 #pragma unroll
                         for (int i = 0; i < MI; ++i) {
+                            if constexpr (M16) {
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+                                    acc16[i][ks][g] = USTRUN_MFMA_16x16x32(bcur[k][g >> 1][g & 1], acar[i], acc16[i][ks][g], 0, 0, 0);
+                            } else {
                             acc[i][0] = USTRUN_MFMA_32x32x16(acar[i], bcur[k][ks][0], acc[i][0], 0, 0, 0);
                             acc[i][1] = USTRUN_MFMA_32x32x16(acar[i], bcur[k][ks][1], acc[i][1], 0, 0, 0);
+                            }
                         }
                         if (in_stage || j < NSTG - 1) {
 #pragma unroll
@@ -491,15 +523,21 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                 for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
+                        if constexpr (M16) {          // ks = the 16-pixel half; the stage's four column groups live in bf[k][g >> 1][g & 1]
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                acc16[i][ks][g] = USTRUN_MFMA_16x16x32(bf[k][g >> 1][g & 1], af[k][ks][i], acc16[i][ks][g], 0, 0, 0);
+                        } else {
                         acc[i][0] = USTRUN_MFMA_32x32x16(af[k][ks][i], bf[k][ks][0], acc[i][0], 0, 0, 0);
                         acc[i][1] = USTRUN_MFMA_32x32x16(af[k][ks][i], bf[k][ks][1], acc[i][1], 0, 0, 0);
+                        }
                     }
             }
             if constexpr (SKEW) {
 #pragma unroll
                 for (int b = 0; b < nitem; ++b) xform_store(jx * BATCH + b, rr[b], Anext, more, rawR);
             }
-            constexpr int nmfma = nt * (BK / 16) * MI * 2;
+            constexpr int nmfma = nt * (BK / 16) * MI * (M16 ? 4 : 2);
             constexpr int vpm = !SKEW ? 0 : (nitem * (NP * 26 + 14) + nmfma - 1) / nmfma;
             if constexpr (APIPE) {
                 // pinned (left alone, hipcc re-fetches each fragment just in time into ONE register set: read -> wait -> 2 MFMAs):
@@ -511,7 +549,7 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                 for (int h = 0; h < nt * (BK / 16); ++h) {
                     const bool next_read = h + 1 < nt * (BK / 16) || j < NSTG - 1;
 #pragma unroll
-                    for (int m = 0; m < 2 * MI; ++m) {
+                    for (int m = 0; m < (M16 ? 4 : 2) * MI; ++m) {
                         if (m == 2 && next_read) __builtin_amdgcn_sched_group_barrier(0x100, MI, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         if constexpr (vpm > 0) __builtin_amdgcn_sched_group_barrier(0x002, vpm, 0);
@@ -583,6 +621,14 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(2))) elt_t bf16x2;
     f32x2 s1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2v[2] = {{0.f, 0.f}, {0.f, 0.f}};    // two pixel rows at a time (packed f32 math)
+    float s1p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // M16: from the stored pieces
+    auto stat_piece = [&](const bf16x8 v8, bool ok) {      // the lane's 8 channels (lane & 7) of one pixel: statistics see the stored values
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float f = ok ? (float)v8[q] : 0.f;
+            s1p[q] += f; s2p[q] += f * f;
+        }
+    };
     constexpr int EPITCH = 144;
     char* ep = smem + wave * (32 * EPITCH);         // the A patches are dead after the last barrier
     const bool full = y0 + TH <= a.Ho && x0 + TW <= a.Wo;     // interior tile: no per-pixel masks
@@ -590,12 +636,23 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
     auto park = [&](int i, auto mask_c, auto stat_c) {
         constexpr bool MASK = decltype(mask_c)::value, STAT = decltype(stat_c)::value;
         const int oyb = y0 + wm * SR * MI + SR * i;
+        if constexpr (M16) {     // D[channel][pixel]: registers 0..3 of tile (half h, group g) = channels 16 g + 4 (l >> 4) + 0..3 of pixel 16 h + (l & 15)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = acc16[M16 ? i : 0][h][g];
+                    bf16x4 h4;
+                    h4[0] = (elt_t)v[0]; h4[1] = (elt_t)v[1]; h4[2] = (elt_t)v[2]; h4[3] = (elt_t)v[3];
+                    *(bf16x4*)(ep + (16 * h + (lane & 15)) * EPITCH + (16 * g + 4 * (lane >> 4)) * 2) = h4;
+                }
+        } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {       // registers r, r+1 are pixel rows row, row+1 of the sub-tile
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const f32x2 v = {acc[i][j][r], acc[i][j][r + 1]};
+                const f32x2 v = {acc[M16 ? 0 : i][j][r], acc[M16 ? 0 : i][j][r + 1]};
                 const bf16x2 h = __builtin_convertvector(v, bf16x2);
                 *(elt_t*)(ep + row * EPITCH + (j * 32 + l31) * 2) = h[0];
                 *(elt_t*)(ep + (row + 1) * EPITCH + (j * 32 + l31) * 2) = h[1];
@@ -611,13 +668,17 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                 s2v[j] += f * f;
             }
         }
+        }
     };
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int oyb = y0 + wm * SR * MI + SR * i;
+        if constexpr (M16) park(i, std::false_type{}, std::false_type{});
+        else {
         if (!a.stat) park(i, std::false_type{}, std::false_type{});        // input-gradient: no statistics
         else if (full) park(i, std::false_type{}, std::true_type{});
         else park(i, std::true_type{}, std::true_type{});
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -632,6 +693,7 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                 const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
                 const long off = TW == 16 ? ((long)(row >> 4) * a.Wo + (row & 15)) * a.C0 : (long)row * a.C0;
                 *(bf16x8*)(base + off) = v8;
+                if constexpr (M16) { if (a.stat) stat_piece(v8, true); }
             }
         } else
 #pragma unroll
@@ -640,6 +702,7 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
             const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
             const int oy = oyb + (TW == 16 ? (row >> 4) : 0), ox = x0 + (row & (TW - 1));
             const int col = n0 + wn * 64 + ch * 8;
+            if constexpr (M16) { if (a.stat) stat_piece(v8, oy < a.Ho && ox < a.Wo); }
             if (oy < a.Ho && ox < a.Wo) {
                 if (col < a.C0) {
                     *(bf16x8*)((elt_t*)a.out0 + (((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col) = v8;
@@ -657,6 +720,17 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
     float s1[2] = {s1v[0][0] + s1v[0][1], s1v[1][0] + s1v[1][1]}, s2[2] = {s2v[0][0] + s2v[0][1], s2v[1][0] + s2v[1][1]};
     if (a.stat) {
         float* red = (float*)(smem + 4 * 32 * EPITCH);   // [WM][2][BN], behind the waves' transpose scratch
+        if constexpr (M16) {                        // lanes with equal lane & 7 hold the same 8 channels
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) { s1p[q] += __shfl_xor(s1p[q], o); s2p[q] += __shfl_xor(s2p[q], o); }
+                if (lane < 8) {
+                    red[(wm * 2 + 0) * BN + wn * 64 + lane * 8 + q] = s1p[q];
+                    red[(wm * 2 + 1) * BN + wn * 64 + lane * 8 + q] = s2p[q];
+                }
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             s1[j] += __shfl_xor(s1[j], 32);
@@ -681,9 +755,9 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
 
 thread_local int g_last_variant = 0;    // (per calling thread) TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF of the last launch (tests: ustrun_debug_last_conv_variant)
 
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false>
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false, bool M16 = false>
 int launch_xf(const IgemmArgs& a, hipStream_t st) {
-    g_last_variant = TH << 24 | TW << 16 | BN << 8 | MI << 4 | NT << 2 | (POOL ? 2 : 0) | (XF ? 1 : 0);
+    g_last_variant = TH << 24 | TW << 16 | BN << 8 | (M16 ? 0x80 : 0) | MI << 4 | NT << 2 | (POOL ? 2 : 0) | (XF ? 1 : 0);
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
     constexpr int DSLOTS = ((TH + 2 * DIL) * (TW + 2 * DIL) * 5 + 63) / 64 * 64;
     constexpr int AIT = (DSLOTS + 255) / 256, NSTG = (9 + NT - 1) / NT, BATCH = (AIT + NSTG - 2) / (NSTG - 1);
@@ -694,8 +768,8 @@ int launch_xf(const IgemmArgs& a, hipStream_t st) {
     // above the 64 KB default (the dilation-4 patch pair: 93 KB; the 16 x 16 x 128 transforming tile: 66 KB): raise the limit
     // whatever the dilation is (the un-dilated 16 x 16 tile used to launch without the attribute)
     if (lds > 64 * 1024)
-        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG>, (int)lds, "conv3x3_halo_bf16"));
-    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG>), grid, block, lds, st, a, tx, ty, nt);
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG, M16>, (int)lds, "conv3x3_halo_bf16"));
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG, M16>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;
 }
@@ -709,6 +783,15 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     if constexpr (POOL) return launch_xf<TH, TW, BN, BK, MI, POOL, NT, true>(a, st);
     else {
         {                                              // weights through registers, one barrier per chunk (debug flag bit 3: off)
+            // the 16x16x32 build (round 4): measured ahead on the input gradients of every layer (profiles/r04_ab_halo_m16.log:
+            // 512 -> 512 at 32 x 32 0.220 -> 0.202 ms, 1024 -> 1024 0.217 -> 0.201, 128 -> 128 -1.5 %): the default for plain
+            // sources on the 256-pixel tiles.  ustrun_debug_flags bit 15 (32768): every register-fed variant on it (A/B runs of
+            // the forward); bit 17 (131072): none.
+            {
+                const bool m16 = !(g_debug_flags & 8) && !(g_debug_flags & 131072) && ((g_debug_flags & 32768) || (!xf && MI == 4 && NT == 1));
+                if (m16)
+                    return xf ? launch_xf<TH, TW, BN, BK, MI, POOL, NT, true, 1, true, true>(a, st) : launch_xf<TH, TW, BN, BK, MI, POOL, NT, false, 1, true, true>(a, st);
+            }
             if (!(g_debug_flags & 8))
                 return xf ? launch_xf<TH, TW, BN, BK, MI, POOL, NT, true, 1, true>(a, st) : launch_xf<TH, TW, BN, BK, MI, POOL, NT, false, 1, true>(a, st);
         }
