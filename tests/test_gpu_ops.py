@@ -290,11 +290,12 @@ def test_conv3x3_bf16_mfma(n, ci, co, h, w, exact):
     assert rel(dw.cpu(), wr.grad) < tol
 
 
+@pytest.mark.parametrize("with_stat", [True, False])
 @pytest.mark.parametrize("elt", ["bf16", "f16"])
 @pytest.mark.parametrize("flags", [0, 16384])
 @pytest.mark.parametrize("n,c,h,w", [(2, 3, 16, 32), (1, 1, 19, 37), (2, 4, 9, 70), (3, 3, 40, 33), (4, 3, 136, 96), (16, 1, 72, 100),
-                                     (2, 2, 200, 64)])
-def test_conv_first_bf16_mfma_exact(n, c, h, w, flags, elt):
+                                     (2, 2, 200, 64), (32, 3, 256, 256), (24, 3, 256, 256), (40, 1, 288, 288)])
+def test_conv_first_bf16_mfma_exact(n, c, h, w, flags, elt, with_stat):
     """First convolution (NCHW f32 network input, C <= 4 -> 64) on the 16-bit matrix cores as an im2col GEMM, both builds (the
     streaming kernel of round 4: a block walks a 32-pixel strip 8 rows per step -- several steps, a ragged last step, ragged
     strips, segments of 8..64 rows; and, with ustrun_debug_flags bit 14, the tile-per-block kernel of rounds 1-3), both
@@ -323,13 +324,16 @@ def test_conv_first_bf16_mfma_exact(n, c, h, w, flags, elt):
     rows = C.c_int(0)
     old = lib.ustrun_debug_flags(flags)
     try:
-        l.check(lib.ustrun_conv3x3_fwd_rows(C.byref(src), 1, wf.data_ptr(), n, h, w, 64, y.data_ptr(), stat.data_ptr(), C.byref(rows),
-                                            code, None))
+        l.check(lib.ustrun_conv3x3_fwd_rows(C.byref(src), 1, wf.data_ptr(), n, h, w, 64, y.data_ptr(), stat.data_ptr() if with_stat else None,
+                                            C.byref(rows), code, None))
     finally:
         lib.ustrun_debug_flags(old)
     yc = from_nhwc(y.float())
     assert rel(yc, y_ref.to(t16).float()) < 1e-6
     assert bool((buf[:Z] == 9.0).all()) and bool((buf[-Z:] == 9.0).all())
+    if not with_stat:                       # the eval-mode forward: no statistics (its own build of the kernel); nothing written to the table
+        assert bool((stat == 7.0).all())
+        return
     assert 0 < rows.value <= rows_max and rows.value % n == 0
     assert bool((stat[rows.value:] == 7.0).all())
     st = stat[:rows.value].view(n, rows.value // n, 2, 64).sum(1).cpu()            # per image

@@ -479,7 +479,11 @@ __global__ __launch_bounds__(256, 3) void conv_first_fwd_stream_kernel(const flo
                 const bf16x8 v8 = *(const bf16x8*)(ep + pr * SPITCH + ch * 16);
                 const int ox = x0 + pr;
                 const bool ok = rowok && ox < W;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v8), ry, ok ? (ox * 64 + ch * 8) * 2 : OOB, oy * W * 128, 0);
+                // (the row offset rides in the VECTOR offset, soffset stays 0: with an SGPR soffset hipcc's hazard recognizer inserts no
+                // wait state between a 128-bit buffer store and a VALU write of its data registers -- an SI-era rule -- and on gfx950,
+                // with the store pipe saturated, the store then ships the overwritten dword for the last lanes of each 16:
+                // 6e-6 of the outputs in the no-statistics build, none in the build whose statistics code sits in between)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v8), ry, ok ? ((oy * W + ox) * 64 + ch * 8) * 2 : OOB, 0, 0);
                 if constexpr (STAT) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {

@@ -272,9 +272,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws64_kernel(const IgemmArgs a,
         const int ylim = min(c.ybeg + p.seg, H);
         u32x4 u = *(const u32x4*)(Ew + (i * 32 + px) * EPITCH + o * 16);
         const bool inimg = live & (y < ylim) & (c.x0 + px < W);
-        const unsigned voff = (unsigned)(st_lane + (tt & 1) * 2048) | (inimg ? 0u : 0x80000000u);
-        // (the scalar offset is wave-uniform; said explicitly, or hipcc wraps the store in a waterfall loop)
-        __builtin_amdgcn_raw_buffer_store_b128(u, ro, voff, __builtin_amdgcn_readfirstlane(c.img * out_bytes + (y * W + c.x0) * 128), 0);
+        // (the row offset is added into the VECTOR offset and soffset stays 0: for a 128-bit buffer store with an SGPR soffset hipcc's
+        // hazard recognizer inserts no wait state in front of a VALU write of the store's data registers -- the selects right below --
+        // and gfx950 then ships the overwritten dword under store pressure: found in conv_first.hip, round 4)
+        const unsigned voff = inimg ? (unsigned)(st_lane + (tt & 1) * 2048 + __builtin_amdgcn_readfirstlane(c.img * out_bytes + (y * W + c.x0) * 128)) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(u, ro, voff, 0, 0);
         if constexpr (STAT) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) u[e] = inimg ? u[e] : 0u;
@@ -948,8 +950,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
         const int ylim = min(c.ybeg + p.seg, H);
         u32x4 u = *(const u32x4*)(Ew + (i * 32 + px) * EPITCH + o * 16);
         const bool inimg = live & (y < ylim) & (c.x0 + px < W);
-        const unsigned voff = (unsigned)(st_lane + (tt & 1) * 2048) | (inimg ? 0u : 0x80000000u);
-        __builtin_amdgcn_raw_buffer_store_b128(u, ro, voff, __builtin_amdgcn_readfirstlane(c.img * out_bytes + (y * W + c.x0) * 128), 0);
+        // (row offset in the vector offset, soffset 0: see the four-wave kernel's epi_B)
+        const unsigned voff = inimg ? (unsigned)(st_lane + (tt & 1) * 2048 + __builtin_amdgcn_readfirstlane(c.img * out_bytes + (y * W + c.x0) * 128)) : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(u, ro, voff, 0, 0);
         if constexpr (STAT) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) u[e] = inimg ? u[e] : 0u;
