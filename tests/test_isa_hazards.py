@@ -18,3 +18,27 @@ def test_no_unpadded_wide_store_with_register_soffset():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_hazard.py"), lib], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "gfx950 code objects" in r.stdout and " 0 followed by" in r.stdout, r.stdout
+
+
+def test_hand_counted_register_loads_are_never_touched_in_flight():
+    """the weight fragments of conv_halo_bf16.hip / convT_bf16.hip arrive by inline-asm buffer loads that hipcc does
+    not know about and are waited for with hand-written vmcnt values; tools/check_inflight_regs.py replays every kernel of the
+    built library and fails if any instruction reads or writes a destination register of such a load before the wait that
+    retires it.  The replay itself is checked on two synthetic snippets first (one clean, one with a copy ahead of the wait)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_inflight_regs as T
+    clean = ["s_nop 4", "buffer_load_dwordx4 v[10:13], v1, s[0:3], s4 offen", "buffer_load_dwordx4 v[14:17], v1, s[0:3], s4 offen offset:512",
+             "global_load_dwordx4 v[20:23], v[2:3], off", "v_add_u32_e32 v5, v6, v7", "s_waitcnt vmcnt(1)",
+             "v_mfma_f32_32x32x16_bf16 v[32:47], v[10:13], v[14:17], v[32:47]"]
+    assert T.replay("k", clean) == []
+    dirty = clean[:4] + ["v_mov_b32_e32 v30, v12"] + clean[4:]                  # a copy of an in-flight destination ahead of the wait
+    hits = T.replay("k", dirty)
+    assert len(hits) == 1 and hits[0][2] == [12], hits
+    short = clean[:5] + ["s_waitcnt vmcnt(2)"] + clean[6:]                      # the wait leaves the second load in flight
+    assert [h[2] for h in T.replay("k", short)] == [[14, 15, 16, 17]]
+    lib = os.path.join(ROOT, "ust-run_amd", "ustrun", "libustrun.so")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight_regs.py"), lib], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import re
+    m = re.search(r"(\d+) hand-counted register loads followed, 0 instructions", r.stdout)
+    assert m and int(m.group(1)) > 1000, r.stdout          # the halo / ConvTranspose kernels really were replayed
