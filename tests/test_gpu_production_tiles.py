@@ -246,14 +246,20 @@ def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):
     assert rel(dw.cpu(), 2 * wr.grad) < 1e-6
 
 
-def test_convT_bf16_batched_passes_exact():
-    """ConvTranspose forward with per-pass BatchNorm constants on its source (the producer's raw output), at the
-    full-resolution level's shape class (128 -> 64 channels), and its weight gradient over the batched passes."""
+@pytest.mark.parametrize("n,G,ci,co,h,w", [
+    (8, 4, 128, 64, 24, 40),                 # the full-resolution level's channel plan, four batched passes, 60 tiles
+    (6, 2, 256, 128, 20, 24),                # 4 K chunks forward / 8 in the gradient, two N tiles forward, a ragged last tile
+    (3, 1, 512, 256, 9, 11),                 # odd extents, M % 128 != 0, 8 K chunks forward / 16 in the gradient, 256-column tiles both ways
+    (8, 2, 128, 64, 128, 128),               # the full-resolution level of the U-Net at its natural extent: 1024 tiles
+])
+def test_convT_bf16_batched_passes_exact(n, G, ci, co, h, w):
+    """ConvTranspose forward with per-pass BatchNorm constants on its source (the producer's raw output), its input gradient and
+    its weight gradient over the batched passes; outputs between sentinel zones; the kernel family each launch ran is asserted."""
+    flags = 0
     l = L()
     lib = l.lib()
-    g = torch.Generator().manual_seed(77)
+    g = torch.Generator().manual_seed(77 + ci + h)
     ri = lambda lo, hi, *s: torch.randint(lo, hi + 1, s, generator=g).float()
-    n, G, ci, co, h, w = 8, 4, 128, 64, 24, 40
     gn = n // G
     y = ri(-3, 3, n, ci, h, w)
     sc = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (G, ci), generator=g)]
@@ -272,18 +278,30 @@ def test_convT_bf16_batched_passes_exact():
     aff = torch.zeros(G, 4, ci)
     aff[:, 0], aff[:, 1] = sc, sh
     affg, yg, bg, dug = aff.cuda(), nhwc16(y), b.cuda(), nhwc16(du)
-    src = l.nhwc_src(yg.data_ptr(), ci, h, w, affg.data_ptr(), affg.data_ptr() + 4 * ci, relu=1, gN=gn, gstride=4 * ci)
-    u = torch.empty(n, 2 * h, 2 * w, co, device="cuda", dtype=E.t)
-    l.check(lib.ustrun_convT2x2_fwd(C.byref(src), wf.data_ptr(), bg.data_ptr(), n, h, w, co, u.data_ptr(), E.code, None))
+    src = l.nhwc_src(yg.data_ptr(), ci, h, w, affg.data_ptr(), affg.data_ptr() + 4 * ci, relu=1, gN=gn if G > 1 else 0, gstride=4 * ci)
+    Z = 4096
+    ubuf = torch.full((Z + n * 4 * h * w * co + Z,), 9.0, device="cuda", dtype=E.t)
+    u = ubuf[Z:Z + n * 4 * h * w * co].view(n, 2 * h, 2 * w, co)
+    old_flags = lib.ustrun_debug_flags(flags)
+    try:
+        l.check(lib.ustrun_convT2x2_fwd(C.byref(src), wf.data_ptr(), bg.data_ptr(), n, h, w, co, u.data_ptr(), E.code, None))
+        vf = lib.ustrun_debug_last_conv_variant()
+        dbuf = torch.full((Z + n * h * w * ci + Z,), 9.0, device="cuda", dtype=E.t)
+        da = dbuf[Z:Z + n * h * w * ci].view(n, h, w, ci)
+        l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), E.code, None))
+        vd = lib.ustrun_debug_last_conv_variant()
+    finally:
+        lib.ustrun_debug_flags(old_flags)
+    assert (vf >> 16) == 0x4354 and (vd >> 16) == 0x4354, (hex(vf), hex(vd))
     assert rel(from_nhwc(u.float()), r16(ref.detach())) < 1e-6
+    assert rel(from_nhwc(da.float()), r16(ar.grad)) < 1e-6
+    for b_ in (ubuf, dbuf):
+        assert bool((b_[:Z] == 9.0).all()) and bool((b_[-Z:] == 9.0).all()), "wrote outside its output"
     nb = max(lib.ustrun_wgrad_partials_bytes(4, ci, co, n * h * w), 512 * co * 4)
     part = torch.empty(nb // 4, device="cuda")
     dw, db = torch.empty(ci, co, 2, 2, device="cuda"), torch.empty(co, device="cuda")
     l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, E.code, None))
     assert rel(dw.cpu(), wr.grad) < 1e-6 and rel(db.cpu(), br.grad) < 1e-6
-    da = torch.empty(n, h, w, ci, device="cuda", dtype=E.t)
-    l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), E.code, None))
-    assert rel(from_nhwc(da.float()), r16(ar.grad)) < 1e-6
 
 
 # 3x3 weight gradient, the three builds of the all-taps kernel (wgrad_halo_bf16.hip): 0x482 = two wave groups in opposite phases

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     }
     const int mtile = bid / nt_total, ntile = bid % nt_total;
     const int n0 = ntile * BN;
-    const long m0 = (long)mtile * BM;
+    const int m0 = mtile * BM;                  // (M < 2^29: the launcher checks)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA bases and role tests stay scalar
@@ -79,51 +79,55 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     const int Ktot = DG ? 4 * a.Cin : a.Cin;
     const int nchunk = Ktot / BK;
     const elt_t* Wp = (const elt_t*)a.W;
-    const elt_t* Ap = (const elt_t*)a.src[0].ptr;
-    const int x0r = (int)(m0 % W);              // x of the tile's first pixel
+    const int x0r = m0 % W;                     // x of the tile's first pixel
 
-    // ---- A items: pixel = (tid + 256 i) / CPR, 8-channel group c8 = tid % CPR ------------------------------
+    // ---- A items: pixel = (tid + 256 i) / CPR, 8-channel group c8 = tid % CPR.
+    // Round 4: 32-bit, TILE-RELATIVE addressing through a buffer resource whose base is the tile's first (gradient: lowest) source
+    // row -- the per-tile setup of this kernel was ~2300 instructions per wave in front of 64 MFMAs, most of them 64-bit index
+    // arithmetic and divisions (profiles/r04_pmc_convT_up4.txt).  The source is dense NHWC (the launchers check), so a forward item
+    // is px * Cin elements behind the tile base; a gradient item is (4 px - 2 x + 2 W) * Cin behind the base (4 m0 - 2 W) * Cin,
+    // which keeps the offset non-negative; rows past M fall behind the tensor's end and read zeros by the range check.
     const int c8 = tid % CPR;
-    long aoff[AIT];                             // element offset of the pixel (forward) / of its tap-(0,0) pixel (dgrad)
-    unsigned aok = 0;
+    constexpr int OOBV = (int)0x80000000;
+    int avoff[AIT];                             // byte offsets behind the tile base
+    const long a_total = DG ? (long)a.M * 4 * a.Cin : (long)a.M * a.Cin;               // source elements
+    const long a_base = DG ? ((long)4 * m0 - 2 * W) * a.Cin : (long)m0 * a.Cin;        // (negative for the first gradient tile: never dereferenced)
 #pragma unroll
     for (int i = 0; i < AIT; ++i) {
         const int px = (tid + 256 * i) / CPR;
-        const long m = m0 + px;
-        aoff[i] = 0;
-        if (m < a.M) {
-            aok |= 1u << i;
+        if (DG) {
             const int x = fastmod(x0r + px, W, invW);
-            if (DG) {
-                aoff[i] = (4 * m - 2 * x) * (long)a.Cin;
-            } else {
-                const int n = (int)(m / HWb);
-                const int y = (int)((m - (long)n * HWb - x) / W);
-                aoff[i] = n * a.src[0].sN + (long)y * a.src[0].sH + (long)x * a.src[0].sW;
-            }
+            avoff[i] = ((4 * px - 2 * x + 2 * W) * a.Cin + 8 * c8) * 2;
+        } else {
+            avoff[i] = (px * a.Cin + 8 * c8) * 2;
         }
-    }
+        if (m0 + px >= a.M) avoff[i] = OOBV;    // (the gradient's rows past M end up behind the tensor anyway; the forward's last tile needs it
+    }                                           //  only when another pass's rows follow in memory -- cheap either way)
+    const long a_left = (a_total - a_base) * 2;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)((const elt_t*)a.src[0].ptr + a_base), 0,
+                                                                          (int)(a_left < 0x7fffffffL ? a_left : 0x7fffffffL), 0x00020000);
     bf16x8 av[AIT];
     f32x4 asc0, asc1, ash0, ash1;
     const bool a_aff = !DG && a.src[0].scale != nullptr;
     // batched passes: a tile never straddles two passes (checked on the host), its pass picks the BatchNorm constants
-    const long goff = (!DG && a.src[0].gN > 0) ? (m0 / ((long)a.src[0].gN * HWb)) * a.src[0].gstride : 0;
+    const long goff = (!DG && a.src[0].gN > 0) ? (long)(m0 / (a.src[0].gN * HWb)) * a.src[0].gstride : 0;
     const bool a_relu = !DG && a.src[0].relu;
     auto load_A = [&](int c) {
-        long koff;
+        int koffb;                              // wave-uniform byte offset of the chunk: rides in the scalar offset
         if (DG) {
             const int k0 = c * BK, tap = k0 / a.Cin, kk = k0 - tap * a.Cin;
-            koff = ((long)(tap >> 1) * 2 * W + (tap & 1)) * a.Cin + kk + 8 * c8;
+            koffb = (((tap >> 1) * 2 * W + (tap & 1)) * a.Cin + kk) * 2;
         } else {
-            koff = c * BK + 8 * c8;
+            koffb = c * BK * 2;
             if (a_aff) {
+                const int koff = c * BK + 8 * c8;
                 asc0 = *(const f32x4*)(a.src[0].scale + goff + koff); asc1 = *(const f32x4*)(a.src[0].scale + goff + koff + 4);
                 ash0 = *(const f32x4*)(a.src[0].shift + goff + koff); ash1 = *(const f32x4*)(a.src[0].shift + goff + koff + 4);
             }
         }
 #pragma unroll
-        for (int i = 0; i < AIT; ++i) av[i] = *(const bf16x8*)(Ap + aoff[i] + koff);   // unconditional (rows past M read pixel 0
-    };                                                                                 // and are zeroed in write_A)
+        for (int i = 0; i < AIT; ++i) av[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff[i], koffb, 0));
+    };
     auto write_A = [&](char* Adst) {
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
             }
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
             u32x4 u = __builtin_bit_cast(u32x4, h);
-            const bool ok = (aok >> i) & 1u;              // a select, not a branch
+            const bool ok = avoff[i] != OOBV;             // a select, not a branch (rows past M: the affine of a zero is not zero)
 #pragma unroll
             for (int q = 0; q < 4; ++q) u[q] = ok ? u[q] : 0u;
             *(bf16x8*)(Adst + px * ROWB + ((c8 ^ swz(px)) * 16)) = __builtin_bit_cast(bf16x8, u);
@@ -188,13 +192,35 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
                      : "v"(bvoff), "s"(wrs), "s"(s0), "s"(s1) : "memory");
     };
 
+    // The product is D[column][pixel] (weights are the MFMA's A operand): lane = pixel l31 of a 32-pixel sub-tile, registers 4g .. 4g + 3
+    // of accumulator j = columns 32 j + 8 g + 4 lh + 0..3 -- four consecutive channels of one pixel, so the epilogue packs them with two
+    // cvt_pk and parks them with ONE ds_write_b64 (round 4: the kernel spent ~1800 VALU instructions per wave and tile beside its 64
+    // MFMAs -- SQ counters in profiles/r04_pmc_convT_up4.txt -- a quarter of them 2-byte LDS scatter of the other orientation).  The
+    // bias of a column is a property of the REGISTER now: the accumulators start from it instead of from zero.
     f32x16 acc[MI][2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
+    {
+        float* bsc = (float*)smem + wave * 64;              // this wave's 64 bias values (the A tiles are not in use yet)
+        const int colw0 = n0 + wn * 64;
+        float bv = 0.f;
+        if (!DG && a.bias) {
+            int co0 = colw0;
+            if (!PLAIN) { const int tp = colw0 / a.Cout; co0 = colw0 - tp * a.Cout; }
+            bv = a.bias[co0 + lane];
+        }
+        bsc[lane] = bv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *(const f32x4*)(bsc + j * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) { acc[i][j][4 * g] = b4[0]; acc[i][j][4 * g + 1] = b4[1]; acc[i][j][4 * g + 2] = b4[2]; acc[i][j][4 * g + 3] = b4[3]; }
+            }
+        __syncthreads();                                    // (the bias scratch aliases the first activation tile)
+    }
 
     if constexpr (BREG) load_Breg(0, 0); else dma_B(0, 0);
     load_A(0);
@@ -233,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
                     for (int i = 0; i < MI; ++i) {
                         const int p = prow0 + 32 * i;
                         const bf16x8 af = *(const bf16x8*)(Acur + p * ROWB + ((ch ^ swz(p)) * 16));
-                        acc[i][0] = USTRUN_MFMA_32x32x16(af, bcur[ks][0], acc[i][0], 0, 0, 0);
-                        acc[i][1] = USTRUN_MFMA_32x32x16(af, bcur[ks][1], acc[i][1], 0, 0, 0);
+                        acc[i][0] = USTRUN_MFMA_32x32x16(bcur[ks][0], af, acc[i][0], 0, 0, 0);      // weights as the A operand: D[column][pixel]
+                        acc[i][1] = USTRUN_MFMA_32x32x16(bcur[ks][1], af, acc[i][1], 0, 0, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -259,8 +285,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
             for (int i = 0; i < MI; ++i) {
                 const int p = prow0 + 32 * i;
                 const bf16x8 af = *(const bf16x8*)(Acur + p * ROWB + ((ch ^ swz(p)) * 16));
-                acc[i][0] = USTRUN_MFMA_32x32x16(af, b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = USTRUN_MFMA_32x32x16(af, b1, acc[i][1], 0, 0, 0);
+                acc[i][0] = USTRUN_MFMA_32x32x16(b0, af, acc[i][0], 0, 0, 0);
+                acc[i][1] = USTRUN_MFMA_32x32x16(b1, af, acc[i][1], 0, 0, 0);
             }
         }
         if (more) write_A(As + (buf ^ 1) * ABYTES);
@@ -268,46 +294,59 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
         buf ^= 1;
     }
 
-    // ---- epilogue: bias, bf16, per-wave LDS transpose, 16-byte stores of 64 contiguous channels ----
+    // ---- epilogue: bf16, per-wave LDS transpose (ds_write_b64: four channels of a pixel), 16-byte stores of 64 contiguous channels ----
     constexpr int EPITCH = 144;
     char* ep = smem + wave * (32 * EPITCH);
     const int colw = n0 + wn * 64;               // first of this wave's 64 columns
     int tap = 0, co0 = colw;
     if (!DG && !PLAIN) { tap = colw / a.Cout; co0 = colw - tap * a.Cout; }
-    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};          // PLAIN: BatchNorm-statistics partials of this lane's two channels
-    const float bias0 = (!DG && a.bias) ? a.bias[co0 + l31] : 0.f, bias1 = (!DG && a.bias) ? a.bias[co0 + 32 + l31] : 0.f;
-    elt_t* outp = (elt_t*)a.out0;
+    float st1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, st2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // PLAIN: statistics of the lane's 8 channels (lane & 7)
+    // stores: 32-bit offsets behind the wave's own base through a buffer resource (soffset 0: see conv_first.hip on why no
+    // register soffset rides on a 128-bit store) -- forward: base = pixel 4 m0 - 2 W + tap offset, channel co0; a piece of row d sits
+    // (4 d - 2 x + 2 W) * Cout + 8 ch behind it; gradient / plain: base = pixel m0, column colw.  Rows past M fall behind the tensor.
     const long tapoff = (long)(tap >> 1) * 2 * W + (tap & 1);
+    const long o_total = (DG || PLAIN) ? (long)a.M * a.Cout : (long)a.M * 4 * a.Cout;
+    const long o_base = (DG || PLAIN) ? (long)m0 * a.Cout + colw : ((long)4 * m0 - 2 * W + tapoff) * a.Cout + co0;
+    const long o_left = (o_total - o_base) * 2;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)((elt_t*)a.out0 + o_base), 0,
+                                                                          (int)(o_left < 0x7fffffffL ? o_left : 0x7fffffffL), 0x00020000);
+    typedef __attribute__((ext_vector_type(4))) elt_t bf16x4;
+    // this lane's pieces of a sub-tile: pixel rows r0 + 8 t (t = 0..3), channel group ch -- x advances by 8 per piece
+    const int r0 = lane >> 3, ch = lane & 7;
+    __syncthreads();                              // every wave is done with the activation tiles the scratch aliases
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const elt_t hv = (elt_t)(acc[i][j][r] + (j ? bias1 : bias0));
-                *(elt_t*)(ep + row * EPITCH + (j * 32 + l31) * 2) = hv;
-                if constexpr (PLAIN) {      // rows past M carry zero activations and 1x1 convs in front of a BatchNorm have no bias
-                    const float f = (float)hv;
-                    st1[j] += f; st2[j] += f * f;
-                }
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 h4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h4[q] = (elt_t)acc[i][j][4 * g + q];
+                *(bf16x4*)(ep + l31 * EPITCH + (j * 32 + 8 * g + 4 * lh) * 2) = h4;
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int d0 = wm * 32 * MI + 32 * i + r0;
+        int x = (DG || PLAIN) ? 0 : fastmod(x0r + d0, W, invW);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int idx = lane + 64 * t, row = idx >> 3, ch = idx & 7;
+            const int row = r0 + 8 * t;
             const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
-            const int d = wm * 32 * MI + 32 * i + row;
-            const long m = m0 + d;
-            if (m < a.M) {
-                if (DG || PLAIN) {
-                    *(bf16x8*)(outp + m * a.Cout + colw + ch * 8) = v8;
-                } else {
-                    const int x = fastmod(x0r + d, W, invW);
-                    *(bf16x8*)(outp + (4 * m - 2 * x + tapoff) * a.Cout + co0 + ch * 8) = v8;
+            const int d = d0 + 8 * t;
+            const bool ok = m0 + d < a.M;
+            const int vo = (DG || PLAIN) ? (d * a.Cout + ch * 8) * 2 : ((4 * d - 2 * x + 2 * W) * a.Cout + ch * 8) * 2;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v8), ors, ok ? vo : OOBV, 0, 0);
+            if constexpr (PLAIN) {                  // statistics see the stored values; rows past M are not counted
+                if (a.stat) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const float f = ok ? (float)v8[q] : 0.f; st1[q] += f; st2[q] += f * f; }
                 }
+            }
+            if (!(DG || PLAIN)) {                   // the next piece is 8 pixels on: x advances without a division from W = 8 up
+                if (W >= 8) { x += 8; x = x >= W ? x - W : x; }
+                else x = fastmod(x0r + d + 8, W, invW);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -315,16 +354,16 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if constexpr (PLAIN) {
-        if (a.stat) {       // fixed order: lane halves, then the WM waves that share these columns -> row mtile of [rows][2][Cout]
+        if (a.stat) {       // fixed order: the lanes that hold the same channels (lane & 7), then the WM waves that share these columns
             __syncthreads();
             float* red = (float*)smem;            // [WM][2][BN]
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                st1[j] += __shfl_xor(st1[j], 32);
-                st2[j] += __shfl_xor(st2[j], 32);
-                if (lh == 0) {
-                    red[(wm * 2 + 0) * BN + wn * 64 + j * 32 + l31] = st1[j];
-                    red[(wm * 2 + 1) * BN + wn * 64 + j * 32 + l31] = st2[j];
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) { st1[q] += __shfl_xor(st1[q], o); st2[q] += __shfl_xor(st2[q], o); }
+                if (lane < 8) {
+                    red[(wm * 2 + 0) * BN + wn * 64 + lane * 8 + q] = st1[q];
+                    red[(wm * 2 + 1) * BN + wn * 64 + lane * 8 + q] = st2[q];
                 }
             }
             __syncthreads();
@@ -359,6 +398,11 @@ bool common_ok(const IgemmArgs& a) {
     if (a.M >= (1l << 29) || a.Wb >= 32768) return false;
     return true;
 }
+// the forward / 1x1 loaders address their source pixel-linearly: dense NHWC only (strided views take the generic kernel)
+bool dense_src(const IgemmArgs& a) {
+    const SrcDev& s = a.src[0];
+    return s.C == a.Cin && s.sW == s.C && s.sH == (long)s.W * s.C && s.sN == (long)s.H * s.W * s.C;
+}
 
 }  // namespace
 
@@ -367,7 +411,7 @@ bool convT_fwd_supported(const IgemmArgs& a) {
     if (a.nz != 4 || a.nseg != 1 || a.s_out != 2 || a.s_in != 1 || a.stat) return false;
     if (!common_ok(a)) return false;
     const SrcDev& s = a.src[0];
-    if (s.LH != a.Hb || s.LW != a.Wb || (s.sN & 7) || (s.sH & 7) || (s.sW & 7)) return false;
+    if (s.LH != a.Hb || s.LW != a.Wb || !dense_src(a)) return false;
     if (s.gN > 0 && ((long)s.gN * a.Hb * a.Wb) % 128) return false;     // 128-pixel tiles must not straddle passes
     return a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.C0 == a.Cout;
 }
@@ -391,7 +435,7 @@ bool conv1x1_supported(const IgemmArgs& a) {
     if (a.nz != 1 || a.nseg != 1 || a.s_out != 1 || a.s_in != 1 || a.d0 != 0) return false;
     if (!common_ok(a)) return false;
     const SrcDev& s = a.src[0];
-    if (s.LH != a.Hb || s.LW != a.Wb || (s.sN & 7) || (s.sH & 7) || (s.sW & 7) || s.gN > 0) return false;
+    if (s.LH != a.Hb || s.LW != a.Wb || !dense_src(a) || s.gN > 0) return false;
     return a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.C0 == a.Cout && a.Ho == a.Hb && a.Wo == a.Wb;
 }
 int conv1x1_launch_bf16(const IgemmArgs& a, hipStream_t st) {
