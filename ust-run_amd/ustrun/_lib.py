@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libustrun.so")
+LIB_PATH = os.environ.get("USTRUN_LIB", os.path.join(_HERE, "libustrun.so"))      # (USTRUN_LIB: A/B runs of two builds on one box)
 
 F32, BF16, F16 = 0, 1, 2
 LOSS_SOFTMAX, LOSS_SIGMOID = 0, 1
