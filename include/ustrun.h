@@ -386,8 +386,8 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  * bits 10-11: force the halo kernel's tile in the 128-column case (1: 8 x 32 px, 2: 16 x 16, 3: 8 x 16; 0: chosen by padding).
  * bit 12 (4096): BatchNorm backward (plain, bf16) on the 4-channel-per-lane kernels instead of the 8-channel ones.
  * The last-variant code of the streaming kernel is 0x57530000 | (eight waves ? 0x100 : consumer / producer ? 0x200 : 0) | XF.
- * bit 15 (32768): the halo-tiled kernel's 256-pixel x 128-channel tiles on v_mfma_f32_16x16x32 for plain sources without
- *   statistics (the input gradients); ustrun_debug_last_conv_variant then carries bit 7 (0x80).
+ * The halo-tiled kernel runs plain sources (the input gradients) on its 256-pixel x 128-channel tiles on v_mfma_f32_16x16x32
+ *   (ustrun_debug_last_conv_variant then carries bit 7, 0x80); bit 15 (32768): on every tile; bit 21 (2097152): on none.
  * bit 14 (16384): first convolution (C <= 4 -> 64) on the tile-per-block kernel of rounds 1-3 instead of the streaming one.
  * bits 16-20: layer + 1 at which ustrun_unet_backward stops early (tests/diag_grad.py; 0: runs through).
  * bit 13 (8192): 64-output-channel 3x3 layers on >= 32-wide maps on the 16 x 32-pixel tile (one block per CU; A/B runs).

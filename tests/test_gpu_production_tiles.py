@@ -124,23 +124,23 @@ CASES = [
     # the concat conv of up4 forward, and the input gradient of a 64 -> 128 layer (a 128 -> 64 product on a plain source)
     ("t512_cat_128_to_64", 8, (64, 64), 64, 128, 128, 2, (16, 32, 64, 4, 1), (8, 32, 128, 4, 1), 8192),
     ("t512_dgrad_128_to_64", 8, (64,), 128, 72, 96, 1, (8, 16, 128, 2, 2), (16, 32, 64, 4, 1), 8192),
-    # ---- the v_mfma_f32_16x16x32 build of the 256-pixel x 128-channel tiles (plain sources without statistics = the input
-    # gradients; ustrun_debug_flags bit 15): wide rows, 16-pixel rows with ragged edges, the bottleneck, a 48 x 48 map
-    ("m16_tall_wide_128", 8, (128,), 128, 128, 128, 2, (8, 32, 128, 4, 1, "m16"), (8, 32, 128, 4, 1, "m16"), 32768),
-    ("m16_tall_narrow_512", 16, (512,), 512, 56, 24, 1, (16, 16, 128, 4, 1, "m16"), (16, 16, 128, 4, 1, "m16"), 32768),
-    ("m16_bottleneck_n64", 64, (1024,), 1024, 16, 16, 4, (16, 16, 128, 4, 1, "m16"), (16, 16, 128, 4, 1, "m16"), 32768),
-    ("m16_cat_128_to_64", 8, (64, 64), 64, 128, 128, 2, (8, 32, 64, 2, 2, "m16"), (8, 32, 128, 4, 1, "m16"), 32768),
-    ("m16_pad_48_512", 16, (512,), 512, 48, 48, 2, (16, 16, 128, 4, 1, "m16"), (16, 16, 128, 4, 1, "m16"), 32768),
+    # ---- the v_mfma_f32_16x16x32 build of the 256-pixel x 128-channel tiles (plain sources = the input gradients; also with
+    # ustrun_debug_flags bit 15): wide rows, 16-pixel rows with ragged edges, the bottleneck, a 48 x 48 map
+    ("m16_tall_wide_128", 8, (128,), 128, 128, 128, 2, (8, 32, 128, 4, 1), (8, 32, 128, 4, 1, "m16"), 32768),
+    ("m16_tall_narrow_512", 16, (512,), 512, 56, 24, 1, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1, "m16"), 32768),
+    ("m16_bottleneck_n64", 64, (1024,), 1024, 16, 16, 4, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1, "m16"), 32768),
+    ("m16_cat_128_to_64", 8, (64, 64), 64, 128, 128, 2, (8, 32, 64, 2, 2), (8, 32, 128, 4, 1, "m16"), 32768),
+    ("m16_pad_48_512", 16, (512,), 512, 48, 48, 2, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1, "m16"), 32768),
 ]
 # the default already runs the input gradients of the 256-pixel tiles on the 16x16x32 build: say so in the expectations above
 CASES = [c[:8] + ((c[8] + ("m16",)) if (isinstance(c[8], tuple) and c[8][3] == 4 and c[8][4] == 1 and len(c[8]) == 5) else c[8],) + c[9:]
          for c in CASES]
-# bit 15: EVERY register-fed variant on the 16x16x32 build -- the forward (BatchNorm + ReLU on load, statistics from the stored
-# pieces) and the 64-column / two-taps-per-stage / small-grid tiles too
+# bit 15: EVERY plain-source tile on the 16x16x32 build -- the input gradients of the 64-column / two-taps-per-stage / small-grid
+# tiles too (the forward reads through BatchNorm + ReLU: it stays on 32x32x16, the transforming variants are not built on 16x16x32)
 for _c in list(CASES):
     if _c[0] in ("tall_wide_128", "cat_128_to_64", "tall_narrow_512", "c64_wide", "c64_narrow", "mid_grid_512", "pad_18_1024", "pad_144_128"):
         tag = lambda v: v if not isinstance(v, tuple) or (len(v) > 5 and v[5] == "m16") else v[:5] + ("m16",)
-        CASES.append(("m16all_" + _c[0],) + _c[1:7] + (tag(_c[7]), tag(_c[8]), 32768))
+        CASES.append(("m16all_" + _c[0],) + _c[1:7] + (_c[7], tag(_c[8]), 32768))
 
 WS_CODE = {"ws4": 0x57530000, "ws8": 0x57530100, "ws": 0x57530200}      # four waves / eight waves / consumer + producer waves (default)
 

@@ -2,7 +2,7 @@
 the same command).  FETCH_SIZE and WRITE_SIZE count KB; on gfx950 FETCH_SIZE reports half of a wide coalesced read
 (MI355X_MICROARCH.md, HBM section), so HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE.
 
-    python tools/pmc_hbm.py FETCH_DIR WRITE_DIR OUT_CSV [OUT_JSON]
+    python tools/pmc_hbm.py FETCH_DIR WRITE_DIR OUT_CSV [OUT_JSON [STEPS]]
 
 OUT_JSON (optional) receives the per-launch bytes of the conv class that bench.py reports in roofline.traffic."""
 import collections, csv, glob, json, re, sys
@@ -28,6 +28,7 @@ def load(d, counter):
 
 def main():
     fdir, wdir, out = sys.argv[1:4]
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 2          # steps the profiled command ran in all (warm-up included)
     ft, fc, fd = load(fdir, "FETCH_SIZE")
     wt, wc, wd = load(wdir, "WRITE_SIZE")
     rows = []
@@ -55,6 +56,7 @@ def main():
                                "separate passes, bench.py --steps 1 --warmup 1 --no-profile (2 steps in all)",
                    "kernel_class": "conv (conv3x3_halo_bf16 + conv3x3_ws64 + convT_bf16 + igemm_bf16 + conv_first_fwd)",
                    "launches": n, "hbm_bytes_per_launch": by / max(n, 1),
+                   "steps": steps, "hbm_bytes_per_step": by / steps, "wgrad_hbm_bytes_per_step": bw / steps,
                    "wgrad_kernel_class": "weight gradients (wgrad_halo*_bf16 + wgradT_bf16 + wgrad_bf16)",
                    "wgrad_launches": nw, "wgrad_hbm_bytes_per_launch": bw / max(nw, 1),
                    "ws64": [{"kernel": r[1], "launches": r[2], "hbm_MB_per_launch": round(r[5], 2)} for r in ws]},

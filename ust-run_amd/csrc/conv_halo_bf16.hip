@@ -68,7 +68,7 @@ template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, in
 __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
     static_assert(BK == 32, "80-byte patch rows hold one 32-channel chunk");
-    static_assert(!M16 || BREG, "the 16x16x32 build takes its weights through registers");
+    static_assert(!M16 || (BREG && !XF), "the 16x16x32 build: plain sources, weights through registers");
     static_assert(!BREG || NT <= 2, "register-fed weights: 16 registers per tap and set");
     constexpr int HW2 = TW + 2 * DIL;
     constexpr int SR = 32 / TW;                 // tile rows per 32-pixel sub-tile (2 or 1)
@@ -150,11 +150,15 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
         dq1 = S.sW; dq2 = S.sH;
         const int by = y0 - DIL - S.off_y, bx = x0 - DIL - S.off_x;
         aokm = 0;
+        // (re)derived from the thread index on every call: hoisted out of the chunk loop, the per-item pixel coordinates are
+        // 3 x AIT registers held across it for a branch taken once per source -- the opaque copy keeps them out of the loop
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int i = 0; i < AIT; ++i) {
-            const int q = tid + 256 * i;
+            const int q = tq + 256 * i;
             const int hp = XF ? (q >> 2) : q / 5;
-            const int g = XF ? p8 : q - 5 * hp;
+            const int g = XF ? (tq & 3) : q - 5 * hp;
             const int hy = hp / HW2, hx = hp - hy * HW2;
             const int ly = by + hy, lx = bx + hx;
             const bool ok = hp < HP && g < 4 && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
@@ -455,6 +459,28 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
 #pragma unroll
                     for (int i = 0; i < MI; ++i) acar[i] = afrag(t0, 0, i);
                 }
+                if constexpr (M16) {
+                    // 16x16x32: a fragment feeds four MFMAs (the four column groups), so it is re-read IN PLACE for the next
+                    // half-stage right behind them -- 12 MFMAs before its next use -- instead of into a second register set:
+                    // MI fragments live, not 2 MI (the second set put this build 12 registers past the file: scratch reloads
+                    // with a full vmcnt drain at the top of every chunk)
+#pragma unroll
+                    for (int k = 0; k < nt; ++k)
+#pragma unroll
+                        for (int ks = 0; ks < BK / 16; ++ks) {
+                            constexpr int dummy = 0; (void)dummy;
+                            const int hn = (k * (BK / 16) + ks + 1);
+                            const bool in_stage = hn < nt * (BK / 16);
+#pragma unroll
+                            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+                                    acc16[i][ks][g] = USTRUN_MFMA_16x16x32(bcur[k][g >> 1][g & 1], acar[i], acc16[i][ks][g], 0, 0, 0);
+                                if (in_stage) acar[i] = afrag(t0 + hn / (BK / 16), hn % (BK / 16), i);
+                                else if (j < NSTG - 1) acar[i] = afrag(t0 + nt, 0, i);
+                            }
+                        }
+                } else
 #pragma unroll
                 for (int k = 0; k < nt; ++k)
 #pragma unroll
@@ -545,6 +571,17 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                 // the other MFMAs -- its fragments are 2 MI - 2 MFMAs old when a half-stage starts; the transform's VALU work in
                 // the MFMAs' shadow, its writes last
                 if constexpr ((j == 0 ? MI : 0) + nitem * NP > 0) __builtin_amdgcn_sched_group_barrier(0x100, (j == 0 ? MI : 0) + nitem * NP, 0);
+                if constexpr (M16) {
+#pragma unroll
+                    for (int h = 0; h < nt * (BK / 16); ++h) {
+                        const bool next_read = h + 1 < nt * (BK / 16) || j < NSTG - 1;
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                            if (next_read) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int h = 0; h < nt * (BK / 16); ++h) {
                     const bool next_read = h + 1 < nt * (BK / 16) || j < NSTG - 1;
@@ -785,12 +822,12 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
         {                                              // weights through registers, one barrier per chunk (debug flag bit 3: off)
             // the 16x16x32 build (round 4): measured ahead on the input gradients of every layer (profiles/r04_ab_halo_m16.log:
             // 512 -> 512 at 32 x 32 0.220 -> 0.202 ms, 1024 -> 1024 0.217 -> 0.201, 128 -> 128 -1.5 %): the default for plain
-            // sources on the 256-pixel tiles.  ustrun_debug_flags bit 15 (32768): every register-fed variant on it (A/B runs of
-            // the forward); bit 17 (131072): none.
+            // sources on the 256-pixel tiles.  ustrun_debug_flags bit 15 (32768): every plain-source tile on it (A/B runs of
+            // the smaller tiles); bit 21 (2097152): none.
             {
-                const bool m16 = !(g_debug_flags & 8) && !(g_debug_flags & 131072) && ((g_debug_flags & 32768) || (!xf && MI == 4 && NT == 1));
-                if (m16)
-                    return xf ? launch_xf<TH, TW, BN, BK, MI, POOL, NT, true, 1, true, true>(a, st) : launch_xf<TH, TW, BN, BK, MI, POOL, NT, false, 1, true, true>(a, st);
+                const bool m16 = !(g_debug_flags & 8) && !(g_debug_flags & 2097152) && ((g_debug_flags & 32768) || (!xf && MI == 4 && NT == 1));
+                if (m16 && !xf)      // (the transforming variants on it sit 160 registers past the file: not built)
+                    return launch_xf<TH, TW, BN, BK, MI, POOL, NT, false, 1, true, true>(a, st);
             }
             if (!(g_debug_flags & 8))
                 return xf ? launch_xf<TH, TW, BN, BK, MI, POOL, NT, true, 1, true>(a, st) : launch_xf<TH, TW, BN, BK, MI, POOL, NT, false, 1, true>(a, st);
