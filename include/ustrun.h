@@ -390,6 +390,8 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  *   (ustrun_debug_last_conv_variant then carries bit 7, 0x80); bit 15 (32768): on every tile; bit 21 (2097152): on none.
  * bit 14 (16384): first convolution (C <= 4 -> 64) on the tile-per-block kernel of rounds 1-3 instead of the streaming one.
  * bits 16-20: layer + 1 at which ustrun_unet_backward stops early (tests/diag_grad.py; 0: runs through).
+ * bit 22 (4194304): ustrun_unet_forward finalizes each layer's BatchNorm statistics in ONE launch (last-ticket pattern) instead of
+ *   two; bit-identical results, measured no faster (profiles/r04_ab_bn_fused_finalize.log), off by default.
  * bit 13 (8192): 64-output-channel 3x3 layers on >= 32-wide maps on the 16 x 32-pixel tile (one block per CU; A/B runs).
  * The value is PER CALLING THREAD (as are the last-variant codes and the stamp buffer below): a thread that sets it changes
  * kernel selection for the launches it issues itself and for nobody else, so the library keeps no process-wide mutable

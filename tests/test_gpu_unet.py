@@ -320,6 +320,35 @@ def test_forward_passes_equals_separate_calls(dtype, base, n, hw):
         assert e < tol, (k, e)
 
 
+@pytest.mark.parametrize("dtype,base,n,hw,passes", [("bf16", 32, 6, 104, 1), ("f16", 32, 4, 128, 3), ("f32", 32, 5, 72, 2)])
+def test_one_launch_statistics_finalize_is_bit_identical(dtype, base, n, hw, passes):
+    """With ustrun_debug_flags bit 22 ustrun_unet_forward finalizes each layer's BatchNorm statistics in ONE launch (stage-1 sums,
+    then the block that draws the channel block's last ticket forms mean / var / scale / shift and the running-buffer update):
+    logits and buffers are bit-identical to the default two-launch form, with row splits of uneven length (the 104^2 and 72^2
+    maps) and with batched passes, three times over on the same workspace (the tickets return to zero)."""
+    import copy
+    from networks.unet_model import UNet
+    from ustrun import _lib
+    lib = _lib.lib()
+    torch.manual_seed(11)
+    m1 = UNet(3, 2, base_channels=base, dtype=dtype).cuda().train()
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(9)
+    for it in range(3):
+        xs = [torch.randn(n, 3, hw, hw, generator=g).cuda() for _ in range(passes)]
+        with torch.no_grad():
+            a = m1.forward_passes(xs) if passes > 1 else m1(xs[0])
+            old = lib.ustrun_debug_flags(4194304)
+            try:
+                b = m2.forward_passes(xs) if passes > 1 else m2(xs[0])
+            finally:
+                lib.ustrun_debug_flags(old)
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), it
+        for (k, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+            assert torch.equal(b1, b2), (it, k)
+
+
 def test_backward_in_two_parts_equals_one_call():
     """Head + decoder, then encoder (the split the data-parallel step uses to start the decoder all-reduce early)
     gives bit-identical gradients to the single backward call, and the hook fires between the halves."""

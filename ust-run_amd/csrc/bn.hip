@@ -36,6 +36,115 @@ __global__ __launch_bounds__(256) void bn_stat_stage1_kernel(float* stat, int ro
     }
 }
 
+// Both stages in ONE launch (the U-Net forward: 52 x 2 launches of ~7.5 us per step were launch latency, not work): block
+// (cb, sp, g) does stage 1 for its row range, then takes a ticket for its channel block; the block that draws the last
+// ticket -- every stage-1 sum of that channel block is then parked and visible (agent-scope release by the writers before
+// the ticket, acquire by the reader after it) -- finalizes the channel block's passes one after the other with the very
+// summation order of bn_finalize_kernel<true> (eight row lanes per pass, lanes added in ascending order), so the constants
+// are bit-identical to the two-launch form.  tickets[cb] returns to 0 for the next launch on the same stream.
+__global__ __launch_bounds__(256) void bn_stat_fused_kernel(float* stat, int rows, int C, double count, int R,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* rm, float* rv, int64_t* nbt, float momentum, float eps,
+                                                            int update, float* scale, float* shift, float* mean, float* rstd,
+                                                            int passes, long astride, unsigned* tickets) {
+    constexpr int PPR = 4;                                 // passes finalized per round (their loads in flight together)
+    __shared__ double red[2][PPR][8][32];
+    __shared__ bool last;
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    {
+        float* st = stat + (long)blockIdx.z * rows * 2 * C;
+        const int r0 = blockIdx.y * R, r1 = min(rows, r0 + R);
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = r0 + rg; r < r1; r += 8) {
+            s1 += (double)st[((long)r * 2 + 0) * C + c];
+            s2 += (double)st[((long)r * 2 + 1) * C + c];
+        }
+        red[0][0][rg][cl] = s1; red[1][0][rg][cl] = s2;
+        __syncthreads();
+        if (rg < 2) {
+            double v = 0.0;
+            for (int k = 0; k < 8; ++k) v += red[rg][0][k][cl];
+            const float hi = (float)v, lo = (float)(v - (double)hi);
+            // write-through (sc1) stores, drained by every storing wave before the barrier in front of the ticket: no agent
+            // release -- that is a write-back of the XCD's L2 (MI355X_MICROARCH.md, fence table), which the convolution has
+            // just filled with dirty output lines: with it this kernel cost the step 0.6 ms MORE than the two launches
+            __hip_atomic_store(st + ((long)(r0 + rg) * 2 + 0) * C + c, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st + ((long)(r0 + rg) * 2 + 1) * C + c, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned total = gridDim.y * gridDim.z;
+        const unsigned t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == total - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // (the other blocks' parked sums: not from this CU's L1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          //  and every load of them below is an sc1 load as well)
+    __syncthreads();
+    double run_m = 0.0, run_v = 0.0;
+    if (update && rg == 0) { run_m = (double)rm[c]; run_v = (double)rv[c]; }
+    // a row lane holds the splits rg, rg + 8, .. (at most four: the launcher splits a table into <= 32 ranges) of up to PPR
+    // passes: every load of the round is issued before the first sum
+    for (int g0 = 0; g0 < passes; g0 += PPR) {
+        float v[PPR][4][4];
+#pragma unroll
+        for (int q = 0; q < PPR; ++q) {
+            const float* st = stat + (long)(g0 + q < passes ? g0 + q : 0) * rows * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sp = rg + 8 * k;
+                const bool ok = g0 + q < passes && sp * R < rows;
+                const long a0 = (long)(sp * R) * 2 * C + c, a1 = (long)(sp * R + 1) * 2 * C + c;
+                const long z = ok ? 0 : -1;               // (absent: the block's own first cell, value unused)
+                const float x0 = __hip_atomic_load(st + (a0 & ~z) , __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float x1 = __hip_atomic_load(st + ((a0 + C) & ~z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float x2 = __hip_atomic_load(st + (a1 & ~z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float x3 = __hip_atomic_load(st + ((a1 + C) & ~z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[q][k][0] = ok ? x0 : 0.f; v[q][k][1] = ok ? x1 : 0.f;
+                v[q][k][2] = ok ? x2 : 0.f; v[q][k][3] = ok ? x3 : 0.f;
+            }
+        }
+        __syncthreads();                                       // (red: the previous round's sums are consumed)
+#pragma unroll
+        for (int q = 0; q < PPR; ++q) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                      // (x + 0.0 leaves x: absent splits do not change the sums)
+                s1 += (double)v[q][k][0] + (double)v[q][k][1];
+                s2 += (double)v[q][k][2] + (double)v[q][k][3];
+            }
+            red[0][q][rg][cl] = s1; red[1][q][rg][cl] = s2;
+        }
+        __syncthreads();
+        if (rg == 0) {
+            for (int q = 0; q < PPR && g0 + q < passes; ++q) {
+                double t1 = 0.0, t2 = 0.0;
+                for (int k = 0; k < 8; ++k) { t1 += red[0][q][k][cl]; t2 += red[1][q][k][cl]; }
+                const double m = t1 / count;
+                double var = t2 / count - m * m;
+                if (var < 0.0) var = 0.0;
+                const double rs = 1.0 / sqrt(var + (double)eps);
+                const long o = (long)(g0 + q) * astride + c;
+                scale[o] = (float)((double)gamma[c] * rs);
+                shift[o] = (float)((double)beta[c] - m * (double)gamma[c] * rs);
+                mean[o] = (float)m; rstd[o] = (float)rs;
+                if (update) {
+                    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                    run_m = (double)(float)((1.0 - momentum) * run_m + momentum * m);
+                    run_v = (double)(float)((1.0 - momentum) * run_v + momentum * unb);
+                }
+            }
+        }
+    }
+    if (update && rg == 0) { rm[c] = (float)run_m; rv[c] = (float)run_v; }
+    if (update && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += passes;
+    if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // `passes` forward passes batched into one launch: pass g owns rows [g*rows, (g+1)*rows) of stat and the constants at
 // scale/shift/mean/rstd + g*astride; the running buffers receive the passes' updates one after the other, exactly as
 // `passes` separate calls would apply them.
@@ -636,7 +745,8 @@ using namespace ustrun;
 namespace ustrun {
 int bn_finalize_passes(float* stat, int mtiles, int passes, int C, int64_t count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
-                       int update_running, float* scale, float* shift, float* mean, float* rstd, long astride, hipStream_t s) {
+                       int update_running, float* scale, float* shift, float* mean, float* rstd, long astride, hipStream_t s,
+                       unsigned* tickets) {
     USTRUN_CHECK(stat && gamma && beta && scale && shift && mean && rstd, "bn_finalize: null pointer");
     USTRUN_CHECK(!update_running || (running_mean && running_var), "bn_finalize: running buffers missing");
     USTRUN_CHECK(mtiles > 0 && passes > 0 && C > 0 && count > 0, "bn_finalize: empty");
@@ -646,6 +756,14 @@ int bn_finalize_passes(float* stat, int mtiles, int passes, int C, int64_t count
     if (mtiles >= 96 && C % 32 == 0) {
         int R = cdiv(mtiles, 32);
         while (mtiles % R == 1) ++R;         // every split needs two rows to park its sums in
+        if (tickets && cdiv(mtiles, R) <= 32) {       // (zeroed by the caller once; C / 32 <= BN_TICKETS counters, back at zero when the launch retires)
+            USTRUN_CHECK(C / 32 <= BN_TICKETS, "bn_finalize: %d channels exceed the ticket table", C);
+            hipLaunchKernelGGL(bn_stat_fused_kernel, dim3(C / 32, cdiv(mtiles, R), passes), dim3(256), 0, s, (float*)stat, mtiles,
+                               C, (double)count, R, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                               update_running, scale, shift, mean, rstd, passes, astride, tickets);
+            USTRUN_LAUNCH_CHECK("bn_stat_fused");
+            return 0;
+        }
         hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(mtiles, R), passes), dim3(256), 0, s, (float*)stat, mtiles,
                            C, R);
         USTRUN_LAUNCH_CHECK("bn_stat_stage1");

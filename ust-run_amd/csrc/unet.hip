@@ -25,7 +25,7 @@ struct Plan {
     long y_off[18], aff_off[18]; // aff: scale, shift, mean, rstd (4*cout)
     long u_off[4];
     long pool_off[4];            // pooled activation feeding Down l+1 (input of conv 2l+2), kept for its weight gradient
-    long stat_off, fwd_total;
+    long stat_off, tick_off, fwd_total;
     long wf_off[18], wd_off[18], uf_off[4], ud_off[4], pack_total;
     long da_off[18], du_off[4], dp_off[4], coef_off, part_off, bwd_total, part_bytes;
     long y_elems(int i) const { return (long)N * Hs[lvl[i]] * Ws[lvl[i]] * cout[i]; }
@@ -81,6 +81,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
         p.pool_off[l] = o; o = align_up(o + (long)p.N * p.Hs[l + 1] * p.Ws[l + 1] * ch[l] * E, 256) + gap();
     }
     p.stat_off = o; o = align_up(o + stat_max * 4, 256);
+    p.tick_off = o; o += 256;              // BN_TICKETS counters of the one-launch statistics finalize (zeroed per forward)
     p.fwd_total = o;
 
     o = 0;
@@ -232,6 +233,15 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
         USTRUN_TRY(bn_eval_affine_layers(18, p.cout, d->bn_w, d->bn_b, (const float* const*)d->bn_rm, (const float* const*)d->bn_rv, affs,
                                          d->eps, p.G, (hipStream_t)s));
     }
+    unsigned* tickets = (unsigned*)(ws + p.tick_off);
+    static_assert(BN_TICKETS * sizeof(unsigned) <= 256, "ticket area");
+    // (one-launch statistics finalize, ustrun_debug_flags bit 22: bit-identical, and measured a wash -- 29.80 vs 29.65 ms per step
+    // on one box, profiles/r04_ab_bn_fused_finalize.log: back-to-back small launches overlap their launch latency, the fused
+    // kernel serialises a last-block tail behind its tickets -- so the two launches stay the default)
+    if (d->train && (g_debug_flags & 4194304)) {
+        const hipError_t e = hipMemsetAsync(tickets, 0, BN_TICKETS * sizeof(unsigned), (hipStream_t)s);
+        USTRUN_CHECK(e == hipSuccess, "unet_forward: ticket reset: %s", hipGetErrorString(e));
+    }
     for (int i = 0; i < 18; ++i) {
         if (i >= 10 && i % 2 == 0) {   // Up: ConvTranspose of the previous level's output first
             const int j = (i - 10) / 2, l = 3 - j;
@@ -253,6 +263,20 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
         const int H = p.Hs[p.lvl[i]], W = p.Ws[p.lvl[i]];
         int stat_rows = 0;
         prof_set_tag(i, p.N);
+        if (i == 0 && d->train && p.G > 1 && !conv_first_supported(srcs[0], p.cout[0])) {
+            // the network input carries no pass structure, and the generic kernels' statistics rows are 128-pixel runs of the
+            // whole batch (the first-convolution kernels' rows never cross an image): one launch per pass keeps every row
+            // inside its pass (base widths other than 64 only)
+            for (int g = 0; g < p.G; ++g) {
+                ustrun_src_t sg = srcs[0];
+                sg.ptr = (const float*)srcs[0].ptr + (long)g * p.gN * srcs[0].sN;
+                int rows = 0;
+                USTRUN_TRY(ustrun_conv3x3_fwd_rows(&sg, 1, pk + p.wf_off[0], p.gN, H, W, p.cout[0],
+                                                   ws + p.y_off[0] + (long)g * p.gN * H * W * p.cout[0] * p.esz,
+                                                   stat + (long)stat_rows * 2 * p.cout[0], &rows, d->dtype, s));
+                stat_rows += rows;
+            }
+        } else
         USTRUN_TRY(ustrun_conv3x3_fwd_rows(srcs, ns, pk + p.wf_off[i], p.N, H, W, p.cout[i], ws + p.y_off[i],
                                            d->train ? stat : nullptr, &stat_rows, d->dtype, s));
         float* aff = affp(i);
@@ -262,7 +286,7 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
             const int rpg = stat_rows / p.G;
             USTRUN_TRY(bn_finalize_passes(stat, rpg, p.G, C, (int64_t)p.gN * H * W, d->bn_w[i], d->bn_b[i], d->bn_rm[i],
                                           d->bn_rv[i], d->bn_nbt[i], d->momentum, d->eps, d->update_running, aff, aff + C,
-                                          aff + 2 * C, aff + 3 * C, 4L * C, (hipStream_t)s));
+                                          aff + 2 * C, aff + 3 * C, 4L * C, (hipStream_t)s, (g_debug_flags & 4194304) ? tickets : nullptr));
         }
     }
     prof_set_tag(-1, 0);
