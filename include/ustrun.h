@@ -392,6 +392,8 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  * bits 16-20: layer + 1 at which ustrun_unet_backward stops early (tests/diag_grad.py; 0: runs through).
  * bit 22 (4194304): ustrun_unet_forward finalizes each layer's BatchNorm statistics in ONE launch (last-ticket pattern) instead of
  *   two; bit-identical results, measured no faster (profiles/r04_ab_bn_fused_finalize.log), off by default.
+ * bit 23 (8388608): ustrun_unet_backward runs the BatchNorm-backward reduce pass of the layer under the head (rounds 1-3)
+ *   instead of taking its two sums from the head kernel's partial rows.
  * bit 13 (8192): 64-output-channel 3x3 layers on >= 32-wide maps on the 16 x 32-pixel tile (one block per CU; A/B runs).
  * The value is PER CALLING THREAD (as are the last-variant codes and the stamp buffer below): a thread that sets it changes
  * kernel selection for the launches it issues itself and for nobody else, so the library keeps no process-wide mutable

@@ -349,6 +349,40 @@ def test_one_launch_statistics_finalize_is_bit_identical(dtype, base, n, hw, pas
             assert torch.equal(b1, b2), (it, k)
 
 
+@pytest.mark.parametrize("dtype,base,n,hw,passes", [("bf16", 64, 3, 64, 1), ("f16", 64, 2, 48, 4), ("f32", 16, 2, 40, 2)])
+def test_head_kernel_bn_sums_equal_the_reduce_pass(dtype, base, n, hw, passes):
+    """The BatchNorm backward of the layer under the head takes sum(da mask) and sum(da mask y) from the head kernel's partial
+    rows (the kernel holds y and da in registers anyway) instead of from a reduce pass over both tensors
+    (ustrun_debug_flags bit 23 = the pass of rounds 1-3): same values summed in another order -- every parameter gradient
+    within 2e-5 of the other form's norm (f32 accumulation order only), logits identical."""
+    import copy
+    from networks.unet_model import UNet
+    from ustrun import _lib
+    lib = _lib.lib()
+    torch.manual_seed(13)
+    m1 = UNet(3, 2, base_channels=base, dtype=dtype).cuda().train()
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.randn(n, 3, hw, hw, generator=g).cuda() for _ in range(passes)]
+    dl = torch.randn(n * passes, 2, hw, hw, generator=g).cuda()
+    a = m1.forward_passes(xs) if passes > 1 else m1(xs[0])
+    a.backward(dl)
+    old = lib.ustrun_debug_flags(8388608)
+    try:
+        b = m2.forward_passes(xs) if passes > 1 else m2(xs[0])
+        b.backward(dl)
+    finally:
+        lib.ustrun_debug_flags(old)
+    assert torch.equal(a.detach(), b.detach())
+    worst = 0.0
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.isfinite(p1.grad).all(), k
+        e = float((p1.grad - p2.grad).norm() / (p2.grad.norm() + 1e-30))
+        worst = max(worst, e)
+        assert e < 2e-5, (k, e)
+    print("head-kernel BN sums vs reduce pass: worst relative gradient difference %.2e" % worst)
+
+
 def test_backward_in_two_parts_equals_one_call():
     """Head + decoder, then encoder (the split the data-parallel step uses to start the decoder all-reduce early)
     gives bit-identical gradients to the single backward call, and the hook fires between the halves."""

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int rows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, float* dgamma, float* dbeta, int accumulate,
-                                       float* coef, int passes, const PassOff po) {
+                                       float* coef, int passes, const PassOff po, long rstride, long roff) {
     __shared__ double red[2][32][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 channels x 32 row lanes
     const int c = blockIdx.x * 32 + cl;
@@ -540,11 +540,11 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int r
         const int g = g0 + gl;
         double s1 = 0.0, s2 = 0.0;
         if (c < C && g < passes) {
-            const float* pt = partials + (long)g * po.part;
+            const float* pt = partials + (long)g * po.part + roff;
 #pragma unroll 8
             for (int r = lane; r < rows; r += LPP) {
-                s1 += (double)pt[((long)r * 2 + 0) * C + c];
-                s2 += (double)pt[((long)r * 2 + 1) * C + c];
+                s1 += (double)pt[(long)r * rstride + c];
+                s2 += (double)pt[(long)r * rstride + C + c];
             }
         }
         red[0][rg][cl] = s1; red[1][rg][cl] = s2;
@@ -904,7 +904,7 @@ int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const fl
                            nwin, C, G, partials, po);
         USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, blocks, C, (double)N * H * W, gamma,
-                           mean, rstd, dgamma, dbeta, accumulate, coef, passes, po);
+                           mean, rstd, dgamma, dbeta, accumulate, coef, passes, po, 2L * C, 0L);
         USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
         return 0;
     }
@@ -917,7 +917,18 @@ int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const fl
 #undef USTRUN_BN_REDUCE
     USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, blocks, C, (double)N * H * W, gamma,
-                       mean, rstd, dgamma, dbeta, accumulate, coef, passes, po);
+                       mean, rstd, dgamma, dbeta, accumulate, coef, passes, po, 2L * C, 0L);
+    USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
+    return 0;
+}
+
+int bn_bwd_finalize_rows(const float* partials, int rows, long rstride, long roff, int C, int64_t count, const float* gamma,
+                         const float* mean, const float* rstd, float* dgamma, float* dbeta, int accumulate, float* coef,
+                         int passes, long aff_stride, hipStream_t s) {
+    USTRUN_CHECK(partials && rows > 0 && C > 0 && gamma && mean && rstd && coef && passes >= 1, "bn_bwd_finalize_rows: bad args");
+    const PassOff po = {0, 0, aff_stride, (long)rows * rstride, 3L * C};
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, rows, C, (double)count, gamma, mean,
+                       rstd, dgamma, dbeta, accumulate, coef, passes, po, rstride, roff);
     USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
     return 0;
 }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 }
 
 // bf16 feature map, C = 8*G channels with G a power of two: G lanes share a pixel, 16 bytes (8 channels) each, the
-// lane's scale/shift/weights live in registers for the whole launch, four pixels in flight per lane; after the
+// lane's scale/shift/weights live in registers for the whole launch, eight pixels in flight per lane; after the
 // butterfly every lane of the group holds the logits and lane k stores class k.
 template <int K>
 __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const elt_t* __restrict__ y, const float* __restrict__ scale,
@@ -64,22 +64,32 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const elt_t* __restr
     typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
     const int g = threadIdx.x % G, pl = threadIdx.x / G, PPB = 256 / G;
     float sc[8], sh[8], wk[K][8];
+    {   // the lane's constants as 16-byte loads, all issued together (they were 8 x (2 + K) dependent 4-byte loads: a few
+        // microseconds in front of a block that streams for ten)
+        f32x4 t[2 + K][2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        sc[j] = scale ? scale[8 * g + j] : 1.f;
-        sh[j] = scale ? shift[8 * g + j] : 0.f;
+        for (int h = 0; h < 2; ++h) {
+            t[0][h] = scale ? *(const f32x4*)(scale + 8 * g + 4 * h) : (f32x4){1.f, 1.f, 1.f, 1.f};
+            t[1][h] = scale ? *(const f32x4*)(shift + 8 * g + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < K; ++k) wk[k][j] = w[k * C + 8 * g + j];
+            for (int k = 0; k < K; ++k) t[2 + k][h] = *(const f32x4*)(w + k * C + 8 * g + 4 * h);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = t[0][j >> 2][j & 3]; sh[j] = t[1][j >> 2][j & 3];
+#pragma unroll
+            for (int k = 0; k < K; ++k) wk[k][j] = t[2 + k][j >> 2][j & 3];
+        }
     }
     const bool relu = scale != nullptr;
     const float bk = g < K ? bias[g] : 0.f;
-    constexpr int U = 4;
+    constexpr int U = 8;                                    // eight 16-byte loads in flight per lane
     for (long p0 = (long)blockIdx.x * PPB * U; p0 < npix; p0 += (long)gridDim.x * PPB * U) {
         bf16x8 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long p = p0 + u * PPB + pl;
-            v[u] = *(const bf16x8*)(y + (p < npix ? p : npix - 1) * C + 8 * g);   // unconditional: four loads in flight
+            v[u] = *(const bf16x8*)(y + (p < npix ? p : npix - 1) * C + 8 * g);   // unconditional: all U loads in flight
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       long npix, int HW, int C, int Krt, int LPP,
                                                       const float* __restrict__ w, float* __restrict__ da,
-                                                      float* __restrict__ partials, long pass_aff) {
+                                                      float* __restrict__ partials, long pass_aff, int bnr) {
     constexpr int KN = KT > 0 ? KT : KMAX;           // accumulators kept
     const int K = KT > 0 ? KT : Krt;
     // blockIdx.y = forward pass of a batched call: its own slice of dl / y / da (npix pixels each), its own BatchNorm
@@ -129,18 +139,22 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         y = (const float*)((const char*)y + g * npix * C * ESZ);
         da = (float*)((char*)da + g * npix * C * ESZ);
         if (scale) { scale += g * pass_aff; shift += g * pass_aff; }
-        partials += g * (long)gridDim.x * (K * C + K);
+        partials += g * (long)gridDim.x * (K * C + K + (bnr ? 2 * C : 0));
     }
     extern __shared__ float red[];   // [PPB][K*C + K] would be large; reduce per k instead (below)
     const int C4 = C / 4, PPB = 256 / LPP;
     const int cq0 = threadIdx.x % LPP, pl = threadIdx.x / LPP;
-    const int row = K * C + K;
+    // bnr: the BatchNorm backward of the layer under the head needs sum(da * mask) and sum(da * mask * y) per channel over
+    // exactly the tensors this kernel already holds in registers (y on load, da before its store): formed here, as two more
+    // 'classes' of the row, instead of by a bn_bwd_reduce pass that reads both tensors again (1.07 GB per step at N = 64)
+    const int row = K * C + K + (bnr ? 2 * C : 0);
     float* out = partials + (long)blockIdx.x * row;
     for (int cb = 0; cb < C4; cb += LPP) {          // uniform trip count (barriers inside)
         const int cq = cb + cq0;
         const bool active = cq < C4;
         const int c = active ? cq * 4 : 0;
         f32x4 dwp[KN]; float dbp[KN];
+        f32x4 bs1 = {0.f, 0.f, 0.f, 0.f}, bs2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < KN; ++k) { dwp[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; dbp[k] = 0.f; }
         f32x4 wk[KN];
@@ -152,6 +166,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             for (long p = (long)blockIdx.x * PPB + pl; p < npix; p += (long)gridDim.x * PPB) {
                 const long n = (unsigned)p / (unsigned)HW, hw = p - n * HW;   // 32-bit divide: p < 2^32 (checked on the host)
                 f32x4 a = ld4t<ESZ>(y, p * C + c);
+                const f32x4 yraw = a;
                 float d[KN];
 #pragma unroll
                 for (int k = 0; k < KN; ++k) d[k] = (KT > 0 || k < K) ? dl[(n * K + k) * HW + hw] : 0.f;
@@ -168,6 +183,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                         dbp[k] += d[k];
                     }
                 st4t<ESZ>(da, p * C + c, g);
+                if (bnr) {                                   // on the values as stored (what a reduce pass would read back)
+                    if (ESZ == 2) { g[0] = (float)(elt_t)g[0]; g[1] = (float)(elt_t)g[1]; g[2] = (float)(elt_t)g[2]; g[3] = (float)(elt_t)g[3]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dz = a[q] > 0.f ? g[q] : 0.f;
+                        bs1[q] += dz; bs2[q] += dz * yraw[q];
+                    }
+                }
             }
         // fixed-order block reduction over the PPB pixel lanes, one class at a time
         for (int k = 0; k < K; ++k) {
@@ -187,6 +210,17 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             }
             __syncthreads();
         }
+        if (bnr)
+            for (int h = 0; h < 2; ++h) {
+                f32x4 v = h ? bs2 : bs1;
+                ((f32x4*)red)[threadIdx.x] = v;
+                __syncthreads();
+                if (pl == 0 && active) {
+                    for (int q = 1; q < PPB; ++q) v += ((f32x4*)red)[q * LPP + cq0];
+                    *(f32x4*)(out + K * C + K + h * C + c) = v;
+                }
+                __syncthreads();
+            }
     }
 }
 
@@ -246,9 +280,10 @@ extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* s
     USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_fwd: C=%d K=%d unsupported", C, K);
     USTRUN_CHECK(npix > 0 && HW > 0 && npix % HW == 0 && npix < (1LL << 32), "head_fwd: bad extent");
     const int G = C / 8;
-    if (dtype == USTRUN_D16 && C % 8 == 0 && G <= 64 && (G & (G - 1)) == 0 && K >= 1 && K <= 4 && K <= G) {
-        long nb = (npix + (256 / G) * 8 - 1) / ((256 / G) * 8);      // two rounds of four pixels per lane
-        if (nb > 8192) nb = 8192;
+    const bool al16 = !(((uintptr_t)w | (uintptr_t)scale | (uintptr_t)shift) & 15);      // the constants go in as 16-byte loads
+    if (dtype == USTRUN_D16 && C % 8 == 0 && G <= 64 && (G & (G - 1)) == 0 && K >= 1 && K <= 4 && K <= G && al16) {
+        long nb = (npix + (256 / G) * 32 - 1) / ((256 / G) * 32);    // >= four rounds of eight pixels per lane (the constants'
+        if (nb > 2048) nb = 2048;                                    // loads and the launch are then a small part of a block)
         dim3 grid((int)nb), block(256);
 #define USTRUN_HF(KK) hipLaunchKernelGGL(head_fwd_bf16_kernel<KK>, grid, block, 0, (hipStream_t)s, (const elt_t*)y, scale, shift, \
                                          (long)npix, HW, C, G, w, bias, logits)
@@ -275,19 +310,23 @@ namespace ustrun {
 // passes' partial rows are summed together in one fixed order
 int head_bwd_passes(const float* dlogits, const void* y, const float* scale, const float* shift, int64_t npix, int HW, int C,
                     int K, const float* w, void* da, float* dw, float* db, int accumulate, float* partials,
-                    int64_t partials_bytes, int dtype, int passes, long pass_aff, hipStream_t s) {
+                    int64_t partials_bytes, int dtype, int passes, long pass_aff, hipStream_t s, int* bn_rows) {
     USTRUN_CHECK(dtype_ok(dtype), "head_bwd: dtype %d not built", dtype);
     USTRUN_CHECK(dlogits && y && w && da && dw && db && partials, "head_bwd: null pointer");
     USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_bwd: C=%d K=%d unsupported", C, K);
     USTRUN_CHECK(npix > 0 && HW > 0 && npix < (1LL << 32) && passes >= 1, "head_bwd: bad extent");
     const int LPP = lanes_per_pixel(C / 4);
     const int blocks = head_blocks(npix, LPP);
-    const long row = (long)K * C + K;
+    // bn_rows: also form the BatchNorm-backward sums of the layer under the head (scale/shift = its constants): row =
+    // [K*C dW | K db | C sum(da mask) | C sum(da mask y)], *bn_rows = rows per pass; K*C + K must keep the sums 16-byte aligned
+    const int bnr = bn_rows && scale && (K * C + K) % 4 == 0;
+    if (bn_rows) *bn_rows = bnr ? blocks : 0;
+    const long row = (long)K * C + K + (bnr ? 2 * C : 0);
     USTRUN_CHECK(partials_bytes >= (int64_t)((long)(passes > 1 ? passes * blocks : 1024) * row * 4),
                  "head_bwd: partials too small (%lld bytes for %d passes)", (long long)partials_bytes, passes);
 #define USTRUN_HB(E, KT)                                                                                                     \
     hipLaunchKernelGGL((head_bwd_kernel<E, KT>), dim3(blocks, passes), dim3(256), (1024 + 256) * sizeof(float), s, dlogits,    \
-                       (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials, pass_aff)
+                       (const float*)y, scale, shift, (long)npix, HW, C, K, LPP, w, (float*)da, partials, pass_aff, bnr)
     if (dtype == USTRUN_D16) { if (K == 2) USTRUN_HB(2, 2); else if (K == 4) USTRUN_HB(2, 4); else USTRUN_HB(2, 0); }
     else { if (K == 2) USTRUN_HB(4, 2); else if (K == 4) USTRUN_HB(4, 4); else USTRUN_HB(4, 0); }
 #undef USTRUN_HB
@@ -302,5 +341,5 @@ extern "C" int ustrun_head_bwd(const float* dlogits, const void* y, const float*
                                int64_t npix, int HW, int C, int K, const float* w, void* da, float* dw, float* db,
                                int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s) {
     return head_bwd_passes(dlogits, y, scale, shift, npix, HW, C, K, w, da, dw, db, accumulate, partials, partials_bytes, dtype, 1,
-                           0, (hipStream_t)s);
+                           0, (hipStream_t)s, nullptr);
 }

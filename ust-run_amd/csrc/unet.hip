@@ -326,12 +326,13 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
     auto affp = [&](int k) { return (const float*)(ws + p.aff_off[k]); };
     const int dt = d->dtype;
 
+    int head_bn_rows = 0;       // > 0: the head kernel also formed layer 17's BatchNorm-backward sums (rows per pass, in `part`)
     if (which <= 1) {   // head: all passes in one launch (blockIdx.y = pass: its BatchNorm constants on load)
         const int C = p.cout[17];
         const long gpix = (long)p.gN * p.H * p.W;
         USTRUN_TRY(head_bwd_passes(dlogits, ws + p.y_off[17], affp(17), affp(17) + C, gpix, p.H * p.W, C, p.K, d->head_w,
                                    sc + p.da_off[17], grads[62], grads[63], accumulate, part, p.part_bytes, dt, p.G, 4L * C,
-                                   (hipStream_t)s));
+                                   (hipStream_t)s, (g_debug_flags & 8388608) ? nullptr : &head_bn_rows));
     }
     // layers 17..10 = decoder, 9..8 = down4 (57 of the encoder's 75 MB of gradients, and the first to finish), 7..0 = the rest
     const int i_hi = which <= 1 ? 17 : (which == 4 ? 7 : 9);
@@ -348,6 +349,12 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
         void* da = sc + p.da_off[i];
         {   // BatchNorm backward is a per-pass reduction: all passes in one launch per kernel (blockIdx.y = pass)
             const long act = (long)p.gN * H * W * C, pl = (long)p.gN * (H / 2) * (W / 2) * C;
+            if (i == 17 && head_bn_rows > 0) {      // the sums came with the head's partial rows: no reduce pass over da and y
+                const long row = (long)p.K * C + p.K + 2L * C;
+                USTRUN_TRY(bn_bwd_finalize_rows(part, head_bn_rows, row, (long)p.K * C + p.K, C, (int64_t)p.gN * H * W, d->bn_w[i],
+                                                aff + 2 * C, aff + 3 * C, grads[gi + 1], grads[gi + 2], accumulate, coef, p.G,
+                                                4L * C, (hipStream_t)s));
+            } else
             USTRUN_TRY(bn_bwd_reduce_passes(da, dp, ws + p.y_off[i], aff, aff + C, aff + 2 * C, aff + 3 * C, d->bn_w[i], p.gN, H, W,
                                             C, grads[gi + 1], grads[gi + 2], accumulate, coef, part, p.part_bytes, dt, p.G, act,
                                             pl, 4L * C, (hipStream_t)s));
