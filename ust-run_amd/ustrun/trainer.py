@@ -15,6 +15,8 @@ import math
 import random
 import time
 
+import os
+
 import numpy as np
 import torch
 
@@ -220,6 +222,11 @@ class SSLTrainer:
         self.last = {}
         self.timeline = None                             # list of (label, perf_counter) when host timing is on
         self._side, self._side_busy = None, False        # side stream of the batch-1 low-quality-sample forward
+        # where the step issues it: "split" = between the decoder and encoder halves of the backward (it then runs under the
+        # encoder's many-block kernels: 29.34-29.42 ms per step against 29.51-29.53 for "start" = right after the student
+        # passes, under the head / up4 weight gradients whose one-block-per-CU grids wait for the CUs it takes; its whole cost is
+        # ~0.5 ms per step wherever it goes -- same-box runs of tools/_ab_env.sh, profiles/r04_ab_side_forward.log)
+        self._side_at = os.environ.get("USTRUN_SIDE_AT", "split")
 
     # ---------------------------------------------------------------------------------------
     def _mark(self, label):
@@ -371,19 +378,29 @@ class SSLTrainer:
         if epoch_num == 0:
             hardness[:] = 1
         lq_idx = int(np.argmax(hardness))
+        side_later = None
         if region_host is not None:
             ib_lq = F.rect_masks([all_cover_rect(region_host.numpy())], self.patch, self.patch, dev)
             # result unused (Q2); student BN running stats still move.  A batch-1 forward fills 16-256 workgroups per
             # launch, so it runs on a side stream underneath the losses and the backward that follow (ordered after
             # the student passes issued so far; joined before the optimizer update touches the parameters).
-            side = self._side_stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
             lb_pick = lb_x_w[new_choice:new_choice + 1]
-            for t_ in (self.lq_u, lb_pick, ib_lq):
-                t_.record_stream(side)
-            with torch.cuda.stream(side), torch.no_grad():
-                model(F.box_mix(self.lq_u, lb_pick, ib_lq))
-            self._side_busy = True
+            lq_prev = self.lq_u
+
+            def issue_side():
+                side = self._side_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                for t_ in (lq_prev, lb_pick, ib_lq):
+                    t_.record_stream(side)
+                with torch.cuda.stream(side), torch.no_grad():
+                    model(F.box_mix(lq_prev, lb_pick, ib_lq))
+                self._side_busy = True
+            if self._side_at in ("split", "mid") and lg_all is not None:
+                side_later = issue_side
+            elif self._side_at == "off_for_measurement_only":      # (its whole cost: never in a run whose statistics matter)
+                pass
+            else:
+                issue_side()
         self.lq_u = ulb_x_w[lq_idx:lq_idx + 1].clone()
         self.lq_pl = pl[lq_idx:lq_idx + 1].clone()
         self.lq_mask = mask[lq_idx:lq_idx + 1].clone()
@@ -434,10 +451,23 @@ class SSLTrainer:
                 dls.append(dl)
         overlap = self.grad_allreduce is not None and hasattr(self.grad_allreduce, "start_tail")
         if lg_all is not None:                    # one backward over the four passes
-            if overlap:                            # decoder gradients go out while the encoder half still runs
-                model._ustrun_backward_split_hook = lambda: self.grad_allreduce.start_tail(self.flat_g, self.dec_off)
-                if hasattr(self.grad_allreduce, "start_mid") and 0 < self.mid_off < self.dec_off:
-                    model._ustrun_backward_mid_hook = lambda: self.grad_allreduce.start_mid(self.flat_g, self.mid_off)
+            if overlap or side_later is not None:  # decoder gradients go out while the encoder half still runs
+                side_mid = side_later is not None and self._side_at == "mid"
+
+                def at_split():
+                    if overlap:
+                        self.grad_allreduce.start_tail(self.flat_g, self.dec_off)
+                    if side_later is not None and not side_mid:
+                        side_later()
+                model._ustrun_backward_split_hook = at_split
+                ar_mid = overlap and hasattr(self.grad_allreduce, "start_mid") and 0 < self.mid_off < self.dec_off
+                if ar_mid or side_mid:
+                    def at_mid():
+                        if ar_mid:
+                            self.grad_allreduce.start_mid(self.flat_g, self.mid_off)
+                        if side_mid:
+                            side_later()
+                    model._ustrun_backward_mid_hook = at_mid
             try:
                 lg_all.backward(torch.cat(dls, 0))
             finally:
