@@ -540,11 +540,18 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int r
         const int g = g0 + gl;
         double s1 = 0.0, s2 = 0.0;
         if (c < C && g < passes) {
-            const float* pt = partials + (long)g * po.part + roff;
-#pragma unroll 8
-            for (int r = lane; r < rows; r += LPP) {
-                s1 += (double)pt[(long)r * rstride + c];
-                s2 += (double)pt[(long)r * rstride + C + c];
+            const float* pt = partials + (long)g * po.part + roff + c;
+            int r = lane;
+            for (; r + 7 * LPP < rows; r += 8 * LPP) {       // eight rows' loads issued before the first sum (written out: left
+                float a[8], b[8];                            // to the unroller, each load was waited for on its own)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const float* q = pt + (long)(r + u * LPP) * rstride; a[u] = q[0]; b[u] = q[C]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
+            }
+            for (; r < rows; r += LPP) {
+                s1 += (double)pt[(long)r * rstride];
+                s2 += (double)pt[(long)r * rstride + C];
             }
         }
         red[0][rg][cl] = s1; red[1][rg][cl] = s2;

@@ -316,7 +316,10 @@ int head_bwd_passes(const float* dlogits, const void* y, const float* scale, con
     USTRUN_CHECK(C % 4 == 0 && C > 0 && K >= 1 && K <= KMAX, "head_bwd: C=%d K=%d unsupported", C, K);
     USTRUN_CHECK(npix > 0 && HW > 0 && npix < (1LL << 32) && passes >= 1, "head_bwd: bad extent");
     const int LPP = lanes_per_pixel(C / 4);
-    const int blocks = head_blocks(npix, LPP);
+    int blocks = head_blocks(npix, LPP);
+    // batched passes: 1024 partial rows in all (four blocks per CU), as the BatchNorm-backward reduce does -- the finalize that
+    // follows walks a pass's rows on eight lanes
+    if (passes > 1 && blocks > 1024 / passes) blocks = 1024 / passes > 64 ? 1024 / passes : 64;
     // bn_rows: also form the BatchNorm-backward sums of the layer under the head (scale/shift = its constants): row =
     // [K*C dW | K db | C sum(da mask) | C sum(da mask y)], *bn_rows = rows per pass; K*C + K must keep the sums 16-byte aligned
     const int bnr = bn_rows && scale && (K * C + K) % 4 == 0;
