@@ -169,7 +169,24 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int
         if (c < C && g < passes) {
             const float* st = stat + (long)g * rows * 2 * C;
             if (PRE) {       // stage-1 doubles parked at rows sp*R / sp*R+1, columns of this channel block
-                for (int sp = lane; sp * R < rows; sp += LPP) {
+                // at most 32 splits (the launcher's R), i.e. four per lane: all sixteen loads issued before the first sum (one
+                // split per trip was four dependent memory round trips in a 7 us kernel); x + 0.0 leaves x, so the absent
+                // splits' zeros do not change the sums
+                float v[4][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int sp = lane + LPP * k;
+                    const bool ok = sp * R < rows;
+                    const long a0 = ok ? (long)(sp * R) * 2 * C + c : c, a1 = ok ? (long)(sp * R + 1) * 2 * C + c : c;
+                    const float x0 = st[a0], x1 = st[a0 + C], x2 = st[a1], x3 = st[a1 + C];
+                    v[k][0] = ok ? x0 : 0.f; v[k][1] = ok ? x1 : 0.f; v[k][2] = ok ? x2 : 0.f; v[k][3] = ok ? x3 : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s1 += (double)v[k][0] + (double)v[k][1];
+                    s2 += (double)v[k][2] + (double)v[k][3];
+                }
+                for (int sp = lane + 4 * LPP; sp * R < rows; sp += LPP) {       // (a table split finer than the launcher does)
                     const long a0 = (long)(sp * R) * 2 * C + c, a1 = (long)(sp * R + 1) * 2 * C + c;
                     s1 += (double)st[a0] + (double)st[a0 + C];
                     s2 += (double)st[a1] + (double)st[a1 + C];
