@@ -20,11 +20,20 @@ __global__ __launch_bounds__(256) void bn_stat_stage1_kernel(float* stat, int ro
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl, r0 = blockIdx.y * R, r1 = min(rows, r0 + R);
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int r = r0 + rg; r < r1; r += 8) {
+    if (c < C) {
+        int r = r0 + rg;
+        for (; r + 24 < r1; r += 32) {               // four rows' loads issued before the first add, sums in ascending row order
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = stat[((long)(r + 8 * u) * 2 + 0) * C + c]; b[u] = stat[((long)(r + 8 * u) * 2 + 1) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
+        }
+        for (; r < r1; r += 8) {
             s1 += (double)stat[((long)r * 2 + 0) * C + c];
             s2 += (double)stat[((long)r * 2 + 1) * C + c];
         }
+    }
     red[0][rg][cl] = s1; red[1][rg][cl] = s2;
     __syncthreads();
     if (rg < 2 && c < C) {                   // rg 0 -> sum into row r0, rg 1 -> sum of squares into row r0+1

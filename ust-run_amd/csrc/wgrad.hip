@@ -177,6 +177,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a, co
     }
 }
 
+// v + slab[k0][i] + .. + slab[k1-1][i], added in that order, eight slabs' loads issued before the first add (one slab per trip
+// left every 16-byte load waited for on its own: these kernels are 7-11 us of memory round trips, 33 launches per step)
+__device__ inline f32x4 sum_slabs(f32x4 v, const float* part, int k0, int k1, long sstride, long i) {
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = ((const f32x4*)(part + (long)(k + u) * sstride))[i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    if (k + 4 <= k1) {
+        f32x4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = ((const f32x4*)(part + (long)(k + u) * sstride))[i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v += t[u];
+        k += 4;
+    }
+    for (; k < k1; ++k) v += ((const f32x4*)(part + (long)k * sstride))[i];
+    return v;
+}
+
 // In-place pre-reduction of long slab lists: group g (blockIdx.y) sums slabs [g*GRP, g*GRP+GRP) into
 // slab g*GRP.  Every thread reads and writes only its own elements, so no ordering is needed.
 constexpr int GRP = 16;
@@ -186,7 +209,7 @@ __global__ __launch_bounds__(256) void reduce_groups_kernel(float* part, int nsl
     float* base = part + (long)k0 * sstride;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 v = ((const f32x4*)base)[i];
-        for (int k = k0 + 1; k < k1; ++k) v += ((const f32x4*)(part + (long)k * sstride))[i];
+        v = sum_slabs(v, part, k0 + 1, k1, sstride, i);
         ((f32x4*)base)[i] = v;
     }
     if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {
@@ -203,7 +226,7 @@ __global__ __launch_bounds__(256) void reduce_plain_kernel(const float* __restri
     const long n4 = total / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 v = ((const f32x4*)part)[i];
-        for (int k = 1; k < nslab; ++k) v += ((const f32x4*)(part + (long)k * sstride))[i];
+        v = sum_slabs(v, part, 1, nslab, sstride, i);
         if (accumulate) v += ((f32x4*)out)[i];
         ((f32x4*)out)[i] = v;
     }
