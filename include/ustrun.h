@@ -99,6 +99,11 @@ int ustrun_bn_relu_apply(const void* y, const float* scale, const float* shift, 
  * dtype (replaces nn.MaxPool2d at unet_parts.py:34 together with the producer's BatchNorm+ReLU); src is a plain
  * contiguous NHWC activation, its pass groups are honoured                                                     */
 int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dtype, ustrun_stream_t s);
+/* the same pass, also writing the un-pooled activation act[N,H,W,C] = relu(src*scale+shift) in the storage dtype (act may be
+ * NULL: then exactly ustrun_pool_act): the encoder output that unet_model.py:33-36 hands to the decoder as the skip operand of
+ * torch.cat (unet_parts.py:66) -- the concat convolution and its weight gradient then read a plain tensor instead of applying
+ * BatchNorm + ReLU per staged item; 16-bit storage and even H, W only                                                     */
+int ustrun_pool_act2(const ustrun_src_t* src, int N, void* out, void* act, int dtype, ustrun_stream_t s);
 /* plain MaxPool2d(2) backward on NHWC tensors (stand-alone Down block): dx[N,H,W,C] from dp[N,H/2,W/2,C] and the
  * pooled input x; first maximum of the window wins (torch's rule)                                              */
 int ustrun_maxpool_bwd(const void* dp, const void* x, int N, int H, int W, int C, void* dx, int dtype,
@@ -394,7 +399,13 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  *   two; bit-identical results, measured no faster (profiles/r04_ab_bn_fused_finalize.log), off by default.
  * bit 23 (8388608): ustrun_unet_backward runs the BatchNorm-backward reduce pass of the layer under the head (rounds 1-3)
  *   instead of taking its two sums from the head kernel's partial rows.
+ * bit 24 (16777216), ENVIRONMENT ONLY (USTRUN_DEBUG_FLAGS at load; ustrun_debug_flags does not change it): the decoder reads
+ *   its skip operands through BatchNorm + ReLU on load (rounds 1-3) instead of the activation tensors ustrun_pool_act2
+ *   materialises -- the switch shapes the workspace that ustrun_unet_forward and _backward share, so it must not differ
+ *   between the threads that call them.
  * bit 13 (8192): 64-output-channel 3x3 layers on >= 32-wide maps on the 16 x 32-pixel tile (one block per CU; A/B runs).
+ * A caller that runs a forward and its backward on different threads sets the same value on both (the Python host does:
+ * ustrun/engine.py hands the forward's flags to autograd's backward thread).
  * The value is PER CALLING THREAD (as are the last-variant codes and the stamp buffer below): a thread that sets it changes
  * kernel selection for the launches it issues itself and for nobody else, so the library keeps no process-wide mutable
  * state.  Every thread starts from the value the environment variable USTRUN_DEBUG_FLAGS had when the library was loaded

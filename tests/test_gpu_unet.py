@@ -1,4 +1,6 @@
 """GPU parity: the HIP U-Net (through the C ABI) against the CPU oracle and the reference goldens."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -353,8 +355,11 @@ def test_one_launch_statistics_finalize_is_bit_identical(dtype, base, n, hw, pas
 def test_head_kernel_bn_sums_equal_the_reduce_pass(dtype, base, n, hw, passes):
     """The BatchNorm backward of the layer under the head takes sum(da mask) and sum(da mask y) from the head kernel's partial
     rows (the kernel holds y and da in registers anyway) instead of from a reduce pass over both tensors
-    (ustrun_debug_flags bit 23 = the pass of rounds 1-3): same values summed in another order -- every parameter gradient
-    within 2e-5 of the other form's norm (f32 accumulation order only), logits identical."""
+    (ustrun_debug_flags bit 23 = the pass of rounds 1-3): same values summed in another order.  The layer's own dgamma / dbeta
+    agree to f32 summation noise (measured 2e-7 / 2e-8); in f32 storage so does every gradient (4e-6); in 16-bit storage the last-bit
+    change of the coefficients flips a rounding of dY here and there and the flips propagate down the backward (measured: 1e-5 one
+    DoubleConv later, 1e-3 (f16) / 9e-3 (bf16) at the first convolution of these random-init nets -- the amplification
+    test_bf16_compute_tracks_f32 documents).  Logits identical."""
     import copy
     from networks.unet_model import UNet
     from ustrun import _lib
@@ -379,8 +384,57 @@ def test_head_kernel_bn_sums_equal_the_reduce_pass(dtype, base, n, hw, passes):
         assert torch.isfinite(p1.grad).all(), k
         e = float((p1.grad - p2.grad).norm() / (p2.grad.norm() + 1e-30))
         worst = max(worst, e)
-        assert e < 2e-5, (k, e)
+        if k.startswith("up4.conv.double_conv.4."):
+            assert 0 < e < 2e-6 or (e == 0 and k.endswith("bias")), (k, e)      # the layer's own dgamma / dbeta: another order, f32 noise
+        bound = 2e-5 if dtype == "f32" else (1e-4 if k.startswith(("up4.conv.", "outc.")) else 5e-2)
+        assert e < bound, (k, e)
     print("head-kernel BN sums vs reduce pass: worst relative gradient difference %.2e" % worst)
+    assert worst > 0                       # (the two forms really ran: identical gradients would mean the switch did nothing)
+
+
+_SKIP_AB = r"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.join(sys.argv[1], "ust-run_amd"))
+from networks.unet_model import UNet
+dtype, n, hw, passes, out = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+torch.manual_seed(17)
+m = UNet(3, 2, base_channels=64, dtype=dtype).cuda().train()
+g = torch.Generator().manual_seed(6)
+xs = [torch.randn(n, 3, hw, hw, generator=g).cuda() for _ in range(passes)]
+dl = torch.randn(n * passes, 2, hw, hw, generator=g).cuda()
+a = m.forward_passes(xs) if passes > 1 else m(xs[0])
+a.backward(dl)
+np.savez(out, logits=a.detach().cpu().numpy(), **{"g_" + k: p.grad.cpu().numpy() for k, p in m.named_parameters()},
+         **{"b_" + k: b.cpu().numpy() for k, b in m.named_buffers() if b.dtype.is_floating_point})
+"""
+
+
+@pytest.mark.parametrize("dtype,n,hw,passes", [("bf16", 2, 64, 1), ("f16", 2, 96, 3)])
+def test_materialised_skip_operands_equal_activation_on_load(dtype, n, hw, passes, tmp_path):
+    """The decoder's skip operands are written out by the pool pass (ustrun_pool_act2) and the concat convolutions / their weight
+    gradients read them as plain tensors; USTRUN_DEBUG_FLAGS bit 24 (environment only: the switch shapes the workspace) =
+    BatchNorm + ReLU applied per staged item on load, as in rounds 1-3.  Two processes, one per setting: the operand VALUES are
+    the same 16-bit numbers either way and the consuming kernels may differ only in f32 summation order -- logits, running
+    statistics and gradients agree to that noise (bit-identical at these sizes, where both settings pick the same tiles)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flags in ("0", str(1 << 24)):
+        o = str(tmp_path / f"skip_{flags}.npz")
+        env = dict(os.environ, USTRUN_DEBUG_FLAGS=flags)
+        r = subprocess.run([sys.executable, "-c", _SKIP_AB, root, dtype, str(n), str(hw), str(passes), o], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(o))
+    a, b = outs
+    tol = 2e-2 if dtype == "bf16" else 3e-3
+    worst = 0.0
+    for k in a.files:
+        assert np.isfinite(a[k]).all() and np.isfinite(b[k]).all(), k
+        e = float(np.linalg.norm(a[k].astype(np.float64) - b[k]) / (np.linalg.norm(b[k].astype(np.float64)) + 1e-30))
+        worst = max(worst, e)
+        assert e < (tol if not k.startswith("g_") else 10 * tol), (k, e)
+    print("materialised skips vs on-load (two processes): worst relative difference %.2e over %d tensors" % (worst, len(a.files)))
 
 
 def test_backward_in_two_parts_equals_one_call():

@@ -281,7 +281,8 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ y, int esz, const
 template <int ESZ>
 __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int relu, int gN, long gstride,
-                                                      int N, int H, int W, int C, float* __restrict__ out) {
+                                                      int N, int H, int W, int C, float* __restrict__ out,
+                                                      elt_t* __restrict__ act) {
     constexpr int V = ESZ == 2 ? 8 : 4;             // channels per thread: one 16-byte load per window pixel
     typedef __attribute__((ext_vector_type(8))) elt_t bf16x8v;
     const int Hp = H / 2, Wp = W / 2, CV = C / V;
@@ -330,7 +331,17 @@ __global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__
             for (int q = 0; q < 4; ++q) {
                 float a = v[q][j] * sc[j] + sh[j];
                 a = relu ? fmaxf(a, 0.f) : a;
+                v[q][j] = a;
                 m[j] = q == 0 ? a : fmaxf(m[j], a);
+            }
+        }
+        if (ESZ == 2 && act) {                      // the window's four activated pixels, as the concat convolution will read them
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x8v a8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = (elt_t)v[q][j % V];
+                *(bf16x8v*)(act + base + ((q >> 1) * (long)W + (q & 1)) * C) = a8;
             }
         }
         const long ob = (((long)n * Hp + py) * Wp + px) * C + cv * V;
@@ -863,8 +874,14 @@ extern "C" int ustrun_bn_relu_apply(const void* y, const float* scale, const flo
 }
 
 extern "C" int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dtype, ustrun_stream_t s) {
+    return ustrun_pool_act2(src, N, out, nullptr, dtype, s);
+}
+
+extern "C" int ustrun_pool_act2(const ustrun_src_t* src, int N, void* out, void* act, int dtype, ustrun_stream_t s) {
     USTRUN_CHECK(dtype_ok(dtype), "pool_act: dtype %d not built", dtype);
     USTRUN_CHECK(src && src->ptr && out && N > 0, "pool_act: bad args");
+    USTRUN_CHECK(!act || (dtype == USTRUN_D16 && !(src->H & 1) && !(src->W & 1)),
+                 "pool_act: the un-pooled activation needs 16-bit storage and even extents (%dx%d)", src->H, src->W);
     const int C = src->C, H = src->H, W = src->W, V = dtype == USTRUN_D16 ? 8 : 4;
     USTRUN_CHECK(C % V == 0 && H >= 2 && W >= 2, "pool_act: C=%d extent %dx%d unsupported", C, H, W);
     USTRUN_CHECK(src->sC == 1 && src->sW == C && src->sH == (int64_t)W * C && src->sN == (int64_t)H * W * C && !src->pool &&
@@ -881,10 +898,10 @@ extern "C" int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dt
     const int gN = src->scale ? src->gN : 0;
     if (dtype == USTRUN_D16)
         hipLaunchKernelGGL(pool_act_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)src->ptr, src->scale,
-                           src->shift, src->relu, gN, (long)src->gstride, N, H, W, C, (float*)out);
+                           src->shift, src->relu, gN, (long)src->gstride, N, H, W, C, (float*)out, (elt_t*)act);
     else
         hipLaunchKernelGGL(pool_act_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)src->ptr, src->scale,
-                           src->shift, src->relu, gN, (long)src->gstride, N, H, W, C, (float*)out);
+                           src->shift, src->relu, gN, (long)src->gstride, N, H, W, C, (float*)out, (elt_t*)nullptr);
     USTRUN_LAUNCH_CHECK("pool_act");
     return 0;
 }

@@ -321,8 +321,9 @@ int head_bwd_passes(const float* dlogits, const void* y, const float* scale, con
     // follows walks a pass's rows on eight lanes
     if (passes > 1 && blocks > 1024 / passes) blocks = 1024 / passes > 64 ? 1024 / passes : 64;
     // bn_rows: also form the BatchNorm-backward sums of the layer under the head (scale/shift = its constants): row =
-    // [K*C dW | K db | C sum(da mask) | C sum(da mask y)], *bn_rows = rows per pass; K*C + K must keep the sums 16-byte aligned
-    const int bnr = bn_rows && scale && (K * C + K) % 4 == 0;
+    // [K*C dW | K db | C sum(da mask) | C sum(da mask y)], *bn_rows = rows per pass (rows are dword-aligned only, as they always
+    // were: 16-byte global stores take that)
+    const int bnr = bn_rows && scale;
     if (bn_rows) *bn_rows = bnr ? blocks : 0;
     const long row = (long)K * C + K + (bnr ? 2 * C : 0);
     USTRUN_CHECK(partials_bytes >= (int64_t)((long)(passes > 1 ? passes * blocks : 1024) * row * 4),

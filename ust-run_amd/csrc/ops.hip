@@ -146,6 +146,7 @@ extern "C" int ustrun_debug_last_wgrad_variant(void) { return wgrad_last_variant
 namespace ustrun {
 static const int g_env_debug_flags = getenv("USTRUN_DEBUG_FLAGS") ? atoi(getenv("USTRUN_DEBUG_FLAGS")) : 0;     // read once, at load
 thread_local int g_debug_flags = g_env_debug_flags;
+int env_debug_flags() { return g_env_debug_flags; }     // the process-wide constant: for switches that shape a plan two calls share
 thread_local DebugBuf g_dbg = {nullptr, 0};
 int debug_buffer_for(long blocks, const char* who, unsigned long long** out) {
     *out = nullptr;

@@ -25,6 +25,8 @@ struct Plan {
     long y_off[18], aff_off[18]; // aff: scale, shift, mean, rstd (4*cout)
     long u_off[4];
     long pool_off[4];            // pooled activation feeding Down l+1 (input of conv 2l+2), kept for its weight gradient
+    long act_off[4];             // un-pooled activation of conv 2l+1 = the decoder's skip operand at level l (-1: read through
+                                 // BatchNorm + ReLU on load instead: f32 storage, odd extents, or USTRUN_DEBUG_FLAGS bit 24)
     long stat_off, tick_off, fwd_total;
     long wf_off[18], wd_off[18], uf_off[4], ud_off[4], pack_total;
     long da_off[18], du_off[4], dp_off[4], coef_off, part_off, bwd_total, part_bytes;
@@ -79,6 +81,17 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     for (int j = 0; j < 4; ++j) { p.u_off[j] = o; o = align_up(o + p.u_elems(j) * E, 256) + gap(); }
     for (int l = 0; l < 4; ++l) {
         p.pool_off[l] = o; o = align_up(o + (long)p.N * p.Hs[l + 1] * p.Ws[l + 1] * ch[l] * E, 256) + gap();
+    }
+    // The skip operands, materialised by the pool pass that reads the same tensor anyway (+2 B per element written) so that the
+    // four concat convolutions and their weight gradients read PLAIN sources: applying BatchNorm + ReLU per staged item costs those
+    // layers 14-19 % (tools/exp_cat_plain.py: 0.505 / 0.50 / 0.54 / 0.81 ms against 0.41 / 0.43 / 0.47 / 0.68 at N = 64), most on the
+    // 64-column tile of up4.conv1, where a block amortises the transform over half the MFMAs
+    for (int l = 0; l < 4; ++l) {
+        // (the switch shapes the workspace the forward and the backward share, and the two may run on different threads -- autograd's
+        // backward does: it is taken from the ENVIRONMENT's flags, a process-wide constant, never from the per-thread value)
+        const bool on = E == 2 && !(p.Hs[l] & 1) && !(p.Ws[l] & 1) && !(env_debug_flags() & (1 << 24));
+        p.act_off[l] = on ? o : -1;
+        if (on) o = align_up(o + p.y_elems(2 * l + 1) * E, 256) + gap();
     }
     p.stat_off = o; o = align_up(o + stat_max * 4, 256);
     p.tick_off = o; o += 256;              // BN_TICKETS counters of the one-launch statistics finalize (zeroed per forward)
@@ -160,7 +173,8 @@ int conv_sources(const Plan& p, const float* x, const char* ws, int i, ustrun_sr
     if (i % 2 == 1) { srcs[0] = act(i - 1, 0); return 1; }
     const int j = (i - 10) / 2, l = 3 - j;
     const int skip = 2 * l + 1;
-    srcs[0] = act(skip, 0);
+    srcs[0] = p.act_off[l] >= 0 ? nhwc_src(ws + p.act_off[l], nullptr, p.cout[skip], p.Hs[l], p.Ws[l], 0, 0, p.G > 1 ? p.gN : 0)
+                                : act(skip, 0);
     ustrun_src_t u = nhwc_src(ws + p.u_off[j], nullptr, p.up_cout[j], 2 * p.Hs[l + 1], 2 * p.Ws[l + 1], 0, 0);
     u.off_y = (p.Hs[l] - 2 * p.Hs[l + 1]) / 2;       // F.pad(diff//2, ...) of the reference
     u.off_x = (p.Ws[l] - 2 * p.Ws[l + 1]) / 2;
@@ -256,7 +270,8 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
             const int l = i / 2;
             ustrun_src_t a = nhwc_src(ws + p.y_off[i - 1], affp(i - 1), p.cout[i - 1], p.Hs[l - 1], p.Ws[l - 1], 1, 0,
                                       p.G > 1 ? p.gN : 0);
-            USTRUN_TRY(ustrun_pool_act(&a, p.N, ws + p.pool_off[l - 1], d->dtype, s));
+            USTRUN_TRY(ustrun_pool_act2(&a, p.N, ws + p.pool_off[l - 1], p.act_off[l - 1] >= 0 ? ws + p.act_off[l - 1] : nullptr,
+                                        d->dtype, s));
         }
         ustrun_src_t srcs[2];
         const int ns = conv_sources(p, x, ws, i, srcs);

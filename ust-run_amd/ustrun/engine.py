@@ -93,11 +93,20 @@ def model_params(model):
     return list(model.parameters())
 
 
+def _current_debug_flags(lib):
+    f = lib.ustrun_debug_flags(0)
+    lib.ustrun_debug_flags(f)
+    return f
+
+
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, feature, groups, *params):
         logits, feat, ws, d = _run_forward(model, x, feature, groups)
         ctx.model, ctx.ws, ctx.desc, ctx.x = model, ws, d, x
+        # ustrun_debug_flags is per calling thread and autograd runs backward() on a thread of its own: the backward runs under
+        # the flags the forward ran under (some of them shape the plan both halves share)
+        ctx.debug_flags = _current_debug_flags(L.lib())
         ctx.nparams = len(params)
         if feature:
             ctx.mark_non_differentiable(feat)
@@ -108,6 +117,14 @@ class _UNetFn(torch.autograd.Function):
     def backward(ctx, dlogits, *unused):
         model, d = ctx.model, ctx.desc
         lib = L.lib()
+        restore = lib.ustrun_debug_flags(ctx.debug_flags)
+        try:
+            return _UNetFn._backward(ctx, lib, model, d, dlogits)
+        finally:
+            lib.ustrun_debug_flags(restore)
+
+    @staticmethod
+    def _backward(ctx, lib, model, d, dlogits):
         dlogits = dlogits.contiguous()
         nbytes = lib.ustrun_unet_bwd_scratch_bytes(C.byref(d))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dlogits.device)

@@ -476,13 +476,20 @@ class DeepLabFn(torch.autograd.Function):
         tape = []
         out = deeplabv2_forward(net, x, tape)
         ctx.net, ctx.tape, ctx.params = net, tape, params
+        lib = L.lib()
+        ctx.debug_flags = lib.ustrun_debug_flags(0)      # (per calling thread; autograd runs backward() on its own thread)
+        lib.ustrun_debug_flags(ctx.debug_flags)
         return out
 
     @staticmethod
     def backward(ctx, dlogits):
         if ctx.tape is None:
             raise RuntimeError("DeepLabFn: the forward's activations were released by an earlier backward")
-        grads = deeplabv2_backward(ctx.net, ctx.tape, dlogits)
+        restore = L.lib().ustrun_debug_flags(ctx.debug_flags)
+        try:
+            grads = deeplabv2_backward(ctx.net, ctx.tape, dlogits)
+        finally:
+            L.lib().ustrun_debug_flags(restore)
         ctx.tape = None
         byid = {id(k): v for k, v in grads.items()}
         named = list(ctx.net.parameters())
