@@ -144,6 +144,23 @@ int ustrun_bn_bwd_apply(const void* da, const void* dp, const void* y, const flo
 int ustrun_conv3x3_dgrad(const void* dy, const void* w_dgrad, int N, int H, int W, int Cout, int Cin,
                          void* da0, int C0, void* da1, int H1, int W1, int o1y, int o1x, int dtype,
                          ustrun_stream_t s);
+/* the same input gradient (single destination) which ALSO forms the BatchNorm-backward sums of the layer whose da it writes
+ * (unet_parts.py:17-21 backward: the BatchNorm2d + ReLU between the two convolutions of a DoubleConv): y = that layer's
+ * pre-BatchNorm output [N,H,W,Cin] (the layout of da), scale / shift = its forward constants (gN images per pass, gstride floats
+ * between the passes' constants; gN = 0: one pass); stat receives *stat_rows rows of [2][Cin] = {sum(da mask), sum(da mask y)},
+ * mask = y scale + shift > 0, over the da values as stored -- what ustrun_bn_bwd_reduce would form from a second read of both
+ * tensors; ustrun_bn_bwd_finalize_stat turns the rows into dgamma / dbeta / coefficients.  *stat_rows = 0 and NO launch when
+ * the shape is not one the fused epilogue covers (16-bit storage, >= 128 input channels, the 256-pixel tiles): the caller then
+ * runs ustrun_conv3x3_dgrad and ustrun_bn_bwd_reduce.  stat: ustrun_conv_mtiles(N, H, W, Cin) rows. */
+int ustrun_conv3x3_dgrad_bnsum(const void* dy, const void* w_dgrad, int N, int H, int W, int Cout, int Cin, void* da,
+                               const void* y, const float* scale, const float* shift, int gN, int64_t gstride,
+                               float* stat, int* stat_rows, int dtype, ustrun_stream_t s);
+/* rows of ustrun_conv3x3_dgrad_bnsum (rows_per_pass x passes rows of [2][C], pass after pass) -> dgamma, dbeta (the passes'
+ * contributions added in order; accumulate != 0 adds to what is there) and coef[pass][3][C] for ustrun_bn_bwd_apply; the table
+ * is reduced in place (it is scratch afterwards)                                                                          */
+int ustrun_bn_bwd_finalize_stat(float* stat, int rows_per_pass, int passes, int C, int64_t count, const float* gamma,
+                                const float* mean, const float* rstd, int64_t aff_stride, float* dgamma, float* dbeta,
+                                int accumulate, float* coef, ustrun_stream_t s);
 /* ---- conv3x3 weight gradient: dw[Cout][Cin][3][3] (torch layout, f32) ---------------------- */
 int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int64_t npix);
 int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const void* dy, int N, int H, int W,
@@ -403,6 +420,8 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  *   its skip operands through BatchNorm + ReLU on load (rounds 1-3) instead of the activation tensors ustrun_pool_act2
  *   materialises -- the switch shapes the workspace that ustrun_unet_forward and _backward share, so it must not differ
  *   between the threads that call them.
+ * bit 25 (33554432): ustrun_unet_backward never asks an input gradient for the BatchNorm-backward sums of the layer it feeds
+ *   (ustrun_conv3x3_dgrad_bnsum): every BatchNorm backward runs its reduce pass, as in rounds 1-3.
  * bit 13 (8192): 64-output-channel 3x3 layers on >= 32-wide maps on the 16 x 32-pixel tile (one block per CU; A/B runs).
  * A caller that runs a forward and its backward on different threads sets the same value on both (the Python host does:
  * ustrun/engine.py hands the forward's flags to autograd's backward thread).

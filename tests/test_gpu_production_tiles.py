@@ -369,3 +369,78 @@ def test_wgrad_all_taps_builds_exact(case):
     assert (v >> 20) == fam, f"weight gradient ran variant {v:#x}"
     assert torch.equal(dw.view(co, ci, 3, 3).cpu(), 2 * wr.grad)
     assert bool((buf[:Z] == 7.0).all()) and bool((buf[-Z:] == 7.0).all())
+
+
+@pytest.mark.parametrize("name,n,G,cin,cout,h,w,tile", [
+    ("wide_128", 16, 2, 128, 128, 128, 128, (8, 32, 128, 4, 1, "m16")),       # 8 x 32 tiles, two passes
+    ("narrow_512_ragged", 16, 1, 512, 512, 56, 24, (16, 16, 128, 4, 1, "m16")),   # 16 x 16 tiles, ragged right / bottom edges
+    ("bottleneck", 64, 4, 1024, 512, 16, 16, (16, 16, 128, 4, 1, "m16")),     # N = 64, four passes, 512 -> 1024 channels back
+    ("too_small", 2, 1, 128, 128, 32, 32, None),                                # a grid the fused epilogue does not cover: rows = 0, no launch
+])
+def test_input_gradient_with_batchnorm_backward_sums_exact(name, n, G, cin, cout, h, w, tile):
+    """ustrun_conv3x3_dgrad_bnsum (round 4): the input gradient of a DoubleConv's second convolution IS da of the BatchNorm + ReLU
+    between the two convolutions (unet_parts.py:17-21); the 16x16x32 epilogue loads y beside each stored da piece and writes
+    sum(da mask), sum(da mask y) as statistics rows instead of leaving them to a reduce pass.  Small-integer data: da must equal the
+    plain input gradient BITWISE, the rows' per-pass column sums must equal torch's exactly, nothing may be written outside the rows
+    the call reports; then ustrun_bn_bwd_finalize_stat against ustrun_bn_bwd_reduce on the same tensors (dgamma, dbeta, coef)."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(len(name) * 17 + n)
+    ri = lambda lo, hi, *s: torch.randint(lo, hi + 1, s, generator=g).float()
+    gn = n // G
+    wt = ri(-1, 1, cout, cin, 3, 3)          # conv: cin -> cout; its input gradient maps dy [cout] back to da [cin]
+    dy = ri(-1, 1, n, cout, h, w)
+    y = ri(-3, 3, n, cin, h, w) * 0.5        # the previous layer's pre-BatchNorm output (halves: exact in 16 bits)
+    sc = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (G, cin), generator=g)]
+    sh = ri(-1, 1, G, cin) * 0.25            # (never makes y sc + sh exactly 0 for y a multiple of 0.5 ... unless both vanish: excluded below)
+    sh[sh == 0] = 0.25
+    aff = torch.zeros(G, 4, cin)
+    aff[:, 0], aff[:, 1] = sc, sh
+    aff[:, 2], aff[:, 3] = ri(-1, 1, G, cin) * 0.5, torch.tensor([0.5, 1.0, 2.0])[torch.randint(0, 3, (G, cin), generator=g)]      # mean, rstd
+    gamma = ri(1, 3, cin) * 0.5
+    da_ref = F.conv_transpose2d(dy, wt, None, 1, 1)          # = conv input gradient
+    assert float(da_ref.abs().max()) < 256
+    wf, wd = pack16(wt)
+    dyg, yg, affg = nhwc16(dy), nhwc16(y), aff.cuda()
+    ZO = 8192
+    dbuf = torch.full((ZO + n * h * w * cin + ZO,), 9.0, device="cuda", dtype=E.t)
+    da = dbuf[ZO:ZO + n * h * w * cin].view(n, h, w, cin)
+    rows_max = lib.ustrun_conv_mtiles(n, h, w, cin)
+    stat = torch.full((rows_max + 64, 2, cin), 5.0, device="cuda")
+    rows = C.c_int(-1)
+    l.check(lib.ustrun_conv3x3_dgrad_bnsum(dyg.data_ptr(), wd.data_ptr(), n, h, w, cout, cin, da.data_ptr(), yg.data_ptr(),
+                                           affg.data_ptr(), affg.data_ptr() + 4 * cin, gn if G > 1 else 0, 4 * cin, stat.data_ptr(),
+                                           C.byref(rows), E.code, None), "dgrad_bnsum")
+    if tile is None:
+        assert rows.value == 0 and bool((dbuf == 9.0).all()) and bool((stat == 5.0).all()), "an unsupported shape must not launch"
+        return
+    assert rows.value > 0 and rows.value % G == 0 and rows.value <= rows_max
+    assert lib.ustrun_debug_last_conv_variant() == variant(*tile, False, False), vstr(lib.ustrun_debug_last_conv_variant())
+    plain = torch.empty(n, h, w, cin, device="cuda", dtype=E.t)
+    l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, cout, cin, plain.data_ptr(), cin, None, 0, 0, 0, 0, E.code, None), "dgrad")
+    assert torch.equal(da, plain) and rel(from_nhwc(da.float()), da_ref) < 1e-6
+    assert bool((dbuf[:ZO] == 9.0).all()) and bool((dbuf[-ZO:] == 9.0).all()) and bool((stat[rows.value:] == 5.0).all())
+    scn, shn = sc.repeat_interleave(gn, 0)[:, :, None, None], sh.repeat_interleave(gn, 0)[:, :, None, None]
+    dz = torch.where(y * scn + shn > 0, da_ref, torch.zeros(()))
+    st = stat[:rows.value].view(G, rows.value // G, 2, cin).double().sum(1).cpu()
+    assert torch.equal(st[:, 0], dz.double().view(G, gn, cin, h, w).sum((1, 3, 4)))
+    assert torch.equal(st[:, 1], (dz * y).double().view(G, gn, cin, h, w).sum((1, 3, 4)))
+    # the finalize over these rows against the reduce pass + its finalize on the same tensors
+    gam, mean, rstd = gamma.cuda(), affg[:, 2].contiguous(), affg[:, 3].contiguous()
+    out = {}
+    for kind in ("rows", "pass"):
+        dg, db, coef = torch.zeros(cin, device="cuda"), torch.zeros(cin, device="cuda"), torch.zeros(G, 3, cin, device="cuda")
+        if kind == "rows":
+            l.check(lib.ustrun_bn_bwd_finalize_stat(stat.data_ptr(), rows.value // G, G, cin, gn * h * w, gam.data_ptr(), affg.data_ptr() + 8 * cin,
+                                                    affg.data_ptr() + 12 * cin, 4 * cin, dg.data_ptr(), db.data_ptr(), 0, coef.data_ptr(), None), "finalize_stat")
+        else:
+            pb = lib.ustrun_bn_bwd_partials_bytes(gn * h * w, cin)
+            part = torch.empty(pb // 4, device="cuda")
+            for p_ in range(G):          # the public reduce entry point takes one pass per call
+                sl = slice(p_ * gn, (p_ + 1) * gn)
+                l.check(lib.ustrun_bn_bwd_reduce(da[sl].data_ptr(), None, yg[sl].data_ptr(), affg[p_, 0].data_ptr(), affg[p_, 1].data_ptr(),
+                                                 affg[p_, 2].data_ptr(), affg[p_, 3].data_ptr(), gam.data_ptr(), gn, h, w, cin, dg.data_ptr(),
+                                                 db.data_ptr(), 1 if p_ else 0, coef[p_].data_ptr(), part.data_ptr(), pb, E.code, None), "bn_bwd_reduce")
+        out[kind] = (dg.cpu(), db.cpu(), coef.cpu())
+    for a_, b_ in zip(out["rows"], out["pass"]):
+        np.testing.assert_allclose(a_.numpy(), b_.numpy(), rtol=2e-6, atol=1e-6)

@@ -392,6 +392,46 @@ def test_head_kernel_bn_sums_equal_the_reduce_pass(dtype, base, n, hw, passes):
     assert worst > 0                       # (the two forms really ran: identical gradients would mean the switch did nothing)
 
 
+@pytest.mark.parametrize("dtype,n,hw,passes", [("bf16", 8, 256, 1), ("f16", 4, 256, 2)])
+def test_input_gradient_bn_sums_equal_the_reduce_pass(dtype, n, hw, passes):
+    """ustrun_unet_backward takes the BatchNorm-backward sums of the layers between the two convolutions of a DoubleConv from the
+    input gradient that writes their da (ustrun_conv3x3_dgrad_bnsum, where its fused epilogue covers the shape: here up3's and
+    down1's first BatchNorm, 128 channels at 128^2) instead of from a reduce pass (ustrun_debug_flags bit 25 = always the pass):
+    same values summed in another order -- logits identical, every gradient above the first fused layer identical, that layer's
+    own dgamma / dbeta apart by f32 summation noise (the switch is live), the rest by the 16-bit rounding flips that noise triggers
+    further down the backward (bounded as in test_head_kernel_bn_sums_equal_the_reduce_pass)."""
+    import copy
+    from networks.unet_model import UNet
+    from ustrun import _lib
+    lib = _lib.lib()
+    torch.manual_seed(19)
+    m1 = UNet(3, 2, base_channels=64, dtype=dtype).cuda().train()
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(8)
+    xs = [torch.randn(n, 3, hw, hw, generator=g).cuda() for _ in range(passes)]
+    dl = torch.randn(n * passes, 2, hw, hw, generator=g).cuda()
+    a = m1.forward_passes(xs) if passes > 1 else m1(xs[0])
+    a.backward(dl)
+    old = lib.ustrun_debug_flags(1 << 25)
+    try:
+        b = m2.forward_passes(xs) if passes > 1 else m2(xs[0])
+        b.backward(dl)
+    finally:
+        lib.ustrun_debug_flags(old)
+    assert torch.equal(a.detach(), b.detach())
+    errs = {k: float((p1.grad - p2.grad).norm() / (p2.grad.norm() + 1e-30)) for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters())}
+    assert all(np.isfinite(v) for v in errs.values())
+    # at N = 8, 256^2 the fused epilogue's tiles (>= 512 blocks of 256 px x 128 ch) are reached by the input gradients of up3.conv2 and
+    # down1.conv2 (128 channels at 128^2); up3's first BatchNorm comes first in the backward: everything above it is identical
+    first = [k for k in errs if k.startswith("up3.conv.double_conv.1.")]
+    assert len(first) == 2, list(errs)
+    above = [k for k in errs if k.startswith(("up4.", "outc.", "up3.conv.double_conv.3.", "up3.conv.double_conv.4."))]
+    print("input-gradient BN sums vs reduce pass: first fused layer's dgamma/dbeta %s, worst %.2e" % (["%.1e" % errs[k] for k in first], max(errs.values())))
+    assert all(errs[k] == 0 for k in above), {k: errs[k] for k in above if errs[k]}
+    assert all(0 < errs[k] < 1e-5 for k in first), {k: errs[k] for k in first}       # another summation order, nothing else
+    assert max(errs.values()) < 5e-2
+
+
 _SKIP_AB = r"""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.join(sys.argv[1], "ust-run_amd"))

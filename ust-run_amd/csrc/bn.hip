@@ -560,10 +560,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 // partials[pass][rows][2][C] -> dgamma, dbeta (the passes' contributions added one after the other, as separate calls
 // would), coef[pass][3][C]
+template <bool PRE>
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int rows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, float* dgamma, float* dbeta, int accumulate,
-                                       float* coef, int passes, const PassOff po, long rstride, long roff) {
+                                       float* coef, int passes, const PassOff po, long rstride, long roff, int R) {
     __shared__ double red[2][32][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 channels x 32 row lanes
     const int c = blockIdx.x * 32 + cl;
@@ -578,7 +579,21 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int r
         double s1 = 0.0, s2 = 0.0;
         if (c < C && g < passes) {
             const float* pt = partials + (long)g * po.part + roff + c;
-            int r = lane;
+            if constexpr (PRE) {     // rows of a convolution's epilogue, pre-reduced in place by bn_stat_stage1_kernel: f64 sums parked as
+                                     // (hi, lo) float pairs at rows sp*R (sum 1) and sp*R+1 (sum 2); at most 32 splits = four per lane
+                float v[4][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int sp = lane + LPP * k;
+                    const bool ok = sp * R < rows;
+                    const long a0 = ok ? (long)(sp * R) * 2 * C : 0, a1 = ok ? (long)(sp * R + 1) * 2 * C : 0;
+                    const float x0 = pt[a0], x1 = pt[a0 + C], x2 = pt[a1], x3 = pt[a1 + C];
+                    v[k][0] = ok ? x0 : 0.f; v[k][1] = ok ? x1 : 0.f; v[k][2] = ok ? x2 : 0.f; v[k][3] = ok ? x3 : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s1 += (double)v[k][0] + (double)v[k][1]; s2 += (double)v[k][2] + (double)v[k][3]; }
+            }
+            int r = PRE ? rows : lane;
             for (; r + 7 * LPP < rows; r += 8 * LPP) {       // eight rows' loads issued before the first sum (written out: left
                 float a[8], b[8];                            // to the unroller, each load was waited for on its own)
 #pragma unroll
@@ -953,8 +968,8 @@ int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const fl
         hipLaunchKernelGGL(bn_bwd_reduce_x8_kernel, dim3(blocks, passes), dim3(256), 0, s, (const elt_t*)da, (const elt_t*)y, scale, shift,
                            nwin, C, G, partials, po);
         USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, blocks, C, (double)N * H * W, gamma,
-                           mean, rstd, dgamma, dbeta, accumulate, coef, passes, po, 2L * C, 0L);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<false>, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, blocks, C, (double)N * H * W, gamma,
+                           mean, rstd, dgamma, dbeta, accumulate, coef, passes, po, 2L * C, 0L, 0);
         USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
         return 0;
     }
@@ -966,8 +981,8 @@ int bn_bwd_reduce_passes(const void* da, const void* dp, const void* y, const fl
     else { if (even) USTRUN_BN_REDUCE(true, 4, true); else if (pool) USTRUN_BN_REDUCE(true, 4, false); else USTRUN_BN_REDUCE(false, 4, false); }
 #undef USTRUN_BN_REDUCE
     USTRUN_LAUNCH_CHECK("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, blocks, C, (double)N * H * W, gamma,
-                       mean, rstd, dgamma, dbeta, accumulate, coef, passes, po, 2L * C, 0L);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<false>, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, blocks, C, (double)N * H * W, gamma,
+                       mean, rstd, dgamma, dbeta, accumulate, coef, passes, po, 2L * C, 0L, 0);
     USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
     return 0;
 }
@@ -977,8 +992,29 @@ int bn_bwd_finalize_rows(const float* partials, int rows, long rstride, long rof
                          int passes, long aff_stride, hipStream_t s) {
     USTRUN_CHECK(partials && rows > 0 && C > 0 && gamma && mean && rstd && coef && passes >= 1, "bn_bwd_finalize_rows: bad args");
     const PassOff po = {0, 0, aff_stride, (long)rows * rstride, 3L * C};
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, rows, C, (double)count, gamma, mean,
-                       rstd, dgamma, dbeta, accumulate, coef, passes, po, rstride, roff);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<false>, dim3(cdiv(C, 32)), dim3(1024), 0, s, partials, rows, C, (double)count, gamma, mean,
+                       rstd, dgamma, dbeta, accumulate, coef, passes, po, rstride, roff, 0);
+    USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
+    return 0;
+}
+
+// rows a convolution epilogue wrote (the forward-statistics table format: [pass][rows][2][C]) -> the same finalize; long tables
+// go through the forward statistics' in-place stage 1 first
+int bn_bwd_finalize_stat(float* stat, int rows, int passes, int C, int64_t count, const float* gamma, const float* mean,
+                         const float* rstd, long aff_stride, float* dgamma, float* dbeta, int accumulate, float* coef, hipStream_t s) {
+    USTRUN_CHECK(stat && rows > 0 && passes >= 1 && C > 0 && gamma && mean && rstd && coef, "bn_bwd_finalize_stat: bad args");
+    const PassOff po = {0, 0, aff_stride, (long)rows * 2 * C, 3L * C};
+    if (rows >= 96 && C % 32 == 0) {
+        int R = cdiv(rows, 32);
+        while (rows % R == 1) ++R;
+        hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(rows, R), passes), dim3(256), 0, s, stat, rows, C, R);
+        USTRUN_LAUNCH_CHECK("bn_stat_stage1");
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<true>, dim3(C / 32), dim3(1024), 0, s, stat, rows, C, (double)count, gamma, mean, rstd,
+                           dgamma, dbeta, accumulate, coef, passes, po, 2L * C, 0L, R);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<false>, dim3(cdiv(C, 32)), dim3(1024), 0, s, stat, rows, C, (double)count, gamma, mean,
+                           rstd, dgamma, dbeta, accumulate, coef, passes, po, 2L * C, 0L, 0);
+    }
     USTRUN_LAUNCH_CHECK("bn_bwd_finalize");
     return 0;
 }
@@ -1016,6 +1052,13 @@ int bn_bwd_apply_passes(const void* da, const void* dp, const void* y, const flo
     return 0;
 }
 }  // namespace ustrun
+
+extern "C" int ustrun_bn_bwd_finalize_stat(float* stat, int rows_per_pass, int passes, int C, int64_t count, const float* gamma,
+                                           const float* mean, const float* rstd, int64_t aff_stride, float* dgamma, float* dbeta,
+                                           int accumulate, float* coef, ustrun_stream_t s) {
+    return bn_bwd_finalize_stat(stat, rows_per_pass, passes, C, count, gamma, mean, rstd, (long)aff_stride, dgamma, dbeta, accumulate,
+                                coef, (hipStream_t)s);
+}
 
 extern "C" int ustrun_bn_bwd_reduce(const void* da, const void* dp, const void* y, const float* scale,
                                     const float* shift, const float* mean, const float* rstd, const float* gamma,

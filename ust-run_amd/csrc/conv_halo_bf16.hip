@@ -64,11 +64,12 @@ template <bool B> struct more_value<std::integral_constant<bool, B>> { static co
 // in the four registers of a tile -> 2 cvt_pk + one ds_write_b64 in the epilogue instead of four 2-byte writes.  Same fragment
 // bytes from LDS, same weight loads, same accumulator count; what differs is the clock the chip holds (MI355X_MICROARCH.md,
 // "DVFS give-back" item 7).
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false, bool M16 = false>
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false, bool M16 = false, bool BNS = false>
 __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
     static_assert(BK == 32, "80-byte patch rows hold one 32-channel chunk");
     static_assert(!M16 || (BREG && !XF), "the 16x16x32 build: plain sources, weights through registers");
+    static_assert(!BNS || M16, "BatchNorm-backward sums ride on the 16x16x32 epilogue (8 channels of a pixel per lane)");
     static_assert(!BREG || NT <= 2, "register-fed weights: 16 registers per tap and set");
     constexpr int HW2 = TW + 2 * DIL;
     constexpr int SR = 32 / TW;                 // tile rows per 32-pixel sub-tile (2 or 1)
@@ -666,6 +667,27 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
             s1p[q] += f; s2p[q] += f * f;
         }
     };
+    // BNS (round 4): this launch is the input gradient that PRODUCES da of a BatchNorm + ReLU layer; the layer's backward needs
+    // sum(da mask) and sum(da mask y) per channel (mask = y scale + shift > 0).  The lane holds the stored da piece anyway: it loads
+    // the 16 bytes of y beside it and forms the two sums in place of the forward statistics -- same rows, same reduction below --
+    // instead of a reduce pass reading both tensors again (4 B per element at 5.2 TB/s).
+    float bsc[8], bsh[8];
+    if constexpr (BNS) {
+        const long go = a.bn_gN > 0 ? (long)(img / a.bn_gN) * a.bn_gstride : 0;
+        const float* ps = a.bnsc + go + n0 + wn * 64 + (lane & 7) * 8;
+        const float* pb = a.bnsh + go + n0 + wn * 64 + (lane & 7) * 8;
+        const f32x4 s0 = *(const f32x4*)ps, s1_ = *(const f32x4*)(ps + 4), b0 = *(const f32x4*)pb, b1 = *(const f32x4*)(pb + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { bsc[q] = s0[q]; bsc[4 + q] = s1_[q]; bsh[q] = b0[q]; bsh[4 + q] = b1[q]; }
+    }
+    auto bns_piece = [&](const bf16x8 v8, const bf16x8 y8, bool ok) {      // (v8: da as stored; y8: the layer's pre-BatchNorm output)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float yf = (float)y8[q];
+            const float dz = (ok && yf * bsc[q] + bsh[q] > 0.f) ? (float)v8[q] : 0.f;
+            s1p[q] += dz; s2p[q] += dz * yf;
+        }
+    };
     constexpr int EPITCH = 144;
     char* ep = smem + wave * (32 * EPITCH);         // the A patches are dead after the last barrier
     const bool full = y0 + TH <= a.Ho && x0 + TW <= a.Wo;     // interior tile: no per-pixel masks
@@ -730,7 +752,8 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                 const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
                 const long off = TW == 16 ? ((long)(row >> 4) * a.Wo + (row & 15)) * a.C0 : (long)row * a.C0;
                 *(bf16x8*)(base + off) = v8;
-                if constexpr (M16) { if (a.stat) stat_piece(v8, true); }
+                if constexpr (BNS) bns_piece(v8, *(const bf16x8*)((const elt_t*)a.bny + (base - (elt_t*)a.out0) + off), true);
+                else if constexpr (M16) { if (a.stat) stat_piece(v8, true); }
             }
         } else
 #pragma unroll
@@ -739,7 +762,11 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
             const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
             const int oy = oyb + (TW == 16 ? (row >> 4) : 0), ox = x0 + (row & (TW - 1));
             const int col = n0 + wn * 64 + ch * 8;
-            if constexpr (M16) { if (a.stat) stat_piece(v8, oy < a.Ho && ox < a.Wo); }
+            if constexpr (BNS) {     // (single destination: the launcher admits nothing else)
+                const bool ok = oy < a.Ho && ox < a.Wo && col < a.C0;
+                const long eo = ok ? (((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col : 0;
+                bns_piece(v8, *(const bf16x8*)((const elt_t*)a.bny + eo), ok);
+            } else if constexpr (M16) { if (a.stat) stat_piece(v8, oy < a.Ho && ox < a.Wo); }
             if (oy < a.Ho && ox < a.Wo) {
                 if (col < a.C0) {
                     *(bf16x8*)((elt_t*)a.out0 + (((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col) = v8;
@@ -792,7 +819,7 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
 
 thread_local int g_last_variant = 0;    // (per calling thread) TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF of the last launch (tests: ustrun_debug_last_conv_variant)
 
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false, bool M16 = false>
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false, bool M16 = false, bool BNS = false>
 int launch_xf(const IgemmArgs& a, hipStream_t st) {
     g_last_variant = TH << 24 | TW << 16 | BN << 8 | (M16 ? 0x80 : 0) | MI << 4 | NT << 2 | (POOL ? 2 : 0) | (XF ? 1 : 0);
     const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
@@ -805,8 +832,8 @@ int launch_xf(const IgemmArgs& a, hipStream_t st) {
     // above the 64 KB default (the dilation-4 patch pair: 93 KB; the 16 x 16 x 128 transforming tile: 66 KB): raise the limit
     // whatever the dilation is (the un-dilated 16 x 16 tile used to launch without the attribute)
     if (lds > 64 * 1024)
-        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG, M16>, (int)lds, "conv3x3_halo_bf16"));
-    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG, M16>), grid, block, lds, st, a, tx, ty, nt);
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG, M16, BNS>, (int)lds, "conv3x3_halo_bf16"));
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG, M16, BNS>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;
 }
@@ -826,6 +853,12 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
             // the smaller tiles); bit 21 (2097152): none.
             {
                 const bool m16 = !(g_debug_flags & 8) && !(g_debug_flags & 2097152) && ((g_debug_flags & 32768) || (!xf && MI == 4 && NT == 1));
+                if constexpr (MI == 4 && NT == 1 && BN == 128) {      // (halo_bnsum_supported admits these two tiles only)
+                    if (a.bny) {
+                        USTRUN_CHECK(m16 && !xf && a.stat && a.bnsc && a.bnsh, "conv3x3_halo: BatchNorm-backward sums need a plain source on the 16x16x32 build");
+                        return launch_xf<TH, TW, BN, BK, MI, POOL, NT, false, 1, true, true, true>(a, st);
+                    }
+                }
                 if (m16 && !xf)      // (the transforming variants on it sit 160 registers past the file: not built)
                     return launch_xf<TH, TW, BN, BK, MI, POOL, NT, false, 1, true, true>(a, st);
             }
@@ -863,6 +896,17 @@ bool halo_supported(const IgemmArgs& a) {
     if (a.Hb < 4 || a.Wb < 8) return false;      // tiny extents: the generic kernel wastes less
     if (dil > 1 && (pool || a.nsrc != 1)) return false;
     return true;
+}
+
+int halo_tile128(const IgemmArgs& a);
+// can this input-gradient launch also form the BatchNorm-backward sums of the layer whose da it writes?  (one plain source, one
+// destination, the two 256-pixel x 128-channel tiles on the 16x16x32 build)
+bool halo_bnsum_supported(const IgemmArgs& a) {
+    if (!halo_supported(a) || halo_dilation(a) != 1 || a.nsrc != 1 || a.out1 || a.C0 != a.Cout || a.Cout % 128) return false;
+    if (a.src[0].scale || a.src[0].relu || a.src[0].pool) return false;
+    if ((g_debug_flags & (8 | 2097152))) return false;
+    const int t = halo_tile128(a);
+    return t == 0 || t == 1;
 }
 
 // 16-row tiles (256 px x 128 ch per block) read fewer LDS/weight bytes per flop but need >= 2 blocks per CU

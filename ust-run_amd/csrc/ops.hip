@@ -266,6 +266,39 @@ extern "C" int ustrun_conv3x3_dgrad(const void* dy, const void* w_dgrad, int N, 
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
 
+/* the same input gradient, single destination, which ALSO forms the BatchNorm-backward sums of the layer whose da it writes:
+ * y = that layer's pre-BatchNorm output [N,H,W,Cin] (the layout of da), aff = its scale / shift (ustrun_src_t conventions for
+ * batched passes: gN images per pass, gstride floats between the passes' constants); stat receives *stat_rows rows of
+ * [2][Cin] = {sum(da mask), sum(da mask y)} per row, mask = y scale + shift > 0, over the stored da values.  *stat_rows = 0 and
+ * NO launch when this shape is not one the fused epilogue covers (the caller then runs the plain input gradient and
+ * ustrun_bn_bwd_reduce). */
+extern "C" int ustrun_conv3x3_dgrad_bnsum(const void* dy, const void* w_dgrad, int N, int H, int W, int Cout, int Cin, void* da,
+                                          const void* y, const float* scale, const float* shift, int gN, int64_t gstride,
+                                          float* stat, int* stat_rows, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(dy && w_dgrad && da && y && scale && shift && stat && stat_rows && N > 0 && H > 0 && W > 0 && Cout > 0 && Cin > 0,
+                 "conv3x3_dgrad_bnsum: bad args");
+    *stat_rows = 0;
+    if (dtype != USTRUN_D16) return 0;
+    IgemmArgs a = {};
+    ustrun_src_t sd = {};
+    sd.ptr = dy; sd.C = Cout; sd.H = H; sd.W = W;
+    sd.sC = 1; sd.sW = Cout; sd.sH = (int64_t)W * Cout; sd.sN = (int64_t)H * W * Cout;
+    a.nsrc = 1; a.src[0] = make_src(sd, dtype); a.Cin = Cout;
+    a.W = (const float*)w_dgrad; a.Cout = Cin;
+    a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
+    a.s_in = 1; a.nseg = 9; a.segw = 3; a.d0 = 1; a.dstep = -1;
+    a.nz = 1; a.s_out = 1;
+    a.out0 = (float*)da; a.C0 = Cin; a.Ho = H; a.Wo = W; a.out_esz = 2;
+    if (ws64_supported(a) && !(g_debug_flags & 1)) return 0;          // (the 64 -> 64 layers run the streaming kernel)
+    if (!halo_bnsum_supported(a)) return 0;
+    a.bny = y; a.bnsc = scale; a.bnsh = shift; a.bn_gN = gN; a.bn_gstride = (long)gstride; a.stat = stat;
+    const int used = halo_stat_rows_used(a);
+    USTRUN_TRY(check_stat_rows(used, N, H, W, Cin, "conv3x3_dgrad_bnsum"));
+    USTRUN_TRY(igemm_launch(a, dtype, (hipStream_t)s));          // (profiled with the conv class; dispatches to the halo kernel)
+    *stat_rows = used;
+    return 0;
+}
+
 extern "C" int ustrun_convT2x2_fwd(const ustrun_src_t* src, const void* w_fwd, const float* bias, int N, int H, int W,
                                    int Cout, void* u, int dtype, ustrun_stream_t s) {
     USTRUN_TRY(check_srcs(src, 1, "convT2x2_fwd"));

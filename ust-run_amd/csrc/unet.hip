@@ -352,6 +352,7 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
     // layers 17..10 = decoder, 9..8 = down4 (57 of the encoder's 75 MB of gradients, and the first to finish), 7..0 = the rest
     const int i_hi = which <= 1 ? 17 : (which == 4 ? 7 : 9);
     const int i_lo = which == 1 ? 10 : (which == 3 ? 8 : 0);
+    int dgrad_bn_rows = 0;      // > 0: the input gradient that wrote this layer's da also formed its BatchNorm-backward sums (rows in `part`)
     for (int i = i_hi; i >= i_lo; --i) {
         if (i == ((g_debug_flags >> 16) & 31) - 1) return 0;      // debugging aid (ustrun_debug_flags bits 16-20 = layer + 1): stop before this layer
 
@@ -369,6 +370,10 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
                 USTRUN_TRY(bn_bwd_finalize_rows(part, head_bn_rows, row, (long)p.K * C + p.K, C, (int64_t)p.gN * H * W, d->bn_w[i],
                                                 aff + 2 * C, aff + 3 * C, grads[gi + 1], grads[gi + 2], accumulate, coef, p.G,
                                                 4L * C, (hipStream_t)s));
+            } else if (dgrad_bn_rows > 0) {         // ... or with the rows the producing input gradient wrote (below)
+                USTRUN_CHECK(dgrad_bn_rows % p.G == 0, "unet_backward: %d sum rows do not split into %d passes", dgrad_bn_rows, p.G);
+                USTRUN_TRY(bn_bwd_finalize_stat(part, dgrad_bn_rows / p.G, p.G, C, (int64_t)p.gN * H * W, d->bn_w[i], aff + 2 * C,
+                                                aff + 3 * C, 4L * C, grads[gi + 1], grads[gi + 2], accumulate, coef, (hipStream_t)s));
             } else
             USTRUN_TRY(bn_bwd_reduce_passes(da, dp, ws + p.y_off[i], aff, aff + C, aff + 2 * C, aff + 3 * C, d->bn_w[i], p.gN, H, W,
                                             C, grads[gi + 1], grads[gi + 2], accumulate, coef, part, p.part_bytes, dt, p.G, act,
@@ -376,6 +381,7 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             USTRUN_TRY(bn_bwd_apply_passes(da, dp, ws + p.y_off[i], aff, aff + C, coef, p.gN, H, W, C, da, dt, p.G, act, pl,
                                            4L * C, (hipStream_t)s));
         }
+        dgrad_bn_rows = 0;
         ustrun_src_t srcs[2];
         const int ns = conv_sources(p, x, ws, i, srcs);
         prof_set_tag(200 + i, p.N);
@@ -404,8 +410,17 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             USTRUN_TRY(ustrun_convT2x2_dgrad(sc + p.du_off[j], pk + p.ud_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
                                              p.up_cin[j], sc + p.da_off[prev], dt, s));
         } else {                               // second conv of a DoubleConv
-            USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, p.cin[i], sc + p.da_off[i - 1], p.cin[i], nullptr, 0, 0, 0,
-                                            0, dt, s));
+            // its input gradient IS da of the BatchNorm + ReLU between the two convolutions: where the halo kernel's fused epilogue
+            // covers the shape (16-bit storage, >= 128 channels, the 256-pixel tiles; ustrun_debug_flags bit 25: never) the launch
+            // also forms that layer's backward sums -- rows in `part`, which nobody touches before the next iteration reads them
+            const float* pa = affp(i - 1);
+            const int Cp = p.cin[i];
+            const long need = (long)ustrun_conv_mtiles(p.N, H, W, Cp) * 2 * Cp * 4;
+            if (!(g_debug_flags & (1 << 25)) && i - 1 >= i_lo && need <= p.part_bytes)
+                USTRUN_TRY(ustrun_conv3x3_dgrad_bnsum(da, wd, p.N, H, W, C, Cp, sc + p.da_off[i - 1], ws + p.y_off[i - 1], pa, pa + Cp,
+                                                      p.G > 1 ? p.gN : 0, 4L * Cp, part, &dgrad_bn_rows, dt, s));
+            if (dgrad_bn_rows == 0)
+                USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, Cp, sc + p.da_off[i - 1], Cp, nullptr, 0, 0, 0, 0, dt, s));
         }
     }
     return 0;
