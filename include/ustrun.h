@@ -169,6 +169,12 @@ int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const void* dy, int
 /* ---- ConvTranspose2d backward --------------------------------------------------------------- */
 int ustrun_convT2x2_dgrad(const void* du, const void* w_dgrad, int N, int H, int W, int Cout, int Cin,
                           void* da, int dtype, ustrun_stream_t s);
+/* the same, also forming the BatchNorm-backward sums of the layer whose da it writes -- the conv2 under this ConvTranspose
+ * (unet_parts.py:56-68 backward into unet_parts.py:17-21): arguments and rows as ustrun_conv3x3_dgrad_bnsum, one row per 128
+ * pixels; *stat_rows = 0 and no launch on a shape the fused epilogue does not cover                                       */
+int ustrun_convT2x2_dgrad_bnsum(const void* du, const void* w_dgrad, int N, int H, int W, int Cout, int Cin, void* da,
+                                const void* y, const float* scale, const float* shift, int gN, int64_t gstride,
+                                float* stat, int* stat_rows, int dtype, ustrun_stream_t s);
 int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, int N, int H, int W, int Cout,
                           float* dw, float* db, int accumulate, float* partials, int64_t partials_bytes,
                           int dtype, ustrun_stream_t s);

@@ -444,3 +444,59 @@ def test_input_gradient_with_batchnorm_backward_sums_exact(name, n, G, cin, cout
         out[kind] = (dg.cpu(), db.cpu(), coef.cpu())
     for a_, b_ in zip(out["rows"], out["pass"]):
         np.testing.assert_allclose(a_.numpy(), b_.numpy(), rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,n,G,cin,cout,h,w,code", [
+    ("up4_like", 8, 2, 128, 64, 64, 64, 0x43541000 | (128 // 32) << 8 | 2 << 4 | 1),      # da [.,64,64,128]: the 128-column build
+    ("up1_like", 64, 4, 1024, 512, 16, 16, 0x43541000 | (256 // 32) << 8 | 2 << 4 | 1),   # N = 64: 512 blocks of 256 columns
+    ("ragged_m", 3, 1, 256, 128, 20, 24, 0x43541000 | (128 // 32) << 8 | 2 << 4 | 1),     # M = 1440: a last tile of 32 pixels
+    ("pass_straddles_tile", 6, 2, 128, 64, 10, 12, None),                                 # 3 x 120 pixels per pass: not covered, no launch
+])
+def test_convT_input_gradient_with_batchnorm_backward_sums_exact(name, n, G, cin, cout, h, w, code):
+    """ustrun_convT2x2_dgrad_bnsum: the ConvTranspose's input gradient IS da of the conv2 one level down (unet_parts.py:56-68 into
+    17-21); its epilogue forms that layer's BatchNorm-backward sums from the stored pieces and y, one row per 128-pixel tile.
+    Integer data: da bitwise equal to the plain input gradient, per-pass column sums equal to torch's, no write outside the rows."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(len(name) * 23 + n)
+    ri = lambda lo, hi, *s: torch.randint(lo, hi + 1, s, generator=g).float()
+    gn = n // G
+    wt = ri(-1, 1, cin, cout, 2, 2)          # ConvTranspose2d(cin, cout, 2, 2): u = convT(a); da = conv2d(du, wt, stride 2)
+    du = ri(-1, 1, n, cout, 2 * h, 2 * w)
+    y = ri(-3, 3, n, cin, h, w) * 0.5
+    sc = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (G, cin), generator=g)]
+    sh = ri(-1, 1, G, cin) * 0.25
+    sh[sh == 0] = 0.25
+    aff = torch.zeros(G, 4, cin)
+    aff[:, 0], aff[:, 1] = sc, sh
+    da_ref = F.conv2d(du, wt, None, 2)
+    assert float(da_ref.abs().max()) < 256
+    nel = 4 * cin * cout
+    wf, wd = torch.zeros(nel, dtype=E.t, device="cuda"), torch.zeros(nel, dtype=E.t, device="cuda")
+    wg = wt.cuda()
+    l.check(lib.ustrun_pack_convT2x2(wg.data_ptr(), cin, cout, wf.data_ptr(), wd.data_ptr(), E.code, None))
+    dug, yg, affg = nhwc16(du), nhwc16(y), aff.cuda()
+    ZO = 8192
+    dbuf = torch.full((ZO + n * h * w * cin + ZO,), 9.0, device="cuda", dtype=E.t)
+    da = dbuf[ZO:ZO + n * h * w * cin].view(n, h, w, cin)
+    rows_max = lib.ustrun_conv_mtiles(n, h, w, cin)
+    stat = torch.full((rows_max + 64, 2, cin), 5.0, device="cuda")
+    rows = C.c_int(-1)
+    l.check(lib.ustrun_convT2x2_dgrad_bnsum(dug.data_ptr(), wd.data_ptr(), n, h, w, cout, cin, da.data_ptr(), yg.data_ptr(), affg.data_ptr(),
+                                            affg.data_ptr() + 4 * cin, gn if G > 1 else 0, 4 * cin, stat.data_ptr(), C.byref(rows), E.code, None),
+            "convT_dgrad_bnsum")
+    if code is None:
+        assert rows.value == 0 and bool((dbuf == 9.0).all()) and bool((stat == 5.0).all())
+        return
+    assert rows.value == (n * h * w + 127) // 128 and rows.value <= rows_max
+    assert lib.ustrun_debug_last_conv_variant() == code, hex(lib.ustrun_debug_last_conv_variant())
+    plain = torch.empty(n, h, w, cin, device="cuda", dtype=E.t)
+    l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, cout, cin, plain.data_ptr(), E.code, None), "convT_dgrad")
+    assert torch.equal(da, plain) and rel(from_nhwc(da.float()), da_ref) < 1e-6
+    assert bool((dbuf[:ZO] == 9.0).all()) and bool((dbuf[-ZO:] == 9.0).all()) and bool((stat[rows.value:] == 5.0).all())
+    scn, shn = sc.repeat_interleave(gn, 0)[:, :, None, None], sh.repeat_interleave(gn, 0)[:, :, None, None]
+    dz = torch.where(y * scn + shn > 0, da_ref, torch.zeros(()))
+    assert rows.value % G == 0
+    st = stat[:rows.value].view(G, rows.value // G, 2, cin).double().sum(1).cpu()
+    assert torch.equal(st[:, 0], dz.double().view(G, gn, cin, h, w).sum((1, 3, 4)))
+    assert torch.equal(st[:, 1], (dz * y).double().view(G, gn, cin, h, w).sum((1, 3, 4)))

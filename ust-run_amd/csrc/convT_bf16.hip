@@ -40,9 +40,10 @@ __device__ __forceinline__ int fastmod(int v, int d, float inv) {      // v mod 
 // fragments of its 64 columns straight from L2 into registers one stage (two k-steps = 4 MI MFMAs) ahead -- no weight
 // tile in LDS, no LDS-DMA beside the compiler-visible activation loads (which made hipcc drain vmcnt(0) at every chunk) -- and the
 // waves share only the activation tile: one barrier per 64-channel chunk.
-template <int BN, int BK, int MODE, bool BREG>
+template <int BN, int BK, int MODE, bool BREG, bool BNS = false>
 __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, const int mt_total, const int nt_total) {
     constexpr bool DG = MODE == 1, PLAIN = MODE == 2;
+    static_assert(!BNS || DG, "BatchNorm-backward sums ride on the input gradient's epilogue");
     static_assert(!BREG || BK == 64, "register-fed weights: two stages of two k-steps per chunk");
     constexpr int BM = 128;
     constexpr int WN = BN / 64, WM = 4 / WN, MI = BM / (32 * WM);
@@ -313,6 +314,20 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     typedef __attribute__((ext_vector_type(4))) elt_t bf16x4;
     // this lane's pieces of a sub-tile: pixel rows r0 + 8 t (t = 0..3), channel group ch -- x advances by 8 per piece
     const int r0 = lane >> 3, ch = lane & 7;
+    // BNS (round 4): da written here is the gradient at a BatchNorm + ReLU layer's output (the conv2 under this ConvTranspose); its
+    // backward sums sum(da mask), sum(da mask y) are formed from the stored pieces and the 16 bytes of y beside each, as one
+    // statistics row per 128-pixel tile (the tile lies inside one pass: the launcher checks) -- conv_halo_bf16.hip, same idea
+    float bsc[8], bsh[8];
+    __amdgpu_buffer_rsrc_t yrs = ors;
+    if constexpr (BNS) {
+        const long go = a.bn_gN > 0 ? (long)(m0 / (a.bn_gN * a.Hb * a.Wb)) * a.bn_gstride : 0;
+        const float* ps = a.bnsc + go + colw + ch * 8;
+        const float* pb = a.bnsh + go + colw + ch * 8;
+        const f32x4 s0 = *(const f32x4*)ps, s1_ = *(const f32x4*)(ps + 4), b0 = *(const f32x4*)pb, b1 = *(const f32x4*)(pb + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { bsc[q] = s0[q]; bsc[4 + q] = s1_[q]; bsh[q] = b0[q]; bsh[4 + q] = b1[q]; }
+        yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((elt_t*)a.bny + o_base), 0, (int)(o_left < 0x7fffffffL ? o_left : 0x7fffffffL), 0x00020000);
+    }
     __syncthreads();                              // every wave is done with the activation tiles the scratch aliases
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -338,6 +353,15 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
             const bool ok = m0 + d < a.M;
             const int vo = (DG || PLAIN) ? (d * a.Cout + ch * 8) * 2 : ((4 * d - 2 * x + 2 * W) * a.Cout + ch * 8) * 2;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v8), ors, ok ? vo : OOBV, 0, 0);
+            if constexpr (BNS) {
+                const bf16x8 y8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(yrs, ok ? vo : OOBV, 0, 0));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float yf = (float)y8[q];
+                    const float dz = (ok && yf * bsc[q] + bsh[q] > 0.f) ? (float)v8[q] : 0.f;
+                    st1[q] += dz; st2[q] += dz * yf;
+                }
+            }
             if constexpr (PLAIN) {                  // statistics see the stored values; rows past M are not counted
                 if (a.stat) {
 #pragma unroll
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if constexpr (PLAIN) {
+    if constexpr (PLAIN || BNS) {
         if (a.stat) {       // fixed order: the lanes that hold the same channels (lane & 7), then the WM waves that share these columns
             __syncthreads();
             float* red = (float*)smem;            // [WM][2][BN]
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     }
 }
 
-template <int BN, int BK, int MODE, bool BREG = false>
+template <int BN, int BK, int MODE, bool BREG = false, bool BNS = false>
 int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const int ncols = MODE == 0 ? 4 * a.Cout : a.Cout;
     const int mt = cdiv(a.M, 128), nt = ncols / BN;
@@ -386,7 +410,7 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const size_t lds = BREG ? (lds_a > lds_ep ? lds_a : lds_ep) : lds_a + 2 * (size_t)(BK / 8) * BN * 16;
     dim3 grid(mt * nt), block(256);
     set_last_variant(0x43540000 | (BREG ? 0x1000 : 0) | (BN / 32) << 8 | (BK / 32) << 4 | MODE);   // 'CT' | register-fed weights | BN/32 | BK/32 | MODE (tests)
-    hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, MODE, BREG>), grid, block, lds, st, a, mt, nt);
+    hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, MODE, BREG, BNS>), grid, block, lds, st, a, mt, nt);
     USTRUN_LAUNCH_CHECK("convT_bf16");
     return 0;
 }
@@ -417,7 +441,7 @@ bool convT_fwd_supported(const IgemmArgs& a) {
 }
 // ConvTranspose input-gradient as built by ustrun_convT2x2_dgrad (4 segments reading du at stride 2)
 bool convT_dgrad_supported(const IgemmArgs& a) {
-    if (a.nz != 1 || a.nseg != 4 || a.segw != 2 || a.s_in != 2 || a.s_out != 1 || a.stat || a.bias) return false;
+    if (a.nz != 1 || a.nseg != 4 || a.segw != 2 || a.s_in != 2 || a.s_out != 1 || (a.stat && !a.bny) || a.bias) return false;
     if (!common_ok(a)) return false;
     const SrcDev& s = a.src[0];
     if (s.scale || s.relu || s.H != 2 * a.Hb || s.W != 2 * a.Wb) return false;
@@ -444,7 +468,18 @@ int conv1x1_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     if (a.Cout % 128 == 0) return old ? launch_cfg<128, 64, 2>(a, st) : launch_cfg<128, 64, 2, true>(a, st);
     return old ? launch_cfg<64, 64, 2>(a, st) : launch_cfg<64, 64, 2, true>(a, st);
 }
+// the input gradient that also forms the BatchNorm-backward sums of the layer whose da it writes (a.bny set): one statistics row per
+// 128-pixel tile; the register-fed builds only, tiles inside one pass
+bool convT_dgrad_bnsum_supported(const IgemmArgs& a) {
+    if (!convT_dgrad_supported(a) || (g_debug_flags & 512)) return false;
+    return a.bn_gN == 0 || ((long)a.bn_gN * a.Hb * a.Wb) % 128 == 0;
+}
 int convT_dgrad_launch_bf16(const IgemmArgs& a, hipStream_t st) {
+    if (a.bny) {
+        USTRUN_CHECK(a.stat && a.bnsc && a.bnsh && convT_dgrad_bnsum_supported(a), "convT_dgrad: BatchNorm-backward sums on an unsupported shape");
+        if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 512) return launch_cfg<256, 64, 1, true, true>(a, st);
+        return launch_cfg<128, 64, 1, true, true>(a, st);
+    }
     const bool old = g_debug_flags & 512;
     if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 512) return old ? launch_cfg<256, 32, 1>(a, st) : launch_cfg<256, 64, 1, true>(a, st);
     return old ? launch_cfg<128, 64, 1>(a, st) : launch_cfg<128, 64, 1, true>(a, st);

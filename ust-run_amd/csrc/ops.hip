@@ -344,6 +344,34 @@ extern "C" int ustrun_convT2x2_dgrad(const void* du, const void* w_dgrad, int N,
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
 
+/* ... and with the BatchNorm-backward sums of the layer whose da it writes (ustrun_conv3x3_dgrad_bnsum's contract; one row per 128
+ * pixels) */
+extern "C" int ustrun_convT2x2_dgrad_bnsum(const void* du, const void* w_dgrad, int N, int H, int W, int Cout, int Cin, void* da,
+                                           const void* y, const float* scale, const float* shift, int gN, int64_t gstride,
+                                           float* stat, int* stat_rows, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(du && w_dgrad && da && y && scale && shift && stat && stat_rows && N > 0 && H > 0 && W > 0 && Cout > 0 && Cin > 0,
+                 "convT2x2_dgrad_bnsum: bad args");
+    *stat_rows = 0;
+    if (dtype != USTRUN_D16) return 0;
+    IgemmArgs a = {};
+    ustrun_src_t sd = {};
+    sd.ptr = du; sd.C = Cout; sd.H = 2 * H; sd.W = 2 * W;
+    sd.sC = 1; sd.sW = Cout; sd.sH = (int64_t)2 * W * Cout; sd.sN = (int64_t)4 * H * W * Cout;
+    a.nsrc = 1; a.src[0] = make_src(sd, dtype); a.Cin = Cout;
+    a.W = (const float*)w_dgrad; a.Cout = Cin;
+    a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
+    a.s_in = 2; a.nseg = 4; a.segw = 2; a.d0 = 0; a.dstep = 1;
+    a.nz = 1; a.s_out = 1;
+    a.out0 = (float*)da; a.C0 = Cin; a.Ho = H; a.Wo = W; a.out_esz = 2;
+    a.bny = y; a.bnsc = scale; a.bnsh = shift; a.bn_gN = gN; a.bn_gstride = (long)gstride; a.stat = stat;
+    if (!convT_dgrad_bnsum_supported(a)) return 0;
+    const int used = cdiv(a.M, 128);
+    USTRUN_TRY(check_stat_rows(used, N, H, W, Cin, "convT2x2_dgrad_bnsum"));
+    USTRUN_TRY(igemm_launch(a, dtype, (hipStream_t)s));
+    *stat_rows = used;
+    return 0;
+}
+
 extern "C" int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int64_t npix) {
     int ks, slabs; long chunk;
     wgrad_plan(nseg, Cin, Cout, npix, &ks, &chunk, &slabs);

@@ -407,6 +407,15 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             USTRUN_TRY(ustrun_convT2x2_wgrad(&a, sc + p.du_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], grads[ub],
                                              grads[ub + 1], accumulate, part, p.part_bytes, dt, s));
             prof_set_tag(120 + j, p.N);
+            // (da of the conv2 one level down: its BatchNorm-backward sums ride along where the layer is handled by this same call)
+            const float* pa = affp(prev);
+            const int Cp = p.up_cin[j];
+            if (!(g_debug_flags & (1 << 25)) && prev >= i_lo &&
+                (long)ustrun_conv_mtiles(p.N, p.Hs[l + 1], p.Ws[l + 1], Cp) * 2 * Cp * 4 <= p.part_bytes)
+                USTRUN_TRY(ustrun_convT2x2_dgrad_bnsum(sc + p.du_off[j], pk + p.ud_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], Cp,
+                                                       sc + p.da_off[prev], ws + p.y_off[prev], pa, pa + Cp, p.G > 1 ? p.gN : 0, 4L * Cp,
+                                                       part, &dgrad_bn_rows, dt, s));
+            if (dgrad_bn_rows == 0)
             USTRUN_TRY(ustrun_convT2x2_dgrad(sc + p.du_off[j], pk + p.ud_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
                                              p.up_cin[j], sc + p.da_off[prev], dt, s));
         } else {                               // second conv of a DoubleConv

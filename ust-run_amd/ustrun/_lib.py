@@ -63,6 +63,7 @@ SIGNATURES = {
     "ustrun_conv3x3_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "ustrun_conv3x3_dgrad_bnsum": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, fp, fp, i32, i64, fp, C.POINTER(i32), i32, vp]),
     "ustrun_bn_bwd_finalize_stat": (i32, [fp, i32, i32, i32, i64, fp, fp, fp, i64, fp, fp, i32, fp, vp]),
+    "ustrun_convT2x2_dgrad_bnsum": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, fp, fp, i32, i64, fp, C.POINTER(i32), i32, vp]),
     "ustrun_wgrad_partials_bytes": (i64, [i32, i32, i32, i64]),
     "ustrun_conv3x3_wgrad": (i32, [PSrc, i32, vp, i32, i32, i32, i32, fp, i32, fp, i64, i32, vp]),
     "ustrun_convT2x2_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
