@@ -376,6 +376,10 @@ def test_wgrad_all_taps_builds_exact(case):
     ("narrow_512_ragged", 16, 1, 512, 512, 56, 24, (16, 16, 128, 4, 1, "m16")),   # 16 x 16 tiles, ragged right / bottom edges
     ("bottleneck", 64, 4, 1024, 512, 16, 16, (16, 16, 128, 4, 1, "m16")),     # N = 64, four passes, 512 -> 1024 channels back
     ("too_small", 2, 1, 128, 128, 32, 32, None),                                # a grid the fused epilogue does not cover: rows = 0, no launch
+    # the 64 -> 64 streaming kernel (consumer / producer build; the sums ride on the producers' stores): two passes; then four
+    # passes on a ragged map (9 row-steps in segments, 2.5 strips of 32 px)
+    ("ws64_n8_128", 8, 2, 64, 64, 128, 128, "ws"),
+    ("ws64_ragged", 16, 4, 64, 64, 72, 80, "ws"),
 ])
 def test_input_gradient_with_batchnorm_backward_sums_exact(name, n, G, cin, cout, h, w, tile):
     """ustrun_conv3x3_dgrad_bnsum (round 4): the input gradient of a DoubleConv's second convolution IS da of the BatchNorm + ReLU
@@ -415,7 +419,10 @@ def test_input_gradient_with_batchnorm_backward_sums_exact(name, n, G, cin, cout
         assert rows.value == 0 and bool((dbuf == 9.0).all()) and bool((stat == 5.0).all()), "an unsupported shape must not launch"
         return
     assert rows.value > 0 and rows.value % G == 0 and rows.value <= rows_max
-    assert lib.ustrun_debug_last_conv_variant() == variant(*tile, False, False), vstr(lib.ustrun_debug_last_conv_variant())
+    if tile == "ws":
+        assert lib.ustrun_debug_last_conv_variant() == 0x57530600, hex(lib.ustrun_debug_last_conv_variant())
+    else:
+        assert lib.ustrun_debug_last_conv_variant() == variant(*tile, False, False), vstr(lib.ustrun_debug_last_conv_variant())
     plain = torch.empty(n, h, w, cin, device="cuda", dtype=E.t)
     l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, cout, cin, plain.data_ptr(), cin, None, 0, 0, 0, 0, E.code, None), "dgrad")
     assert torch.equal(da, plain) and rel(from_nhwc(da.float()), da_ref) < 1e-6

@@ -720,8 +720,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64x8_kernel(const IgemmArgs 
 // statistics rows as the four-wave kernel: results are bit-identical to it.
 constexpr int LDSBCP = RINGB + 4 * EWAVE + DUMMYB;
 
-template <bool XF, bool STAT, bool DIAG = false>
+// BNS (round 4): the launch is the input gradient that writes da of a BatchNorm + ReLU layer (inc.conv1 / up4.conv1 under their second
+// convolution); the producers, which store the parked rows anyway, also form that layer's backward sums sum(da mask) and
+// sum(da mask y) in place of the forward statistics (same rows, same flush).  The 16 bytes of y beside each stored piece are
+// fetched like the input rows: one buffer load per piece, issued right after the piece of the PREVIOUS step was consumed, i.e. half
+// an iteration (~2 us) or more before its use -- eight pieces (32 registers) in flight per producer lane.
+template <bool XF, bool STAT, bool DIAG = false, bool BNS = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs a, const WsPlan p) {
+    static_assert(!BNS || (!XF && !STAT), "BatchNorm-backward sums: plain source, no forward statistics");
     unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dt0 = 0, dt1 = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
@@ -903,6 +909,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    // BNS: y pieces in flight ([0..3]: half 1 of the step stored first in an iteration, [4..7]: half 0 of the next), the layer's
+    // constants for the lane's 8 channels under the two cursors an iteration stores for
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(BNS ? a.bny : a.out0), 0, (int)min((long)a.N * H * W * 128, 0x7fffffffL), 0x00020000);
+    u32x4 ypre[8];
+    float bsc[2][8], bsh[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ypre[i] = (u32x4){0u, 0u, 0u, 0u};
+    auto bns_consts = [&](const Cur& c, int set) __attribute__((always_inline)) {
+        if constexpr (BNS) {
+            int grp = 0;
+            if (a.bn_gN > 0) {
+#pragma unroll
+                for (int q = 1; q < 8; ++q) grp += (c.img >= q * a.bn_gN) ? 1 : 0;      // (passes <= 8: the launcher checks; no division here)
+            }
+            const float* ps = a.bnsc + (long)grp * a.bn_gstride + 32 * wn + 8 * o;
+            const float* pb = a.bnsh + (long)grp * a.bn_gstride + 32 * wn + 8 * o;
+            const f32x4 x0 = *(const f32x4*)ps, x1 = *(const f32x4*)(ps + 4), b0 = *(const f32x4*)pb, b1 = *(const f32x4*)(pb + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bsc[set][e] = x0[e]; bsc[set][4 + e] = x1[e]; bsh[set][e] = b0[e]; bsh[set][4 + e] = b1[e]; }
+        }
+    };
     unsigned offL[NR], okmL = 0;
     unsigned xokm = 0;
     int xok_x0 = -(1 << 20);
@@ -944,7 +971,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
         }
     };
     // the parked rows of a half -> global (16 px x 64 B per store instruction) + statistics of the stored values
-    auto epi_B = [&](int HF, int tt, const Cur& c, bool live) __attribute__((always_inline)) {
+    // byte offset of piece tt of half HF of cursor c's step in the output (and in y: same layout); bit 31 set outside the image
+    auto piece_off = [&](int HF, int tt, const Cur& c, bool live) __attribute__((always_inline)) {
+        const int i = 2 * HF + (tt >> 1), px = 16 * (tt & 1) + pp;
+        const int y = c.ybeg + 8 * (c.k - 1) + 4 * wm + i;
+        const int ylim = min(c.ybeg + p.seg, H);
+        const bool inimg = live & (y < ylim) & (c.x0 + px < W);
+        return inimg ? (unsigned)(st_lane + (tt & 1) * 2048 + __builtin_amdgcn_readfirstlane(c.img * out_bytes + (y * W + c.x0) * 128)) : 0x80000000u;
+    };
+    auto epi_B = [&](int HF, int tt, const Cur& c, bool live, int set = 0) __attribute__((always_inline)) {
         const int i = 2 * HF + (tt >> 1), px = 16 * (tt & 1) + pp;
         const int y = c.ybeg + 8 * (c.k - 1) + 4 * wm + i;
         const int ylim = min(c.ybeg + p.seg, H);
@@ -953,6 +988,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
         // (row offset in the vector offset, soffset 0: see the four-wave kernel's epi_B)
         const unsigned voff = inimg ? (unsigned)(st_lane + (tt & 1) * 2048 + __builtin_amdgcn_readfirstlane(c.img * out_bytes + (y * W + c.x0) * 128)) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(u, ro, voff, 0, 0);
+        if constexpr (BNS) {         // (the y piece was fetched from the same offset one step ago: zeros outside the image, like u below)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = inimg ? u[e] : 0u;
+            const bf16x8 v = __builtin_bit_cast(bf16x8, u), y8 = __builtin_bit_cast(bf16x8, ypre[(HF ? 0 : 4) + tt]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float yf = (float)y8[e];
+                const float dz = fma_scalar(yf, bsc[set][e], bsh[set][e]) > 0.f ? (float)v[e] : 0.f;
+                s1[e] = add_scalar(s1[e], dz);
+                s2[e] = fma_scalar(dz, yf, s2[e]);
+            }
+        }
         if constexpr (STAT) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) u[e] = inimg ? u[e] : 0u;
@@ -966,7 +1013,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
         }
     };
     auto stat_flush = [&](const Cur& c) __attribute__((always_inline)) {
-        if constexpr (STAT) {
+        if constexpr (STAT || BNS) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -995,6 +1042,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
         // and the copies hipcc places at the loop's back edge wait vmcnt(0) -- for the row fetches just issued: ~2000 cycles per
         // iteration that no stamp inside the segments showed
         load_consts(cw);
+        bns_consts(cp, 0); bns_consts(cc, 1);
         char* wdst = ring + bW * BANKB + loff0;
         char* wd8 = tp < 128 ? wdst + 8 * (32 * PITCH) : smem + wd8_dummy;
         const Cur cn = advance(cl);
@@ -1007,8 +1055,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
         // ---- consumers' half 0: the owed stores of the previous step's half 1, then the staging of the next group ----
         if constexpr (DIAG) dt0 = stamp();
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) epi_B(1, tt, cp, pend);
+        for (int tt = 0; tt < 4; ++tt) epi_B(1, tt, cp, pend, 0);
         if (pend && cp.k == cp.S) stat_flush(cp);
+        if constexpr (BNS) {         // half 1 of THIS step is stored at the top of the next iteration (its cp = cc, its pend = live)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) ypre[tt] = __builtin_amdgcn_raw_buffer_load_b128(ry, piece_off(1, tt, cc, live), 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < NR; ++i) offsets_one(cl, i);
 #pragma unroll
@@ -1020,7 +1072,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
         if constexpr (DIAG) { dt1 = stamp(); dsum[1] += dt1 - dt0; dt0 = dt1; }
         // ---- consumers' half 1: the stores of half 0, the rest of the staging ----
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) epi_B(0, tt, cc, live);
+        for (int tt = 0; tt < 4; ++tt) epi_B(0, tt, cc, live, 1);
+        if constexpr (BNS) {         // half 0 of the NEXT step (its cc = cw) is stored in the next iteration's second half
+            const bool live_n = cw.valid && cw.k >= 1;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) ypre[4 + tt] = __builtin_amdgcn_raw_buffer_load_b128(ry, piece_off(0, tt, cw, live_n), 0, 0);
+        }
 #pragma unroll
         for (int i = 5; i < NR; ++i) stage(i);
         okmW = okmL;
@@ -1087,6 +1144,13 @@ bool ws64_supported(const IgemmArgs& a) {
 
 int ws64_stat_rows(const IgemmArgs& a) { return ws_plan(a).items * 2; }
 
+// can the streaming kernel's input gradient also form the BatchNorm-backward sums of the layer whose da it writes?
+bool ws64_bnsum_supported(const IgemmArgs& a) {
+    if (!ws64_supported(a) || a.src[0].scale || a.src[0].relu) return false;
+    if (g_debug_flags & (1 | 2 | 4 | 16)) return false;              // (another build of the kernel, or the tiled kernel, is forced)
+    return a.bn_gN == 0 || a.N <= 8 * a.bn_gN;                       // at most eight passes (the producers count them without a division)
+}
+
 int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     WsPlan p = ws_plan(a);
     const int grid = cdiv(p.items, p.ipb);
@@ -1112,6 +1176,14 @@ int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st) {
         if (xf) hipLaunchKernelGGL((conv3x3_ws64cp_kernel<true, true, true>), dim3(grid), dim3(512), LDSBCP, st, a, p);
         else hipLaunchKernelGGL((conv3x3_ws64cp_kernel<false, false, true>), dim3(grid), dim3(512), LDSBCP, st, a, p);
         USTRUN_LAUNCH_CHECK("conv3x3_ws64cp_bf16 (diag)");
+        return 0;
+    }
+    if (a.bny) {                  // input gradient + BatchNorm-backward sums: the consumer / producer build only (ws64_bnsum_supported)
+        USTRUN_CHECK(cpw && !p.dbg && !xf && a.stat && a.bnsc && a.bnsh, "conv3x3_ws64: BatchNorm-backward sums need the plain consumer / producer build");
+        set_last_variant(0x57530000 | 0x200 | 0x400);                 // 'WS' | consumer/producer | sums
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<false, false, false, true>, LDSBCP, "conv3x3_ws64cp_bf16"));
+        hipLaunchKernelGGL((conv3x3_ws64cp_kernel<false, false, false, true>), dim3(grid), dim3(512), LDSBCP, st, a, p);
+        USTRUN_LAUNCH_CHECK("conv3x3_ws64cp_bf16");
         return 0;
     }
     if (cpw && !p.dbg) {

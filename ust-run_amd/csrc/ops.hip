@@ -289,10 +289,11 @@ extern "C" int ustrun_conv3x3_dgrad_bnsum(const void* dy, const void* w_dgrad, i
     a.s_in = 1; a.nseg = 9; a.segw = 3; a.d0 = 1; a.dstep = -1;
     a.nz = 1; a.s_out = 1;
     a.out0 = (float*)da; a.C0 = Cin; a.Ho = H; a.Wo = W; a.out_esz = 2;
-    if (ws64_supported(a) && !(g_debug_flags & 1)) return 0;          // (the 64 -> 64 layers run the streaming kernel)
-    if (!halo_bnsum_supported(a)) return 0;
-    a.bny = y; a.bnsc = scale; a.bnsh = shift; a.bn_gN = gN; a.bn_gstride = (long)gstride; a.stat = stat;
-    const int used = halo_stat_rows_used(a);
+    a.bn_gN = gN; a.bn_gstride = (long)gstride;
+    const bool ws = ws64_supported(a) && !(g_debug_flags & 1);        // (the 64 -> 64 full-resolution layers run the streaming kernel)
+    if (ws ? !ws64_bnsum_supported(a) : !halo_bnsum_supported(a)) return 0;
+    a.bny = y; a.bnsc = scale; a.bnsh = shift; a.stat = stat;
+    const int used = ws ? ws64_stat_rows(a) : halo_stat_rows_used(a);
     USTRUN_TRY(check_stat_rows(used, N, H, W, Cin, "conv3x3_dgrad_bnsum"));
     USTRUN_TRY(igemm_launch(a, dtype, (hipStream_t)s));          // (profiled with the conv class; dispatches to the halo kernel)
     *stat_rows = used;
