@@ -1,6 +1,6 @@
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4d
+O=$R/gpurun_out/r4g
 mkdir -p $O
 cd $R
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err

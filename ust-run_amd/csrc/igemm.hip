@@ -301,7 +301,9 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     const double out_elems = (double)a.M * a.nz * a.Cout;
     const double w_elems = (double)a.nseg * a.nz * a.Cin * a.Cout;
     const double aesz = dtype == USTRUN_D16 ? 2.0 : 4.0;     // stored element size of activations and packed weights
-    prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, aesz * (in_elems + out_elems + w_elems), st);
+    // (an input gradient that also forms the BatchNorm-backward sums reads y beside every output element it stores)
+    const double y_elems = a.bny ? out_elems : 0.0;
+    prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, aesz * (in_elems + out_elems + y_elems + w_elems), st);
     int rc;
     bool grouped = false;
     for (int i = 0; i < a.nsrc; ++i) grouped |= a.src[i].gN > 0;
