@@ -1,4 +1,4 @@
-# same-box A/B of whole-step time under an environment variable: tools/_ab_env.sh VAR "v1 v2" [reps]
+# same-box A/B of whole-step time under an environment variable: tools/ab_env.sh VAR "v1 v2" [reps]
 set -e
 mkdir -p gpurun_out/ab
 for rep in $(seq 1 ${3:-2}); do

@@ -1,4 +1,4 @@
-# same-box A/B of two builds of the library: tools/_ab_lib.sh "libA.so libB.so" [reps]   (paths relative to ust-run_amd/ustrun/)
+# same-box A/B of two builds of the library: tools/ab_lib.sh "libA.so libB.so" [reps]   (paths relative to ust-run_amd/ustrun/)
 set -e
 mkdir -p gpurun_out/ab
 for rep in $(seq 1 ${2:-2}); do

@@ -1,4 +1,4 @@
-# same-box A/B of whole-step time under ustrun_debug_flags values: tools/_ab_step.sh "0 4194304 2097152" [reps]
+# same-box A/B of whole-step time under ustrun_debug_flags values: tools/ab_step.sh "0 4194304 2097152" [reps]
 set -e
 mkdir -p gpurun_out/ab
 for rep in $(seq 1 ${2:-2}); do

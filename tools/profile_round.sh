@@ -1,6 +1,8 @@
+# one GPU call: bench.py (full line), rocprofv3 --kernel-trace --stats, the two --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs), tools/pmc_hbm.py
+# -> gpurun_out/profile_round/{bench.json,kernel_stats.csv,pmc_hbm.csv,traffic_bf16.json}; copy what is to be judged into profiles/
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4g
+O=$R/gpurun_out/profile_round
 mkdir -p $O
 cd $R
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err

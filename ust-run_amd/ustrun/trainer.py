@@ -225,7 +225,7 @@ class SSLTrainer:
         # where the step issues it: "split" = between the decoder and encoder halves of the backward (it then runs under the
         # encoder's many-block kernels: 29.34-29.42 ms per step against 29.51-29.53 for "start" = right after the student
         # passes, under the head / up4 weight gradients whose one-block-per-CU grids wait for the CUs it takes; its whole cost is
-        # ~0.5 ms per step wherever it goes -- same-box runs of tools/_ab_env.sh, profiles/r04_ab_side_forward.log)
+        # ~0.5 ms per step wherever it goes -- same-box runs of tools/ab_env.sh, profiles/r04_ab_side_forward.log)
         self._side_at = os.environ.get("USTRUN_SIDE_AT", "split")
 
     # ---------------------------------------------------------------------------------------
