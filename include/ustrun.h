@@ -98,6 +98,10 @@ int ustrun_bn_relu_apply(const void* y, const float* scale, const float* shift, 
 /* materialise the Down block's pooled input: out[N,H/2,W/2,C] = MaxPool2d(2)(relu(src*scale+shift)) in the storage
  * dtype (replaces nn.MaxPool2d at unet_parts.py:34 together with the producer's BatchNorm+ReLU); src is a plain
  * contiguous NHWC activation, its pass groups are honoured                                                     */
+/* a[N,H,W,C] = relu(src*scale+shift) in the 16-bit storage dtype (src: plain contiguous NHWC with its BatchNorm constants, pass
+ * groups honoured): the input of a DoubleConv's second convolution (unet_parts.py:16-21) written out once, for the layers where
+ * that costs less than applying BatchNorm + ReLU per staged item in the convolution AND its weight gradient                */
+int ustrun_act16(const ustrun_src_t* src, int N, void* out, int dtype, ustrun_stream_t s);
 int ustrun_pool_act(const ustrun_src_t* src, int N, void* out, int dtype, ustrun_stream_t s);
 /* the same pass, also writing the un-pooled activation act[N,H,W,C] = relu(src*scale+shift) in the storage dtype (act may be
  * NULL: then exactly ustrun_pool_act): the encoder output that unet_model.py:33-36 hands to the decoder as the skip operand of
@@ -428,6 +432,8 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  *   between the threads that call them.
  * bit 25 (33554432): ustrun_unet_backward never asks an input gradient for the BatchNorm-backward sums of the layer it feeds
  *   (ustrun_conv3x3_dgrad_bnsum): every BatchNorm backward runs its reduce pass, as in rounds 1-3.
+ * bit 26 (67108864), ENVIRONMENT ONLY like bit 24: the second convolution of every DoubleConv reads its operand through
+ *   BatchNorm + ReLU on load (rounds 1-3) instead of the activation ustrun_act16 writes out on the levels from 256 channels.
  * bit 13 (8192): 64-output-channel 3x3 layers on >= 32-wide maps on the 16 x 32-pixel tile (one block per CU; A/B runs).
  * A caller that runs a forward and its backward on different threads sets the same value on both (the Python host does:
  * ustrun/engine.py hands the forward's flags to autograd's backward thread).

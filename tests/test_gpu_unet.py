@@ -452,18 +452,20 @@ np.savez(out, logits=a.detach().cpu().numpy(), **{"g_" + k: p.grad.cpu().numpy()
 """
 
 
-@pytest.mark.parametrize("dtype,n,hw,passes", [("bf16", 2, 64, 1), ("f16", 2, 96, 3)])
-def test_materialised_skip_operands_equal_activation_on_load(dtype, n, hw, passes, tmp_path):
+@pytest.mark.parametrize("dtype,n,hw,passes,bits", [("bf16", 2, 64, 1, 1 << 24), ("f16", 2, 96, 3, 1 << 24), ("bf16", 3, 64, 2, 1 << 26),
+                                                    ("f16", 2, 128, 1, (1 << 24) | (1 << 26))])
+def test_materialised_skip_operands_equal_activation_on_load(dtype, n, hw, passes, bits, tmp_path):
     """The decoder's skip operands are written out by the pool pass (ustrun_pool_act2) and the concat convolutions / their weight
     gradients read them as plain tensors; USTRUN_DEBUG_FLAGS bit 24 (environment only: the switch shapes the workspace) =
-    BatchNorm + ReLU applied per staged item on load, as in rounds 1-3.  Two processes, one per setting: the operand VALUES are
+    BatchNorm + ReLU applied per staged item on load, as in rounds 1-3.  Bit 26: the same for the operand of every DoubleConv's
+    second convolution on the levels from 256 channels (ustrun_act16).  Two processes, one per setting: the operand VALUES are
     the same 16-bit numbers either way and the consuming kernels may differ only in f32 summation order -- logits, running
     statistics and gradients agree to that noise (bit-identical at these sizes, where both settings pick the same tiles)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for flags in ("0", str(1 << 24)):
+    for flags in ("0", str(bits)):
         o = str(tmp_path / f"skip_{flags}.npz")
         env = dict(os.environ, USTRUN_DEBUG_FLAGS=flags)
         r = subprocess.run([sys.executable, "-c", _SKIP_AB, root, dtype, str(n), str(hw), str(passes), o], env=env, capture_output=True, text=True)

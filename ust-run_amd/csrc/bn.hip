@@ -274,6 +274,42 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ y, int esz, const
     }
 }
 
+// a = relu(y*scale+shift) in the 16-bit storage type, NHWC -> NHWC, per-pass constants: the operand of a DoubleConv's second
+// convolution written out once (8 channels = 16 bytes per lane, four pixels in flight per thread) where applying BatchNorm + ReLU
+// per staged item costs that convolution and its weight gradient more than this pass does (unet.hip: the levels from 256 channels)
+__global__ __launch_bounds__(256) void act16_kernel(const elt_t* __restrict__ y, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, int relu, int gN, long gstride,
+                                                    long npix, int HW, int C, elt_t* __restrict__ out) {
+    typedef __attribute__((ext_vector_type(8))) elt_t bf16x8v;
+    const int CV = C / 8, PPB = 256 / CV;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    if (pl >= PPB) return;
+    constexpr int U = 4;
+    const long stride = (long)gridDim.x * PPB;
+    for (long p0 = (long)blockIdx.x * PPB + pl; p0 < npix; p0 += U * stride) {
+        bf16x8v r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const long p = p0 + u * stride; r[u] = *(const bf16x8v*)(y + (p < npix ? p : npix - 1) * C + cv * 8); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long p = p0 + u * stride;
+            if (p >= npix) break;
+            const int grp = gN > 0 ? (int)((unsigned)((unsigned)p / (unsigned)HW) / (unsigned)gN) : 0;      // (pixels < 2^32: host check)
+            const float* ps = scale + grp * gstride + cv * 8;
+            const float* pb = shift + grp * gstride + cv * 8;
+            const f32x4 s0 = *(const f32x4*)ps, s1 = *(const f32x4*)(ps + 4), b0 = *(const f32x4*)pb, b1 = *(const f32x4*)(pb + 4);
+            bf16x8v o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = (float)r[u][j] * (j < 4 ? s0[j & 3] : s1[j & 3]) + (j < 4 ? b0[j & 3] : b1[j & 3]);
+                a = relu ? fmaxf(a, 0.f) : a;
+                o[j] = (elt_t)a;
+            }
+            *(bf16x8v*)(out + p * C + cv * 8) = o;
+        }
+    }
+}
+
 // pooled activation p[n][y][x][c] = max over the 2x2 window of relu(s*y + b): the Down block's MaxPool2d input,
 // materialised once (a quarter of y) so that the Down convolution and its weight gradient read a plain tensor by
 // LDS-DMA instead of pooling four pixels per staged item in an issue-bound kernel.  8 channels (ESZ = 2) or 4
@@ -885,6 +921,25 @@ extern "C" int ustrun_bn_relu_apply(const void* y, const float* scale, const flo
     hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)y, act_esz(dtype), scale,
                        shift, (long)npix, C, HW, out, out_nchw);
     USTRUN_LAUNCH_CHECK("bn_relu_apply");
+    return 0;
+}
+
+extern "C" int ustrun_act16(const ustrun_src_t* src, int N, void* out, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(dtype == USTRUN_D16, "act16: 16-bit storage only (dtype %d)", dtype);
+    USTRUN_CHECK(src && src->ptr && src->scale && src->shift && out && N > 0, "act16: bad args");
+    const int C = src->C, H = src->H, W = src->W;
+    USTRUN_CHECK(src->sC == 1 && src->sW == C && src->sH == (int64_t)W * C && src->sN == (int64_t)H * W * C && !src->pool &&
+                 !src->off_y && !src->off_x && !src->f32, "act16: source must be a plain contiguous NHWC activation");
+    USTRUN_CHECK(C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, "act16: C=%d unsupported", C);
+    const long npix = (long)N * H * W;
+    USTRUN_CHECK(npix < (1L << 32), "act16: %ld pixels", npix);
+    const int ppb = 256 / (C / 8);
+    long nb = (npix + ppb * 8 - 1) / (ppb * 8);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(act16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)s, (const elt_t*)src->ptr, src->scale, src->shift,
+                       src->relu, src->gN, (long)src->gstride, npix, H * W, C, (elt_t*)out);
+    USTRUN_LAUNCH_CHECK("act16");
     return 0;
 }
 

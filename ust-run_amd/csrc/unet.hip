@@ -25,6 +25,8 @@ struct Plan {
     long y_off[18], aff_off[18]; // aff: scale, shift, mean, rstd (4*cout)
     long u_off[4];
     long pool_off[4];            // pooled activation feeding Down l+1 (input of conv 2l+2), kept for its weight gradient
+    long act1_off[9];            // activation of conv 2k (the first of DoubleConv k) = the operand of conv 2k+1, written out by
+                                 // ustrun_act16 on the levels from 256 channels (-1: applied on load)
     long act_off[4];             // un-pooled activation of conv 2l+1 = the decoder's skip operand at level l (-1: read through
                                  // BatchNorm + ReLU on load instead: f32 storage, odd extents, or USTRUN_DEBUG_FLAGS bit 24)
     long stat_off, tick_off, fwd_total;
@@ -93,6 +95,15 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
         p.act_off[l] = on ? o : -1;
         if (on) o = align_up(o + p.y_elems(2 * l + 1) * E, 256) + gap();
     }
+    // ... and the operand of a DoubleConv's second convolution where a 4 B-per-element pass is cheaper than the transform it removes
+    // from that convolution (14-19 %) and from its weight gradient (the activation is 1800-2300 of the 3200-3500 cycles a wave group
+    // spends preparing a tile, 8.7): from 256 channels on (priced in DESIGN.md 9.13; 128 and 64 channels: the pass costs more)
+    for (int k = 0; k < 9; ++k) {
+        // (threshold measured on one box, 28.05-28.15 ms per step at 256: 128 -> 28.24, 64 -> 29.0, 512 -> 28.11)
+        const bool on = E == 2 && p.cout[2 * k] >= 256 && !(env_debug_flags() & (1 << 26));
+        p.act1_off[k] = on ? o : -1;
+        if (on) o = align_up(o + p.y_elems(2 * k) * E, 256) + gap();
+    }
     p.stat_off = o; o = align_up(o + stat_max * 4, 256);
     p.tick_off = o; o += 256;              // BN_TICKETS counters of the one-launch statistics finalize (zeroed per forward)
     p.fwd_total = o;
@@ -156,6 +167,12 @@ int conv_sources(const Plan& p, const float* x, const char* ws, int i, ustrun_sr
         return nhwc_src(ws + p.y_off[k], (const float*)(ws + p.aff_off[k]), p.cout[k], p.Hs[p.lvl[k]], p.Ws[p.lvl[k]], 1, pool,
                         p.G > 1 ? p.gN : 0);
     };
+    auto act1 = [&](int i2) {       // operand of the second convolution i2 of a DoubleConv: written out, or through the transform
+        const int k = (i2 - 1) / 2, c1 = i2 - 1;
+        if (p.act1_off[k] >= 0)
+            return nhwc_src(ws + p.act1_off[k], nullptr, p.cout[c1], p.Hs[p.lvl[c1]], p.Ws[p.lvl[c1]], 0, 0, p.G > 1 ? p.gN : 0);
+        return act(c1, 0);
+    };
     if (i == 0) {   // network input, NCHW
         ustrun_src_t s = {};
         s.ptr = x; s.C = p.C; s.H = p.H; s.W = p.W;
@@ -165,12 +182,12 @@ int conv_sources(const Plan& p, const float* x, const char* ws, int i, ustrun_sr
         return 1;
     }
     if (i < 10) {
-        if (i % 2 == 1) { srcs[0] = act(i - 1, 0); return 1; }
+        if (i % 2 == 1) { srcs[0] = act1(i); return 1; }
         const int l = i / 2;       // Down l: the pooled activation was materialised by ustrun_pool_act (plain tensor)
         srcs[0] = nhwc_src(ws + p.pool_off[l - 1], nullptr, p.cout[i - 1], p.Hs[l], p.Ws[l], 0, 0, p.G > 1 ? p.gN : 0);
         return 1;
     }
-    if (i % 2 == 1) { srcs[0] = act(i - 1, 0); return 1; }
+    if (i % 2 == 1) { srcs[0] = act1(i); return 1; }
     const int j = (i - 10) / 2, l = 3 - j;
     const int skip = 2 * l + 1;
     srcs[0] = p.act_off[l] >= 0 ? nhwc_src(ws + p.act_off[l], nullptr, p.cout[skip], p.Hs[l], p.Ws[l], 0, 0, p.G > 1 ? p.gN : 0)
@@ -302,6 +319,10 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
             USTRUN_TRY(bn_finalize_passes(stat, rpg, p.G, C, (int64_t)p.gN * H * W, d->bn_w[i], d->bn_b[i], d->bn_rm[i],
                                           d->bn_rv[i], d->bn_nbt[i], d->momentum, d->eps, d->update_running, aff, aff + C,
                                           aff + 2 * C, aff + 3 * C, 4L * C, (hipStream_t)s, (g_debug_flags & 4194304) ? tickets : nullptr));
+        }
+        if (i % 2 == 0 && p.act1_off[i / 2] >= 0) {        // the second convolution's operand, written out (see make_plan)
+            ustrun_src_t a = nhwc_src(ws + p.y_off[i], aff, C, H, W, 1, 0, p.G > 1 ? p.gN : 0);
+            USTRUN_TRY(ustrun_act16(&a, p.N, ws + p.act1_off[i / 2], d->dtype, s));
         }
     }
     prof_set_tag(-1, 0);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "ustrun_bn_relu_apply": (i32, [vp, fp, fp, i64, i32, i32, fp, i32, i32, vp]),
     "ustrun_pool_act": (i32, [PSrc, i32, vp, i32, vp]),
     "ustrun_pool_act2": (i32, [PSrc, i32, vp, vp, i32, vp]),
+    "ustrun_act16": (i32, [PSrc, i32, vp, i32, vp]),
     "ustrun_maxpool_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "ustrun_convT2x2_fwd": (i32, [PSrc, vp, fp, i32, i32, i32, i32, vp, i32, vp]),
     "ustrun_head_fwd": (i32, [vp, fp, fp, i64, i32, i32, i32, fp, fp, fp, i32, vp]),
