@@ -431,7 +431,9 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             // (da of the conv2 one level down: its BatchNorm-backward sums ride along where the layer is handled by this same call)
             const float* pa = affp(prev);
             const int Cp = p.up_cin[j];
-            if (!(g_debug_flags & (1 << 25)) && prev >= i_lo &&
+            // (not for down4's second BatchNorm, j = 0: the backward may be split right there -- parts 1 | 2 -- and the split and
+            // the un-split call must sum in the same order: test_backward_in_two_parts_equals_one_call)
+            if (!(g_debug_flags & (1 << 25)) && j > 0 && prev >= i_lo &&
                 (long)ustrun_conv_mtiles(p.N, p.Hs[l + 1], p.Ws[l + 1], Cp) * 2 * Cp * 4 <= p.part_bytes)
                 USTRUN_TRY(ustrun_convT2x2_dgrad_bnsum(sc + p.du_off[j], pk + p.ud_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], Cp,
                                                        sc + p.da_off[prev], ws + p.y_off[prev], pa, pa + Cp, p.G > 1 ? p.gN : 0, 4L * Cp,
