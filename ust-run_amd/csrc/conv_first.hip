@@ -227,8 +227,11 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
                                                               int ttotal, int tiles_per) {
     // im2col source: xs[c][kw][hy][16] bf16 = patch shifted by kw so that 8 consecutive pixels are 16-B aligned
     __shared__ __attribute__((aligned(16))) elt_t xs[CMAX][3][FTH + 2][FTW];
-    __shared__ __attribute__((aligned(16))) char dys[FTH * FTW * WRB];
-    __shared__ float accs[4][32][64];
+    // (the end-of-block sum of the four waves' accumulators reuses the dY tile's memory: 36 KB per block instead of 60 -- all
+    // 1024 blocks, four per CU, are resident at once; with 60 KB two per CU were, and the kernel ran its grid in two rounds)
+    constexpr int DYSB = FTH * FTW * WRB > 4 * 32 * 64 * 4 ? FTH * FTW * WRB : 4 * 32 * 64 * 4;
+    __shared__ __attribute__((aligned(16))) char dys[DYSB];
+    float (*accs)[32][64] = (float (*)[32][64])dys;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     f32x16 acc[2];
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
         }
     }
     // sum the four waves (fixed order) and write the block's slab
+    __syncthreads();                              // (every wave is done reading the last dY tile: accs lives in its memory)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
