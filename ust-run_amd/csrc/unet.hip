@@ -100,7 +100,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     // spends preparing a tile, 8.7): from 256 channels on (priced in DESIGN.md 9.13; 128 and 64 channels: the pass costs more)
     for (int k = 0; k < 9; ++k) {
         // (threshold measured on one box, 28.05-28.15 ms per step at 256: 128 -> 28.24, 64 -> 29.0, 512 -> 28.11)
-        const bool on = E == 2 && p.cout[2 * k] >= 256 && !(env_debug_flags() & (1 << 26));
+        const bool on = E == 2 && p.cout[2 * k] >= 256 && p.cout[2 * k] % 8 == 0 && p.cout[2 * k] / 8 <= 256 && !(env_debug_flags() & (1 << 26));
         p.act1_off[k] = on ? o : -1;
         if (on) o = align_up(o + p.y_elems(2 * k) * E, 256) + gap();
     }
