@@ -48,6 +48,16 @@ def test_counted_kernels_do_not_spill_and_reductions_keep_loads_in_flight():
     """tools/check_kernel_props.py on the built library: no scratch instruction in any kernel that counts its own vmcnt waits (a
     spill reload shifts the counts and drains the queue), and the row loops of the small fixed-order reductions issue a batch of
     loads before their first wait (round 4: both were found by what they cost, 5 % of the input gradients and 0.2 ms per step)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_kernel_props as K
+    # the checker itself, on synthetic kernels: a spill in a counted kernel, a reduction whose loads are waited for one by one
+    assert K.findings("conv3x3_halo_bf16_kernelIx", ["v_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]", "s_endpgm"]) == (True, False, [])
+    c, b, f = K.findings("conv3x3_halo_bf16_kernelIx", ["scratch_store_dword off, v1, off", "scratch_load_dword v1, off, off", "s_waitcnt vmcnt(0)"])
+    assert c and not b and len(f) == 1 and "2 scratch" in f[0]
+    serial = ["global_load_dword v1, v[2:3], off", "s_waitcnt vmcnt(0)", "v_add_f64 v[4:5], v[4:5], v[6:7]"] * 8
+    assert len(K.findings("bn_bwd_finalize_kernelILb0EE", serial)[2]) == 1
+    batched = ["global_load_dword v1, v[2:3], off"] * 8 + ["s_waitcnt vmcnt(7)"] + ["v_add_f64 v[4:5], v[4:5], v[6:7]"] * 8
+    assert K.findings("bn_bwd_finalize_kernelILb0EE", batched) == (False, True, [])
     lib = os.path.join(ROOT, "ust-run_amd", "ustrun", "libustrun.so")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kernel_props.py"), lib], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -43,6 +43,29 @@ def kernels(text):
         yield name, body
 
 
+def findings(name, body):
+    """-> (counted kernel?, batched reduction?, list of findings) for one disassembled kernel"""
+    out, counted, batched = [], False, False
+    if any(k in name for k in COUNTED):
+        counted = True
+        ns = sum(1 for t in body if t.startswith("scratch_"))
+        if ns:
+            out.append(f"{name[:110]}: {ns} scratch instructions in a kernel with hand-counted waits")
+    for k, need in BATCHED.items():
+        if k in name:
+            batched = True
+            best = run = 0          # longest run of vector loads not interrupted by a wait on the vector-memory counter
+            for t in body:
+                if t.startswith(("global_load", "buffer_load")):
+                    run += 1
+                    best = max(best, run)
+                elif t.startswith("s_waitcnt") and "vmcnt" in t:
+                    run = 0
+            if best < need:
+                out.append(f"{name[:110]}: at most {best} loads issued between waits (needs {need})")
+    return counted, batched, out
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "ust-run_amd", "ustrun", "libustrun.so")
@@ -57,24 +80,10 @@ def main():
             open(p, "wb").write(o)
             text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", p], capture_output=True, text=True).stdout
             for name, body in kernels(text):
-                if any(k in name for k in COUNTED):
-                    ncounted += 1
-                    ns = sum(1 for t in body if t.startswith("scratch_"))
-                    if ns:
-                        bad.append(f"{name[:110]}: {ns} scratch instructions in a kernel with hand-counted waits")
-                for k, need in BATCHED.items():
-                    if k in name:
-                        nbatched += 1
-                        # longest run of vector loads not interrupted by a wait on the vector-memory counter
-                        best = run = 0
-                        for t in body:
-                            if t.startswith(("global_load", "buffer_load")):
-                                run += 1
-                                best = max(best, run)
-                            elif t.startswith("s_waitcnt") and "vmcnt" in t:
-                                run = 0
-                        if best < need:
-                            bad.append(f"{name[:110]}: at most {best} loads issued between waits (needs {need})")
+                c, b_, f = findings(name, body)
+                ncounted += c
+                nbatched += b_
+                bad += f
     print(f"{len(objs)} gfx950 code objects: {ncounted} kernels with hand-counted waits checked for scratch, {nbatched} fixed-order "
           f"reductions checked for loads in flight, {len(bad)} findings")
     for b in bad[:30]:
