@@ -434,6 +434,7 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  *   (ustrun_conv3x3_dgrad_bnsum): every BatchNorm backward runs its reduce pass, as in rounds 1-3.
  * bit 26 (67108864), ENVIRONMENT ONLY like bit 24: the second convolution of every DoubleConv reads its operand through
  *   BatchNorm + ReLU on load (rounds 1-3) instead of the activation ustrun_act16 writes out on the levels from 256 channels.
+ * bit 27 (134217728): ustrun_head_fwd on its generic 16-bit kernel instead of the 64-channel one.
  * bit 13 (8192): 64-output-channel 3x3 layers on >= 32-wide maps on the 16 x 32-pixel tile (one block per CU; A/B runs).
  * A caller that runs a forward and its backward on different threads sets the same value on both (the Python host does:
  * ustrun/engine.py hands the forward's flags to autograd's backward thread).

@@ -535,3 +535,36 @@ def test_bn_backward_bf16_builds(n, c, h, w, pool, flags):
     err = (outs[1][2] - want).abs()
     assert bool((err <= want.abs() * 2 ** -7 + 1e-6).all()), float((err / (want.abs() + 1e-6)).max())
     assert rel(outs[1][2], want.bfloat16().float()) < 2e-3
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+@pytest.mark.parametrize("dt,tdt", [(1, torch.bfloat16), (2, torch.float16)])
+def test_head_fwd_64_channel_kernel_is_bit_identical(k, dt, tdt):
+    """ustrun_head_fwd on 16-bit storage with C = 64 and H*W % 256 == 0 runs head_fwd_bf16_g8_kernel (round 4: one scalar divide per
+    256-pixel trip, the class sums reduce-scattered over the pixel's eight lanes); ustrun_debug_flags bit 27 keeps the generic
+    kernel.  Same pairing of the same additions: the logits must be bit-identical, with and without BatchNorm constants, and match
+    torch on the rounded activations."""
+    l = L()
+    lib = l.lib()
+    n, c, h, w = 3, 64, 32, 40          # 1280 pixels per image
+    g = torch.Generator().manual_seed(40 + k)
+    y = torch.randn(n, h, w, c, generator=g).cuda().to(tdt)
+    sc, sh = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
+    wt, b = (torch.randn(k, c, generator=g) / 8).cuda(), torch.randn(k, generator=g).cuda()
+    for aff in (True, False):
+        outs = []
+        for flags in (0, 1 << 27):
+            old = lib.ustrun_debug_flags(flags)
+            try:
+                lg = torch.full((n, k, h, w), 7.0, device="cuda")
+                l.check(lib.ustrun_head_fwd(y.data_ptr(), sc.data_ptr() if aff else None, sh.data_ptr() if aff else None, n * h * w, h * w, c, k,
+                                            wt.data_ptr(), b.data_ptr(), lg.data_ptr(), dt, None))
+            finally:
+                lib.ustrun_debug_flags(old)
+            outs.append(lg)
+        assert torch.equal(outs[0], outs[1])
+        a = y.float()
+        if aff:
+            a = torch.relu(a * sc + sh)
+        ref = torch.einsum("nhwc,kc->nkhw", a.double(), wt.double()) + b.double()[None, :, None, None]
+        assert rel(outs[0].cpu(), ref.cpu()) < 1e-6

@@ -99,10 +99,10 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const elt_t* __restr
             for (int k = 0; k < K; ++k) acc[k] = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {                   // (out-of-range lanes compute on the clamped pixel, never store)
-                float a = (float)v[u][j] * sc[j] + sh[j];
-                a = relu ? fmaxf(a, 0.f) : a;
+                float a = __builtin_fmaf((float)v[u][j], sc[j], sh[j]);      // (explicit fused forms: this kernel and the 64-channel
+                a = relu ? fmaxf(a, 0.f) : a;                                // one below must round alike, whatever hipcc contracts)
 #pragma unroll
-                for (int k = 0; k < K; ++k) acc[k] += a * wk[k][j];
+                for (int k = 0; k < K; ++k) acc[k] = __builtin_fmaf(a, wk[k][j], acc[k]);
             }
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -114,6 +114,81 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const elt_t* __restr
                 const long n = (unsigned)p / (unsigned)HW, hw = p - n * HW;   // 32-bit divide: p < 2^32 (checked on the host)
                 logits[(n * K + g) * HW + hw] = out + bk;
             }
+        }
+    }
+}
+
+// The same for C = 64 (eight lanes per pixel) and H*W a multiple of 256 -- the head of every U-Net configuration of the step --
+// with what made the generic kernel VALU-bound (about 100 VALU instructions per 16-byte piece: 3.2 TB/s) taken out: a trip's 256
+// pixels lie inside one image (no per-pixel division, no clamped addresses, one scalar divide per trip); the eight lanes of a pixel
+// reduce the K class sums as a reduce-scatter (at every xor step a lane keeps half of the classes it still holds and sends the
+// other half: K = 2 takes three shuffles instead of six) -- same pairing and the same additions as the butterfly, commuted:
+// bit-identical logits; class k ends on lane 4 (k & 1) [K <= 2] or 4 (k >> 1) + 2 (k & 1) [K <= 4].
+template <int K>
+__global__ __launch_bounds__(256) void head_fwd_bf16_g8_kernel(const elt_t* __restrict__ y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, long npix, int HW,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ logits) {
+    typedef __attribute__((ext_vector_type(8))) elt_t bf16x8;
+    constexpr int C = 64, PPB = 32, U = 8, KP = K <= 1 ? 1 : (K <= 2 ? 2 : 4);
+    const int g = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float sc[8], sh[8], wk[KP][8];
+    {
+        f32x4 t[2 + KP][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            t[0][h] = scale ? *(const f32x4*)(scale + 8 * g + 4 * h) : (f32x4){1.f, 1.f, 1.f, 1.f};
+            t[1][h] = scale ? *(const f32x4*)(shift + 8 * g + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KP; ++k) t[2 + k][h] = k < K ? *(const f32x4*)(w + k * C + 8 * g + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = t[0][j >> 2][j & 3]; sh[j] = t[1][j >> 2][j & 3];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) wk[k][j] = t[2 + k][j >> 2][j & 3];
+        }
+    }
+    const bool relu = scale != nullptr;
+    // the class this lane ends up holding, and whether it stores
+    const int kcls = KP == 1 ? 0 : (KP == 2 ? (g >> 2) : ((g >> 2) * 2 + ((g >> 1) & 1)));
+    const bool writer = (KP == 1 ? g == 0 : (KP == 2 ? (g & 3) == 0 : (g & 1) == 0)) && kcls < K;
+    const float bk = writer ? bias[kcls] : 0.f;
+    for (long p0 = (long)blockIdx.x * PPB * U; p0 < npix; p0 += (long)gridDim.x * PPB * U) {
+        const int n = __builtin_amdgcn_readfirstlane((int)((unsigned)p0 / (unsigned)HW));     // the trip's image (uniform)
+        const int hw0 = (int)(p0 - (long)n * HW);
+        bf16x8 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *(const bf16x8*)(y + (p0 + u * PPB + pl) * C + 8 * g);
+        float* lrow = logits + ((long)n * K + kcls) * HW + hw0 + pl;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float acc[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = __builtin_fmaf((float)v[u][j], sc[j], sh[j]);
+                a = relu ? fmaxf(a, 0.f) : a;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) acc[k] = __builtin_fmaf(a, wk[k][j], acc[k]);
+            }
+            float r;
+            if constexpr (KP == 1) {
+                r = acc[0];
+                r += __shfl_xor(r, 4); r += __shfl_xor(r, 2); r += __shfl_xor(r, 1);
+            } else if constexpr (KP == 2) {
+                const bool hi = g & 4;
+                r = (hi ? acc[1] : acc[0]) + __shfl_xor(hi ? acc[0] : acc[1], 4);
+                r += __shfl_xor(r, 2); r += __shfl_xor(r, 1);
+            } else {
+                const bool hi = g & 4, mid = g & 2;
+                const float k0 = (hi ? acc[2] : acc[0]) + __shfl_xor(hi ? acc[0] : acc[2], 4);
+                const float k1 = (hi ? acc[3] : acc[1]) + __shfl_xor(hi ? acc[1] : acc[3], 4);
+                r = (mid ? k1 : k0) + __shfl_xor(mid ? k0 : k1, 2);
+                r += __shfl_xor(r, 1);
+            }
+            if (writer) lrow[u * PPB] = r + bk;
         }
     }
 }
@@ -285,6 +360,14 @@ extern "C" int ustrun_head_fwd(const void* y, const float* scale, const float* s
         long nb = (npix + (256 / G) * 32 - 1) / ((256 / G) * 32);    // >= four rounds of eight pixels per lane (the constants'
         if (nb > 2048) nb = 2048;                                    // loads and the launch are then a small part of a block)
         dim3 grid((int)nb), block(256);
+        if (C == 64 && HW % 256 == 0 && !(g_debug_flags & (1 << 27))) {      // (bit 27: the generic kernel, A/B and parity runs)
+#define USTRUN_HF8(KK) hipLaunchKernelGGL(head_fwd_bf16_g8_kernel<KK>, grid, block, 0, (hipStream_t)s, (const elt_t*)y, scale, shift, \
+                                          (long)npix, HW, w, bias, logits)
+            if (K == 1) USTRUN_HF8(1); else if (K == 2) USTRUN_HF8(2); else if (K == 3) USTRUN_HF8(3); else USTRUN_HF8(4);
+#undef USTRUN_HF8
+            USTRUN_LAUNCH_CHECK("head_fwd_bf16_g8");
+            return 0;
+        }
 #define USTRUN_HF(KK) hipLaunchKernelGGL(head_fwd_bf16_kernel<KK>, grid, block, 0, (hipStream_t)s, (const elt_t*)y, scale, shift, \
                                          (long)npix, HW, C, G, w, bias, logits)
         if (K == 1) USTRUN_HF(1); else if (K == 2) USTRUN_HF(2); else if (K == 3) USTRUN_HF(3); else USTRUN_HF(4);
