@@ -213,6 +213,29 @@ int ustrun_upload_small(void* dst, const void* src_host, int nbytes, ustrun_stre
 /* CutMix image compositing out = a*(1-box) + b*box on NCHW images: train.py:644-646,688,691   */
 int ustrun_box_mix(const float* a, const float* b, const float* box, int N, int C, int HW,
                    float* out, ustrun_stream_t s);
+/* One launch that ASSEMBLES a batch from rows that live anywhere on the device: out row r (row_bytes bytes each, a multiple of
+ * 16; every pointer 16-byte aligned) = a byte copy of rows[r].a when rows[r].b is NULL, else the CutMix composite of f32 rows
+ * a*(1-box) + b*box with box[HW] broadcast over the row's channels (the arithmetic of ustrun_box_mix).  The row table is a HOST
+ * array (device ADDRESSES computed by the caller: base + index * stride) and travels in the launch's argument block.  Replaces
+ * the reference's fancy indexing / torch.cat / clone chains around its forward calls: cut_img[choice], cut_label[choice],
+ * cut_mask[choice] (train.py:627,690-697), the three teacher inputs (:643-647), the student's inputs (:689-702,734), the
+ * memory bank's torch.cat (:764-780) -- without materialising the concatenations or the index tensors.              */
+typedef struct ustrun_asm_row { const void* a; const void* b; const float* box; } ustrun_asm_row_t;
+#define USTRUN_ASM_MAX 128
+int ustrun_assemble(const ustrun_asm_row_t* rows_host, int nrows, int64_t row_bytes, int HW, void* out, ustrun_stream_t s);
+/* Label decoding of the loop head, one pass: train.py:590-608 / train_mnms.py:549-556.  y: the loader's f32 label tensor.
+ * kind 0 (fundus):   y [N,HW]   -> out f32 [N,2,HW] = {y == 0, y <= 128}
+ * kind 1 (prostate): y [N,HW]   -> out i64 [N,HW]   = (y == 0)
+ * kind 2 (BUSI):     y [N,HW]   -> out i64 [N,HW]   = (y == 255)
+ * kind 3 (MNMS):     y [N,HW,3] -> out i64 [N,HW]   = 3 if y[..,2]==255 else 2 if y[..,1]==255 else 1 if y[..,0]==255 else 0 */
+int ustrun_decode_labels(const float* y, int kind, int N, int HW, void* out, ustrun_stream_t s);
+/* Bounding rectangle of the union of up to four planes' non-zero pixels (train.py:722-730 + obtain_all_cover_box :242-251: the
+ * low-quality sample's region = its pseudo-label planes united with the picked labelled sample's mask planes): plane k is
+ * f32 or i64 (is_i64 bit k) of H*W elements; partial[USTRUN_BBOX_BLOCKS][4] int32 = per-block {min y, max y, min x, max x}
+ * ({H, -1, W, -1} for a block that saw none) -- 1 KB that the host copies and folds: the 256 KB region map never exists.  */
+#define USTRUN_BBOX_BLOCKS 64
+int ustrun_region_bbox(const void* const* planes_host, int nplanes, int is_i64_bits, int H, int W, int32_t* partial,
+                       ustrun_stream_t s);
 
 /* ---- FFT low-frequency amplitude mix: replaces train.py:158-207,628-636 (numpy on the host) --------
  * src/trg/out are normalised NCHW images (k/127.5-1); per image n the (2b+1)^2 window of src's
@@ -287,6 +310,11 @@ typedef struct ustrun_unet_desc {
     int32_t update_running;      /* update BN running buffers (train mode)                    */
     int32_t groups;              /* > 1: N = groups * n images of `groups` independent forward passes batched into one
                                   * call; BatchNorm statistics (and running-buffer updates, in order) are per pass  */
+    int32_t tail;                /* > 0: N = groups * n + tail: `tail` (< n) more images follow as one further, shorter forward
+                                  * pass (its own BatchNorm statistics, its running-buffer update after the others') whose
+                                  * logits nobody reads: the head skips it and ustrun_unet_backward covers the first
+                                  * groups * n images only (train.py:740: the low-quality sample's forward, Q2)      */
+    int32_t reserved0;
     float   momentum, eps;
     /* parameters/buffers, torch layouts, in state_dict order:                 */
     const float* conv_w[18];     /* inc.0, inc.3, down1..4 (.0,.3), up1..4.conv (.0,.3)        */

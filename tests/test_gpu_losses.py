@@ -156,6 +156,90 @@ def test_rect_masks_equal_oracle_cutmix_and_cover_maps():
         F().rect_masks(np.zeros((0, 4)), 8, 8, "cuda")
 
 
+def test_assemble_gathers_copies_and_composites_exactly():
+    """ustrun_assemble against the torch expressions it replaces (train.py:627,643-647,689-702): rows gathered by address from two
+    tensors (cat + fancy index), CutMix composites with the box broadcast over channels, int64 label rows, one row aliased many
+    times -- bit-exact."""
+    Fn = F()
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(5, 3, 24, 24, generator=g).cuda()
+    b = torch.randn(4, 3, 24, 24, generator=g).cuda()
+    box = (torch.rand(5, 24, 24, generator=g) > 0.6).float().cuda()
+    choice = [6, 0, 8, 3, 3]
+    rows_ab = Fn.row_ptrs(a) + Fn.row_ptrs(b)
+    bx = Fn.row_ptrs(box)
+    cut = [rows_ab[c] for c in choice]
+    ar = Fn.row_ptrs(a)
+    out = Fn.assemble([(p, 0, 0) for p in ar] + [(ar[i], cut[i], bx[i]) for i in range(5)] + [(cut[i], ar[i], bx[i]) for i in range(5)] +
+                      [(c, 0, 0) for c in cut], a, 24 * 24)
+    mix = torch.cat((a, b), 0)[choice]
+    bb = box[:, None]
+    ref = torch.cat((a, a * (1 - bb) + mix * bb, mix * (1 - bb) + a * bb, mix), 0)
+    assert torch.equal(out, ref)
+    lab = torch.randint(0, 4, (6, 40, 24), generator=g).cuda()
+    sel = [5, 5, 0, 2]
+    lr = Fn.row_ptrs(lab)
+    assert torch.equal(Fn.assemble([(lr[i], 0, 0) for i in sel], lab), lab[sel])
+    ones = torch.ones(1, 2, 24, 24).cuda()
+    m = torch.rand(3, 2, 24, 24, generator=g).cuda()
+    rows = [ones.data_ptr()] * 4 + Fn.row_ptrs(m)
+    pick = [0, 6, 3, 4]
+    assert torch.equal(Fn.assemble([(rows[i], 0, 0) for i in pick], ones), torch.cat((ones.expand(4, -1, -1, -1), m), 0)[pick])
+    big = torch.randn(130, 1, 16, 16, generator=g).cuda()           # more rows than one launch's table holds
+    perm = torch.randperm(130, generator=g).tolist()
+    br = Fn.row_ptrs(big)
+    assert torch.equal(Fn.assemble([(br[i], 0, 0) for i in perm], big), big[perm])
+
+
+@pytest.mark.parametrize("dataset", ["fundus", "prostate", "BUSI", "MNMS"])
+def test_decode_labels_equals_the_loop_head(dataset):
+    """ustrun_decode_labels == the torch expressions of train.py:590-608 / train_mnms.py:549-556 (oracle/step_ref.decode_labels)."""
+    from oracle import step_ref as S
+    from ustrun import synthetic
+    y = synthetic.labels(dataset, 3, 48, torch.Generator().manual_seed(2))
+    got = F().decode_labels(dataset, y.cuda())
+    ref = S.decode_labels(dataset, y)
+    assert got.dtype == ref.dtype and got.shape == ref.shape
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_region_bbox_equals_the_cover_box_of_the_region():
+    """ustrun_region_bbox + fold_bbox == oracle/host_ref.all_cover_box (train.py:242-251) of the region train.py:722-729 builds,
+    for float (fundus) and int64 (softmax datasets) planes, an empty region and a single pixel."""
+    from ustrun import trainer as T
+    Fn = F()
+    g = torch.Generator().manual_seed(7)
+    for trial in range(6):
+        S = 40
+        planes = [torch.zeros(S, S) for _ in range(4)]
+        for p in planes[:3]:
+            if trial == 4:
+                continue
+            y0, x0 = int(torch.randint(0, S - 8, (1,), generator=g)), int(torch.randint(0, S - 8, (1,), generator=g))
+            p[y0:y0 + int(torch.randint(1, 8, (1,), generator=g)), x0:x0 + int(torch.randint(1, 8, (1,), generator=g))] = 1
+        if trial == 5:
+            planes = [torch.zeros(S, S) for _ in range(4)]
+            planes[2][17, 31] = 1
+        region = planes[1].clone()                            # the reference's construction (fundus form)
+        region[planes[0].long() == 1] = 1
+        region[planes[2].long() == 1] = 1
+        region[planes[3].long() == 1] = 1
+        part = torch.empty(64, 4, dtype=torch.int32, device="cuda")
+        Fn.region_bbox_partials([planes[1].cuda(), planes[0].cuda(), planes[2].cuda(), planes[3].cuda()], S, S, part)
+        rect = Fn.fold_bbox(part.cpu().numpy())
+        if trial == 4:
+            assert rect is None
+            continue
+        assert np.array_equal(T.rect_map(rect, S), H.all_cover_box(region.numpy())), trial
+        lab = (planes[0] * 3).long().cuda()                   # class ids: non-zero = set
+        part2 = torch.empty(64, 4, dtype=torch.int32, device="cuda")
+        Fn.region_bbox_partials([lab, planes[2].long().cuda()], S, S, part2)
+        r2 = region * 0
+        r2[planes[0] != 0] = 1
+        r2[planes[2] != 0] = 1
+        assert np.array_equal(T.rect_map(Fn.fold_bbox(part2.cpu().numpy()), S), H.all_cover_box(r2.numpy())), trial
+
+
 def test_upload_small_round_trip():
     for arr, dt in ((np.arange(16)[::-1].copy(), torch.long), (np.linspace(0, 1, 7, dtype=np.float32), torch.float32),
                     (np.zeros(0, dtype=np.int64), torch.long), (np.arange(256), torch.long)):

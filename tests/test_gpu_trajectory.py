@@ -29,10 +29,12 @@ pytestmark = pytest.mark.gpu
 DICE_TOL = 1e-3            # north_star, on the EMA teacher
 STUDENT_TOL = 1e-2         # the student's own Dice moves by 4e-3 between rounding-equivalent runs
 LOSS_RTOL_EARLY = 2e-2     # steps <= 50: trajectories still rounding-close (f32, f16)
-LOSS_RTOL_EARLY_BF16 = 3e-2   # bf16: two builds of the library whose kernels differ only in their f32 summation ORDER (round 4: the
-                              # 16x16x32 MFMA shape in the input gradients, the ConvTranspose bias as the accumulators' start value)
-                              # sit 1.9 % and 2.1 % from the oracle at step 30 -- 8-bit significands amplify a last-bit change; the
-                              # Dice gates below are the north_star's and do not move
+LOSS_RTOL_EARLY_BF16 = 3e-2   # bf16, PER STEP: two builds of the library whose kernels differ only in their f32 summation ORDER (round 4:
+                              # the 16x16x32 MFMA shape in the input gradients, the ConvTranspose bias as the accumulators' start
+                              # value) sit 1.9 % and 2.1 % from the oracle at step 30 (gpurun_out/r4_full2.log; the per-step
+                              # deviations are printed below and kept in profiles/r05_traj_bf16_loss.log) -- 8-bit significands
+                              # amplify a last-bit change.  The MEAN deviation over those steps keeps the 2e-2 bar, so a real 1 %
+                              # shift of the bf16 arithmetic still fails; the Dice gates below are the north_star's and do not move
 LOSS_ATOL_LATE = 1e-2      # later: same basin, different rounding path
 
 
@@ -93,7 +95,10 @@ def test_200_step_trajectory_lands_on_the_oracle(dtype):
     assert abs(float(np.mean(val[200][1])) - ref_t) <= DICE_TOL
     assert abs(float(np.mean(val[200][0])) - ref_s) <= STUDENT_TOL
     early = steps <= 50
+    dev_early = np.abs(loss[early] - g["loss"][early]) / np.abs(g["loss"][early])
+    print(f"[{dtype}] early-loss relative deviation per logged step {np.round(dev_early, 4).tolist()}, mean {dev_early.mean():.4f}")
     np.testing.assert_allclose(loss[early], g["loss"][early], rtol=LOSS_RTOL_EARLY_BF16 if dtype == "bf16" else LOSS_RTOL_EARLY)
+    assert float(dev_early.mean()) <= LOSS_RTOL_EARLY
     assert float(np.abs(loss - g["loss"]).max()) <= LOSS_ATOL_LATE
     for st in (100,):                                       # half way: rounding-equivalent runs are still 1e-4 apart
         assert abs(float(np.mean(val[st][1])) - float(np.mean(g[f"val_teacher_{st}"]))) <= DICE_TOL

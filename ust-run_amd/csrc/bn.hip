@@ -14,9 +14,15 @@ namespace {
 // in f64 and parks the two sums IN PLACE, each as a (hi, lo) float pair, in its OWN cells: row sp*R holds
 // the sum (q=0 cell: hi, q=1 cell: lo), row sp*R+1 the sum of squares.  Only this block reads those cells,
 // and it does so before the barrier that precedes the writes.
-__global__ __launch_bounds__(256) void bn_stat_stage1_kernel(float* stat, int rows, int C, int R) {
+// A shorter TAIL pass may follow the `passes` equal ones (BnTail: its rows start where theirs end; R = 0: too few rows for a first
+// stage, the finalize sums them directly -- each pass goes through exactly the arithmetic a call of its own would).
+__global__ __launch_bounds__(256) void bn_stat_stage1_kernel(float* stat, int rows, int C, int R, int passes, BnTail tail) {
     __shared__ double red[2][8][32];
     stat += (long)blockIdx.z * rows * 2 * C;            // blockIdx.z = forward pass (its own rows)
+    if ((int)blockIdx.z == passes) {                    // the tail pass
+        rows = tail.rows; R = tail.R;
+        if ((int)blockIdx.y * R >= rows) return;
+    }
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl, r0 = blockIdx.y * R, r1 = min(rows, r0 + R);
     double s1 = 0.0, s2 = 0.0;
@@ -161,9 +167,13 @@ template <bool PRE>
 __global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int C, double count, int R,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* rm, float* rv, int64_t* nbt, float momentum, float eps, int update,
-                                   float* scale, float* shift, float* mean, float* rstd, int passes, long astride) {
+                                   float* scale, float* shift, float* mean, float* rstd, int passes, long astride, BnTail tail) {
     __shared__ double red[2][32][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;      // 32 channels x 32 row lanes
+    const int full = passes;                                     // the equal passes; then the tail, if any
+    const int rows_f = rows, R_f = R;
+    const double count_f = count;
+    if (tail.rows > 0) ++passes;
     const int c = blockIdx.x * 32 + cl;
     double run_m = 0.0, run_v = 0.0;
     if (update && rg == 0 && c < C) { run_m = (double)rm[c]; run_v = (double)rv[c]; }
@@ -176,8 +186,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int
         const int g = g0 + gl;
         double s1 = 0.0, s2 = 0.0;
         if (c < C && g < passes) {
-            const float* st = stat + (long)g * rows * 2 * C;
-            if (PRE) {       // stage-1 doubles parked at rows sp*R / sp*R+1, columns of this channel block
+            const float* st = stat + (long)g * rows_f * 2 * C;
+            rows = g < full ? rows_f : tail.rows; R = g < full ? R_f : tail.R;
+            if (PRE && R > 0) {       // stage-1 doubles parked at rows sp*R / sp*R+1, columns of this channel block
                 // at most 32 splits (the launcher's R), i.e. four per lane: all sixteen loads issued before the first sum (one
                 // split per trip was four dependent memory round trips in a 7 us kernel); x + 0.0 leaves x, so the absent
                 // splits' zeros do not change the sums
@@ -214,6 +225,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stat, int rows, int
             for (int q = 0; q < PPR && g0 + q < passes; ++q) {     // the round's passes, in order
                 double t1 = 0.0, t2 = 0.0;
                 for (int k = 0; k < LPP; ++k) { t1 += red[0][q * LPP + k][cl]; t2 += red[1][q * LPP + k][cl]; }
+                count = g0 + q < full ? count_f : tail.count;
                 const double m = t1 / count;
                 double var = t2 / count - m * m;
                 if (var < 0.0) var = 0.0;
@@ -841,8 +853,15 @@ namespace ustrun {
 int bn_finalize_passes(float* stat, int mtiles, int passes, int C, int64_t count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                        int update_running, float* scale, float* shift, float* mean, float* rstd, long astride, hipStream_t s,
-                       unsigned* tickets) {
+                       unsigned* tickets, int tail_rows, int64_t tail_count) {
     USTRUN_CHECK(stat && gamma && beta && scale && shift && mean && rstd, "bn_finalize: null pointer");
+    USTRUN_CHECK(tail_rows >= 0 && tail_rows <= mtiles && (tail_rows == 0 || tail_count > 0), "bn_finalize: tail of %d rows", tail_rows);
+    BnTail tail = {tail_rows, 0, (double)tail_count};
+    if (tail_rows >= 96 && C % 32 == 0) {       // the split a call of its own would choose for these rows
+        tail.R = cdiv(tail_rows, 32);
+        while (tail_rows % tail.R == 1) ++tail.R;
+    }
+    if (tail_rows > 0) tickets = nullptr;       // (the one-launch form knows no tail)
     USTRUN_CHECK(!update_running || (running_mean && running_var), "bn_finalize: running buffers missing");
     USTRUN_CHECK(mtiles > 0 && passes > 0 && C > 0 && count > 0, "bn_finalize: empty");
     // Two stages from 96 rows up (the first one rewrites `stat` in place): one block per 32 channels pulls the whole table
@@ -859,16 +878,16 @@ int bn_finalize_passes(float* stat, int mtiles, int passes, int C, int64_t count
             USTRUN_LAUNCH_CHECK("bn_stat_fused");
             return 0;
         }
-        hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(mtiles, R), passes), dim3(256), 0, s, (float*)stat, mtiles,
-                           C, R);
+        hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(mtiles, R), passes + (tail.R > 0 ? 1 : 0)), dim3(256), 0, s,
+                           (float*)stat, mtiles, C, R, passes, tail);
         USTRUN_LAUNCH_CHECK("bn_stat_stage1");
         hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3(C / 32), dim3(1024), 0, s, stat, mtiles, C, (double)count, R, gamma,
                            beta, running_mean, running_var, num_batches_tracked, momentum, eps, update_running, scale, shift,
-                           mean, rstd, passes, astride);
+                           mean, rstd, passes, astride, tail);
     } else {
         hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3(cdiv(C, 32)), dim3(1024), 0, s, stat, mtiles, C, (double)count, 0,
                            gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, update_running, scale,
-                           shift, mean, rstd, passes, astride);
+                           shift, mean, rstd, passes, astride, tail);
     }
     USTRUN_LAUNCH_CHECK("bn_finalize");
     return 0;
@@ -1062,7 +1081,7 @@ int bn_bwd_finalize_stat(float* stat, int rows, int passes, int C, int64_t count
     if (rows >= 96 && C % 32 == 0) {
         int R = cdiv(rows, 32);
         while (rows % R == 1) ++R;
-        hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(rows, R), passes), dim3(256), 0, s, stat, rows, C, R);
+        hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(rows, R), passes), dim3(256), 0, s, stat, rows, C, R, passes, BnTail{0, 0, 0.0});
         USTRUN_LAUNCH_CHECK("bn_stat_stage1");
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<true>, dim3(C / 32), dim3(1024), 0, s, stat, rows, C, (double)count, gamma, mean, rstd,
                            dgamma, dbeta, accumulate, coef, passes, po, 2L * C, 0L, R);

@@ -1148,6 +1148,7 @@ int ws64_stat_rows(const IgemmArgs& a) { return ws_plan(a).items * 2; }
 bool ws64_bnsum_supported(const IgemmArgs& a) {
     if (!ws64_supported(a) || a.src[0].scale || a.src[0].relu) return false;
     if (g_debug_flags & (1 | 2 | 4 | 16)) return false;              // (another build of the kernel, or the tiled kernel, is forced)
+    if (g_dbg.p) return false;              // (a stamp buffer selects the DIAG build, which forms no sums: the caller runs the reduce pass)
     return a.bn_gN == 0 || a.N <= 8 * a.bn_gN;                       // at most eight passes (the producers count them without a division)
 }
 

@@ -633,6 +633,109 @@ extern "C" int ustrun_box_mix(const float* a, const float* b, const float* box, 
     return 0;
 }
 
+namespace ustrun { namespace {
+struct AsmArgs { ustrun_asm_row_t r[USTRUN_ASM_MAX]; };
+// blockIdx.y = output row; 16 bytes per thread and trip
+__global__ __launch_bounds__(256) void assemble_kernel(const AsmArgs t, long row16, int HW, float* __restrict__ out) {
+    const ustrun_asm_row_t r = t.r[blockIdx.y];
+    f32x4* o = (f32x4*)out + (long)blockIdx.y * row16;
+    const f32x4* a = (const f32x4*)r.a;
+    if (!r.b) {
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < row16; e += (long)gridDim.x * 256) o[e] = a[e];
+        return;
+    }
+    const f32x4* b = (const f32x4*)r.b;
+    const f32x4* bx = (const f32x4*)r.box;
+    const int hw4 = HW / 4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < row16; e += (long)gridDim.x * 256) {
+        const f32x4 va = a[e], vb = b[e], x = bx[e % hw4];
+        f32x4 v;
+        v.x = va.x * (1.f - x.x) + vb.x * x.x; v.y = va.y * (1.f - x.y) + vb.y * x.y;       // (box_mix_kernel's expression)
+        v.z = va.z * (1.f - x.z) + vb.z * x.z; v.w = va.w * (1.f - x.w) + vb.w * x.w;
+        o[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void decode_labels_kernel(const float* __restrict__ y, int kind, long npix, int HW, void* out) {
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        if (kind == 0) {
+            const long n = p / HW, hw = p - n * HW;
+            const float v = y[p];
+            float* o = (float*)out + n * 2 * HW + hw;
+            o[0] = v == 0.f ? 1.f : 0.f; o[HW] = v <= 128.f ? 1.f : 0.f;
+        } else if (kind == 1) ((long long*)out)[p] = y[p] == 0.f ? 1 : 0;
+        else if (kind == 2) ((long long*)out)[p] = y[p] == 255.f ? 1 : 0;
+        else {
+            const float a = y[3 * p], b = y[3 * p + 1], c = y[3 * p + 2];
+            ((long long*)out)[p] = c == 255.f ? 3 : (b == 255.f ? 2 : (a == 255.f ? 1 : 0));
+        }
+    }
+}
+
+struct BboxArgs { const void* p[4]; };
+__global__ __launch_bounds__(256) void region_bbox_kernel(const BboxArgs a, int np, int i64bits, int H, int W, int* __restrict__ partial) {
+    __shared__ int red[4][4];
+    int y0 = H, y1 = -1, x0 = W, x1 = -1;
+    const int HW = H * W;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < HW; e += gridDim.x * 256) {
+        bool nz = false;
+        for (int k = 0; k < np; ++k)
+            nz |= ((i64bits >> k) & 1) ? ((const long long*)a.p[k])[e] != 0 : ((const float*)a.p[k])[e] != 0.f;
+        if (nz) {
+            const int y = e / W, x = e - y * W;
+            y0 = min(y0, y); y1 = max(y1, y); x0 = min(x0, x); x1 = max(x1, x);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        y0 = min(y0, __shfl_xor(y0, o)); y1 = max(y1, __shfl_xor(y1, o));
+        x0 = min(x0, __shfl_xor(x0, o)); x1 = max(x1, __shfl_xor(x1, o));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = y0; red[w][1] = y1; red[w][2] = x0; red[w][3] = x1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { y0 = min(y0, red[k][0]); y1 = max(y1, red[k][1]); x0 = min(x0, red[k][2]); x1 = max(x1, red[k][3]); }
+        int* o = partial + blockIdx.x * 4;
+        o[0] = y0; o[1] = y1; o[2] = x0; o[3] = x1;
+    }
+}
+} }
+extern "C" int ustrun_assemble(const ustrun_asm_row_t* rows_host, int nrows, int64_t row_bytes, int HW, void* out, ustrun_stream_t s) {
+    USTRUN_CHECK(rows_host && out && nrows > 0 && nrows <= USTRUN_ASM_MAX, "assemble: 1..USTRUN_ASM_MAX rows per call (%d)", nrows);
+    USTRUN_CHECK(row_bytes > 0 && row_bytes % 16 == 0 && ((uintptr_t)out & 15) == 0, "assemble: rows of %ld bytes (16-byte units)", (long)row_bytes);
+    AsmArgs t;
+    memset(&t, 0, sizeof t);
+    for (int r = 0; r < nrows; ++r) {
+        const ustrun_asm_row_t& q = rows_host[r];
+        USTRUN_CHECK(q.a && ((uintptr_t)q.a & 15) == 0 && ((uintptr_t)q.b & 15) == 0 && ((uintptr_t)q.box & 15) == 0, "assemble: row %d pointers", r);
+        USTRUN_CHECK(!q.b || (q.box && HW > 0 && HW % 4 == 0 && (row_bytes / 4) % HW == 0), "assemble: row %d mixes with HW=%d", r, HW);
+        t.r[r] = q;
+    }
+    long bx = (row_bytes / 16 + 256 * 4 - 1) / (256 * 4);
+    const long cap = (2048 + nrows - 1) / nrows;
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(assemble_kernel, dim3((int)bx, nrows), dim3(256), 0, (hipStream_t)s, t, (long)(row_bytes / 16), HW, (float*)out);
+    USTRUN_LAUNCH_CHECK("assemble");
+    return 0;
+}
+extern "C" int ustrun_decode_labels(const float* y, int kind, int N, int HW, void* out, ustrun_stream_t s) {
+    USTRUN_CHECK(y && out && N > 0 && HW > 0 && kind >= 0 && kind <= 3, "decode_labels: bad args");
+    const long npix = (long)N * HW;
+    hipLaunchKernelGGL(decode_labels_kernel, dim3(stream_blocks(npix)), dim3(256), 0, (hipStream_t)s, y, kind, npix, HW, out);
+    USTRUN_LAUNCH_CHECK("decode_labels");
+    return 0;
+}
+extern "C" int ustrun_region_bbox(const void* const* planes_host, int nplanes, int is_i64_bits, int H, int W, int32_t* partial,
+                                  ustrun_stream_t s) {
+    USTRUN_CHECK(planes_host && partial && nplanes >= 1 && nplanes <= 4 && H > 0 && W > 0 && (long)H * W < (1L << 30), "region_bbox: bad args");
+    BboxArgs a = {};
+    for (int k = 0; k < nplanes; ++k) { USTRUN_CHECK(planes_host[k], "region_bbox: plane %d missing", k); a.p[k] = planes_host[k]; }
+    hipLaunchKernelGGL(region_bbox_kernel, dim3(USTRUN_BBOX_BLOCKS), dim3(256), 0, (hipStream_t)s, a, nplanes, is_i64_bits, H, W, (int*)partial);
+    USTRUN_LAUNCH_CHECK("region_bbox");
+    return 0;
+}
+
 /* Small host values reach the device inside the kernel-argument block: no copy engine, no host wait, ordered on the
  * stream like any launch.  (A pinned hipMemcpyAsync on a busy stream cost the step 20 ms here; a pageable copy drains
  * the queue.) */

@@ -129,8 +129,9 @@ static int src_groups(const ustrun_src_t* srcs, int nsrc, int N, int* gN) {
         }
     *gN = g;
     if (g == 0) return 1;
-    return (N % g == 0) ? N / g : -1;
+    return (N + g - 1) / g;         // (the last pass may be shorter: ustrun_unet_desc_t::tail)
 }
+static inline int pass_images(int g, int gN, int N) { return N - g * gN < gN ? N - g * gN : gN; }
 static ustrun_src_t src_slice(const ustrun_src_t& s, int g, int gN, int dtype) {
     ustrun_src_t t = s;
     const int esz = (s.f32 || dtype != USTRUN_D16) ? 4 : 2;
@@ -140,6 +141,9 @@ static ustrun_src_t src_slice(const ustrun_src_t& s, int g, int gN, int dtype) {
     return t;
 }
 
+// rows the LAST pass of the calling thread's latest ustrun_conv3x3_fwd_rows wrote when it ran one launch per pass (-1: one launch over
+// the whole batch, every image the same number of rows): how the U-Net plan splits the rows of a batch with a shorter tail pass
+namespace ustrun { thread_local int g_last_pass_rows = -1; int conv_last_pass_rows() { return g_last_pass_rows; } }
 extern "C" int ustrun_debug_last_conv_variant(void) { return halo_last_variant(); }
 extern "C" int ustrun_debug_last_wgrad_variant(void) { return wgrad_last_variant(); }
 // (USTRUN_DEBUG_FLAGS in the environment presets the flags: A/B runs of whole programs on one box)
@@ -217,14 +221,16 @@ extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const
             ustrun_src_t sl[2];
             for (int i = 0; i < nsrc; ++i) sl[i] = src_slice(srcs[i], g, gN, dtype);
             int rows = 0;
-            USTRUN_TRY(ustrun_conv3x3_fwd_rows(sl, nsrc, w_fwd, gN, H, W, Cout,
+            USTRUN_TRY(ustrun_conv3x3_fwd_rows(sl, nsrc, w_fwd, pass_images(g, gN, N), H, W, Cout,
                                                (char*)y + (int64_t)g * gN * H * W * Cout * act_esz(dtype),
                                                stat ? stat + (int64_t)total * 2 * Cout : nullptr, &rows, dtype, s));
             total += rows;
+            g_last_pass_rows = rows;
         }
         if (stat_rows) *stat_rows = total;
         return 0;
     }
+    g_last_pass_rows = -1;          // one launch: rows per image are uniform
     if (stat) {
         const int rows = ustrun_conv_mtiles(N, H, W, Cout);
         const int used = first ? conv_first_stat_rows(N, H, W, dtype) : igemm_stat_rows_used(a, dtype);
@@ -320,7 +326,7 @@ extern "C" int ustrun_convT2x2_fwd(const ustrun_src_t* src, const void* w_fwd, c
         if (G > 1 && !(dtype == USTRUN_D16 && convT_fwd_supported(a))) {
             for (int g = 0; g < G; ++g) {
                 const ustrun_src_t sl = src_slice(*src, g, gN, dtype);
-                USTRUN_TRY(ustrun_convT2x2_fwd(&sl, w_fwd, bias, gN, H, W, Cout,
+                USTRUN_TRY(ustrun_convT2x2_fwd(&sl, w_fwd, bias, pass_images(g, gN, N), H, W, Cout,
                                                (char*)u + (int64_t)g * gN * 4 * H * W * Cout * act_esz(dtype), dtype, s));
             }
             return 0;
@@ -420,8 +426,8 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
             for (int g = 0; g < G; ++g) {
                 ustrun_src_t sl[2];
                 for (int i = 0; i < nsrc; ++i) sl[i] = src_slice(srcs[i], g, gN, dtype);
-                USTRUN_TRY(ustrun_conv3x3_wgrad(sl, nsrc, (const char*)dy + (int64_t)g * gN * H * W * Cout * act_esz(dtype), gN, H,
-                                                W, Cout, dw, g == 0 ? accumulate : 1, partials, partials_bytes, dtype, s));
+                USTRUN_TRY(ustrun_conv3x3_wgrad(sl, nsrc, (const char*)dy + (int64_t)g * gN * H * W * Cout * act_esz(dtype),
+                                                pass_images(g, gN, N), H, W, Cout, dw, g == 0 ? accumulate : 1, partials, partials_bytes, dtype, s));
             }
             return 0;
         }
@@ -492,8 +498,8 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
         if (G > 1 && !(dtype == USTRUN_D16 && wgradT_supported(a))) {
             for (int g = 0; g < G; ++g) {
                 const ustrun_src_t sl = src_slice(*src, g, gN, dtype);
-                USTRUN_TRY(ustrun_convT2x2_wgrad(&sl, (const char*)du + (int64_t)g * gN * 4 * H * W * Cout * act_esz(dtype), gN, H, W,
-                                                 Cout, dw, db, g == 0 ? accumulate : 1, partials, partials_bytes, dtype, s));
+                USTRUN_TRY(ustrun_convT2x2_wgrad(&sl, (const char*)du + (int64_t)g * gN * 4 * H * W * Cout * act_esz(dtype),
+                                                 pass_images(g, gN, N), H, W, Cout, dw, db, g == 0 ? accumulate : 1, partials, partials_bytes, dtype, s));
             }
             return 0;
         }

@@ -7,7 +7,9 @@
 //   Down input        = pool_act(y_i, scale_i, shift_i)             (MaxPool2d of the activation, one streaming pass:
 //                                                                     pooling on load cost the conv kernels more)
 //   Up input          = loader(skip y_s) ++ loader(u_j, offset)     (pad + cat on load)
-// A call may carry several forward passes of equal shape (desc.groups): BatchNorm statistics and constants per pass.
+// A call may carry several forward passes of equal shape (desc.groups): BatchNorm statistics and constants per pass; a shorter
+// pass may follow them (desc.tail: forward only -- the reference's low-quality-sample forward, train.py:740, whose logits nobody
+// reads, rides behind the student's four gradient passes and moves the running statistics last, as it does there).
 #include "common.h"
 #include <string.h>
 
@@ -17,6 +19,9 @@ namespace {
 struct Plan {
     int N, C, H, W, K, base;
     int G, gN;                   // forward passes batched into this call, images per pass (BatchNorm is per pass)
+    int T, GP, Nb, pg, pgb;      // images of the shorter tail pass behind them (forward only, logits unused); passes incl. the tail;
+                                 // G * gN = the images the head and the backward cover; pg = gN when the forward's batch has a pass
+                                 // structure, pgb = the same for the backward's (which never sees the tail)
     int Hs[5], Ws[5];            // extent per level
     int cin[18], cout[18], lvl[18];
     int up_cin[4], up_cout[4];   // convT j: level of its input = 4-j (j = 0..3), output level 3-j
@@ -46,8 +51,12 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     USTRUN_CHECK(dtype_ok(d->dtype), "unet: dtype %d not built", d->dtype);
     p.N = d->N; p.C = d->C; p.H = d->H; p.W = d->W; p.K = d->K; p.base = d->base;
     p.G = d->groups > 1 ? d->groups : 1;
-    USTRUN_CHECK(d->N % p.G == 0, "unet: N=%d is not a multiple of groups=%d", d->N, p.G);
-    p.gN = d->N / p.G;
+    p.T = d->tail;
+    USTRUN_CHECK(p.T >= 0 && p.T < d->N && (d->N - p.T) % p.G == 0, "unet: N=%d is not groups=%d equal passes + a tail of %d", d->N, p.G, p.T);
+    p.gN = (d->N - p.T) / p.G;
+    USTRUN_CHECK(p.T < p.gN, "unet: the tail pass (%d images) must be shorter than the others (%d)", p.T, p.gN);
+    p.GP = p.G + (p.T > 0); p.Nb = p.G * p.gN; p.pg = p.GP > 1 ? p.gN : 0; p.pgb = p.G > 1 ? p.gN : 0;
+    USTRUN_CHECK(p.GP <= 8, "unet: %d passes in one call (at most 8)", p.GP);
     p.Hs[0] = d->H; p.Ws[0] = d->W;
     for (int l = 1; l < 5; ++l) { p.Hs[l] = p.Hs[l - 1] / 2; p.Ws[l] = p.Ws[l - 1] / 2; }
     const int b = d->base;
@@ -76,7 +85,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     auto gap = [&]() { return (long)(2 * (nplaced++ % 8) + 1) * 69632; };
     for (int i = 0; i < 18; ++i) {
         p.y_off[i] = o; o = align_up(o + p.y_elems(i) * E, 256) + gap();
-        p.aff_off[i] = o; o = align_up(o + 16L * p.cout[i] * p.G, 256);       // [G][scale, shift, mean, rstd]
+        p.aff_off[i] = o; o = align_up(o + 16L * p.cout[i] * p.GP, 256);      // [pass][scale, shift, mean, rstd]
         const long st = (long)ustrun_conv_mtiles(p.N, p.Hs[p.lvl[i]], p.Ws[p.lvl[i]], p.cout[i]) * 2 * p.cout[i];
         if (st > stat_max) stat_max = st;
     }
@@ -162,15 +171,17 @@ ustrun_src_t nhwc_src(const void* ptr, const float* aff, int C, int H, int W, in
 }
 
 // sources of conv i (forward input), from the saved workspace
-int conv_sources(const Plan& p, const float* x, const char* ws, int i, ustrun_src_t* srcs) {
+int conv_sources(const Plan& p0, const float* x, const char* ws, int i, ustrun_src_t* srcs, bool bwd = false) {
+    Plan p = p0;
+    if (bwd) p.pg = p.pgb;
     auto act = [&](int k, int pool) {
         return nhwc_src(ws + p.y_off[k], (const float*)(ws + p.aff_off[k]), p.cout[k], p.Hs[p.lvl[k]], p.Ws[p.lvl[k]], 1, pool,
-                        p.G > 1 ? p.gN : 0);
+                        p.pg);
     };
     auto act1 = [&](int i2) {       // operand of the second convolution i2 of a DoubleConv: written out, or through the transform
         const int k = (i2 - 1) / 2, c1 = i2 - 1;
         if (p.act1_off[k] >= 0)
-            return nhwc_src(ws + p.act1_off[k], nullptr, p.cout[c1], p.Hs[p.lvl[c1]], p.Ws[p.lvl[c1]], 0, 0, p.G > 1 ? p.gN : 0);
+            return nhwc_src(ws + p.act1_off[k], nullptr, p.cout[c1], p.Hs[p.lvl[c1]], p.Ws[p.lvl[c1]], 0, 0, p.pg);
         return act(c1, 0);
     };
     if (i == 0) {   // network input, NCHW
@@ -184,13 +195,13 @@ int conv_sources(const Plan& p, const float* x, const char* ws, int i, ustrun_sr
     if (i < 10) {
         if (i % 2 == 1) { srcs[0] = act1(i); return 1; }
         const int l = i / 2;       // Down l: the pooled activation was materialised by ustrun_pool_act (plain tensor)
-        srcs[0] = nhwc_src(ws + p.pool_off[l - 1], nullptr, p.cout[i - 1], p.Hs[l], p.Ws[l], 0, 0, p.G > 1 ? p.gN : 0);
+        srcs[0] = nhwc_src(ws + p.pool_off[l - 1], nullptr, p.cout[i - 1], p.Hs[l], p.Ws[l], 0, 0, p.pg);
         return 1;
     }
     if (i % 2 == 1) { srcs[0] = act1(i); return 1; }
     const int j = (i - 10) / 2, l = 3 - j;
     const int skip = 2 * l + 1;
-    srcs[0] = p.act_off[l] >= 0 ? nhwc_src(ws + p.act_off[l], nullptr, p.cout[skip], p.Hs[l], p.Ws[l], 0, 0, p.G > 1 ? p.gN : 0)
+    srcs[0] = p.act_off[l] >= 0 ? nhwc_src(ws + p.act_off[l], nullptr, p.cout[skip], p.Hs[l], p.Ws[l], 0, 0, p.pg)
                                 : act(skip, 0);
     ustrun_src_t u = nhwc_src(ws + p.u_off[j], nullptr, p.up_cout[j], 2 * p.Hs[l + 1], 2 * p.Ws[l + 1], 0, 0);
     u.off_y = (p.Hs[l] - 2 * p.Hs[l + 1]) / 2;       // F.pad(diff//2, ...) of the reference
@@ -262,7 +273,7 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
         float* affs[18];
         for (int i = 0; i < 18; ++i) affs[i] = affp(i);
         USTRUN_TRY(bn_eval_affine_layers(18, p.cout, d->bn_w, d->bn_b, (const float* const*)d->bn_rm, (const float* const*)d->bn_rv, affs,
-                                         d->eps, p.G, (hipStream_t)s));
+                                         d->eps, p.GP, (hipStream_t)s));
     }
     unsigned* tickets = (unsigned*)(ws + p.tick_off);
     static_assert(BN_TICKETS * sizeof(unsigned) <= 256, "ticket area");
@@ -278,7 +289,7 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
             const int j = (i - 10) / 2, l = 3 - j;
             const int prev = (j == 0) ? 9 : i - 1;
             ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0,
-                                      p.G > 1 ? p.gN : 0);
+                                      p.pg);
             prof_set_tag(20 + j, p.N);
             USTRUN_TRY(ustrun_convT2x2_fwd(&a, pk + p.uf_off[j], d->up_b[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
                                            ws + p.u_off[j], d->dtype, s));
@@ -286,7 +297,7 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
         if (i >= 2 && i < 10 && i % 2 == 0) {      // MaxPool2d of the previous level's activated output
             const int l = i / 2;
             ustrun_src_t a = nhwc_src(ws + p.y_off[i - 1], affp(i - 1), p.cout[i - 1], p.Hs[l - 1], p.Ws[l - 1], 1, 0,
-                                      p.G > 1 ? p.gN : 0);
+                                      p.pg);
             USTRUN_TRY(ustrun_pool_act2(&a, p.N, ws + p.pool_off[l - 1], p.act_off[l - 1] >= 0 ? ws + p.act_off[l - 1] : nullptr,
                                         d->dtype, s));
         }
@@ -295,33 +306,45 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
         const int H = p.Hs[p.lvl[i]], W = p.Ws[p.lvl[i]];
         int stat_rows = 0;
         prof_set_tag(i, p.N);
-        if (i == 0 && d->train && p.G > 1 && !conv_first_supported(srcs[0], p.cout[0])) {
+        int tail_rows = 0;           // statistics rows of the tail pass (the last ones)
+        if (i == 0 && d->train && p.GP > 1 && !conv_first_supported(srcs[0], p.cout[0])) {
             // the network input carries no pass structure, and the generic kernels' statistics rows are 128-pixel runs of the
             // whole batch (the first-convolution kernels' rows never cross an image): one launch per pass keeps every row
             // inside its pass (base widths other than 64 only)
-            for (int g = 0; g < p.G; ++g) {
+            for (int g = 0; g < p.GP; ++g) {
                 ustrun_src_t sg = srcs[0];
                 sg.ptr = (const float*)srcs[0].ptr + (long)g * p.gN * srcs[0].sN;
                 int rows = 0;
-                USTRUN_TRY(ustrun_conv3x3_fwd_rows(&sg, 1, pk + p.wf_off[0], p.gN, H, W, p.cout[0],
+                USTRUN_TRY(ustrun_conv3x3_fwd_rows(&sg, 1, pk + p.wf_off[0], g < p.G ? p.gN : p.T, H, W, p.cout[0],
                                                    ws + p.y_off[0] + (long)g * p.gN * H * W * p.cout[0] * p.esz,
                                                    stat + (long)stat_rows * 2 * p.cout[0], &rows, d->dtype, s));
                 stat_rows += rows;
+                if (g >= p.G) tail_rows = rows;
             }
-        } else
-        USTRUN_TRY(ustrun_conv3x3_fwd_rows(srcs, ns, pk + p.wf_off[i], p.N, H, W, p.cout[i], ws + p.y_off[i],
-                                           d->train ? stat : nullptr, &stat_rows, d->dtype, s));
+        } else {
+            USTRUN_TRY(ustrun_conv3x3_fwd_rows(srcs, ns, pk + p.wf_off[i], p.N, H, W, p.cout[i], ws + p.y_off[i],
+                                               d->train ? stat : nullptr, &stat_rows, d->dtype, s));
+            if (p.T > 0 && d->train) {       // one launch per pass: the last pass's rows; one launch: every image the same number
+                tail_rows = conv_last_pass_rows();
+                if (tail_rows < 0) {
+                    USTRUN_CHECK(stat_rows % p.N == 0, "unet_forward: %d statistics rows over %d images", stat_rows, p.N);
+                    tail_rows = stat_rows / p.N * p.T;
+                }
+            }
+        }
         float* aff = affp(i);
         const int C = p.cout[i];
         if (d->train) {     // statistics per pass, running buffers updated pass after pass as separate calls would
-            USTRUN_CHECK(stat_rows % p.G == 0, "unet_forward: %d statistics rows do not split into %d passes", stat_rows, p.G);
-            const int rpg = stat_rows / p.G;
+            USTRUN_CHECK((stat_rows - tail_rows) % p.G == 0 && tail_rows >= 0 && (tail_rows > 0) == (p.T > 0),
+                         "unet_forward: %d statistics rows (%d of the tail) do not split into %d passes", stat_rows, tail_rows, p.G);
+            const int rpg = (stat_rows - tail_rows) / p.G;
             USTRUN_TRY(bn_finalize_passes(stat, rpg, p.G, C, (int64_t)p.gN * H * W, d->bn_w[i], d->bn_b[i], d->bn_rm[i],
                                           d->bn_rv[i], d->bn_nbt[i], d->momentum, d->eps, d->update_running, aff, aff + C,
-                                          aff + 2 * C, aff + 3 * C, 4L * C, (hipStream_t)s, (g_debug_flags & 4194304) ? tickets : nullptr));
+                                          aff + 2 * C, aff + 3 * C, 4L * C, (hipStream_t)s, (g_debug_flags & 4194304) ? tickets : nullptr,
+                                          tail_rows, (int64_t)p.T * H * W));
         }
         if (i % 2 == 0 && p.act1_off[i / 2] >= 0) {        // the second convolution's operand, written out (see make_plan)
-            ustrun_src_t a = nhwc_src(ws + p.y_off[i], aff, C, H, W, 1, 0, p.G > 1 ? p.gN : 0);
+            ustrun_src_t a = nhwc_src(ws + p.y_off[i], aff, C, H, W, 1, 0, p.pg);
             USTRUN_TRY(ustrun_act16(&a, p.N, ws + p.act1_off[i / 2], d->dtype, s));
         }
     }
@@ -404,42 +427,42 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
         }
         dgrad_bn_rows = 0;
         ustrun_src_t srcs[2];
-        const int ns = conv_sources(p, x, ws, i, srcs);
-        prof_set_tag(200 + i, p.N);
-        USTRUN_TRY(ustrun_conv3x3_wgrad(srcs, ns, da, p.N, H, W, C, grads[gi], accumulate, part, p.part_bytes, dt, s));
+        const int ns = conv_sources(p, x, ws, i, srcs, true);
+        prof_set_tag(200 + i, p.Nb);
+        USTRUN_TRY(ustrun_conv3x3_wgrad(srcs, ns, da, p.Nb, H, W, C, grads[gi], accumulate, part, p.part_bytes, dt, s));
         prof_set_tag(-1, 0);
         if (i == 0) break;
         const float* wd = pk + p.wd_off[i];
         struct Untag { ~Untag() { prof_set_tag(-1, 0); } } untag_;
-        prof_set_tag(100 + i, p.N);
+        prof_set_tag(100 + i, p.Nb);
         if (i < 10 && i % 2 == 0) {            // Down conv: grad wrt the pooled activation of conv i-1
-            USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, p.cin[i], sc + p.dp_off[3 - (l - 1)], p.cin[i], nullptr, 0,
+            USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.Nb, H, W, C, p.cin[i], sc + p.dp_off[3 - (l - 1)], p.cin[i], nullptr, 0,
                                             0, 0, 0, dt, s));
         } else if (i >= 10 && i % 2 == 0) {    // Up conv: split into the skip grad and the ConvTranspose-output grad
             const int j = (i - 10) / 2, skip = 2 * l + 1;
             const int uh = 2 * p.Hs[l + 1], uw = 2 * p.Ws[l + 1];
-            USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, p.cin[i], sc + p.da_off[skip], p.cout[skip],
+            USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.Nb, H, W, C, p.cin[i], sc + p.da_off[skip], p.cout[skip],
                                             sc + p.du_off[j], uh, uw, (H - uh) / 2, (W - uw) / 2, dt, s));
             const int prev = (j == 0) ? 9 : i - 1;
             ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0,
-                                      p.G > 1 ? p.gN : 0);
+                                      p.pgb);
             const int ub = 30 + j * 8;
-            prof_set_tag(220 + j, p.N);
-            USTRUN_TRY(ustrun_convT2x2_wgrad(&a, sc + p.du_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], grads[ub],
+            prof_set_tag(220 + j, p.Nb);
+            USTRUN_TRY(ustrun_convT2x2_wgrad(&a, sc + p.du_off[j], p.Nb, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], grads[ub],
                                              grads[ub + 1], accumulate, part, p.part_bytes, dt, s));
-            prof_set_tag(120 + j, p.N);
+            prof_set_tag(120 + j, p.Nb);
             // (da of the conv2 one level down: its BatchNorm-backward sums ride along where the layer is handled by this same call)
             const float* pa = affp(prev);
             const int Cp = p.up_cin[j];
             // (not for down4's second BatchNorm, j = 0: the backward may be split right there -- parts 1 | 2 -- and the split and
             // the un-split call must sum in the same order: test_backward_in_two_parts_equals_one_call)
             if (!(g_debug_flags & (1 << 25)) && j > 0 && prev >= i_lo &&
-                (long)ustrun_conv_mtiles(p.N, p.Hs[l + 1], p.Ws[l + 1], Cp) * 2 * Cp * 4 <= p.part_bytes)
-                USTRUN_TRY(ustrun_convT2x2_dgrad_bnsum(sc + p.du_off[j], pk + p.ud_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], Cp,
-                                                       sc + p.da_off[prev], ws + p.y_off[prev], pa, pa + Cp, p.G > 1 ? p.gN : 0, 4L * Cp,
+                (long)ustrun_conv_mtiles(p.Nb, p.Hs[l + 1], p.Ws[l + 1], Cp) * 2 * Cp * 4 <= p.part_bytes)
+                USTRUN_TRY(ustrun_convT2x2_dgrad_bnsum(sc + p.du_off[j], pk + p.ud_off[j], p.Nb, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], Cp,
+                                                       sc + p.da_off[prev], ws + p.y_off[prev], pa, pa + Cp, p.pgb, 4L * Cp,
                                                        part, &dgrad_bn_rows, dt, s));
             if (dgrad_bn_rows == 0)
-            USTRUN_TRY(ustrun_convT2x2_dgrad(sc + p.du_off[j], pk + p.ud_off[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
+            USTRUN_TRY(ustrun_convT2x2_dgrad(sc + p.du_off[j], pk + p.ud_off[j], p.Nb, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
                                              p.up_cin[j], sc + p.da_off[prev], dt, s));
         } else {                               // second conv of a DoubleConv
             // its input gradient IS da of the BatchNorm + ReLU between the two convolutions: where the halo kernel's fused epilogue
@@ -447,12 +470,12 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             // also forms that layer's backward sums -- rows in `part`, which nobody touches before the next iteration reads them
             const float* pa = affp(i - 1);
             const int Cp = p.cin[i];
-            const long need = (long)ustrun_conv_mtiles(p.N, H, W, Cp) * 2 * Cp * 4;
+            const long need = (long)ustrun_conv_mtiles(p.Nb, H, W, Cp) * 2 * Cp * 4;
             if (!(g_debug_flags & (1 << 25)) && i - 1 >= i_lo && need <= p.part_bytes)
-                USTRUN_TRY(ustrun_conv3x3_dgrad_bnsum(da, wd, p.N, H, W, C, Cp, sc + p.da_off[i - 1], ws + p.y_off[i - 1], pa, pa + Cp,
-                                                      p.G > 1 ? p.gN : 0, 4L * Cp, part, &dgrad_bn_rows, dt, s));
+                USTRUN_TRY(ustrun_conv3x3_dgrad_bnsum(da, wd, p.Nb, H, W, C, Cp, sc + p.da_off[i - 1], ws + p.y_off[i - 1], pa, pa + Cp,
+                                                      p.pgb, 4L * Cp, part, &dgrad_bn_rows, dt, s));
             if (dgrad_bn_rows == 0)
-                USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.N, H, W, C, Cp, sc + p.da_off[i - 1], Cp, nullptr, 0, 0, 0, 0, dt, s));
+                USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.Nb, H, W, C, Cp, sc + p.da_off[i - 1], Cp, nullptr, 0, 0, 0, 0, dt, s));
         }
     }
     return 0;

@@ -56,20 +56,41 @@ class UNet(nn.Module):
         logits = self.outc(y)
         return (logits, y) if feature else logits
 
-    def forward_passes(self, xs, feature=False):
+    def forward_batched(self, x, groups, tail=0, feature=False):
+        """`forward_passes` for a batch the caller has already laid out end to end: x = `groups` equal passes followed by a
+        shorter tail pass of `tail` images (0: none; output discarded, see `forward_passes`)."""
+        import torch
+        _hip_only(x)
+        n = (len(x) - tail) // max(groups, 1)
+        if groups < 1 or n * groups + tail != len(x) or (tail and tail >= n):
+            raise RuntimeError(f"forward_batched: {len(x)} images are not {groups} equal passes + a shorter tail of {tail}")
+        if self.bilinear:
+            return self.forward_passes(list(x[:n * groups].split(n)), feature, tail=x[n * groups:] if tail else None)
+        from ustrun import engine
+        return engine.unet_forward(self, x, feature, groups=groups, tail=tail)
+
+    def forward_passes(self, xs, feature=False, tail=None):
         """Additive API (not in the reference): run several forward passes of equal shape as ONE batched call.
         Equivalent to `[self(x) for x in xs]` -- BatchNorm batch statistics and running-buffer updates stay per
         pass, in order -- but every kernel sees the concatenated batch (better GPU fill on the deep, small layers,
         a third of the launches, one weight-gradient reduction for all passes).  Returns the logits of the
-        concatenated batch; split them with `.split(len(xs[0]))`."""
+        concatenated batch; split them with `.split(len(xs[0]))`.
+        `tail`: a shorter batch that goes through the network as one more pass AFTER `xs` and whose output is discarded --
+        `self(tail)` for its side effect on the BatchNorm running statistics only (the reference's low-quality-sample
+        forward, train.py:740); it gets no gradient."""
         import torch
         xs = list(xs)
         if len({tuple(x.shape) for x in xs}) != 1:
             raise RuntimeError("forward_passes: all passes must have the same shape")
-        x = torch.cat(xs, 0) if len(xs) > 1 else xs[0]
+        if tail is not None and (tuple(tail.shape[1:]) != tuple(xs[0].shape[1:]) or not 0 < len(tail) < len(xs[0])):
+            raise RuntimeError("forward_passes: the tail pass must have the passes' image shape and fewer images")
+        x = torch.cat(xs + ([tail] if tail is not None else []), 0) if len(xs) > 1 or tail is not None else xs[0]
         _hip_only(x)
         if self.bilinear:                                   # no batched plan: pass by pass, in order
             outs = [self._forward_blocks(t, feature) for t in xs]
+            if tail is not None:
+                with torch.no_grad():
+                    self._forward_blocks(tail, False)
             return tuple(torch.cat(o, 0) for o in zip(*outs)) if feature else torch.cat(outs, 0)
         from ustrun import engine
-        return engine.unet_forward(self, x, feature, groups=len(xs))
+        return engine.unet_forward(self, x, feature, groups=len(xs), tail=0 if tail is None else len(tail))

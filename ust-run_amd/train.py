@@ -135,6 +135,11 @@ def train(args, snapshot_path):
         return model.to(dev)
 
     model, ema_model = create_model(), create_model(ema=True)
+    # (the reference trains under fp16 autocast + GradScaler by default, train.py:54,551-552: so does a plain `python train.py`
+    # here; --amp 0 or --backend_dtype f32 selects the exact f32 path that was this script's default before round 4)
+    logging.info("compute dtype %s (--amp %d, --amp_dtype %s, --backend_dtype '%s'); dynamic loss scale: %s", compute_dtype(args),
+                 args.amp, args.amp_dtype, args.backend_dtype, "on (GradScaler semantics, initial scale 65536)"
+                 if compute_dtype(args) == "f16" else "off")
     trainer = SSLTrainer(args.dataset, model, ema_model, base_lr=args.base_lr, max_iterations=args.max_iterations,
                          threshold=args.threshold, ema_decay=args.ema_decay, consistency=args.consistency,
                          consistency_rampup=args.consistency_rampup, cutmix_prob=args.cutmix_prob, LB=args.LB,

@@ -25,10 +25,18 @@ class Src(C.Structure):
 class UNetDesc(C.Structure):
     """ustrun_unet_desc_t"""
     _fields_ = [("N", i32), ("C", i32), ("H", i32), ("W", i32), ("K", i32), ("base", i32), ("dtype", i32),
-                ("train", i32), ("update_running", i32), ("groups", i32), ("momentum", f32), ("eps", f32),
+                ("train", i32), ("update_running", i32), ("groups", i32), ("tail", i32), ("reserved0", i32), ("momentum", f32), ("eps", f32),
                 ("conv_w", vp * 18), ("bn_w", vp * 18), ("bn_b", vp * 18), ("bn_rm", vp * 18),
                 ("bn_rv", vp * 18), ("bn_nbt", vp * 18), ("up_w", vp * 4), ("up_b", vp * 4),
                 ("head_w", vp), ("head_b", vp), ("packed", vp)]
+
+
+class AsmRow(C.Structure):
+    """ustrun_asm_row_t"""
+    _fields_ = [("a", vp), ("b", vp), ("box", vp)]
+
+
+ASM_MAX, BBOX_BLOCKS = 128, 64
 
 
 class ProfRec(C.Structure):
@@ -72,6 +80,9 @@ SIGNATURES = {
     "ustrun_pseudo_label": (i32, [fp, i32, i32, i32, f32, i32, vp, fp, vp]),
     "ustrun_mix_targets": (i32, [i32, i32, i32, i32, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp, fp, vp]),
     "ustrun_box_mix": (i32, [fp, fp, fp, i32, i32, i32, fp, vp]),
+    "ustrun_assemble": (i32, [vp, i32, i64, i32, vp, vp]),
+    "ustrun_decode_labels": (i32, [fp, i32, i32, i32, vp, vp]),
+    "ustrun_region_bbox": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "ustrun_upsample2x_fwd": (i32, [fp, i32, i32, i32, i32, fp, vp]),
     "ustrun_upsample2x_bwd": (i32, [fp, i32, i32, i32, i32, fp, vp]),
     "ustrun_rect_masks": (i32, [vp, i32, i32, i32, fp, vp]),

@@ -51,13 +51,20 @@ def seg_loss_fwd(logits, target, mask, mode):
     return out
 
 
-def seg_loss_bwd(logits, target, mask, mode, sums, gscale=1.0, ce_weight=1.0, dice_weight=1.0, gdev=None):
+def seg_loss_bwd(logits, target, mask, mode, sums, gscale=1.0, ce_weight=1.0, dice_weight=1.0, gdev=None, out=None):
+    """out: where the gradient goes (a contiguous f32 tensor of the logits' shape, e.g. this term's slice of the batched
+    passes' gradient); a new tensor otherwise."""
     lib = L.lib()
     logits = _f32c(logits, "logits")
     target = target.contiguous()
     mask = None if mask is None else _f32c(mask, "mask")
     N, K, HW = _shape(logits)
-    dl = torch.empty_like(logits)
+    if out is None:
+        dl = torch.empty_like(logits)
+    else:
+        if out.shape != logits.shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != logits.device:
+            raise RuntimeError("seg_loss_bwd: out must be a contiguous float32 tensor of the logits' shape on their device")
+        dl = out
     L.check(lib.ustrun_seg_loss_bwd(logits.data_ptr(), target.data_ptr(), L.ptr(mask), N, K, HW, _MODE[mode],
                                     sums.data_ptr(), L.ptr(gdev), float(gscale), float(ce_weight), float(dice_weight),
                                     dl.data_ptr(), stream_ptr()), "ustrun_seg_loss_bwd")
@@ -191,6 +198,90 @@ def box_mix(a, b, box):
     L.check(lib.ustrun_box_mix(a.data_ptr(), b.data_ptr(), box.data_ptr(), N, C, a[0, 0].numel(), out.data_ptr(),
                                stream_ptr()), "ustrun_box_mix")
     return out
+
+
+def row_ptrs(t):
+    """Device address of every row t[i] of a contiguous tensor (for `assemble`)."""
+    if not t.is_cuda or not t.is_contiguous():
+        raise RuntimeError("row_ptrs: expected a contiguous HIP tensor")
+    base, step = t.data_ptr(), (t[0].numel() * t.element_size() if len(t) else 0)
+    return [base + i * step for i in range(len(t))]
+
+
+def assemble(rows, like, HW=0, out=None):
+    """One launch that builds a batch from rows scattered over the device (ustrun_assemble): `rows` = a list of
+    (a, b, box) device ADDRESSES -- b = box = 0: row = the bytes at a; else the f32 CutMix composite a*(1-box) + b*box with
+    box [HW] broadcast over the row's channels.  `like`: a tensor whose [0] gives the row's shape and dtype (e.g. one of the
+    sources).  Replaces x[index], torch.cat and clone chains around the forwards (train.py:627,643-647,689-702,734)
+    without an index tensor or an intermediate concatenation.  The caller keeps the source tensors alive until this returns
+    (the launch is then ordered on the stream)."""
+    lib = L.lib()
+    n = len(rows)
+    row_shape, row_bytes = tuple(like.shape[1:]), like[0].numel() * like.element_size()
+    if out is None:
+        out = torch.empty((n,) + row_shape, dtype=like.dtype, device=like.device)
+    elif tuple(out.shape) != (n,) + row_shape or out.dtype != like.dtype or not out.is_contiguous():
+        raise RuntimeError("assemble: out does not match the rows")
+    for o in range(0, n, L.ASM_MAX):
+        part = rows[o:o + L.ASM_MAX]
+        tab = (L.AsmRow * len(part))()
+        for i, (a, b, bx) in enumerate(part):
+            tab[i].a, tab[i].b, tab[i].box = a, b or None, bx or None
+        L.check(lib.ustrun_assemble(tab, len(part), row_bytes, int(HW), out.data_ptr() + o * row_bytes, stream_ptr()),
+                "ustrun_assemble")
+    return out
+
+
+_LABEL_KIND = {"fundus": 0, "prostate": 1, "BUSI": 2, "MNMS": 3}
+
+
+def decode_labels(dataset, y):
+    """train.py:590-608, train_mnms.py:549-556 in one pass (ustrun_decode_labels): the loader's float label tensor ->
+    fundus: float [N,2,H,W] {cup = y == 0, disc = y <= 128}; prostate / BUSI: int64 [N,H,W] foreground map; MNMS: int64
+    class map from the three 255-coded channels."""
+    lib = L.lib()
+    y = _f32c(y, "labels")
+    kind = _LABEL_KIND[dataset]
+    if kind == 3:
+        if y.dim() != 4 or y.shape[-1] != 3:
+            raise RuntimeError(f"MNMS labels must be [N,H,W,3], got {tuple(y.shape)}")
+        sp = tuple(y.shape[1:3])
+    else:
+        if y.dim() != 3:
+            raise RuntimeError(f"{dataset} labels must be [N,H,W], got {tuple(y.shape)}")
+        sp = tuple(y.shape[1:])
+    N, HW = y.shape[0], sp[0] * sp[1]
+    if kind == 0:
+        out = torch.empty((N, 2) + sp, dtype=torch.float32, device=y.device)
+    else:
+        out = torch.empty((N,) + sp, dtype=torch.int64, device=y.device)
+    L.check(lib.ustrun_decode_labels(y.data_ptr(), kind, N, HW, out.data_ptr(), stream_ptr()), "ustrun_decode_labels")
+    return out
+
+
+def region_bbox_partials(planes, H, W, out):
+    """Per-block bounding rectangles of the union of the planes' non-zero pixels -> `out` (int32 [BBOX_BLOCKS,4] on the
+    device: {min y, max y, min x, max x}, {H,-1,W,-1} where a block saw none); fold them with `fold_bbox` on the host."""
+    import ctypes as C
+    lib = L.lib()
+    bits = 0
+    arr = (C.c_void_p * len(planes))()
+    for k, t in enumerate(planes):
+        if not t.is_cuda or not t.is_contiguous() or t.numel() != H * W or t.dtype not in (torch.float32, torch.int64):
+            raise RuntimeError("region_bbox: planes must be contiguous float32 / int64 HIP tensors of H*W elements")
+        bits |= int(t.dtype == torch.int64) << k
+        arr[k] = t.data_ptr()
+    L.check(lib.ustrun_region_bbox(arr, len(planes), bits, H, W, out.data_ptr(), stream_ptr()), "ustrun_region_bbox")
+    return out
+
+
+def fold_bbox(partial):
+    """numpy int32 [blocks,4] -> the rectangle {y0, y1, x0, x1} of train.py:242-251 (exclusive ends), or None when no pixel is set."""
+    y0, y1 = int(partial[:, 0].min()), int(partial[:, 1].max())
+    x0, x1 = int(partial[:, 2].min()), int(partial[:, 3].max())
+    if y1 < 0:
+        return None
+    return (y0, y1 + 1, x0, x1 + 1)
 
 
 def rect_masks(rects, H, W, device):

@@ -24,6 +24,7 @@ from utils import metrics, ramps
 
 from . import engine
 from . import functional as F
+from ._lib import BBOX_BLOCKS as L_BBOX
 
 DATASETS = {
     # name: (in_channels, patch, classes, loss mode, parts, max_iterations)   train.py:404-436, train_mnms.py:397-404
@@ -221,12 +222,7 @@ class SSLTrainer:
         self.lq_u = self.lq_pl = self.lq_mask = None
         self.last = {}
         self.timeline = None                             # list of (label, perf_counter) when host timing is on
-        self._side, self._side_busy = None, False        # side stream of the batch-1 low-quality-sample forward
-        # where the step issues it: "split" = between the decoder and encoder halves of the backward (it then runs under the
-        # encoder's many-block kernels: 29.34-29.42 ms per step against 29.51-29.53 for "start" = right after the student
-        # passes, under the head / up4 weight gradients whose one-block-per-CU grids wait for the CUs it takes; its whole cost is
-        # ~0.5 ms per step wherever it goes -- same-box runs of tools/ab_env.sh, profiles/r04_ab_side_forward.log)
-        self._side_at = os.environ.get("USTRUN_SIDE_AT", "split")
+        self._pin, self._ones = {}, None                 # pinned host buffers / a row of ones, kept across steps
 
     # ---------------------------------------------------------------------------------------
     def _mark(self, label):
@@ -240,11 +236,6 @@ class SSLTrainer:
         20 ms/step slower on this ROCm.)"""
         return F.upload_small(arr, dev, dtype)
 
-    def _side_stream(self, dev):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
-        return self._side
-
     def _pl(self, logits):
         return F.pseudo_label(logits, self.threshold, self.mode)
 
@@ -254,9 +245,11 @@ class SSLTrainer:
             cnt = F.dice_counts(pred, gt, by_class=True, n_classes=3)
         else:
             cnt = F.dice_counts(pred, gt)
-        host = torch.empty(cnt.shape, dtype=cnt.dtype, pin_memory=True)
+        host = self._pinned("dice", cnt.shape, cnt.dtype)
         host.copy_(cnt, non_blocking=True)
-        return host, None
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
 
     @staticmethod
     def _dice_from_host(host):
@@ -272,9 +265,8 @@ class SSLTrainer:
         c = cnt.cpu().numpy().astype(np.float64)          # [B, parts, 3]
         return metrics.dice_from_counts(c[..., 0], c[..., 1], c[..., 2]).T
 
-    def _freq_mix(self, mix_img, ulb_x_w, n):
-        degree = self.iter_num / self.max_iterations
-        ratios = [random.uniform(0, degree) for _ in range(n)]     # one draw per image (train.py:182)
+    def _freq_mix(self, mix_img, ulb_x_w, n, ratios):
+        """ratios: one draw per image, random.uniform(0, iter / max_iterations) (train.py:182), drawn by the caller."""
         if self.fft == "host":
             src = ((mix_img[:n] + 1) * 127.5).cpu().numpy()
             trg = ((ulb_x_w[:n] + 1) * 127.5).cpu().numpy()
@@ -285,49 +277,94 @@ class SSLTrainer:
                                       h2d=lambda r: self._h2d(np.asarray(r, dtype=np.float32), mix_img.device, torch.float32))
 
     # ---------------------------------------------------------------------------------------
+    def _pinned(self, name, shape, dtype):
+        """A pinned host buffer kept across steps (allocating one per step is a hipHostMalloc per step)."""
+        buf = self._pin.get(name)
+        if buf is None or tuple(buf.shape) != tuple(shape) or buf.dtype != dtype:
+            buf = self._pin[name] = torch.empty(shape, dtype=dtype, pin_memory=True)
+        return buf
+
+    def _ones_row(self, shape, dev):
+        """One row of ones of a mask's per-sample shape: the labelled samples' cut_mask rows all point at it (train.py:615,620)."""
+        t = self._ones
+        if t is None or tuple(t.shape[1:]) != tuple(shape) or t.device != dev:
+            t = self._ones = torch.ones((1,) + tuple(shape), dtype=torch.float32, device=dev)
+        return t
+
     def step(self, lb_x_w, lb_y, ulb_x_w, ulb_x_s, ulb_y, epoch_start=False):
         ds, mode, K = self.dataset, self.mode, self.n_classes
         model, ema = self.model, self.ema_model
         dev = lb_x_w.device
-        B = len(ulb_x_s)
+        B, nlb = len(ulb_x_s), len(lb_x_w)
+        HW = self.patch * self.patch
         epoch_num = self.iter_num // self.num_eval_iter
         self._mark("start")
         if epoch_start:
             self.lq_u = self.lq_pl = self.lq_mask = None
-        lb_mask = decode_labels(ds, lb_y)
-        ulb_mask = decode_labels(ds, ulb_y)
-        mshape = [len(lb_x_w), K if ds == "fundus" else 1, self.patch, self.patch]
+        lb_x_w, ulb_x_w, ulb_x_s = (F._f32c(t, "images") for t in (lb_x_w, ulb_x_w, ulb_x_s))
+        lb_mask = F.decode_labels(ds, lb_y)
+        ulb_mask = F.decode_labels(ds, ulb_y)
 
-        # CutMix partner selection (train.py:612-627)
-        ones = torch.ones(mshape, device=dev)
-        if self.simple_ulb is None or len(self.simple_ulb) == 0:
-            cut_img, cut_label, cut_mask = lb_x_w, lb_mask, ones
-            choice = np.random.randint(0, len(lb_x_w), B)
+        # ---- every host random number of the iteration, in the reference's order; none of them depends on device data:
+        # CutMix partners (train.py:612-625), one FFT ratio per image (:182 via :631), the B CutMix boxes (:639), the labelled
+        # partner of the low-quality sample (:721).  (The cover box's fallback draw, :242-251, follows once its region is known;
+        # nothing draws in between.)
+        bank = self.simple_ulb if self.simple_ulb is not None and len(self.simple_ulb) > 0 else None
+        if bank is None:
+            choice = np.random.randint(0, nlb, B)
         else:
-            cut_img = torch.cat((lb_x_w, self.simple_ulb), 0)
-            cut_label = torch.cat((lb_mask, self.cor_pl), 0)
-            cut_mask = torch.cat((ones, self.cor_mask), 0)
-            n_s = min(int(B * 0.5), len(self.simple_ulb))
-            c_lb = np.random.randint(0, len(lb_x_w), B - n_s)
-            c_s = np.random.randint(len(lb_x_w), len(lb_x_w) + len(self.simple_ulb), n_s)
+            n_s = min(int(B * 0.5), len(bank))
+            c_lb = np.random.randint(0, nlb, B - n_s)
+            c_s = np.random.randint(nlb, nlb + len(bank), n_s)
             choice = np.random.permutation(np.concatenate((c_lb, c_s)))
-        idx = self._h2d(np.asarray(choice), dev, torch.long)
-        mix_img = cut_img.index_select(0, idx)
-        cut_label_c, cut_mask_c = cut_label.index_select(0, idx), cut_mask.index_select(0, idx)
+        degree = self.iter_num / self.max_iterations
+        ratios = [random.uniform(0, degree) for _ in range(nlb)]
+        rects = [cutmix_rect(self.patch, p=self.cutmix_prob) for _ in range(B)]
+        new_choice = np.random.randint(0, nlb) if self.lq_u is not None else None
+
+        # ---- the low-quality sample's region (train.py:722-729) is last step's pseudo-label united with this step's picked label:
+        # its bounding rectangle is asked for NOW (one small kernel, 1 KB to pinned memory) and read when the student's inputs are
+        # put together -- with the teacher's passes queued in between, the host never waits for it with the GPU idle
+        bbox_ev = None
+        if new_choice is not None:
+            if ds == "fundus":
+                planes = [self.lq_pl[0, 1], self.lq_pl[0, 0], lb_mask[new_choice, 0], lb_mask[new_choice, 1]]
+            else:
+                planes = [self.lq_pl[0], lb_mask[new_choice]]
+            part = F.region_bbox_partials(planes, self.patch, self.patch,
+                                          torch.empty((L_BBOX, 4), dtype=torch.int32, device=dev))
+            bbox_host = self._pinned("bbox", part.shape, part.dtype)
+            bbox_host.copy_(part, non_blocking=True)
+            bbox_ev = torch.cuda.Event()
+            bbox_ev.record()
+
+        # ---- teacher inputs and the CutMix partners, gathered by address (train.py:627,643-647): rows of lb_x_w / the memory bank
+        def rows_of(first, more):
+            return F.row_ptrs(first) + (F.row_ptrs(more) if more is not None else [])
+        box = F.rect_masks(rects, self.patch, self.patch, dev)
+        bx, uw = F.row_ptrs(box), F.row_ptrs(ulb_x_w)
+        img_rows = rows_of(lb_x_w, bank)
+        cut = [img_rows[c] for c in choice]
+        t_buf = F.assemble([(u, 0, 0) for u in uw] + [(uw[i], cut[i], bx[i]) for i in range(B)] +
+                           [(cut[i], uw[i], bx[i]) for i in range(B)] + [(c, 0, 0) for c in cut], ulb_x_w, HW)
+        mix_img = t_buf[3 * B:]
+        lab_rows = rows_of(lb_mask, self.cor_pl if bank is not None else None)
+        cut_label_c = F.assemble([(lab_rows[c], 0, 0) for c in choice], lb_mask)
+        mshape = [K if ds == "fundus" else 1, self.patch, self.patch]
+        ones = self._ones_row(mshape, dev)
+        msk_rows = [ones.data_ptr()] * nlb + (F.row_ptrs(self.cor_mask) if bank is not None else [])
+        cut_mask_c = F.assemble([(msk_rows[c], 0, 0) for c in choice], ones)
 
         # FFT low-frequency amplitude mix (train.py:628-636, Q13)
-        move_transx = self._freq_mix(mix_img, ulb_x_w, len(lb_x_w))
+        move_transx = self._freq_mix(mix_img, ulb_x_w, nlb, ratios)
         self._mark("select+freqmix")
 
         with torch.no_grad():
-            box = F.rect_masks([cutmix_rect(self.patch, p=self.cutmix_prob) for _ in range(B)], self.patch, self.patch, dev)
-            self._mark("boxes")
             # teacher: three train-mode forwards (train.py:638-667, Q11), batched into one call with BatchNorm per pass
-            t_in = [ulb_x_w, F.box_mix(ulb_x_w, mix_img, box), F.box_mix(mix_img, ulb_x_w, box)]
             if self.batch_passes:
-                t_out = ema.forward_passes(t_in).split(B)
+                t_out = ema.forward_batched(t_buf[:3 * B], 3).split(B)
             else:
-                t_out = [ema(t) for t in t_in]
+                t_out = [ema(t) for t in t_buf[:3 * B].split(B)]
             pl, mask = self._pl(t_out[0])
             pl_w_ul, mask_w_ul = self._pl(t_out[1])
             pl_w_lu, mask_w_lu = self._pl(t_out[2])
@@ -335,141 +372,61 @@ class SSLTrainer:
             stu_pl, _ = self._pl(model(ulb_x_w))
             pl_w, mask_w, pl_ul, mask_ul, pl_lu, mask_lu = F.mix_targets(
                 mode, box, pl, mask, pl_w_ul, mask_w_ul, pl_w_lu, mask_w_lu, cut_label_c, cut_mask_c)
-            x_s_ul = F.box_mix(ulb_x_s, move_transx, box)
-            x_s_lu = F.box_mix(move_transx, ulb_x_s, box)
 
-        # Everything the host decides from device data this step -- the per-sample Dice behind the hardness ranking and
-        # the low-quality sample's region -- is computed and copied to pinned host memory NOW, in front of the student's
-        # gradient passes in stream order: the host reads it while those passes run instead of draining the queue
-        # after them (the GPU sat idle for the 1.5 ms of host work that followed).  The np.random draw keeps its place
-        # in the stream of draws (nothing else consumes it in between).
+        # the per-sample Dice behind the hardness ranking: counted and copied to pinned memory in front of the student's
+        # passes, read at the END of the step (nothing before the next step depends on it): never a wait
         dice_host, dice_ev = self._sample_dice_async(stu_pl, pl)
-        region_host = new_choice = None
-        if self.lq_u is not None:
-            new_choice = np.random.randint(0, len(lb_x_w))
-            if ds == "fundus":
-                region = self.lq_pl[0, 1].clone()
-                region[self.lq_pl[0, 0].long() == 1] = 1
-                region[lb_mask[new_choice, 0].long() == 1] = 1
-                region[lb_mask[new_choice, 1].long() == 1] = 1
-            else:
-                region = self.lq_pl[0].clone()
-                region[lb_mask[new_choice].long() > 0] = 1
-            region_host = torch.empty(region.shape, dtype=region.dtype, pin_memory=True)
-            region_host.copy_(region, non_blocking=True)
-        host_ev = torch.cuda.Event()
-        host_ev.record()
-
         self._mark("teacher+targets issued")
-        # student: four forwards that carry gradient (train.py:699-702)
+
+        # ---- student: four forwards that carry gradient (train.py:699-702) and, behind them, the low-quality sample's
+        # (train.py:734-740: result unused, Q2 -- only the BatchNorm running statistics move, after the other four's): ONE batch,
+        # put together in one launch
+        us, mt, lbr = F.row_ptrs(ulb_x_s), F.row_ptrs(move_transx), F.row_ptrs(lb_x_w)
+        rows = [(p, 0, 0) for p in lbr] + [(us[i], mt[i], bx[i]) for i in range(B)] + \
+               [(mt[i], us[i], bx[i]) for i in range(B)] + [(p, 0, 0) for p in us]
+        ib_lq = None
+        if new_choice is not None:
+            bbox_ev.synchronize()
+            rect = F.fold_bbox(bbox_host.numpy())
+            if rect is None:                                    # empty region: a random box (train.py:245-246)
+                rect = cutmix_rect(self.patch, p=1.0)
+            ib_lq = F.rect_masks([rect], self.patch, self.patch, dev)
+            rows.append((self.lq_u.data_ptr(), lbr[new_choice], ib_lq.data_ptr()))
+        x_all = F.assemble(rows, lb_x_w, HW)
+        n4 = nlb + 3 * B
         lg_all = None
-        if self.batch_passes and len(lb_x_w) == B:
-            lg_all = model.forward_passes([lb_x_w, x_s_ul, x_s_lu, ulb_x_s])
+        if self.batch_passes and nlb == B and B > 1:
+            lg_all = model.forward_batched(x_all, 4, tail=len(x_all) - n4)
             lg_lb, lg_ul, lg_lu, lg_s = lg_all.detach().split(B)
         else:
-            lg_lb, lg_ul, lg_lu, lg_s = model(lb_x_w), model(x_s_ul), model(x_s_lu), model(ulb_x_s)
+            lg_lb, lg_ul, lg_lu, lg_s = (model(t) for t in x_all[:n4].split([nlb, B, B, B]))
+            if ib_lq is not None:
+                with torch.no_grad():
+                    model(x_all[n4:])
         self._mark("student fwd issued")
 
-        # hardness and the low-quality sample forward (train.py:705-747, Q2, Q7)
-        host_ev.synchronize()                     # the copies were queued in front of the student passes
-        d = self._dice_from_host(dice_host)
-        self._mark("dice on host")
-        hardness = 1 - d.sum(0) / self.n_part
-        if epoch_num == 0:
-            hardness[:] = 1
-        lq_idx = int(np.argmax(hardness))
-        side_later = None
-        if region_host is not None:
-            ib_lq = F.rect_masks([all_cover_rect(region_host.numpy())], self.patch, self.patch, dev)
-            # result unused (Q2); student BN running stats still move.  A batch-1 forward fills 16-256 workgroups per
-            # launch, so it runs on a side stream underneath the losses and the backward that follow (ordered after
-            # the student passes issued so far; joined before the optimizer update touches the parameters).
-            lb_pick = lb_x_w[new_choice:new_choice + 1]
-            lq_prev = self.lq_u
-
-            def issue_side():
-                side = self._side_stream(dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                for t_ in (lq_prev, lb_pick, ib_lq):
-                    t_.record_stream(side)
-                with torch.cuda.stream(side), torch.no_grad():
-                    model(F.box_mix(lq_prev, lb_pick, ib_lq))
-                self._side_busy = True
-            if self._side_at in ("split", "mid") and lg_all is not None:
-                side_later = issue_side
-            elif self._side_at == "off_for_measurement_only":      # (its whole cost: never in a run whose statistics matter)
-                pass
-            else:
-                issue_side()
-        self.lq_u = ulb_x_w[lq_idx:lq_idx + 1].clone()
-        self.lq_pl = pl[lq_idx:lq_idx + 1].clone()
-        self.lq_mask = mask[lq_idx:lq_idx + 1].clone()
-
-        # memory bank of easy unlabelled samples (train.py:749-782)
-        simple = hardness < self.choice_th
-        n_cur = int(simple.sum())
-        sel = self._h2d(np.nonzero(simple)[0], dev, torch.long)        # indices from the host: no device-side nonzero, no sync
-
-        def pick(t):
-            return t.index_select(0, sel)
-        if self.simple_ulb is None or len(self.simple_ulb) == 0:
-            self.simple_ulb, self.cor_pl = pick(ulb_x_w), pick(pl)
-            self.cor_gt, self.cor_mask = pick(ulb_mask), pick(mask)
-            self.cor_hardness = hardness[simple].copy()
-            if len(self.simple_ulb) > 0:
-                self.choice_th = min(self.choice_th, self.cor_hardness.max())
-        elif n_cur > 0:
-            # train.py:768-771.  The reference's `newlen = max_len - cur_simple_num` goes NEGATIVE once a batch holds more
-            # easy samples than the queue is long (possible only with unlabel_bs > queue_len = 10; the reference runs 4),
-            # and `bank[:negative]` then lets the bank grow by up to unlabel_bs - queue_len entries per step without bound
-            # (29 GB after 1000 steps at B = 16).  Clamped at 0: identical whenever unlabel_bs <= queue_len.
-            keep = max(0, self.queue_len - n_cur) if len(self.simple_ulb) + n_cur > self.queue_len else len(self.simple_ulb)
-            self.simple_ulb = torch.cat((pick(ulb_x_w), self.simple_ulb[:keep]), 0)
-            self.cor_pl = torch.cat((pick(pl), self.cor_pl[:keep]), 0)
-            self.cor_gt = torch.cat((pick(ulb_mask), self.cor_gt[:keep]), 0)
-            self.cor_mask = torch.cat((pick(mask), self.cor_mask[:keep]), 0)
-            self.cor_hardness = np.concatenate((hardness[simple], self.cor_hardness[:keep]))
-            self.choice_th = min(self.choice_th, self.cor_hardness.max())
-        else:
-            self.choice_th = min(self.increase * self.choice_th, 0.1)
-
-        self._mark("lq+bank")
         # losses and backward (train.py:816-848; Q5, Q6): loss = sup + w*(ul + lu + w*s)
         w = self.consistency * ramps.sigmoid_rampup(self.iter_num // (self.max_iterations / self.rampup), self.rampup)
         terms = ((lg_lb, lb_mask, None, 1.0), (lg_ul, pl_ul, mask_ul, w), (lg_lu, pl_lu, mask_lu, w), (lg_s, pl_w, mask_w, w * w))
         outs = []
         model._ustrun_sink_fresh = True
-        dls = []
-        for lg, tgt, msk, coef in terms:
+        dl_all = torch.empty_like(lg_all) if lg_all is not None else None
+        for k, (lg, tgt, msk, coef) in enumerate(terms):
             out = F.seg_loss_fwd(lg.detach(), tgt, msk, mode)
             outs.append(out)
             dl = F.seg_loss_bwd(lg.detach(), tgt, msk, mode, out, gscale=coef,
-                                gdev=self.scaler.state if self.scaler is not None else None)     # scaler.scale(loss)
+                                gdev=self.scaler.state if self.scaler is not None else None,       # scaler.scale(loss)
+                                out=dl_all[k * B:(k + 1) * B] if dl_all is not None else None)
             if lg_all is None:
                 lg.backward(dl)
-            else:
-                dls.append(dl)
         overlap = self.grad_allreduce is not None and hasattr(self.grad_allreduce, "start_tail")
         if lg_all is not None:                    # one backward over the four passes
-            if overlap or side_later is not None:  # decoder gradients go out while the encoder half still runs
-                side_mid = side_later is not None and self._side_at == "mid"
-
-                def at_split():
-                    if overlap:
-                        self.grad_allreduce.start_tail(self.flat_g, self.dec_off)
-                    if side_later is not None and not side_mid:
-                        side_later()
-                model._ustrun_backward_split_hook = at_split
-                ar_mid = overlap and hasattr(self.grad_allreduce, "start_mid") and 0 < self.mid_off < self.dec_off
-                if ar_mid or side_mid:
-                    def at_mid():
-                        if ar_mid:
-                            self.grad_allreduce.start_mid(self.flat_g, self.mid_off)
-                        if side_mid:
-                            side_later()
-                    model._ustrun_backward_mid_hook = at_mid
+            if overlap:                           # decoder gradients go out while the encoder half still runs
+                model._ustrun_backward_split_hook = lambda: self.grad_allreduce.start_tail(self.flat_g, self.dec_off)
+                if hasattr(self.grad_allreduce, "start_mid") and 0 < self.mid_off < self.dec_off:
+                    model._ustrun_backward_mid_hook = lambda: self.grad_allreduce.start_mid(self.flat_g, self.mid_off)
             try:
-                lg_all.backward(torch.cat(dls, 0))
+                lg_all.backward(dl_all)
             finally:
                 model._ustrun_backward_split_hook = None
                 model._ustrun_backward_mid_hook = None
@@ -480,11 +437,6 @@ class SSLTrainer:
             else:
                 self.grad_allreduce(self.flat_g)
 
-        # The low-quality-sample forward on the side stream reads BatchNorm gamma/beta, the ConvTranspose biases and the
-        # head straight from flat_p (only the conv weights are packed copies): join it BEFORE the update rewrites flat_p.
-        if self._side_busy:
-            torch.cuda.current_stream(dev).wait_stream(self._side)
-            self._side_busy = False
         # SGD + EMA (train.py:848-851; alpha from the pre-increment iter_num, Q10), poly LR for the NEXT step
         alpha = min(1 - 1 / (self.iter_num + 1), self.ema_decay)
         if self.scaler is not None:               # scaler.step(optimizer); scaler.update() -- and the EMA line, in one pass
@@ -498,6 +450,50 @@ class SSLTrainer:
         engine.invalidate_packed(ema)
         self.lr = self.base_lr * (1.0 - self.iter_num / self.max_iterations) ** 0.9
         self.iter_num += 1
+        self._mark("update issued")
+
+        # ---- what the host keeps for the next iteration (train.py:705-718,749-782): hardness ranking, the low-quality sample,
+        # the memory bank.  The Dice counts were copied in front of the student's passes; the GPU is far past that point
+        dice_ev.synchronize()
+        d = self._dice_from_host(dice_host)
+        hardness = 1 - d.sum(0) / self.n_part
+        if epoch_num == 0:
+            hardness[:] = 1                                   # Q7
+        lq_idx = int(np.argmax(hardness))
+        self.lq_u = ulb_x_w[lq_idx:lq_idx + 1].clone()        # (the caller may reuse its input buffers)
+        self.lq_pl = pl[lq_idx:lq_idx + 1]                    # (pl / mask are this step's own outputs: nobody writes them again)
+        self.lq_mask = mask[lq_idx:lq_idx + 1]
+
+        # memory bank of easy unlabelled samples (train.py:749-782)
+        simple = hardness < self.choice_th
+        n_cur = int(simple.sum())
+        sel = [int(i) for i in np.nonzero(simple)[0]]
+
+        def merged(cur, old, keep):                # rows `sel` of cur, then the first `keep` rows of the old bank: one launch
+            rows = [F.row_ptrs(cur)[i] for i in sel] + (F.row_ptrs(old)[:keep] if old is not None else [])
+            if not rows:
+                return cur[:0]
+            return F.assemble([(r, 0, 0) for r in rows], cur)
+        if bank is None:
+            self.simple_ulb, self.cor_pl = merged(ulb_x_w, None, 0), merged(pl, None, 0)
+            self.cor_gt, self.cor_mask = merged(ulb_mask, None, 0), merged(mask, None, 0)
+            self.cor_hardness = hardness[simple].copy()
+            if len(self.simple_ulb) > 0:
+                self.choice_th = min(self.choice_th, self.cor_hardness.max())
+        elif n_cur > 0:
+            # train.py:768-771.  The reference's `newlen = max_len - cur_simple_num` goes NEGATIVE once a batch holds more
+            # easy samples than the queue is long (possible only with unlabel_bs > queue_len = 10; the reference runs 4),
+            # and `bank[:negative]` then lets the bank grow by up to unlabel_bs - queue_len entries per step without bound
+            # (29 GB after 1000 steps at B = 16).  Clamped at 0: identical whenever unlabel_bs <= queue_len.
+            keep = max(0, self.queue_len - n_cur) if len(bank) + n_cur > self.queue_len else len(bank)
+            keep = min(keep, len(bank))
+            self.simple_ulb, self.cor_pl = merged(ulb_x_w, self.simple_ulb, keep), merged(pl, self.cor_pl, keep)
+            self.cor_gt, self.cor_mask = merged(ulb_mask, self.cor_gt, keep), merged(mask, self.cor_mask, keep)
+            self.cor_hardness = np.concatenate((hardness[simple], self.cor_hardness[:keep]))
+            self.choice_th = min(self.choice_th, self.cor_hardness.max())
+        else:
+            self.choice_th = min(self.increase * self.choice_th, 0.1)
+
         self.last = {"outs": outs, "w": w, "pl": pl, "ulb_mask": ulb_mask, "mask": mask}
         self._mark("end")
         return self.last
