@@ -304,6 +304,71 @@ def test_convT_bf16_batched_passes_exact(n, G, ci, co, h, w):
     assert rel(dw.cpu(), wr.grad) < 1e-6 and rel(db.cpu(), br.grad) < 1e-6
 
 
+# ConvTranspose weight + bias gradient, the round-5 kernel (wgradT_bf16.hip: 256- / 128-ci x 256-column tiles, both operands by
+# buffer-addressed LDS-DMA three stages deep).  Exact (integer data): rows of 16 pixels (a 32-pixel stage spans two image rows), 18 /
+# 24 / 36 / 48 pixels (one or two wraps at changing positions: the M&Ms and prostate levels), pixel counts that are not a multiple of
+# the stage, several ci tiles (only the first forms the bias sums), plain and transforming sources, batched passes, accumulation;
+# the kernel that ran is asserted, the slabs' consumer (dw, db) sits between sentinel zones.
+CONVT_WGRAD_CASES = [
+    # (id, N, Cin, Cout, H, W, passes, transform, flags, expected variant)
+    ("t256_w16", 4, 256, 128, 16, 16, 2, True, 0, 0x54320100),
+    ("t256_w18_tail", 3, 512, 256, 18, 18, 1, True, 0, 0x54320100),
+    ("t256_w24_plain", 2, 256, 64, 24, 24, 1, False, 0, 0x54320100),
+    ("t256_w48", 2, 1024, 512, 12, 48, 1, True, 0, 0x54320100),
+    ("t128_w36", 4, 128, 64, 36, 36, 2, True, 0, 0x54320080),
+    ("t128_w144_tail", 1, 128, 64, 9, 144, 1, True, 0, 0x54320080),
+    ("t128_w256", 2, 128, 64, 64, 256, 2, True, 0, 0x54320080),
+    ("old_forced", 4, 256, 128, 16, 16, 2, True, 1 << 27, 0x54310000),
+]
+
+
+@pytest.mark.parametrize("name,n,ci,co,h,w,G,xf,flags,variant", CONVT_WGRAD_CASES, ids=[c[0] for c in CONVT_WGRAD_CASES])
+def test_convT_weight_gradient_round5_kernel_exact(name, n, ci, co, h, w, G, xf, flags, variant):
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(31 + ci + w)
+    ri = lambda lo, hi, *s: torch.randint(lo, hi + 1, s, generator=g).float()
+    gn = n // G
+    y = ri(-3, 3, n, ci, h, w)
+    du = ri(-2, 2, n, co, 2 * h, 2 * w)
+    if xf:
+        sc = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (G, ci), generator=g)]
+        sh = ri(-1, 1, G, ci)
+        a = torch.relu(y * sc.repeat_interleave(gn, 0)[:, :, None, None] + sh.repeat_interleave(gn, 0)[:, :, None, None])
+    else:
+        a = y
+    wt = ri(-2, 2, ci, co, 2, 2)
+    ar, wr, br = a.clone().requires_grad_(True), wt.clone().requires_grad_(True), torch.zeros(co, requires_grad=True)
+    F.conv_transpose2d(ar, wr, br, stride=2).backward(du)
+    yg, dug = nhwc16(y), nhwc16(du)
+    if xf:
+        aff = torch.zeros(G, 4, ci)
+        aff[:, 0], aff[:, 1] = sc, sh
+        affg = aff.cuda()
+        src = l.nhwc_src(yg.data_ptr(), ci, h, w, affg.data_ptr(), affg.data_ptr() + 4 * ci, relu=1, gN=gn if G > 1 else 0, gstride=4 * ci)
+    else:
+        src = l.nhwc_src(yg.data_ptr(), ci, h, w, gN=gn if G > 1 else 0, gstride=4 * ci)
+    nb = max(lib.ustrun_wgrad_partials_bytes(4, ci, co, n * h * w), 512 * co * 4)
+    part = torch.full((nb // 4 + 1024,), 5.0, device="cuda")
+    Z = 1024
+    wbuf = torch.full((Z + 4 * ci * co + Z,), 9.0, device="cuda")
+    bbuf = torch.full((Z + co + Z,), 9.0, device="cuda")
+    dw, db = wbuf[Z:Z + 4 * ci * co].view(ci, co, 2, 2), bbuf[Z:Z + co]
+    old = lib.ustrun_debug_flags(flags)
+    try:
+        l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, E.code, None))
+        v = lib.ustrun_debug_last_wgrad_variant()
+        assert v == variant, (hex(v), hex(variant))
+        assert rel(dw.cpu(), wr.grad) < 1e-6 and rel(db.cpu(), br.grad) < 1e-6, (rel(dw.cpu(), wr.grad), rel(db.cpu(), br.grad))
+        l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 1, part.data_ptr(), nb, E.code, None))
+        assert rel(dw.cpu(), 2 * wr.grad) < 1e-6 and rel(db.cpu(), 2 * br.grad) < 1e-6
+    finally:
+        lib.ustrun_debug_flags(old)
+    for b_ in (wbuf, bbuf):
+        assert bool((b_[:Z] == 9.0).all()) and bool((b_[-Z:] == 9.0).all()), "wrote outside its output"
+    assert bool((part[nb // 4:] == 5.0).all()), "slabs beyond the published partials bound"
+
+
 # 3x3 weight gradient, the three builds of the all-taps kernel (wgrad_halo_bf16.hip): 0x482 = two wave groups in opposite phases
 # (>= 256 channels: 16 (ci, co) pairs), 0x481 = buffer-addressed transfers, 256-thread blocks, 0x480 = the round-2 kernel (kept for
 # operands beyond 2 GB per image; forced here with ustrun_debug_flags 64).  Exact (integer data), ragged extents, a source placed at

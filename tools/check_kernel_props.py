@@ -22,7 +22,8 @@ from check_store_hazard import OBJDUMP, code_objects  # noqa: E402
 
 # (the eight-wave build of the streaming kernel -- conv3x3_ws64x8_kernel, debug flag bit 2, never the default -- spills 8-64
 # registers and leaves its waits to the compiler: not in this list)
-COUNTED = ("conv3x3_halo_bf16_kernel", "conv3x3_ws64cp_kernel", "conv3x3_ws64_kernel", "convT_bf16_kernel", "conv_first_fwd_stream_kernel")
+COUNTED = ("conv3x3_halo_bf16_kernel", "conv3x3_ws64cp_kernel", "conv3x3_ws64_kernel", "convT_bf16_kernel", "conv_first_fwd_stream_kernel",
+           "wgradT2_bf16_kernel", "wgrad_halo4_bf16_kernel")
 BATCHED = {"bn_bwd_finalize_kernel": 8, "bn_finalize_kernel": 8, "reduce_rows_kernel": 4, "bn_stat_fused_kernel": 8, "bn_stat_stage1_kernel": 8,
            "reduce_plain_kernel": 8, "reduce_groups_kernel": 8}
 

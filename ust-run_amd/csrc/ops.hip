@@ -394,10 +394,14 @@ extern "C" int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int6
         wgrad_tap_plan(t, &kt, &ct);
         if (kt > slabs) slabs = kt;
     }
-    if (nseg == 4 && Cin % 128 == 0 && Cout % 32 == 0) {         // the ConvTranspose all-taps bf16 kernel
+    if (nseg == 4 && Cin % 128 == 0 && Cout % 32 == 0) {         // the ConvTranspose all-taps bf16 kernels
         int kt; long ct;
         wgradT_plan(Cin, Cout, npix, &kt, &ct);
         if (kt > slabs) slabs = kt;
+        if (Cout % 64 == 0) {
+            wgradT2_plan(Cin, Cout, npix, &kt, &ct);
+            if (kt > slabs) slabs = kt;
+        }
     }
     int64_t b = (int64_t)slabs * nseg * Cin * Cout * sizeof(float);
     if (nseg == 4) b += (int64_t)slabs * Cout * sizeof(float);    // bias column sums ride behind the slabs
@@ -505,7 +509,7 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
         }
     }
     if (dtype == USTRUN_D16 && wgradT_supported(a)) {       // all four taps (and the bias) in one GEMM: wgradT_bf16.hip
-        wgradT_plan(a.Cin, Cout, a.M, &a.ksplit, &a.kchunk);
+        wgradT_plan_for(a, &a.ksplit, &a.kchunk);
         slabs = a.ksplit;
         const int64_t slab_bytes = (int64_t)slabs * 4 * a.Cin * Cout * 4;
         USTRUN_CHECK(partials_bytes >= slab_bytes + (db ? (int64_t)slabs * Cout * 4 : 0), "convT2x2_wgrad: partials too small");
