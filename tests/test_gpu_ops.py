@@ -290,6 +290,44 @@ def test_conv3x3_bf16_mfma(n, ci, co, h, w, exact):
     assert rel(dw.cpu(), wr.grad) < tol
 
 
+@pytest.mark.parametrize("elt", ["bf16", "f16"])
+@pytest.mark.parametrize("flags", [0, 1 << 28])
+@pytest.mark.parametrize("n,c,h,w", [(2, 3, 16, 32), (1, 1, 19, 37), (2, 4, 9, 70), (3, 3, 40, 33), (4, 3, 136, 96), (16, 1, 72, 100),
+                                     (64, 3, 64, 64), (8, 3, 256, 256), (5, 1, 288, 288)])
+def test_conv_first_weight_gradient_exact(n, c, h, w, flags, elt):
+    """Weight gradient of the first convolution (NCHW f32 network input, C <= 4 -> 64; autograd of nn.Conv2d at unet_parts.py:16 for
+    `inc`): the streaming kernel of round 5 (a wave walks a 16-pixel strip a row a step, dY and the lane's im2col row of x fetched
+    four steps ahead through range-checked buffer loads, masks applied at use) and, with ustrun_debug_flags bit 28, the tile kernel
+    of rounds 1-4.  Small-integer data is exact: image borders (rows above / below, columns left / right), ragged strips (w % 16),
+    segments that do not divide the height, im2col rows past 9 C and accumulation all show as O(1) errors; dw sits between sentinels."""
+    l = L()
+    lib = l.lib()
+    t16, code = (torch.bfloat16, 1) if elt == "bf16" else (torch.float16, 2)
+    g = torch.Generator().manual_seed(7 * c + w)
+    x = torch.randint(-3, 4, (n, c, h, w), generator=g).float()
+    dy = torch.randint(-2, 3, (n, 64, h, w), generator=g).float()
+    wr = torch.zeros(64, c, 3, 3, requires_grad=True)
+    F.conv2d(x, wr, None, 1, 1).backward(dy)
+    xg = x.contiguous().cuda()
+    dyg = dy.permute(0, 2, 3, 1).contiguous().cuda().to(t16)
+    src = l.nchw_src(xg.data_ptr(), c, h, w)
+    nb = lib.ustrun_wgrad_partials_bytes(9, c, 64, n * h * w)
+    part = torch.full((nb // 4 + 1024,), 5.0, device="cuda")
+    Z = 512
+    buf = torch.full((Z + 64 * c * 9 + Z,), 9.0, device="cuda")
+    dw = buf[Z:Z + 64 * c * 9].view(64, c, 3, 3)
+    old = lib.ustrun_debug_flags(flags)
+    try:
+        l.check(lib.ustrun_conv3x3_wgrad(C.byref(src), 1, dyg.data_ptr(), n, h, w, 64, dw.data_ptr(), 0, part.data_ptr(), nb, code, None))
+        assert rel(dw.cpu(), wr.grad) < 1e-6, rel(dw.cpu(), wr.grad)
+        l.check(lib.ustrun_conv3x3_wgrad(C.byref(src), 1, dyg.data_ptr(), n, h, w, 64, dw.data_ptr(), 1, part.data_ptr(), nb, code, None))
+        assert rel(dw.cpu(), 2 * wr.grad) < 1e-6
+    finally:
+        lib.ustrun_debug_flags(old)
+    assert bool((buf[:Z] == 9.0).all()) and bool((buf[-Z:] == 9.0).all())
+    assert bool((part[nb // 4:] == 5.0).all()), "slabs beyond the published partials bound"
+
+
 @pytest.mark.parametrize("with_stat", [True, False])
 @pytest.mark.parametrize("elt", ["bf16", "f16"])
 @pytest.mark.parametrize("flags", [0, 16384])

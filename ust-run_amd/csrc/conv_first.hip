@@ -333,29 +333,148 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
     }
 }
 
-// dw[co][c][t] (+)= sum_k partials[k][c*9+t][co]
+// ---- weight gradient, streaming form (round 5) -----------------------------------------------------------------------------
+// The layer is a 537 MB read of dY (N = 64) beside 17 GFLOP: the tile kernel above moved it at 2.8 TB/s -- 4 MFMAs per wave between
+// two block barriers per 16 KB tile, one tile of prefetch.  Here nothing is shared between waves: a wave owns a 16-pixel-wide strip
+// of `seg_rows` rows of one image and walks it a row a step; a step's dY row piece (16 px x 64 ch = 2 KB, contiguous) and the eight
+// x values of the lane's im2col row (c, kh, kw) -- straight from the NCHW image, which stays in L2 -- are fetched into REGISTERS
+// four steps ahead (the compiler counts those waits itself), the dY piece passes through a wave-private LDS slot for the
+// transposing fragment reads, two MFMAs, next step.  No barrier until the block's four accumulator sets are summed at the end.
+template <int D>
+__global__ __launch_bounds__(256) void conv_first_wgrad_stream_kernel(const float* __restrict__ x, int sN, int sC, int sH, int C,
+                                                                      int H, int W, int xbytes, const elt_t* __restrict__ dy,
+                                                                      int dybytes, float* __restrict__ partials, int strips, int segs,
+                                                                      int seg_rows, int items) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    __shared__ __attribute__((aligned(16))) char dys[4 * 2 * FTW * WRB > 4 * 32 * 64 * 4 ? 4 * 2 * FTW * WRB : 4 * 32 * 64 * 4];
+    float (*accs)[32][64] = (float (*)[32][64])dys;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int item = blockIdx.x * 4 + wave;
+    if (item < items) {
+        // (strip fastest: the four waves of a block read four neighbouring 2 KB pieces of the same dY rows)
+        const int sx = item % strips, sg = (item / strips) % segs, img = item / (segs * strips);
+        const int x0 = sx * FTW, r0 = sg * seg_rows, r1 = min(H, r0 + seg_rows);
+        // this lane's im2col row i = l31 -> (c, kh, kw); rows >= 9C are zero
+        const int ic = l31 / 9, it = l31 % 9, ikh = it / 3, ikw = it % 3;
+        const bool ivalid = l31 < 9 * C;
+        // Both tensors are read through ONE buffer resource each, every load issued unconditionally: an offset outside the tensor
+        // (one float in front of the first row, a few behind the last) fails the range check and returns zeros; what must not
+        // count -- image rows above / below, columns left / right of the image, im2col rows past 9 C, rows past the segment --
+        // is masked when the values are USED, four steps later: a select around a load would put its wait right behind the load.
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, xbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dybytes, 0x00020000);
+        const int col0 = x0 + 8 * lh + ikw - 1;                       // first of the lane's eight pixels' x columns
+        // (the one lane column that starts a float in FRONT of its row -- x0 = 0, kw = 0 -- would start the tensor's very first row at
+        // offset -4: the whole 16-byte load fails the range check, not just its first word.  Those lanes fetch one column to the
+        // right and shift the values back when they use them.)
+        const bool shl = col0 < 0;
+        const int xoff0 = (img * sN + (ivalid ? ic : 0) * sC + col0 + (shl ? 1 : 0)) * 4;
+        unsigned cm[8];                                               // per column: all ones where it lies in the image
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cm[q] = (ivalid && (unsigned)(col0 + q) < (unsigned)W) ? 0xffffffffu : 0u;
+        // dY: lane fetches 16-byte piece 64 i + lane of the row's 2 KB: pixel (64 i + lane) >> 3, channel group lane & 7
+        const int dpx0 = lane >> 3, dpx1 = 8 + (lane >> 3), dcg = lane & 7;
+        const unsigned dm0 = x0 + dpx0 < W ? 0xffffffffu : 0u, dm1 = x0 + dpx1 < W ? 0xffffffffu : 0u;
+        const int doff0 = ((img * H * W + x0 + dpx0) * 64 + dcg * 8) * 2, doff1 = doff0 + 8 * 64 * 2;
+        char* slot = dys + wave * (2 * FTW * WRB);
+        const int lrow = 8 * lh + ((lane & 15) >> 2), lcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        u32x4 xr[D][2], dr[D][2];
+        unsigned rm[D];                                               // per slot: all ones where the lane's x row lies in the image
+        auto prefetch = [&](int u, int y) {
+            const int yy = y + ikh - 1;
+            rm[u] = (y < r1 && (unsigned)yy < (unsigned)H) ? 0xffffffffu : 0u;
+            const int xo = xoff0 + yy * sH * 4;
+            xr[u][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo, 0, 0));
+            xr[u][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo + 16, 0, 0));
+            const int dofs = min(y, r1 - 1) * W * 128;
+            dr[u][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, doff0 + dofs, 0, 0));
+            dr[u][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, doff1 + dofs, 0, 0));
+        };
+        auto consume = [&](int u, int par, bool live) {
+            char* sl = slot + par * (FTW * WRB);
+            u32x4 d0 = dr[u][0], d1 = dr[u][1];
+            const unsigned lm = live ? 0xffffffffu : 0u;              // (wave-uniform: rows past the segment add nothing)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { d0[q] &= dm0 & lm; d1[q] &= dm1 & lm; }
+            *(u32x4*)(sl + dpx0 * WRB + dcg * 16) = d0;
+            *(u32x4*)(sl + dpx1 * WRB + dcg * 16) = d1;
+            bf16x8 a;
+            unsigned v[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = xr[u][0][q]; v[4 + q] = xr[u][1][q]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned t = shl ? (q ? v[q - 1] : 0u) : v[q];
+                a[q] = (elt_t)__builtin_bit_cast(float, t & cm[q] & rm[u]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const char* base = sl + lrow * WRB + (j * 32 + lcol) * 2;
+                const bf16x4 lo = USTRUN_DS_READ_TR16((lds_bf16x4*)base);
+                const bf16x4 hi = USTRUN_DS_READ_TR16((lds_bf16x4*)(base + 4 * WRB));
+                bf16x8 b;
+                b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = lo[3]; b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = hi[3];
+                acc[j] = USTRUN_MFMA_32x32x16(a, b, acc[j], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < D; ++u) prefetch(u, r0 + u);
+        for (int y = r0; y < r1; y += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                consume(u, u & 1, y + u < r1);
+                prefetch(u, y + u + D);
+            }
+        }
+    }
+    // sum the four waves (fixed order) and write the block's slab
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][j * 32 + l31] = acc[j][r];
+    __syncthreads();
+    float* slab = partials + (long)blockIdx.x * 32 * 64;
+    for (int e = tid; e < 32 * 64; e += 256) {
+        const int i = e >> 6, co = e & 63;
+        slab[e] = accs[0][i][co] + accs[1][i][co] + accs[2][i][co] + accs[3][i][co];
+    }
+}
+
+// dw[co][c][t] (+)= sum_k partials[k][c*9+t][co].  Block = 8 outputs (consecutive co of one im2col row: 32 contiguous bytes per
+// slab) x 128 slab lanes; a lane's slabs k = lane, lane + 128, .. are ALL loaded before the first add (up to eight in flight: the
+// 1024-slab table is one memory round trip, where 32 lanes x four in flight made it eight dependent ones -- 35 us for 8 MB), summed
+// in ascending k, then the lanes in ascending order: a fixed order, f64.
 __global__ __launch_bounds__(1024) void conv_first_wgrad_reduce_kernel(const float* __restrict__ partials, int nslab, int C,
                                                                      float* __restrict__ dw, int accumulate) {
-    __shared__ double red[32][32];
-    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;         // 32 outputs x 32 slab lanes (1024 threads)
-    const int e = blockIdx.x * 32 + el;
+    __shared__ double red[128][8];
+    const int ol = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int e = blockIdx.x * 8 + ol;                   // (im2col row i, co) in i-major order
+    const int i = e >> 6, co = e & 63;
     double v = 0.0;
-    if (e < 64 * C * 9) {
-        const int co = e / (C * 9), i = e % (C * 9);
+    if (i < 9 * C) {
         const float* p0 = partials + (long)i * 64 + co;
-        int k = sl;
-        for (; k + 96 < nslab; k += 128) {                            // four slabs in flight, summed in order
-            const float a0 = p0[(long)k * 2048], a1 = p0[(long)(k + 32) * 2048], a2 = p0[(long)(k + 64) * 2048],
-                        a3 = p0[(long)(k + 96) * 2048];
-            v += (double)a0; v += (double)a1; v += (double)a2; v += (double)a3;
+        for (int k0 = sl; k0 < nslab; k0 += 1024) {
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = k0 + 128 * u; a[u] = p0[(long)(k < nslab ? k : k0) * 2048]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += (k0 + 128 * u < nslab) ? (double)a[u] : 0.0;
         }
-        for (; k < nslab; k += 32) v += (double)p0[(long)k * 2048];
     }
-    red[sl][el] = v;
+    red[sl][ol] = v;
     __syncthreads();
-    if (sl == 0 && e < 64 * C * 9) {
-        for (int k = 1; k < 32; ++k) v += red[k][el];
-        dw[e] = accumulate ? dw[e] + (float)v : (float)v;
+    if (sl == 0 && i < 9 * C) {
+        for (int k = 1; k < 128; ++k) v += red[k][ol];
+        const int o = co * (C * 9) + i;
+        dw[o] = accumulate ? dw[o] + (float)v : (float)v;
     }
 }
 
@@ -586,6 +705,29 @@ int conv_first_wgrad(const ustrun_src_t& s, const void* dy, int dy_esz, int N, f
     int blocks = ttotal < 1024 ? ttotal : 1024;
     const int per = cdiv(ttotal, blocks);
     blocks = cdiv(ttotal, per);
+    // (ustrun_debug_flags bit 28: the tile kernel of rounds 1-4, for A/B runs)
+    const long xbytes = (long)N * s.sN * 4, dybytes = (long)N * s.H * s.W * 64 * 2;
+    if (dy_esz == 2 && s.sW == 1 && s.f32 && !(g_debug_flags & (1 << 28)) && xbytes < (1L << 31) - 64 && dybytes < (1L << 31) - 64 &&
+        s.sN == (int64_t)s.C * s.sC && s.sC == (int64_t)s.H * s.sH) {
+        const int strips = cdiv(s.W, FTW);
+        long segs = 4096 / ((long)N * strips);
+        if (segs > s.H / 8) segs = s.H / 8;
+        if (segs < 1) segs = 1;
+        const int seg_rows = cdiv(s.H, segs);
+        const int nseg = cdiv(s.H, seg_rows);
+        const long items = (long)N * strips * nseg;
+        if (items <= 4096) {
+            blocks = cdiv(items, 4);
+            hipLaunchKernelGGL(conv_first_wgrad_stream_kernel<4>, dim3(blocks), dim3(256), 0, st, (const float*)s.ptr, (int)s.sN, (int)s.sC,
+                               (int)s.sH, s.C, s.H, s.W, (int)xbytes, (const elt_t*)dy, (int)dybytes, partials, strips, nseg, seg_rows,
+                               (int)items);
+            USTRUN_LAUNCH_CHECK("conv_first_wgrad_stream");
+            hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(cdiv(64 * s.C * 9, 8)), dim3(1024), 0, st, partials, blocks, s.C, dw,
+                               accumulate);
+            USTRUN_LAUNCH_CHECK("conv_first_wgrad_reduce");
+            return 0;
+        }
+    }
     if (dy_esz == 2)
         hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(blocks), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
                            (long)s.sH, (long)s.sW, s.C, s.H, s.W, (const float*)dy, partials, tx, ty, ttotal, per);
@@ -593,7 +735,7 @@ int conv_first_wgrad(const ustrun_src_t& s, const void* dy, int dy_esz, int N, f
         hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(blocks), dim3(256), 0, st, (const float*)s.ptr, (long)s.sN, (long)s.sC,
                            (long)s.sH, (long)s.sW, s.C, s.H, s.W, (const float*)dy, partials, tx, ty, ttotal, per);
     USTRUN_LAUNCH_CHECK("conv_first_wgrad");
-    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(cdiv(64 * s.C * 9, 32)), dim3(1024), 0, st, partials, blocks, s.C, dw,
+    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(cdiv(64 * s.C * 9, 8)), dim3(1024), 0, st, partials, blocks, s.C, dw,
                        accumulate);
     USTRUN_LAUNCH_CHECK("conv_first_wgrad_reduce");
     return 0;

@@ -436,7 +436,9 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
             return 0;
         }
     }
-    if (dtype == USTRUN_D16 && nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W && srcs[0].f32)
+    // (its im2col tile holds 32 rows = 9 taps of at most three channels: a 4-channel input -- 36 rows -- takes the generic kernel)
+    if (dtype == USTRUN_D16 && nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W && srcs[0].f32 &&
+        9 * srcs[0].C <= 32)
         return conv_first_wgrad(srcs[0], dy, act_esz(dtype), N, dw, accumulate, partials, partials_bytes, (hipStream_t)s);
     if (dtype == USTRUN_D16 && wgrad_halo_supported(a)) {
         int per;
