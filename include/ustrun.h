@@ -21,6 +21,10 @@
  *     scale: ustrun_seg_loss_bwd's gscale carries it in, ustrun_sgd_ema_scaled takes it out and skips
  *     the update when the scaled gradient is not finite).  `void*` activation arguments follow
  *     dtype; the network input, logits, parameters and gradients of parameters are always f32.
+ *     USTRUN_F32X3: every tensor, loader and epilogue of USTRUN_F32, with the products of the 3x3 convolutions (and the
+ *     ConvTranspose pair) on the BF16 matrix cores over three-term operand splits x = x0 + x1 + x2, six MFMAs per product
+ *     (csrc/x3.hip): f32-level results (the north_star tolerance: 1e-4 on logits, arg-max bit-exact outside 1e-4 margins) at a
+ *     multiple of the f32 matrix rate.  Its packed weights are the f32 pack followed by the three bf16 planes: 2.5x the floats.
  */
 #ifndef USTRUN_H
 #define USTRUN_H
@@ -31,7 +35,7 @@ extern "C" {
 #endif
 
 #define USTRUN_VERSION 100
-enum { USTRUN_F32 = 0, USTRUN_BF16 = 1, USTRUN_F16 = 2 };
+enum { USTRUN_F32 = 0, USTRUN_BF16 = 1, USTRUN_F16 = 2, USTRUN_F32X3 = 3 };
 enum { USTRUN_LOSS_SOFTMAX = 0, USTRUN_LOSS_SIGMOID = 1 };
 
 typedef void* ustrun_stream_t;
@@ -64,7 +68,8 @@ typedef struct ustrun_src {
 
 /* ---- weight packing (done once per optimizer step) ---------------------------------------
  * conv3x3: torch [Cout][Cin][3][3] -> fwd [9][Cin][Cout] and dgrad [9][Cout][Cin]
- * convT2x2: torch [Cin][Cout][2][2] -> fwd [4][Cin][Cout] and dgrad [4][Cout][Cin]            */
+ * convT2x2: torch [Cin][Cout][2][2] -> fwd [4][Cin][Cout] and dgrad [4][Cout][Cin]
+ * (USTRUN_F32X3: each of the two buffers holds 2.5 x that many floats -- the f32 pack, then its bf16 planes)  */
 int ustrun_pack_conv3x3(const float* w, int Cout, int Cin, void* w_fwd, void* w_dgrad, int dtype, ustrun_stream_t s);
 int ustrun_pack_convT2x2(const float* w, int Cin, int Cout, void* w_fwd, void* w_dgrad, int dtype, ustrun_stream_t s);
 

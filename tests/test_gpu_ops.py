@@ -231,6 +231,89 @@ def test_head_fwd_bwd(n, c, k, h, w):
     assert rel(dw.cpu(), wr.grad) < 1e-5 and rel(db.cpu(), br.grad) < 1e-5
 
 
+# ---- dtype = 3 (USTRUN_F32X3): f32 tensors, products as six bf16 MFMAs over three-term operand splits (csrc/x3.hip) -------------
+def pack_conv_x3(w):
+    l = L()
+    co, ci = w.shape[:2]
+    n = 9 * ci * co
+    wf = torch.zeros(3 * n, device="cuda")          # the f32 pack + its three bf16 planes (2.5 n floats)
+    wd = torch.zeros(3 * n, device="cuda")
+    wg = w.contiguous().cuda()
+    l.check(l.lib().ustrun_pack_conv3x3(wg.data_ptr(), co, ci, wf.data_ptr(), wd.data_ptr(), 3, None))
+    return wf, wd
+
+
+@pytest.mark.parametrize("n,c0,c1,co,h,w,exact", [(2, 64, 0, 64, 16, 16, True), (2, 64, 0, 64, 16, 16, False), (3, 64, 64, 128, 9, 21, False),
+                                                  (2, 256, 0, 128, 12, 10, False), (1, 128, 0, 192, 37, 19, True), (4, 512, 0, 512, 8, 8, False)])
+def test_conv3x3_f32x3(n, c0, c1, co, h, w, exact):
+    """The 3x3 convolution trio under dtype 3 against torch in float64: small integers are exact (x1 = x2 = 0), random data lands
+    within f32 summation noise of the exact-f32 matrix-core path -- bounded by 3x torch-f32's own distance from float64, i.e. NOT the
+    4e-3 of a single bf16 rounding; BatchNorm + ReLU on load, concat with an offset window, ragged M tiles, statistics rows, the input
+    gradient whole and split, the weight gradient with accumulation; the kernels that ran are the x3 ones (flag bit 29 switches them
+    off: the results then come from the f32 matrix-core kernels and agree to the same bound)."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(c0 + co + h)
+    ci = c0 + c1
+    rnd = (lambda *s: torch.randint(-3, 4, s, generator=g).float()) if exact else (lambda *s: torch.randn(*s, generator=g))
+    y0 = rnd(n, c0, h, w)
+    sc = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (c0,), generator=g)] if exact else 1 + 0.3 * torch.randn(c0, generator=g)
+    sh = torch.randint(-1, 2, (c0,), generator=g).float() if exact else 0.2 * torch.randn(c0, generator=g)
+    parts = [torch.relu(y0 * sc[None, :, None, None] + sh[None, :, None, None])]
+    if c1:
+        up = rnd(n, c1, h - 3, w - 2)
+        parts.append(F.pad(up, [1, 1, 1, 2]))
+    a = torch.cat(parts, 1)
+    wt = rnd(co, ci, 3, 3) if exact else torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+    dy = rnd(n, co, h, w)
+
+    def ref(dt):
+        ar, wr = a.to(dt).clone().requires_grad_(True), wt.to(dt).clone().requires_grad_(True)
+        out = F.conv2d(ar, wr, None, 1, 1)
+        out.backward(dy.to(dt))
+        return out.detach(), ar.grad, wr.grad
+    y64, da64, dw64 = ref(torch.float64)
+    y32, da32, dw32 = ref(torch.float32)
+    tol = lambda r32, r64: 1e-7 if exact else max(3 * rel(r32, r64), 2e-6)
+    wf, wd = pack_conv_x3(wt)
+    y0g, scg, shg = nhwc(y0), sc.cuda(), sh.cuda()
+    srcs = (l.Src * 2)()
+    srcs[0] = l.nhwc_src(y0g.data_ptr(), c0, h, w, scg.data_ptr(), shg.data_ptr(), relu=1)
+    if c1:
+        ug = nhwc(up)
+        srcs[1] = l.nhwc_src(ug.data_ptr(), c1, h - 3, w - 2, off=(1, 1))
+    ns = 2 if c1 else 1
+    for flags in (0, 1 << 29):
+        old = lib.ustrun_debug_flags(flags)
+        try:
+            y = torch.empty(n, h, w, co, device="cuda")
+            mt = lib.ustrun_conv_mtiles(n, h, w, co)
+            stat = torch.zeros(mt, 2, co, device="cuda")
+            l.check(lib.ustrun_conv3x3_fwd(srcs, ns, wf.data_ptr(), n, h, w, co, y.data_ptr(), stat.data_ptr(), 3, None))
+            assert rel(from_nhwc(y), y64) < tol(y32, y64), (flags, rel(from_nhwc(y), y64), rel(y32, y64))
+            np.testing.assert_allclose(stat[:, 0].sum(0).cpu().numpy(), y64.sum((0, 2, 3)).numpy(), rtol=1e-3, atol=2e-3)
+            dyg = nhwc(dy)
+            da = torch.empty(n, h, w, ci, device="cuda")
+            if c1:        # split over the two sources' gradients (the second through its offset window)
+                d0 = torch.empty(n, h, w, c0, device="cuda")
+                d1 = torch.empty(n, h - 3, w - 2, c1, device="cuda")
+                l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, d0.data_ptr(), c0, d1.data_ptr(), h - 3, w - 2, 1, 1, 3, None))
+                assert rel(from_nhwc(d0), da64[:, :c0]) < tol(da32[:, :c0], da64[:, :c0])
+                assert rel(from_nhwc(d1), da64[:, c0:, 1:h - 2, 1:w - 1]) < tol(da32[:, c0:, 1:h - 2, 1:w - 1], da64[:, c0:, 1:h - 2, 1:w - 1])
+            else:
+                l.check(lib.ustrun_conv3x3_dgrad(dyg.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 3, None))
+                assert rel(from_nhwc(da), da64) < tol(da32, da64), (flags, rel(from_nhwc(da), da64))
+            nb = lib.ustrun_wgrad_partials_bytes(9, ci, co, n * h * w)
+            part = torch.empty(nb // 4, device="cuda")
+            dw = torch.empty(co, ci, 3, 3, device="cuda")
+            l.check(lib.ustrun_conv3x3_wgrad(srcs, ns, dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 0, part.data_ptr(), nb, 3, None))
+            assert rel(dw.cpu(), dw64) < tol(dw32, dw64), (flags, rel(dw.cpu(), dw64), rel(dw32, dw64))
+            l.check(lib.ustrun_conv3x3_wgrad(srcs, ns, dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 1, part.data_ptr(), nb, 3, None))
+            assert rel(dw.cpu(), 2 * dw64) < tol(dw32, dw64)
+        finally:
+            lib.ustrun_debug_flags(old)
+
+
 # ---- dtype = 1: bf16 tensors in HBM, bf16 MFMA operands, f32 accumulate/statistics -------------
 def nhwc16(t):
     return nhwc(t).bfloat16()

@@ -316,6 +316,8 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
         else if (convT_dgrad_supported(a)) rc = convT_dgrad_launch_bf16(a, st);
         else if (grouped) { set_error("igemm: batched passes reached a kernel without per-pass BatchNorm constants"); rc = 1; }
         else rc = igemm_launch_bf16(a, st);
+    } else if (dtype == USTRUN_F32X3 && !grouped && igemm_x3_supported(a)) {     // three-term bf16 products (x3.hip)
+        rc = igemm_x3_launch(a, st);
     } else if (pick_bm(a.Cout) == 128 || pool) {   // (narrow outputs with a pooled source only occur in tiny test nets)
         rc = pool ? launch_cfg<2, 2, true>(a, st) : launch_cfg<2, 2, false>(a, st);
     } else {

@@ -51,6 +51,10 @@ extern "C" int ustrun_pack_conv3x3(const float* w, int Cout, int Cin, void* w_fw
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(pack_blocks((long)Cout * Cin * 9)), dim3(256), 0, (hipStream_t)s, w, Cout,
                        Cin, (float*)w_fwd, (float*)w_dgrad);
     USTRUN_LAUNCH_CHECK("pack_conv3x3");
+    if (dtype == USTRUN_F32X3) {          // the three bf16 planes behind each f32 pack (x3.hip)
+        USTRUN_TRY(pack_x3((const float*)w_fwd, 9, Cin, Cout, (hipStream_t)s));
+        if (w_dgrad) USTRUN_TRY(pack_x3((const float*)w_dgrad, 9, Cout, Cin, (hipStream_t)s));
+    }
     return 0;
 }
 
@@ -62,6 +66,10 @@ extern "C" int ustrun_pack_convT2x2(const float* w, int Cin, int Cout, void* w_f
     hipLaunchKernelGGL(pack_convT_kernel, dim3(pack_blocks((long)Cout * Cin * 4)), dim3(256), 0, (hipStream_t)s, w, Cin,
                        Cout, (float*)w_fwd, (float*)w_dgrad);
     USTRUN_LAUNCH_CHECK("pack_convT2x2");
+    if (dtype == USTRUN_F32X3) {
+        USTRUN_TRY(pack_x3((const float*)w_fwd, 4, Cin, Cout, (hipStream_t)s));
+        if (w_dgrad) USTRUN_TRY(pack_x3((const float*)w_dgrad, 4, Cout, Cin, (hipStream_t)s));
+    }
     return 0;
 }
 
@@ -210,7 +218,7 @@ extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const
     a.out0 = (float*)y; a.out1 = nullptr; a.C0 = Cout; a.Ho = H; a.Wo = W;
     a.bias = nullptr; a.stat = stat; a.out_esz = act_esz(dtype);
     const bool first = nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W &&
-                       (srcs[0].f32 || dtype == USTRUN_F32);
+                       (srcs[0].f32 || dtype != USTRUN_D16);
     int gN = 0;
     const int G = src_groups(srcs, nsrc, N, &gN);
     USTRUN_CHECK(G >= 1, "conv3x3_fwd: inconsistent pass groups");
@@ -446,6 +454,16 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
         USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 9 * a.Cin * Cout * 4, "conv3x3_wgrad: partials too small");
         prof_begin(1, 2.0 * a.M * 9 * a.Cin * Cout, 2.0 * ((double)a.M * a.Cin + (double)a.M * Cout) + 36.0 * a.Cin * Cout, (hipStream_t)s);
         const int rc = wgrad_halo_launch_bf16(a, slabs, per, (hipStream_t)s);
+        prof_end((hipStream_t)s);
+        USTRUN_TRY(rc);
+        return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 2, accumulate, (hipStream_t)s);   // slabs are in torch layout
+    }
+    if (dtype == USTRUN_F32X3 && wgrad_x3_supported(a)) {        // all nine taps per block, operands split at staging (x3.hip)
+        int per;
+        wgrad_x3_plan(a, &slabs, &per);
+        USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 9 * a.Cin * Cout * 4, "conv3x3_wgrad: partials too small");
+        prof_begin(1, 2.0 * a.M * 9 * a.Cin * Cout, 4.0 * ((double)a.M * a.Cin + (double)a.M * Cout) + 36.0 * a.Cin * Cout, (hipStream_t)s);
+        const int rc = wgrad_x3_launch(a, slabs, per, (hipStream_t)s);
         prof_end((hipStream_t)s);
         USTRUN_TRY(rc);
         return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 2, accumulate, (hipStream_t)s);   // slabs are in torch layout

@@ -119,12 +119,13 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
 
     o = 0;
     for (int i = 0; i < 18; ++i) {
-        const long n = 9L * align_up(p.cin[i], 8) * align_up(p.cout[i], 8);   // covers f32 and the K-padded bf16 layout
+        // (covers f32 and the K-padded bf16 layout; USTRUN_F32X3: the f32 pack + its three bf16 planes = 2.5x, rounded up to 3x)
+        const long n = 9L * align_up(p.cin[i], 8) * align_up(p.cout[i], 8) * (d->dtype == USTRUN_F32X3 ? 3 : 1);
         p.wf_off[i] = o; o = align_up(o + n, 64);
         p.wd_off[i] = o; o = align_up(o + n, 64);
     }
     for (int j = 0; j < 4; ++j) {
-        const long n = 4L * align_up(p.up_cin[j], 8) * align_up(p.up_cout[j], 8);
+        const long n = 4L * align_up(p.up_cin[j], 8) * align_up(p.up_cout[j], 8) * (d->dtype == USTRUN_F32X3 ? 3 : 1);
         p.uf_off[j] = o; o = align_up(o + n, 64);
         p.ud_off[j] = o; o = align_up(o + n, 64);
     }

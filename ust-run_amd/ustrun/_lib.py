@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USTRUN_LIB", os.path.join(_HERE, "libustrun.so"))      # (USTRUN_LIB: A/B runs of two builds on one box)
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, F32X3 = 0, 1, 2, 3
 LOSS_SOFTMAX, LOSS_SIGMOID = 0, 1
 
 vp, fp, i32, i64, f32 = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib as L
 
-_DT = {"f32": L.F32, "bf16": L.BF16, "f16": L.F16}
+_DT = {"f32": L.F32, "bf16": L.BF16, "f16": L.F16, "f32x3": L.F32X3}
 
 
 def stream_ptr():
