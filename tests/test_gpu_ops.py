@@ -283,7 +283,7 @@ def test_conv3x3_f32x3(n, c0, c1, co, h, w, exact):
         ug = nhwc(up)
         srcs[1] = l.nhwc_src(ug.data_ptr(), c1, h - 3, w - 2, off=(1, 1))
     ns = 2 if c1 else 1
-    for flags in (0, 1 << 29):
+    for flags in (0, 1 << 30, 1 << 29):          # halo-tiled x3 kernel; the generic x3 kernel (what the ConvTranspose pair runs); the f32 matrix cores
         old = lib.ustrun_debug_flags(flags)
         try:
             y = torch.empty(n, h, w, co, device="cuda")
@@ -312,6 +312,74 @@ def test_conv3x3_f32x3(n, c0, c1, co, h, w, exact):
             assert rel(dw.cpu(), 2 * dw64) < tol(dw32, dw64)
         finally:
             lib.ustrun_debug_flags(old)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 3, 16, 32), (1, 1, 19, 37), (3, 3, 40, 33), (4, 3, 136, 96), (8, 3, 256, 256)])
+def test_conv_first_weight_gradient_f32x3(n, c, h, w):
+    """The first convolution's weight gradient under dtype 3 (f32 dY): the streaming kernel with three-term products against
+    torch in float64 -- random data within f32 summation noise (3x torch-f32's own distance), integers exact."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(5 * c + w)
+    for exact in (True, False):
+        x = torch.randint(-3, 4, (n, c, h, w), generator=g).float() if exact else torch.randn(n, c, h, w, generator=g)
+        dy = torch.randint(-2, 3, (n, 64, h, w), generator=g).float() if exact else torch.randn(n, 64, h, w, generator=g)
+        def ref(dt):
+            wr = torch.zeros(64, c, 3, 3, dtype=dt, requires_grad=True)
+            F.conv2d(x.to(dt), wr, None, 1, 1).backward(dy.to(dt))
+            return wr.grad
+        g64, g32 = ref(torch.float64), ref(torch.float32)
+        xg, dyg = x.contiguous().cuda(), nhwc(dy)
+        src = l.nchw_src(xg.data_ptr(), c, h, w)
+        nb = lib.ustrun_wgrad_partials_bytes(9, c, 64, n * h * w)
+        part = torch.empty(nb // 4, device="cuda")
+        dw = torch.empty(64, c, 3, 3, device="cuda")
+        l.check(lib.ustrun_conv3x3_wgrad(C.byref(src), 1, dyg.data_ptr(), n, h, w, 64, dw.data_ptr(), 0, part.data_ptr(), nb, 3, None))
+        tol = 1e-7 if exact else max(3 * rel(g32, g64), 2e-6)
+        assert rel(dw.cpu(), g64) < tol, (exact, rel(dw.cpu(), g64), rel(g32, g64))
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 128, 64, 5, 7), (3, 256, 128, 12, 10), (1, 64, 64, 3, 50), (2, 256, 128, 32, 32), (2, 1024, 512, 4, 4)])
+def test_convT2x2_f32x3(n, ci, co, h, w):
+    """The ConvTranspose trio under dtype 3: forward and input gradient on the generic three-term kernel, the weight gradient on
+    its own (four parity classes as four accumulators), bias gradient; float64 torch as the reference, f32 summation noise as the bound."""
+    l = L()
+    lib = l.lib()
+    g = torch.Generator().manual_seed(ci + 3 * w)
+    y = torch.randn(n, ci, h, w, generator=g)
+    sc, sh = 1 + 0.3 * torch.randn(ci, generator=g), 0.2 * torch.randn(ci, generator=g)
+    a = torch.relu(y * sc[None, :, None, None] + sh[None, :, None, None])
+    wt, b = torch.randn(ci, co, 2, 2, generator=g) / ci ** 0.5, torch.randn(co, generator=g)
+    du = torch.randn(n, co, 2 * h, 2 * w, generator=g)
+
+    def ref(dt):
+        ar, wr, br = a.to(dt).clone().requires_grad_(True), wt.to(dt).clone().requires_grad_(True), b.to(dt).clone().requires_grad_(True)
+        out = F.conv_transpose2d(ar, wr, br, stride=2)
+        out.backward(du.to(dt))
+        return out.detach(), ar.grad, wr.grad, br.grad
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    tol = lambda k: max(3 * rel(r32[k], r64[k]), 2e-6)
+    nel = 4 * ci * co
+    wf, wd = torch.zeros(3 * nel, device="cuda"), torch.zeros(3 * nel, device="cuda")
+    wg = wt.cuda()
+    l.check(lib.ustrun_pack_convT2x2(wg.data_ptr(), ci, co, wf.data_ptr(), wd.data_ptr(), 3, None))
+    yg, scg, shg, bg, dug = nhwc(y), sc.cuda(), sh.cuda(), b.cuda(), nhwc(du)
+    src = l.nhwc_src(yg.data_ptr(), ci, h, w, scg.data_ptr(), shg.data_ptr(), relu=1)
+    u = torch.empty(n, 2 * h, 2 * w, co, device="cuda")
+    l.check(lib.ustrun_convT2x2_fwd(C.byref(src), wf.data_ptr(), bg.data_ptr(), n, h, w, co, u.data_ptr(), 3, None))
+    assert rel(from_nhwc(u), r64[0]) < tol(0)
+    da = torch.empty(n, h, w, ci, device="cuda")
+    l.check(lib.ustrun_convT2x2_dgrad(dug.data_ptr(), wd.data_ptr(), n, h, w, co, ci, da.data_ptr(), 3, None))
+    assert rel(from_nhwc(da), r64[1]) < tol(1)
+    nb = max(lib.ustrun_wgrad_partials_bytes(4, ci, co, n * h * w), 512 * co * 4)
+    part = torch.full((nb // 4 + 256,), 5.0, device="cuda")
+    dw, db = torch.empty(ci, co, 2, 2, device="cuda"), torch.empty(co, device="cuda")
+    l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 0, part.data_ptr(), nb, 3, None))
+    assert rel(dw.cpu(), r64[2]) < tol(2), (rel(dw.cpu(), r64[2]), rel(r32[2], r64[2]))
+    assert rel(db.cpu(), r64[3]) < max(tol(3), 1e-5)
+    assert bool((part[nb // 4:] == 5.0).all()), "slabs beyond the published partials bound"
+    l.check(lib.ustrun_convT2x2_wgrad(C.byref(src), dug.data_ptr(), n, h, w, co, dw.data_ptr(), db.data_ptr(), 1, part.data_ptr(), nb, 3, None))
+    assert rel(dw.cpu(), 2 * r64[2]) < tol(2)
 
 
 # ---- dtype = 1: bf16 tensors in HBM, bf16 MFMA operands, f32 accumulate/statistics -------------

@@ -448,6 +448,141 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_stream_kernel(const floa
     }
 }
 
+// ---- ... and for dtype USTRUN_F32X3 (f32 dY): the same walk with both operands split into three bf16 terms at use (x3.hip's
+// arithmetic: six MFMAs per product, f32-level result): 4 KB of dY per step, three LDS planes per slot.
+template <int D>
+__global__ __launch_bounds__(256) void conv_first_wgrad_stream_x3_kernel(const float* __restrict__ x, int sN, int sC, int sH, int C,
+                                                                         int H, int W, int xbytes, const float* __restrict__ dy,
+                                                                         int dybytes, float* __restrict__ partials, int strips, int segs,
+                                                                         int seg_rows, int items) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(8))) __bf16 b16x8;
+    typedef __attribute__((ext_vector_type(4))) __bf16 b16x4;
+    constexpr int SLOT = 3 * FTW * WRB;                                // three planes of [16 px][WRB]
+    extern __shared__ __attribute__((aligned(16))) char dys[];         // 4 waves x 2 slots (>= 4 x 32 x 64 floats for the final sum)
+    float (*accs)[32][64] = (float (*)[32][64])dys;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    auto split1 = [](float v, __bf16& h0, __bf16& h1, __bf16& h2) {
+        h0 = (__bf16)v;
+        const float r1 = v - (float)h0;
+        h1 = (__bf16)r1;
+        h2 = (__bf16)(r1 - (float)h1);
+    };
+    const int item = blockIdx.x * 4 + wave;
+    if (item < items) {
+        const int sx = item % strips, sg = (item / strips) % segs, img = item / (segs * strips);
+        const int x0 = sx * FTW, r0 = sg * seg_rows, r1 = min(H, r0 + seg_rows);
+        const int ic = l31 / 9, it = l31 % 9, ikh = it / 3, ikw = it % 3;
+        const bool ivalid = l31 < 9 * C;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, xbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dybytes, 0x00020000);
+        const int col0 = x0 + 8 * lh + ikw - 1;
+        const bool shl = col0 < 0;                                     // (see the 16-bit kernel: the one lane column that starts in front of its row)
+        const int xoff0 = (img * sN + (ivalid ? ic : 0) * sC + col0 + (shl ? 1 : 0)) * 4;
+        unsigned cm[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cm[q] = (ivalid && (unsigned)(col0 + q) < (unsigned)W) ? 0xffffffffu : 0u;
+        // dY: lane fetches 16-byte piece 64 i + lane (i < 4) of the row's 4 KB: pixel 4 i + (lane >> 4), 4-channel group lane & 15
+        const int dpx = lane >> 4, dcg = lane & 15;
+        unsigned dm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dm[i] = x0 + 4 * i + dpx < W ? 0xffffffffu : 0u;
+        const int doff0 = ((img * H * W + x0 + dpx) * 64 + dcg * 4) * 4;
+        char* slot = dys + wave * (2 * SLOT);
+        const int lrow = 8 * lh + ((lane & 15) >> 2), lcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        u32x4 xr[D][2], dr[D][4];
+        unsigned rm[D];
+        auto prefetch = [&](int u, int y) {
+            const int yy = y + ikh - 1;
+            rm[u] = (y < r1 && (unsigned)yy < (unsigned)H) ? 0xffffffffu : 0u;
+            const int xo = xoff0 + yy * sH * 4;
+            xr[u][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo, 0, 0));
+            xr[u][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo + 16, 0, 0));
+            const int dofs = min(y, r1 - 1) * W * 256;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dr[u][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, doff0 + dofs + i * 4 * 256, 0, 0));
+        };
+        auto consume = [&](int u, int par, bool live) {
+            char* sl = slot + par * SLOT;
+            const unsigned lm = live ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                b16x4 h0, h1, h2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    __bf16 t0, t1, t2;
+                    split1(__builtin_bit_cast(float, dr[u][i][q] & dm[i] & lm), t0, t1, t2);
+                    h0[q] = t0; h1[q] = t1; h2[q] = t2;
+                }
+                char* dst = sl + (4 * i + dpx) * WRB + dcg * 8;
+                *(u32x2*)dst = __builtin_bit_cast(u32x2, h0);
+                *(u32x2*)(dst + FTW * WRB) = __builtin_bit_cast(u32x2, h1);
+                *(u32x2*)(dst + 2 * FTW * WRB) = __builtin_bit_cast(u32x2, h2);
+            }
+            b16x8 a[3];
+            unsigned v[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = xr[u][0][q]; v[4 + q] = xr[u][1][q]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned t = shl ? (q ? v[q - 1] : 0u) : v[q];
+                __bf16 t0, t1, t2;
+                split1(__builtin_bit_cast(float, t & cm[q] & rm[u]), t0, t1, t2);
+                a[0][q] = t0; a[1][q] = t1; a[2][q] = t2;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                b16x8 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const char* base = sl + p * FTW * WRB + lrow * WRB + (j * 32 + lcol) * 2;
+                    const b16x4 lo = __builtin_bit_cast(b16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ustrun_lds_s16x4*)base));
+                    const b16x4 hi = __builtin_bit_cast(b16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ustrun_lds_s16x4*)(base + 4 * WRB)));
+                    b[p][0] = lo[0]; b[p][1] = lo[1]; b[p][2] = lo[2]; b[p][3] = lo[3];
+                    b[p][4] = hi[0]; b[p][5] = hi[1]; b[p][6] = hi[2]; b[p][7] = hi[3];
+                }
+                f32x16 c = acc[j];                     // small terms first (x3.hip)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+                acc[j] = c;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < D; ++u) prefetch(u, r0 + u);
+        for (int y = r0; y < r1; y += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                consume(u, u & 1, y + u < r1);
+                prefetch(u, y + u + D);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][j * 32 + l31] = acc[j][r];
+    __syncthreads();
+    float* slab = partials + (long)blockIdx.x * 32 * 64;
+    for (int e = tid; e < 32 * 64; e += 256) {
+        const int i = e >> 6, co = e & 63;
+        slab[e] = accs[0][i][co] + accs[1][i][co] + accs[2][i][co] + accs[3][i][co];
+    }
+}
+
 // dw[co][c][t] (+)= sum_k partials[k][c*9+t][co].  Block = 8 outputs (consecutive co of one im2col row: 32 contiguous bytes per
 // slab) x 128 slab lanes; a lane's slabs k = lane, lane + 128, .. are ALL loaded before the first add (up to eight in flight: the
 // 1024-slab table is one memory round trip, where 32 lanes x four in flight made it eight dependent ones -- 35 us for 8 MB), summed
@@ -699,13 +834,36 @@ int conv_first_fwd(const ustrun_src_t& s, const void* w_fwd, int dtype, int N, v
 int64_t conv_first_wgrad_partials_bytes() { return (int64_t)1024 * 32 * 64 * sizeof(float); }
 
 int conv_first_wgrad(const ustrun_src_t& s, const void* dy, int dy_esz, int N, float* dw, int accumulate, float* partials,
-                     int64_t partials_bytes, hipStream_t st) {
+                     int64_t partials_bytes, hipStream_t st, bool x3) {
     USTRUN_CHECK(partials_bytes >= conv_first_wgrad_partials_bytes(), "conv_first_wgrad: partials too small");
     const int tx = cdiv(s.W, FTW), ty = cdiv(s.H, FTH), ttotal = N * ty * tx;
     int blocks = ttotal < 1024 ? ttotal : 1024;
     const int per = cdiv(ttotal, blocks);
     blocks = cdiv(ttotal, per);
     // (ustrun_debug_flags bit 28: the tile kernel of rounds 1-4, for A/B runs)
+    if (dy_esz == 4 && x3) {            // dtype USTRUN_F32X3: f32 dY, three-term products
+        const long xb = (long)N * s.sN * 4, db = (long)N * s.H * s.W * 64 * 4;
+        USTRUN_CHECK(s.sW == 1 && s.f32 && xb < (1L << 31) - 64 && db < (1L << 31) - 64 && s.sN == (int64_t)s.C * s.sC &&
+                     s.sC == (int64_t)s.H * s.sH, "conv_first_wgrad: layout outside the streaming kernel's range");
+        const int strips = cdiv(s.W, FTW);
+        long segs = 4096 / ((long)N * strips);
+        if (segs > s.H / 8) segs = s.H / 8;
+        if (segs < 1) segs = 1;
+        const int seg_rows = cdiv(s.H, segs);
+        const int nseg = cdiv(s.H, seg_rows);
+        const long items = (long)N * strips * nseg;
+        USTRUN_CHECK(items <= 4096, "conv_first_wgrad: %ld strip segments", items);
+        blocks = cdiv(items, 4);
+        const int lds = 4 * 2 * 3 * FTW * WRB;
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv_first_wgrad_stream_x3_kernel<4>, lds, "conv_first_wgrad_x3"));
+        hipLaunchKernelGGL(conv_first_wgrad_stream_x3_kernel<4>, dim3(blocks), dim3(256), lds, st, (const float*)s.ptr, (int)s.sN, (int)s.sC,
+                           (int)s.sH, s.C, s.H, s.W, (int)xb, (const float*)dy, (int)db, partials, strips, nseg, seg_rows, (int)items);
+        USTRUN_LAUNCH_CHECK("conv_first_wgrad_x3");
+        hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(cdiv(64 * s.C * 9, 8)), dim3(1024), 0, st, partials, blocks, s.C, dw,
+                           accumulate);
+        USTRUN_LAUNCH_CHECK("conv_first_wgrad_reduce");
+        return 0;
+    }
     const long xbytes = (long)N * s.sN * 4, dybytes = (long)N * s.H * s.W * 64 * 2;
     if (dy_esz == 2 && s.sW == 1 && s.f32 && !(g_debug_flags & (1 << 28)) && xbytes < (1L << 31) - 64 && dybytes < (1L << 31) - 64 &&
         s.sN == (int64_t)s.C * s.sC && s.sC == (int64_t)s.H * s.sH) {

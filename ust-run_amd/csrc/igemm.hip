@@ -282,6 +282,7 @@ int igemm_mtiles(int64_t M, int Cout) { (void)Cout; return cdiv(M, 128); }
 int igemm_stat_rows_used(const IgemmArgs& a, int dtype) {
     if (dtype == USTRUN_D16 && !(g_debug_flags & 1) && ws64_supported(a)) return ws64_stat_rows(a);
     if (dtype == USTRUN_D16 && halo_supported(a)) return halo_stat_rows_used(a);
+    if (dtype == USTRUN_F32X3 && conv3x3_x3_supported(a)) return conv3x3_x3_stat_rows(a);
     return cdiv(a.M, 128);
 }
 

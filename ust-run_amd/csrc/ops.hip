@@ -402,6 +402,11 @@ extern "C" int64_t ustrun_wgrad_partials_bytes(int nseg, int Cin, int Cout, int6
         wgrad_tap_plan(t, &kt, &ct);
         if (kt > slabs) slabs = kt;
     }
+    if (nseg == 4 && Cin % 64 == 0 && Cout % 64 == 0) {          // dtype USTRUN_F32X3's ConvTranspose kernel: at most one block per CU and pair
+        const long pairs = (long)(Cin / 64) * (Cout / 64);
+        const int kx = (int)((256 + pairs - 1) / pairs);
+        if (kx > slabs) slabs = kx;
+    }
     if (nseg == 4 && Cin % 128 == 0 && Cout % 32 == 0) {         // the ConvTranspose all-taps bf16 kernels
         int kt; long ct;
         wgradT_plan(Cin, Cout, npix, &kt, &ct);
@@ -458,6 +463,12 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
         USTRUN_TRY(rc);
         return reduce_partials(partials, slabs, 9, a.Cin, Cout, dw, 2, accumulate, (hipStream_t)s);   // slabs are in torch layout
     }
+    // (dtype USTRUN_F32X3's first convolution: the streaming kernel with three-term products)
+    if (dtype == USTRUN_F32X3 && nsrc == 1 && conv_first_supported(srcs[0], Cout) && srcs[0].H == H && srcs[0].W == W && srcs[0].f32 &&
+        9 * srcs[0].C <= 32 && srcs[0].sW == 1 && srcs[0].sN == (int64_t)srcs[0].C * srcs[0].sC && srcs[0].sC == (int64_t)H * srcs[0].sH &&
+        (int64_t)N * H * W * 256 < (1LL << 31) - 64 && (int64_t)N * srcs[0].sN * 4 < (1LL << 31) - 64 && (int64_t)N * cdiv(W, 16) <= 4096 &&
+        !(g_debug_flags & (1 << 29)))
+        return conv_first_wgrad(srcs[0], dy, 4, N, dw, accumulate, partials, partials_bytes, (hipStream_t)s, true);
     if (dtype == USTRUN_F32X3 && wgrad_x3_supported(a)) {        // all nine taps per block, operands split at staging (x3.hip)
         int per;
         wgrad_x3_plan(a, &slabs, &per);
@@ -541,10 +552,21 @@ extern "C" int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, in
         if (db) USTRUN_TRY(reduce_rows(a.bias_partials, slabs, Cout, 0, Cout, db, accumulate, (hipStream_t)s));
         return reduce_partials(partials, slabs, 4, a.Cin, Cout, dw, 2, accumulate, (hipStream_t)s);
     }
+    if (dtype == USTRUN_F32X3 && wgradT_x3_supported(a)) {       // the four parity classes as four accumulators, three-term products (x3.hip)
+        int per;
+        wgradT_x3_plan(a, &slabs, &per);
+        USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 4 * a.Cin * Cout * 4, "convT2x2_wgrad: partials too small");
+        prof_begin(1, 2.0 * a.M * 4 * a.Cin * Cout, 4.0 * (a.M * (double)a.Cin + 4.0 * a.M * Cout) + 16.0 * a.Cin * Cout, (hipStream_t)s);
+        const int rc = wgradT_x3_launch(a, slabs, per, (hipStream_t)s);
+        prof_end((hipStream_t)s);
+        USTRUN_TRY(rc);
+        USTRUN_TRY(reduce_partials(partials, slabs, 4, a.Cin, Cout, dw, 2, accumulate, (hipStream_t)s));      // slabs are in torch layout
+    } else {
     wgrad_plan(4, a.Cin, Cout, a.M, &a.ksplit, &a.kchunk, &slabs);
     USTRUN_CHECK(partials_bytes >= (int64_t)slabs * 4 * a.Cin * Cout * 4, "convT2x2_wgrad: partials too small");
     USTRUN_TRY(wgrad_launch(a, dtype, (hipStream_t)s));
     USTRUN_TRY(reduce_partials(partials, slabs, 4, a.Cin, Cout, dw, 1, accumulate, (hipStream_t)s));
+    }
     if (db) {
         const long npix = (long)N * 4 * H * W;
         int blocks = cdiv(npix, 512);

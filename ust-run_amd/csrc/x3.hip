@@ -21,6 +21,7 @@
 // Everything else of this dtype (first convolution, ConvTranspose weight gradient, BatchNorm, head, losses) runs the f32 kernels.
 #include "common.h"
 #include "loader.h"
+#include <type_traits>
 
 namespace ustrun {
 namespace {
@@ -282,6 +283,210 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const IgemmArgs a, con
     }
 }
 
+// ---- 3x3 convolution, halo-tiled -------------------------------------------------------------------------------------------
+// The generic kernel above stages (and splits) an activation once per TAP and per column tile: at 40 VALU instructions per four
+// values the split, not the matrix pipe, paced it (4.4 VALU per MFMA; 112 TF/s-equivalent).  Here a block owns an 8 x 16-pixel tile
+// and stages the tile's 10 x 18 halo patch of a 32-channel chunk ONCE -- three planes of 80-byte rows -- for all nine taps: a tap is
+// a constant byte offset into the patch (forward: (kh - 1, kw - 1); input gradient: the mirrored tap, FLIP), 432 MFMAs per wave and
+// chunk against one split of 180 x 32 values.  Weight fragments come straight from L2, one tap ahead.  WM = 2: 128 output columns
+// (waves 2 x 2, wave tile 64 px x 64 columns); WM = 4: 64 output columns (waves 4 x 1, wave tile 32 px x 64 columns).
+constexpr int CTH = 8, CTW = 16, CPW = CTW + 2, CPP = (CTH + 2) * CPW;     // 180 patch pixels
+constexpr int CPLANE = CPP * XAP;                                          // one plane of the patch: 14400 B
+constexpr int CIT = (CPP * 8 + 255) / 256;                                 // float4 items per thread and chunk: 6
+
+template <int WM, bool FLIP>
+__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y, const int nt_total) {
+    constexpr int WN = 4 / WM, RT = 4 / WM;          // column waves; 32-row tiles per wave (2 or 1)
+    constexpr int BN = 64 * WN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [3][180 px][XAP]
+    const int mt_total = a.N * tiles_y * tiles_x;
+    const int ntiles = mt_total * nt_total;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, j = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int mtile = bid / nt_total, ntile = bid % nt_total;
+    const int img = mtile / (tiles_y * tiles_x), trem = mtile - img * tiles_y * tiles_x;
+    const int y0 = (trem / tiles_x) * CTH, x0 = (trem % tiles_x) * CTW;
+    const int n0 = ntile * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nchunk = a.Cin / XBK, K8 = a.Cin / 8;
+    const __bf16* W3 = (const __bf16*)(a.W + 9L * a.Cin * a.Cout);
+    const long plane = (long)K8 * a.Cout * 8;
+
+    // ---- staging: item i = patch pixel (tid + 256 i) >> 3, 4-channel group tid & 7; geometry per source, not per chunk ----
+    const int c4 = tid & 7;
+    long goff[CIT];
+    unsigned gok = 0;
+    int cur_second = -1, cbase = 0, s_relu = 0;
+    const float* sptr = nullptr;
+    const float* sscale = nullptr;
+    const float* sshift = nullptr;
+    auto geometry = [&](int second) {
+        cur_second = second;
+        const SrcDev S = pick_src(a.src[0], a.src[1], second != 0);
+        sptr = S.ptr; sscale = S.scale; sshift = S.shift; s_relu = S.relu;
+        cbase = second ? a.src[0].C : 0;
+        gok = 0;
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) {
+            const int px = (tid + 256 * i) >> 3;
+            const int py = px / CPW, pxx = px - py * CPW;
+            const int ly = y0 - 1 + py - S.off_y, lx = x0 - 1 + pxx - S.off_x;
+            const bool ok = px < CPP && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
+            gok |= (ok ? 1u : 0u) << i;
+            goff[i] = ok ? img * S.sN + (long)ly * S.sH + (long)lx * S.sW : 0;
+        }
+    };
+    f32x4 av[CIT];
+    f32x4 asc, ash;
+    auto fetch = [&](int c) {
+        const int c0 = c * XBK;
+        const int second = (a.nsrc == 2 && c0 >= a.src[0].C) ? 1 : 0;
+        if (second != cur_second) geometry(second);
+        const int cl = c0 + 4 * c4 - cbase;
+        asc = (f32x4){1.f, 1.f, 1.f, 1.f}; ash = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (sscale) { asc = *(const f32x4*)(sscale + cl); ash = *(const f32x4*)(sshift + cl); }
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) av[i] = *(const f32x4*)(sptr + goff[i] + cl);
+    };
+    auto write_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) {
+            const int px = (tid + 256 * i) >> 3;
+            if (px < CPP) {
+                f32x4 v = av[i] * asc + ash;
+                if (s_relu) v = relu4(v);
+                if (!((gok >> i) & 1u)) v = (f32x4){0.f, 0.f, 0.f, 0.f};      // zero padding is applied after the activation
+                u32x2 p0, p1, p2;
+                split4(v, p0, p1, p2);
+                char* dst = smem + px * XAP + c4 * 8;
+                *(u32x2*)dst = p0; *(u32x2*)(dst + CPLANE) = p1; *(u32x2*)(dst + 2 * CPLANE) = p2;
+            }
+        }
+    };
+    // weight fragments of (chunk, tap): [k step][column tile][plane]
+    auto load_b = [&](u32x4 (&b)[2][2][3], int c, int tap) {
+        const __bf16* ws = W3 + (long)tap * 3 * plane;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                const long o = ((long)(c * (XBK / 8) + 2 * ks + lh) * a.Cout + (n < a.Cout ? n : 0)) * 8;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[ks][j][p] = *(const u32x4*)(ws + p * plane + o);
+            }
+    };
+
+    f32x16 acc[RT][2];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // this lane's A-fragment base: tile row 2 RT wm + 2 i + (l31 >> 4), column l31 & 15, at patch offset (+1, +1); k half lh
+    const char* Ap = smem + ((2 * RT * wm + (l31 >> 4) + 1) * CPW + (l31 & 15) + 1) * XAP + lh * 16;
+    u32x4 bfr[2][2][2][3];
+    fetch(0);
+    load_b(bfr[0], 0, 0);
+    // nine taps per chunk alternate between the two fragment sets, so a chunk starts on the set its predecessor ended on: the set
+    // index is (tap + PAR) & 1 with PAR the chunk's parity -- a compile-time constant of two copies of the body
+    auto chunk_body = [&](int c, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
+        if (c) __syncthreads();                       // every wave is done reading the previous chunk's patch
+        write_patch();
+        __syncthreads();
+        if (c + 1 < nchunk) fetch(c + 1);             // registers, in flight under the nine taps below
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // the NEXT tap's fragments (the next chunk's first tap behind the last one) load under this tap's 48 / 24 MFMAs
+            if (t < 8) load_b(bfr[(t + 1 + PAR) & 1], c, t + 1);
+            else if (c + 1 < nchunk) load_b(bfr[(t + 1 + PAR) & 1], c + 1, 0);
+            const int kh = t / 3, kw = t % 3;
+            const int dy = FLIP ? 1 - kh : kh - 1, dx = FLIP ? 1 - kw : kw - 1;
+            const char* At = Ap + (dy * CPW + dx) * XAP;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                b16x8 af[RT][3];
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) af[i][p] = __builtin_bit_cast(b16x8, *(const u32x4*)(At + p * CPLANE + 2 * i * CPW * XAP + ks * 32));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    b16x8 bf[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(b16x8, bfr[(t + PAR) & 1][ks][j][p]);
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[i][j] = mfma6(af[i], bf, acc[i][j]);
+                }
+            }
+        }
+    };
+    int c = 0;
+#pragma unroll 1
+    for (; c + 1 < nchunk; c += 2) {
+        chunk_body(c, std::integral_constant<int, 0>{});
+        chunk_body(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (c < nchunk) chunk_body(c, std::integral_constant<int, 0>{});
+
+    // ---- epilogue: D[row = pixel][col = channel]; col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the 32-row tile
+    const int C1 = a.Cout - a.C0;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        const bool cok = col < a.Cout;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int oy = y0 + 2 * RT * wm + 2 * i + (row >> 4), ox = x0 + (row & 15);
+                if (oy < a.Hb && ox < a.Wb && cok) {
+                    const float v = acc[i][j][r];
+                    if (col < a.C0) {
+                        a.out0[(((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col] = v;
+                    } else {
+                        const int y1 = oy - a.o1y, x1 = ox - a.o1x;
+                        if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
+                            a.out1[(((long)img * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0)] = v;
+                    }
+                    s1[j] += v; s2[j] += v * v;
+                }
+            }
+        }
+    }
+    if (a.stat) {                                     // one statistics row per tile (fixed order: lane halves, then the row waves)
+        __syncthreads();
+        float* red = (float*)smem;                    // [WM][2][BN]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+            if (lh == 0) {
+                red[(wm * 2 + 0) * BN + wn * 64 + j * 32 + l31] = s1[j];
+                red[(wm * 2 + 1) * BN + wn * 64 + j * 32 + l31] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += 256) {
+            const int q = t / BN, c = t % BN;
+            float v = red[q * BN + c];
+#pragma unroll
+            for (int w = 1; w < WM; ++w) v += red[(w * 2 + q) * BN + c];
+            if (n0 + c < a.Cout) a.stat[((long)mtile * 2 + q) * a.Cout + n0 + c] = v;
+        }
+    }
+}
+
 // ---- weight gradient, all nine taps per block ----------------------------------------------------------------------------------
 constexpr int TH = 4, TW = 16, HW2 = TW + 2, HP = (TH + 2) * HW2;   // 4 x 16 tile, 6 x 18 = 108 halo pixels
 constexpr int RB = 192;                                              // LDS row pitch: 64 bf16 + 64 bytes (conflict-free transposing reads)
@@ -426,6 +631,128 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const WgradArgs a, con
     }
 }
 
+
+// ---- ConvTranspose2d(k = 2, s = 2) weight gradient: dW[tap][ci][co] = sum_p A[p][ci] du[2 p + tap][co] -------------------------------
+// The four taps are the four parity classes of the hi-resolution gradient: a block owns a 2 x 16 low-resolution tile (32 pixels), its
+// activation tile and the 4 x 32 hi-resolution patch of du de-interleaved into four 32-pixel tap tiles, all split into three planes
+// at staging; four accumulators per wave (32 ci x 32 co x 4 taps), 48 MFMAs per wave and tile.
+constexpr int UTH = 2, UPX = UTH * TW;                       // 32 low-resolution pixels per tile
+constexpr int UATILE = UPX * RB, UDTILE = 4 * UPX * RB;      // one plane: activation tile / the four tap tiles
+constexpr int UAIT = UPX * 16 / 256, UDIT = 4 * UPX * 16 / 256;      // float4 items per thread: 2 / 8
+
+__global__ __launch_bounds__(256, 1) void wgradT_x3_kernel(const WgradArgs a, const int ntn, const int tiles_x, const int tiles_y,
+                                                           const int tiles_per) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                               // [3][32 px][RB]
+    char* Ds = smem + 3 * UATILE;                  // [3][4 taps][32 px][RB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int mtile = blockIdx.x / ntn, ntile = blockIdx.x % ntn;
+    const int ci0 = mtile * 64, co0 = ntile * 64;
+    const int ttotal = a.N * tiles_y * tiles_x;
+    const int tbeg = blockIdx.y * tiles_per;
+    const int tend = min(ttotal, tbeg + tiles_per);
+    const int c4 = tid & 15;
+    const SrcDev& S = a.src[0];
+    f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+    if (S.scale) { asc = *(const f32x4*)(S.scale + ci0 + 4 * c4); ash = *(const f32x4*)(S.shift + ci0 + 4 * c4); }
+    const float* sp = S.ptr + ci0 + 4 * c4;
+    const float* dup = a.dy + co0 + 4 * c4;
+
+    f32x4 av[UAIT], dv[UDIT];
+    unsigned aok = 0;
+    auto fetch_tile = [&](int t) {
+        const int img = t / (tiles_y * tiles_x);
+        const int rem = t - img * tiles_y * tiles_x;
+        const int y0 = (rem / tiles_x) * UTH, x0 = (rem % tiles_x) * TW;
+        aok = 0;
+#pragma unroll
+        for (int i = 0; i < UAIT; ++i) {
+            const int px = (tid + 256 * i) >> 4;
+            const int ly = y0 + (px >> 4), lx = x0 + (px & 15);
+            const bool ok = ly < a.Hb && lx < a.Wb;
+            av[i] = *(const f32x4*)(sp + img * S.sN + (long)(ok ? ly : 0) * S.sH + (long)(ok ? lx : 0) * S.sW);
+            aok |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < UDIT; ++i) {
+            const int hr = (tid + 256 * i) >> 4;                      // hi-resolution pixel of the 4 x 32 patch
+            const int hy = hr >> 5, hx = hr & 31;
+            const bool ok = y0 + (hy >> 1) < a.Hb && x0 + (hx >> 1) < a.Wb;
+            const f32x4 v = *(const f32x4*)(dup + (((long)img * a.dyH + (ok ? 2 * y0 + hy : 0)) * a.dyW + (ok ? 2 * x0 + hx : 0)) * a.Cout);
+            dv[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < UAIT; ++i) {
+            const int px = (tid + 256 * i) >> 4;
+            f32x4 v = av[i] * asc + ash;
+            if (S.relu) v = relu4(v);
+            if (!((aok >> i) & 1u)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            u32x2 p0, p1, p2;
+            split4(v, p0, p1, p2);
+            char* dst = As + px * RB + c4 * 8;
+            *(u32x2*)dst = p0; *(u32x2*)(dst + UATILE) = p1; *(u32x2*)(dst + 2 * UATILE) = p2;
+        }
+#pragma unroll
+        for (int i = 0; i < UDIT; ++i) {
+            const int hr = (tid + 256 * i) >> 4;
+            const int hy = hr >> 5, hx = hr & 31;
+            const int tap = (hy & 1) * 2 + (hx & 1), px = (hy >> 1) * TW + (hx >> 1);
+            u32x2 p0, p1, p2;
+            split4(dv[i], p0, p1, p2);
+            char* dst = Ds + (tap * UPX + px) * RB + c4 * 8;
+            *(u32x2*)dst = p0; *(u32x2*)(dst + UDTILE) = p1; *(u32x2*)(dst + 2 * UDTILE) = p2;
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int lrow = 8 * (lane >> 5) + ((lane & 15) >> 2), lcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const char* Ab = As + lrow * RB + (wi * 32 + lcol) * 2;
+    const char* Db = Ds + lrow * RB + (wj * 32 + lcol) * 2;
+
+    if (tbeg < tend) { fetch_tile(tbeg); write_tile(); }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = tbeg; t < tend; ++t) {
+        const bool more = t + 1 < tend;
+        if (more) fetch_tile(t + 1);
+#pragma unroll
+        for (int r = 0; r < UTH; ++r) {
+            b16x8 af[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = tr_frag(Ab + p * UATILE, r * TW);
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                b16x8 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = tr_frag(Db + p * UDTILE + tap * UPX * RB, r * TW);
+                acc[tap] = mfma6(b, af, acc[tap]);      // D[co][ci]
+            }
+        }
+        __syncthreads();
+        if (more) write_tile();
+        __syncthreads();
+    }
+
+    // slab in the torch layout [Cin][Cout][2][2]
+    float* slab = a.partials + (long)blockIdx.y * 4 * a.Cin * a.Cout;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ci = ci0 + wi * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float* o = slab + ((long)ci * a.Cout + co) * 4;
+        *(f32x4*)o = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    }
+}
+
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -452,7 +779,34 @@ bool igemm_x3_supported(const IgemmArgs& a) {
     return true;
 }
 
+// the halo-tiled kernel: a plain 3x3 convolution (forward, or the input gradient's mirrored taps) without output stride / parity
+bool conv3x3_x3_supported(const IgemmArgs& a) {
+    if (!igemm_x3_supported(a) || (g_debug_flags & (1 << 30))) return false;      // (bit 30: the generic x3 kernel, for A/B runs)
+    if (a.nseg != 9 || a.segw != 3 || a.nz != 1 || a.s_in != 1 || a.s_out != 1 || a.bias) return false;
+    if (!((a.d0 == -1 && a.dstep == 1) || (a.d0 == 1 && a.dstep == -1))) return false;
+    if (a.Ho != a.Hb || a.Wo != a.Wb) return false;
+    return true;
+}
+int conv3x3_x3_stat_rows(const IgemmArgs& a) { return a.N * cdiv(a.Hb, CTH) * cdiv(a.Wb, CTW); }
+
 int igemm_x3_launch(const IgemmArgs& a, hipStream_t st) {
+    if (conv3x3_x3_supported(a)) {
+        const int tx = cdiv(a.Wb, CTW), ty = cdiv(a.Hb, CTH);
+        const bool wide = a.Cout % 128 == 0 || a.Cout > 128;
+        const int nt = cdiv(a.Cout, wide ? 128 : 64);
+        dim3 grid(a.N * ty * tx * nt), block(256);
+        const int lds = 3 * CPLANE;
+        const bool flip = a.d0 == 1;
+        if (wide) {
+            if (flip) hipLaunchKernelGGL((conv3x3_x3_kernel<2, true>), grid, block, lds, st, a, tx, ty, nt);
+            else hipLaunchKernelGGL((conv3x3_x3_kernel<2, false>), grid, block, lds, st, a, tx, ty, nt);
+        } else {
+            if (flip) hipLaunchKernelGGL((conv3x3_x3_kernel<4, true>), grid, block, lds, st, a, tx, ty, nt);
+            else hipLaunchKernelGGL((conv3x3_x3_kernel<4, false>), grid, block, lds, st, a, tx, ty, nt);
+        }
+        USTRUN_LAUNCH_CHECK("conv3x3_x3");
+        return 0;
+    }
     constexpr int BM = 128, BN = 128;
     const int mt = cdiv(a.M, BM), nt = cdiv(a.Cout, BN);
     const int lds = 3 * BM * XAP + BM * (int)sizeof(RowInfo);
@@ -483,6 +837,33 @@ int wgrad_x3_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
     if (ks < 1) ks = 1;
     const int per = cdiv(ttotal, ks);
     *tiles_per = per; *ksplit = cdiv(ttotal, per);
+    return 0;
+}
+
+bool wgradT_x3_supported(const WgradArgs& a) {
+    if (g_debug_flags & (1 << 29)) return false;
+    if (a.nseg != 4 || a.segw != 2 || a.dy_s != 2 || a.astep != 0 || a.d0 != 0 || a.ashift != 0 || a.dy_esz != 4 || a.nsrc != 1) return false;
+    const SrcDev& s = a.src[0];
+    if (s.esz != 4 || s.sC != 1 || s.pool || s.off_y || s.off_x || s.LH != a.Hb || s.LW != a.Wb || s.gN > 0) return false;
+    if ((s.sN | s.sH | s.sW) & 3) return false;
+    return a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.dyH == 2 * a.Hb && a.dyW == 2 * a.Wb;
+}
+int wgradT_x3_plan(const WgradArgs& a, int* ksplit, int* tiles_per) {
+    const long pairs = (long)(a.Cin / 64) * (a.Cout / 64);
+    const int ttotal = a.N * cdiv(a.Hb, UTH) * cdiv(a.Wb, TW);
+    long ks = (256 + pairs - 1) / pairs;
+    if (ks > ttotal / 8) ks = ttotal / 8;
+    if (ks < 1) ks = 1;
+    const int per = cdiv(ttotal, ks);
+    *tiles_per = per; *ksplit = cdiv(ttotal, per);
+    return 0;
+}
+int wgradT_x3_launch(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t st) {
+    const int lds = 3 * (UATILE + UDTILE);
+    USTRUN_TRY(ensure_dynamic_lds((const void*)wgradT_x3_kernel, lds, "wgradT_x3"));
+    dim3 grid((a.Cin / 64) * (a.Cout / 64), ksplit), block(256);
+    hipLaunchKernelGGL(wgradT_x3_kernel, grid, block, lds, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, UTH), tiles_per);
+    USTRUN_LAUNCH_CHECK("wgradT_x3");
     return 0;
 }
 

@@ -31,7 +31,7 @@ parser.add_argument('--save_img', action='store_true')
 # additive flags of this build
 parser.add_argument('--synthetic', type=int, default=1)
 parser.add_argument('--test_batches', type=int, default=8, help='synthetic batches per domain')
-parser.add_argument('--backend_dtype', default='f32', choices=['f32', 'bf16', 'f16'])
+parser.add_argument('--backend_dtype', default='f32', choices=['f32', 'f32x3', 'bf16', 'f16'])
 parser.add_argument('--seed', type=int, default=1337)
 parser.add_argument('--load_path', type=str, default='', help='state_dict file (default: the reference\'s path)')
 parser.add_argument('--backbone', default='resnet101', choices=['resnet50', 'resnet101'], help='--model deeplabv2')

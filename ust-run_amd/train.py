@@ -64,7 +64,7 @@ parser.add_argument('--synthetic', type=int, default=1, help='seeded synthetic b
 parser.add_argument('--amp_dtype', default='fp16', choices=['fp16', 'bf16'],
                     help="storage / matrix-core type under --amp 1: 'fp16' = the reference's torch.cuda.amp autocast + GradScaler "
                          "(train.py:30,551-552,842-845: IEEE half, dynamic loss scale on the device), 'bf16' = bfloat16, no loss scale")
-parser.add_argument('--backend_dtype', default='', choices=['', 'f32', 'bf16', 'f16'],
+parser.add_argument('--backend_dtype', default='', choices=['', 'f32', 'f32x3', 'bf16', 'f16'],
                     help="explicit override of what --amp / --amp_dtype select ('' = follow them; --amp 0 = f32, the exact path)")
 parser.add_argument('--fft', default='device', choices=['host', 'device'])
 parser.add_argument('--data_root', type=str, default='../../data')
