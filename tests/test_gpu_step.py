@@ -25,11 +25,14 @@ def synth(dataset, B, C, H, seed):
     return img(), lab(), img(), img(), lab()
 
 
-@pytest.mark.parametrize("dataset,C,K", [("prostate", 1, 2), ("fundus", 3, 2), ("MNMS", 1, 4)])
-def test_ssl_step_matches_oracle(dataset, C, K):
+@pytest.mark.parametrize("dataset,C,K,base,dtype", [("prostate", 1, 2, 8, "f32"), ("fundus", 3, 2, 8, "f32"), ("MNMS", 1, 4, 8, "f32"),
+                                                     ("fundus", 3, 2, 64, "f32x3"), ("prostate", 1, 2, 64, "f32x3")])
+def test_ssl_step_matches_oracle(dataset, C, K, base, dtype):
+    """(base 64 / f32x3: the reference's channel plan, so that every convolution of the step runs the three-term bf16 kernels of
+    csrc/x3.hip -- held to the f32 path's bars)"""
     from networks.unet_model import UNet
     from ustrun.trainer import SSLTrainer
-    B, H, base, steps = 2, 32, 8, 3
+    B, H, steps = 2, 32, 3
     torch.manual_seed(1)
     sd_s = U.make_state_dict(C, K, base=base)
     sd_t = U.make_state_dict(C, K, base=base)
@@ -37,7 +40,7 @@ def test_ssl_step_matches_oracle(dataset, C, K):
 
     ref = RefTrainer(dataset, sd_s, **kw)
     ref.set_teacher(sd_t)
-    stu, tea = UNet(C, K, base_channels=base), UNet(C, K, base_channels=base)
+    stu, tea = UNet(C, K, base_channels=base, dtype=dtype), UNet(C, K, base_channels=base, dtype=dtype)
     stu.load_state_dict({k: v.clone() for k, v in sd_s.items()})
     tea.load_state_dict({k: v.clone() for k, v in sd_t.items()})
     trn = SSLTrainer(dataset, stu.cuda(), tea.cuda(), **kw)
@@ -54,7 +57,9 @@ def test_ssl_step_matches_oracle(dataset, C, K):
         for key in ("sup", "ul", "lu", "s", "loss"):
             np.testing.assert_allclose(o[key], r[key], rtol=2e-3, atol=1e-5, err_msg=key)
         assert o["w"] == r["w"]
-        np.testing.assert_allclose(o["ulb_dice"], r["ulb_dice"], rtol=1e-3, atol=1e-4)
+        # (at the reference's width a random-init net leaves more pixels within rounding of the 0.52 threshold / the arg-max tie: one
+        # flipped pixel of the 2 x 32 x 32 is 5e-4 of Dice -- the margin-filtered comparison is test_reference_golden_full_size)
+        np.testing.assert_allclose(o["ulb_dice"], r["ulb_dice"], rtol=1e-3 if base == 8 else 3e-3, atol=1e-4)
     assert trn.iter_num == ref.iter_num and abs(trn.lr - ref.lr) < 1e-12
     # parameters (student and EMA teacher) and BN running stats after the trajectory
     for name, sd_ref, m in (("student", ref.student, stu), ("teacher", ref.teacher, tea)):

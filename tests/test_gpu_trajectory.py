@@ -29,12 +29,9 @@ pytestmark = pytest.mark.gpu
 DICE_TOL = 1e-3            # north_star, on the EMA teacher
 STUDENT_TOL = 1e-2         # the student's own Dice moves by 4e-3 between rounding-equivalent runs
 LOSS_RTOL_EARLY = 2e-2     # steps <= 50: trajectories still rounding-close (f32, f16)
-LOSS_RTOL_EARLY_BF16 = 3e-2   # bf16, PER STEP: two builds of the library whose kernels differ only in their f32 summation ORDER (round 4:
-                              # the 16x16x32 MFMA shape in the input gradients, the ConvTranspose bias as the accumulators' start
-                              # value) sit 1.9 % and 2.1 % from the oracle at step 30 (gpurun_out/r4_full2.log; the per-step
-                              # deviations are printed below and kept in profiles/r05_traj_bf16_loss.log) -- 8-bit significands
-                              # amplify a last-bit change.  The MEAN deviation over those steps keeps the 2e-2 bar, so a real 1 %
-                              # shift of the bf16 arithmetic still fails; the Dice gates below are the north_star's and do not move
+LOSS_RTOL_EARLY_BF16 = 2e-2   # bf16: the same bar again.  Round 4 had widened it to 3e-2 after one build landed 2.1 % from the oracle at
+                              # step 30; with this round's step (profiles/r05_traj_loss_deviation.log) bf16 sits within 0.3 % at every
+                              # logged step <= 50 (f32x3: 0.2 %), so the original bar holds with a wide margin
 LOSS_ATOL_LATE = 1e-2      # later: same basin, different rounding path
 
 
@@ -54,7 +51,7 @@ def _run(dtype, g):
     model, ema = UNet(C, K, dtype=dtype), UNet(C, K, dtype=dtype)
     model.load_state_dict({k: v.clone() for k, v in sd_s.items()})
     ema.load_state_dict({k: v.clone() for k, v in sd_t.items()})
-    tr = SSLTrainer(T.DATASET, model.cuda(), ema.cuda(), fft="host" if dtype == "f32" else "device", max_iterations=T.MAX_ITER,
+    tr = SSLTrainer(T.DATASET, model.cuda(), ema.cuda(), fft="host" if dtype in ("f32", "f32x3") else "device", max_iterations=T.MAX_ITER,
                     num_eval_iter=T.NUM_EVAL_ITER)
     random.seed(T.PY_SEED); np.random.seed(T.NP_SEED)
     loaders = [[(x.cuda(), y.cuda()) for x, y in dom] for dom in T.val_loaders(task, C, H)]
@@ -74,7 +71,7 @@ def _run(dtype, g):
     return np.array(loss), np.array(dice), val, norms
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f32x3", "bf16", "f16"])
 def test_200_step_trajectory_lands_on_the_oracle(dtype):
     """(f16 = `--amp 1` of the reference: IEEE-half kernels + the device-side GradScaler; a skipped step would be a lost update
     against the f32 oracle, so the run also asserts that the default scale 65536 never overflowed here)"""
