@@ -432,6 +432,14 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
+                # the counters belong to ONE build of the library: a file read from another build says nothing about this run
+                import hashlib
+                so = os.path.join(ROOT, "ust-run_amd", "ustrun", "libustrun.so")
+                sha = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
+                if tj.get("library_sha16") != sha:
+                    roof["traffic_note"] = (f"profiles/traffic_{a.dtype}.json was measured on library build {tj.get('library_sha16')}, "
+                                            f"this run loaded {sha}: traffic dropped (re-run tools/profile_round.sh)")
+                    raise KeyError("stale traffic file")
                 roof["traffic"] = tj["hbm_bytes_per_launch"]
                 if "wgrad" in roof:
                     roof["wgrad"]["traffic"] = tj.get("wgrad_hbm_bytes_per_launch")
@@ -442,7 +450,7 @@ def main():
                 if "wgrad" in roof:
                     roof["wgrad"]["traffic_per_step"] = tj.get("wgrad_hbm_bytes_per_step")
             except Exception:
-                pass
+                roof.setdefault("traffic", None)
     if prof and roof is not None:
         lib.ustrun_profile_stream(torch.cuda.current_stream(dev).cuda_stream, 0)      # every stream: bytes only, times unused
         lib.ustrun_profile_enable(1)

@@ -330,9 +330,9 @@ def test_forward_passes_equals_separate_calls(dtype, base, n, hw):
         assert e < tol, (k, e)
 
 
-@pytest.mark.parametrize("dtype,base,n,hw,passes,tail,exact", [("bf16", 64, 4, 64, 4, 1, False), ("f16", 32, 3, 128, 2, 2, False),
-                                                               ("f32", 16, 2, 40, 3, 1, False), ("bf16", 64, 2, 256, 4, 1, True),
-                                                               ("bf16", 16, 3, 72, 1, 1, False), ("bf16", 64, 16, 128, 4, 1, True)])
+@pytest.mark.parametrize("dtype,base,n,hw,passes,tail,exact", [("bf16", 64, 4, 64, 4, 1, False), ("f16", 32, 3, 128, 2, 2, True),
+                                                               ("f32", 16, 2, 40, 3, 1, True), ("bf16", 64, 2, 256, 4, 1, False),
+                                                               ("bf16", 16, 3, 72, 1, 1, True), ("bf16", 64, 16, 128, 4, 1, False)])
 def test_tail_pass_equals_a_call_of_its_own(dtype, base, n, hw, passes, tail, exact):
     """`passes` equal forward passes with a shorter tail pass behind them in ONE call (ustrun_unet_desc_t::tail -- the reference's
     low-quality-sample forward, train.py:740, riding behind the student's four gradient passes) against the same passes as
@@ -349,16 +349,26 @@ def test_tail_pass_equals_a_call_of_its_own(dtype, base, n, hw, passes, tail, ex
     xs = [torch.randn(n, 3, hw, hw, generator=g).cuda() for _ in range(passes)]
     xt = torch.randn(tail, 3, hw, hw, generator=g).cuda() + 0.5          # (other statistics than the full passes')
     dl = torch.randn(n * passes, 2, hw, hw, generator=g).cuda()
+    m4 = copy.deepcopy(m1)
     a = m1.forward_passes(xs) if passes > 1 else m1(xs[0])
     with torch.no_grad():
         m1(xt)
     a.backward(dl)
     b = m2.forward_passes(xs, tail=xt)
     assert b.shape == a.shape
+    # the same call again on a copy of the model, with the allocator's free blocks overwritten in between: a kernel that read a
+    # statistics row, a constant or a workspace cell nobody had written would not reproduce its own logits and running statistics
+    junk = [torch.full((1 << 26,), float("nan"), device="cuda") for _ in range(4)]
+    del junk
+    with torch.no_grad():
+        b2 = m4.forward_passes(xs, tail=xt)
+    assert torch.equal(b.detach(), b2), "the batched call with a tail pass does not reproduce itself"
+    for (k, v2), (_, v4) in zip(m2.named_buffers(), m4.named_buffers()):
+        assert torch.equal(v2, v4), k
     b.backward(dl)
-    # (a launch picks its tile from the number of blocks, so one more image can move a small layer to another tile -- another MFMA
-    # shape, another f32 summation order: the logits of the passes in front of the tail are bit-identical where the tiles are, and
-    # within rounding of the storage type otherwise)
+    # (a launch picks its tile -- and the 64 -> 64 streaming kernel its strip segments, hence the grouping of its statistics rows -- from
+    # the number of blocks, so one more image can move a layer to another tile or split: another f32 summation order.  The logits of
+    # the passes in front of the tail are bit-identical where tiles and splits are, and within rounding of the storage type otherwise)
     same = torch.equal(a.detach(), b.detach())
     rel = float((a.detach() - b.detach()).norm() / a.detach().norm())
     print("tail pass: logits of the gradient passes %s (rel-L2 %.2e)" % ("bit-identical" if same else "differ by tile choice", rel))

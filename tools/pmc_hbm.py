@@ -5,7 +5,7 @@ the same command).  FETCH_SIZE and WRITE_SIZE count KB; on gfx950 FETCH_SIZE rep
     python tools/pmc_hbm.py FETCH_DIR WRITE_DIR OUT_CSV [OUT_JSON [STEPS]]
 
 OUT_JSON (optional) receives the per-launch bytes of the conv class that bench.py reports in roofline.traffic."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 
 
 def load(d, counter):
@@ -48,16 +48,19 @@ def main():
         conv = [r for r in rows if any(s in r[1] for s in ("conv3x3_halo_bf16", "conv3x3_ws64", "igemm_bf16", "conv_first_fwd", "convT_bf16"))]
         n = sum(r[2] for r in conv)
         by = sum(r[0] for r in conv) * 1024
-        wg = [r for r in rows if any(s in r[1] for s in ("wgrad_halo", "wgradT_bf16", "wgrad_bf16_kernel"))]
+        wg = [r for r in rows if any(s in r[1] for s in ("wgrad_halo", "wgradT_bf16", "wgradT2_bf16", "wgrad_bf16_kernel"))]
         nw = sum(r[2] for r in wg)
         bw = sum(r[0] for r in wg) * 1024
         ws = [r for r in rows if "conv3x3_ws64" in r[1]]
-        json.dump({"counters": "FETCH_SIZE (KB, doubled per MI355X_MICROARCH HBM note) + WRITE_SIZE (KB), rocprofv3 --pmc, "
+        import hashlib
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ust-run_amd", "ustrun", "libustrun.so")
+        lib_sha = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]          # the build these counters were read from
+        json.dump({"library_sha16": lib_sha, "counters": "FETCH_SIZE (KB, doubled per MI355X_MICROARCH HBM note) + WRITE_SIZE (KB), rocprofv3 --pmc, "
                                "separate passes, bench.py --steps 1 --warmup 1 --no-profile (2 steps in all)",
                    "kernel_class": "conv (conv3x3_halo_bf16 + conv3x3_ws64 + convT_bf16 + igemm_bf16 + conv_first_fwd)",
                    "launches": n, "hbm_bytes_per_launch": by / max(n, 1),
                    "steps": steps, "hbm_bytes_per_step": by / steps, "wgrad_hbm_bytes_per_step": bw / steps,
-                   "wgrad_kernel_class": "weight gradients (wgrad_halo*_bf16 + wgradT_bf16 + wgrad_bf16)",
+                   "wgrad_kernel_class": "weight gradients (wgrad_halo*_bf16 + wgradT_bf16 / wgradT2_bf16 + wgrad_bf16)",
                    "wgrad_launches": nw, "wgrad_hbm_bytes_per_launch": bw / max(nw, 1),
                    "ws64": [{"kernel": r[1], "launches": r[2], "hbm_MB_per_launch": round(r[5], 2)} for r in ws]},
                   open(sys.argv[4], "w"), indent=1)
