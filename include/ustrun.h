@@ -319,7 +319,11 @@ typedef struct ustrun_unet_desc {
                                   * pass (its own BatchNorm statistics, its running-buffer update after the others') whose
                                   * logits nobody reads: the head skips it and ustrun_unet_backward covers the first
                                   * groups * n images only (train.py:740: the low-quality sample's forward, Q2)      */
-    int32_t reserved0;
+    int32_t lead;                /* > 0: the first `lead` (< groups) passes carry no gradient: the forward treats them as any other pass
+                                  * (statistics, running-buffer updates in order, logits), ustrun_unet_backward starts behind them --
+                                  * dlogits keeps the forward's layout (N - tail images; the leading passes' rows are ignored).
+                                  * train.py:668: the student's forward on the weak view, whose arg-max alone is used (Q3), runs as
+                                  * the first pass of the call that carries the four gradient passes of :699-702          */
     float   momentum, eps;
     /* parameters/buffers, torch layouts, in state_dict order:                 */
     const float* conv_w[18];     /* inc.0, inc.3, down1..4 (.0,.3), up1..4.conv (.0,.3)        */

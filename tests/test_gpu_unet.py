@@ -330,6 +330,43 @@ def test_forward_passes_equals_separate_calls(dtype, base, n, hw):
         assert e < tol, (k, e)
 
 
+@pytest.mark.parametrize("dtype,base,n,hw,passes,lead,tail", [("bf16", 64, 2, 64, 5, 1, 1), ("f16", 32, 3, 96, 3, 1, 0), ("f32", 16, 2, 40, 3, 2, 1),
+                                                              ("f32x3", 64, 2, 32, 2, 1, 0), ("bf16", 64, 4, 128, 5, 1, 1)])
+def test_leading_passes_without_gradient(dtype, base, n, hw, passes, lead, tail):
+    """`lead` forward-only passes in front of the gradient passes of one batched call (ustrun_unet_desc_t::lead: the student's
+    forward on the weak view, train.py:668, ahead of the four gradient passes of :699-702) against the same call WITHOUT the
+    backward skipping anything but with zero gradient at the leading passes' logits: same logits and buffers (the forward does
+    not know about `lead`), and the parameter gradients of a backward that starts behind the leading passes equal those of the
+    full backward fed zeros there -- to f32 summation order, since zero rows add nothing but regroup nothing either: equal to
+    1e-6 (f32) / the storage type's noise."""
+    import copy
+    from networks.unet_model import UNet
+    torch.manual_seed(29)
+    m1 = UNet(3, 2, base_channels=base, dtype=dtype).cuda().train()
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(n * passes + tail, 3, hw, hw, generator=g).cuda()
+    dl = torch.randn(n * passes, 2, hw, hw, generator=g).cuda()
+    dl0 = dl.clone()
+    dl0[:lead * n] = 0
+    a = m1.forward_batched(x, passes, tail=tail)
+    a.backward(dl0)
+    b = m2.forward_batched(x, passes, tail=tail, lead=lead)
+    junk = dl.clone()
+    junk[:lead * n] = float("nan")                       # the leading passes' rows of the gradient are never read
+    b.backward(junk)
+    assert torch.equal(a.detach(), b.detach())
+    for (k, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        assert torch.equal(b1, b2), k
+    worst = 0.0
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.isfinite(p2.grad).all(), k
+        e = float((p1.grad - p2.grad).norm() / (p1.grad.norm() + 1e-30))
+        worst = max(worst, e)
+        assert e < (1e-5 if dtype in ("f32", "f32x3") else 5e-2), (k, e)
+    print("leading passes: worst relative gradient difference against the zero-fed full backward %.2e" % worst)
+
+
 @pytest.mark.parametrize("dtype,base,n,hw,passes,tail,exact", [("bf16", 64, 4, 64, 4, 1, False), ("f16", 32, 3, 128, 2, 2, True),
                                                                ("f32", 16, 2, 40, 3, 1, True), ("bf16", 64, 2, 256, 4, 1, False),
                                                                ("bf16", 16, 3, 72, 1, 1, True), ("bf16", 64, 16, 128, 4, 1, False)])

@@ -19,6 +19,8 @@ namespace {
 struct Plan {
     int N, C, H, W, K, base;
     int G, gN;                   // forward passes batched into this call, images per pass (BatchNorm is per pass)
+    int L, Gb, ob;               // leading passes WITHOUT gradient (forward as any other; the backward starts behind them), the
+                                 // passes the backward covers, the first image it covers
     int T, GP, Nb, pg, pgb;      // images of the shorter tail pass behind them (forward only, logits unused); passes incl. the tail;
                                  // G * gN = the images the head and the backward cover; pg = gN when the forward's batch has a pass
                                  // structure, pgb = the same for the backward's (which never sees the tail)
@@ -55,7 +57,10 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     USTRUN_CHECK(p.T >= 0 && p.T < d->N && (d->N - p.T) % p.G == 0, "unet: N=%d is not groups=%d equal passes + a tail of %d", d->N, p.G, p.T);
     p.gN = (d->N - p.T) / p.G;
     USTRUN_CHECK(p.T < p.gN, "unet: the tail pass (%d images) must be shorter than the others (%d)", p.T, p.gN);
-    p.GP = p.G + (p.T > 0); p.Nb = p.G * p.gN; p.pg = p.GP > 1 ? p.gN : 0; p.pgb = p.G > 1 ? p.gN : 0;
+    p.L = d->lead;
+    USTRUN_CHECK(p.L >= 0 && p.L < p.G, "unet: %d leading passes without gradient of %d passes", p.L, p.G);
+    p.Gb = p.G - p.L; p.ob = p.L * p.gN;
+    p.GP = p.G + (p.T > 0); p.Nb = p.Gb * p.gN; p.pg = p.GP > 1 ? p.gN : 0; p.pgb = p.Gb > 1 ? p.gN : 0;
     USTRUN_CHECK(p.GP <= 8, "unet: %d passes in one call (at most 8)", p.GP);
     p.Hs[0] = d->H; p.Ws[0] = d->W;
     for (int l = 1; l < 5; ++l) { p.Hs[l] = p.Hs[l - 1] / 2; p.Ws[l] = p.Ws[l - 1] / 2; }
@@ -172,9 +177,22 @@ ustrun_src_t nhwc_src(const void* ptr, const float* aff, int C, int H, int W, in
 }
 
 // sources of conv i (forward input), from the saved workspace
+// bwd: the sources as the backward sees them -- its first image is p.ob (behind the leading passes), its pass structure p.pgb
+int conv_sources_fwd(const Plan& p, const float* x, const char* ws, int i, ustrun_src_t* srcs);
 int conv_sources(const Plan& p0, const float* x, const char* ws, int i, ustrun_src_t* srcs, bool bwd = false) {
+    if (!bwd) return conv_sources_fwd(p0, x, ws, i, srcs);
     Plan p = p0;
-    if (bwd) p.pg = p.pgb;
+    p.pg = p.pgb;
+    const int ns = conv_sources_fwd(p, x, ws, i, srcs);
+    for (int k = 0; k < ns; ++k) {
+        ustrun_src_t& s = srcs[k];
+        const int esz = (s.f32 || p.esz == 4) ? 4 : 2;
+        s.ptr = (const char*)s.ptr + (int64_t)p.ob * s.sN * esz;
+        if (s.scale) { s.scale += (int64_t)p.L * s.gstride; s.shift += (int64_t)p.L * s.gstride; }
+    }
+    return ns;
+}
+int conv_sources_fwd(const Plan& p, const float* x, const char* ws, int i, ustrun_src_t* srcs) {
     auto act = [&](int k, int pool) {
         return nhwc_src(ws + p.y_off[k], (const float*)(ws + p.aff_off[k]), p.cout[k], p.Hs[p.lvl[k]], p.Ws[p.lvl[k]], 1, pool,
                         p.pg);
@@ -383,15 +401,18 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
     const float* pk = (const float*)d->packed;
     float* coef = (float*)(sc + p.coef_off);
     float* part = (float*)(sc + p.part_off);
-    auto affp = [&](int k) { return (const float*)(ws + p.aff_off[k]); };
+    // (everything the backward reads starts behind the leading passes: image p.ob of every tensor, pass p.L of every constant table)
+    auto affp = [&](int k) { return (const float*)(ws + p.aff_off[k]) + 4L * p.cout[k] * p.L; };
+    auto yb = [&](int k) { return ws + p.y_off[k] + (long)p.ob * p.Hs[p.lvl[k]] * p.Ws[p.lvl[k]] * p.cout[k] * p.esz; };
+    dlogits += (long)p.ob * p.K * p.H * p.W;
     const int dt = d->dtype;
 
     int head_bn_rows = 0;       // > 0: the head kernel also formed layer 17's BatchNorm-backward sums (rows per pass, in `part`)
     if (which <= 1) {   // head: all passes in one launch (blockIdx.y = pass: its BatchNorm constants on load)
         const int C = p.cout[17];
         const long gpix = (long)p.gN * p.H * p.W;
-        USTRUN_TRY(head_bwd_passes(dlogits, ws + p.y_off[17], affp(17), affp(17) + C, gpix, p.H * p.W, C, p.K, d->head_w,
-                                   sc + p.da_off[17], grads[62], grads[63], accumulate, part, p.part_bytes, dt, p.G, 4L * C,
+        USTRUN_TRY(head_bwd_passes(dlogits, yb(17), affp(17), affp(17) + C, gpix, p.H * p.W, C, p.K, d->head_w,
+                                   sc + p.da_off[17], grads[62], grads[63], accumulate, part, p.part_bytes, dt, p.Gb, 4L * C,
                                    (hipStream_t)s, (g_debug_flags & 8388608) ? nullptr : &head_bn_rows));
     }
     // layers 17..10 = decoder, 9..8 = down4 (57 of the encoder's 75 MB of gradients, and the first to finish), 7..0 = the rest
@@ -413,17 +434,17 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             if (i == 17 && head_bn_rows > 0) {      // the sums came with the head's partial rows: no reduce pass over da and y
                 const long row = (long)p.K * C + p.K + 2L * C;
                 USTRUN_TRY(bn_bwd_finalize_rows(part, head_bn_rows, row, (long)p.K * C + p.K, C, (int64_t)p.gN * H * W, d->bn_w[i],
-                                                aff + 2 * C, aff + 3 * C, grads[gi + 1], grads[gi + 2], accumulate, coef, p.G,
+                                                aff + 2 * C, aff + 3 * C, grads[gi + 1], grads[gi + 2], accumulate, coef, p.Gb,
                                                 4L * C, (hipStream_t)s));
             } else if (dgrad_bn_rows > 0) {         // ... or with the rows the producing input gradient wrote (below)
-                USTRUN_CHECK(dgrad_bn_rows % p.G == 0, "unet_backward: %d sum rows do not split into %d passes", dgrad_bn_rows, p.G);
-                USTRUN_TRY(bn_bwd_finalize_stat(part, dgrad_bn_rows / p.G, p.G, C, (int64_t)p.gN * H * W, d->bn_w[i], aff + 2 * C,
+                USTRUN_CHECK(dgrad_bn_rows % p.Gb == 0, "unet_backward: %d sum rows do not split into %d passes", dgrad_bn_rows, p.Gb);
+                USTRUN_TRY(bn_bwd_finalize_stat(part, dgrad_bn_rows / p.Gb, p.Gb, C, (int64_t)p.gN * H * W, d->bn_w[i], aff + 2 * C,
                                                 aff + 3 * C, 4L * C, grads[gi + 1], grads[gi + 2], accumulate, coef, (hipStream_t)s));
             } else
-            USTRUN_TRY(bn_bwd_reduce_passes(da, dp, ws + p.y_off[i], aff, aff + C, aff + 2 * C, aff + 3 * C, d->bn_w[i], p.gN, H, W,
-                                            C, grads[gi + 1], grads[gi + 2], accumulate, coef, part, p.part_bytes, dt, p.G, act,
+            USTRUN_TRY(bn_bwd_reduce_passes(da, dp, yb(i), aff, aff + C, aff + 2 * C, aff + 3 * C, d->bn_w[i], p.gN, H, W,
+                                            C, grads[gi + 1], grads[gi + 2], accumulate, coef, part, p.part_bytes, dt, p.Gb, act,
                                             pl, 4L * C, (hipStream_t)s));
-            USTRUN_TRY(bn_bwd_apply_passes(da, dp, ws + p.y_off[i], aff, aff + C, coef, p.gN, H, W, C, da, dt, p.G, act, pl,
+            USTRUN_TRY(bn_bwd_apply_passes(da, dp, yb(i), aff, aff + C, coef, p.gN, H, W, C, da, dt, p.Gb, act, pl,
                                            4L * C, (hipStream_t)s));
         }
         dgrad_bn_rows = 0;
@@ -445,7 +466,7 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.Nb, H, W, C, p.cin[i], sc + p.da_off[skip], p.cout[skip],
                                             sc + p.du_off[j], uh, uw, (H - uh) / 2, (W - uw) / 2, dt, s));
             const int prev = (j == 0) ? 9 : i - 1;
-            ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0,
+            ustrun_src_t a = nhwc_src(yb(prev), affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0,
                                       p.pgb);
             const int ub = 30 + j * 8;
             prof_set_tag(220 + j, p.Nb);
@@ -460,7 +481,7 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             if (!(g_debug_flags & (1 << 25)) && j > 0 && prev >= i_lo &&
                 (long)ustrun_conv_mtiles(p.Nb, p.Hs[l + 1], p.Ws[l + 1], Cp) * 2 * Cp * 4 <= p.part_bytes)
                 USTRUN_TRY(ustrun_convT2x2_dgrad_bnsum(sc + p.du_off[j], pk + p.ud_off[j], p.Nb, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], Cp,
-                                                       sc + p.da_off[prev], ws + p.y_off[prev], pa, pa + Cp, p.pgb, 4L * Cp,
+                                                       sc + p.da_off[prev], yb(prev), pa, pa + Cp, p.pgb, 4L * Cp,
                                                        part, &dgrad_bn_rows, dt, s));
             if (dgrad_bn_rows == 0)
             USTRUN_TRY(ustrun_convT2x2_dgrad(sc + p.du_off[j], pk + p.ud_off[j], p.Nb, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
@@ -473,7 +494,7 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             const int Cp = p.cin[i];
             const long need = (long)ustrun_conv_mtiles(p.Nb, H, W, Cp) * 2 * Cp * 4;
             if (!(g_debug_flags & (1 << 25)) && i - 1 >= i_lo && need <= p.part_bytes)
-                USTRUN_TRY(ustrun_conv3x3_dgrad_bnsum(da, wd, p.Nb, H, W, C, Cp, sc + p.da_off[i - 1], ws + p.y_off[i - 1], pa, pa + Cp,
+                USTRUN_TRY(ustrun_conv3x3_dgrad_bnsum(da, wd, p.Nb, H, W, C, Cp, sc + p.da_off[i - 1], yb(i - 1), pa, pa + Cp,
                                                       p.pgb, 4L * Cp, part, &dgrad_bn_rows, dt, s));
             if (dgrad_bn_rows == 0)
                 USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.Nb, H, W, C, Cp, sc + p.da_off[i - 1], Cp, nullptr, 0, 0, 0, 0, dt, s));

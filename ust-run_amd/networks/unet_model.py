@@ -56,18 +56,26 @@ class UNet(nn.Module):
         logits = self.outc(y)
         return (logits, y) if feature else logits
 
-    def forward_batched(self, x, groups, tail=0, feature=False):
+    def forward_batched(self, x, groups, tail=0, feature=False, lead=0):
         """`forward_passes` for a batch the caller has already laid out end to end: x = `groups` equal passes followed by a
-        shorter tail pass of `tail` images (0: none; output discarded, see `forward_passes`)."""
+        shorter tail pass of `tail` images (0: none; output discarded, see `forward_passes`).  `lead`: the first `lead` passes
+        are forward-only (`with torch.no_grad(): self(x_k)` in front of the others): their logits come back with the rest, the
+        backward skips them."""
         import torch
         _hip_only(x)
         n = (len(x) - tail) // max(groups, 1)
         if groups < 1 or n * groups + tail != len(x) or (tail and tail >= n):
             raise RuntimeError(f"forward_batched: {len(x)} images are not {groups} equal passes + a shorter tail of {tail}")
-        if self.bilinear:
-            return self.forward_passes(list(x[:n * groups].split(n)), feature, tail=x[n * groups:] if tail else None)
+        if self.bilinear or lead and feature:
+            parts = list(x[:n * groups].split(n))
+            with torch.no_grad():
+                head = [self._forward_blocks(t, False) if self.bilinear else self(t) for t in parts[:lead]]
+            rest = self.forward_passes(parts[lead:], feature, tail=x[n * groups:] if tail else None)
+            if not lead:
+                return rest
+            return torch.cat(head + [rest], 0)
         from ustrun import engine
-        return engine.unet_forward(self, x, feature, groups=groups, tail=tail)
+        return engine.unet_forward(self, x, feature, groups=groups, tail=tail, lead=lead)
 
     def forward_passes(self, xs, feature=False, tail=None):
         """Additive API (not in the reference): run several forward passes of equal shape as ONE batched call.

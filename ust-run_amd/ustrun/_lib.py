@@ -25,7 +25,7 @@ class Src(C.Structure):
 class UNetDesc(C.Structure):
     """ustrun_unet_desc_t"""
     _fields_ = [("N", i32), ("C", i32), ("H", i32), ("W", i32), ("K", i32), ("base", i32), ("dtype", i32),
-                ("train", i32), ("update_running", i32), ("groups", i32), ("tail", i32), ("reserved0", i32), ("momentum", f32), ("eps", f32),
+                ("train", i32), ("update_running", i32), ("groups", i32), ("tail", i32), ("lead", i32), ("momentum", f32), ("eps", f32),
                 ("conv_w", vp * 18), ("bn_w", vp * 18), ("bn_b", vp * 18), ("bn_rm", vp * 18),
                 ("bn_rv", vp * 18), ("bn_nbt", vp * 18), ("up_w", vp * 4), ("up_b", vp * 4),
                 ("head_w", vp), ("head_b", vp), ("packed", vp)]

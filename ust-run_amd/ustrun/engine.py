@@ -35,11 +35,11 @@ def _check_param(t, name):
         raise RuntimeError(f"{name}: parameters/buffers must be contiguous float32 HIP tensors")
 
 
-def _desc(model, N, H, W, train, groups=1, tail=0):
+def _desc(model, N, H, W, train, groups=1, tail=0, lead=0):
     pairs, ups, head = conv_bn_list(model)
     d = L.UNetDesc()
     d.N, d.C, d.H, d.W, d.K = N, model.n_channels, H, W, model.n_classes
-    d.groups, d.tail = groups, tail
+    d.groups, d.tail, d.lead = groups, tail, lead
     d.base, d.dtype = model.base_channels, _DT[model.compute_dtype]
     d.train, d.update_running = int(train), int(train)
     bn0 = pairs[0][1]
@@ -101,8 +101,8 @@ def _current_debug_flags(lib):
 
 class _UNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, model, feature, groups, tail, *params):
-        logits, feat, ws, d = _run_forward(model, x, feature, groups, tail)
+    def forward(ctx, x, model, feature, groups, tail, lead, *params):
+        logits, feat, ws, d = _run_forward(model, x, feature, groups, tail, lead)
         ctx.model, ctx.ws, ctx.desc, ctx.x = model, ws, d, x
         # ustrun_debug_flags is per calling thread and autograd runs backward() on a thread of its own: the backward runs under
         # the flags the forward ran under (some of them shape the plan both halves share)
@@ -157,10 +157,10 @@ class _UNetFn(torch.autograd.Function):
                     mid()
         ctx.ws = None
         grads = (None,) * ctx.nparams if sink is not None else tuple(targets)
-        return (None, None, None, None, None) + grads
+        return (None, None, None, None, None, None) + grads
 
 
-def _run_forward(model, x, feature, groups=1, tail=0):
+def _run_forward(model, x, feature, groups=1, tail=0, lead=0):
     lib = L.lib()
     if x.dim() != 4 or x.shape[1] != model.n_channels:
         raise RuntimeError(f"UNet: expected input [N,{model.n_channels},H,W], got {tuple(x.shape)}")
@@ -170,7 +170,9 @@ def _run_forward(model, x, feature, groups=1, tail=0):
     N, _, H, W = x.shape
     if groups < 1 or tail < 0 or tail >= N or (N - tail) % groups or (tail and tail >= (N - tail) // groups):
         raise RuntimeError(f"UNet: batch {N} does not split into {groups} passes" + (f" and a shorter tail of {tail}" if tail else ""))
-    d = _desc(model, N, H, W, model.training, groups, tail)
+    if lead < 0 or lead >= groups:
+        raise RuntimeError(f"UNet: {lead} leading passes without gradient of {groups} passes")
+    d = _desc(model, N, H, W, model.training, groups, tail, lead)
     _ensure_packed(model, d)
     nbytes = lib.ustrun_unet_fwd_workspace_bytes(C.byref(d))
     if nbytes < 0:
@@ -186,17 +188,18 @@ def _run_forward(model, x, feature, groups=1, tail=0):
     return logits, feat, ws, d
 
 
-def unet_forward(model, x, feature=False, groups=1, tail=0):
+def unet_forward(model, x, feature=False, groups=1, tail=0, lead=0):
     """groups > 1: x holds `groups` independent forward passes laid end to end along the batch axis; they run as one
     batched call with BatchNorm statistics (and running-buffer updates, in order) kept per pass -- the results are
     those of `groups` separate calls, at the launch count and GPU fill of one.  tail > 0: the last `tail` images of x are
     one more, shorter pass whose output nobody needs (it only moves the BatchNorm running statistics, after the others):
-    the returned logits cover the passes in front of it."""
+    the returned logits cover the passes in front of it.  lead > 0: the first `lead` passes get no gradient (their rows of the
+    logits' gradient are ignored): a no-grad forward that must come first in BatchNorm order rides in the same call."""
     params = model_params(model)
     needs_grad = torch.is_grad_enabled() and model.training and any(p.requires_grad for p in params)
     if x.requires_grad:
         raise NotImplementedError("gradient w.r.t. the network input is not on the hot path (train.py never needs it)")
     if needs_grad:
-        return _UNetFn.apply(x, model, feature, groups, tail, *params)
-    logits, feat, _, _ = _run_forward(model, x, feature, groups, tail)
+        return _UNetFn.apply(x, model, feature, groups, tail, lead, *params)
+    logits, feat, _, _ = _run_forward(model, x, feature, groups, tail, lead)
     return (logits, feat) if feature else logits

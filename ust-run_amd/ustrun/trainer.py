@@ -368,22 +368,23 @@ class SSLTrainer:
             pl, mask = self._pl(t_out[0])
             pl_w_ul, mask_w_ul = self._pl(t_out[1])
             pl_w_lu, mask_w_lu = self._pl(t_out[2])
-            # student forward on the weak view: only its pseudo-label is used (Q3)
-            stu_pl, _ = self._pl(model(ulb_x_w))
             pl_w, mask_w, pl_ul, mask_ul, pl_lu, mask_lu = F.mix_targets(
                 mode, box, pl, mask, pl_w_ul, mask_w_ul, pl_w_lu, mask_w_lu, cut_label_c, cut_mask_c)
-
-        # the per-sample Dice behind the hardness ranking: counted and copied to pinned memory in front of the student's
-        # passes, read at the END of the step (nothing before the next step depends on it): never a wait
-        dice_host, dice_ev = self._sample_dice_async(stu_pl, pl)
+        # the student's forward on the weak view (train.py:668: only its arg-max is used, Q3 -- but its BatchNorm updates come
+        # first): as the LEADING, gradient-free pass of the student's batched call below, or as a call of its own
+        fold_weak = self.batch_passes and nlb == B and B > 1
+        stu_pl = None
+        if not fold_weak:
+            with torch.no_grad():
+                stu_pl, _ = self._pl(model(ulb_x_w))
         self._mark("teacher+targets issued")
 
         # ---- student: four forwards that carry gradient (train.py:699-702) and, behind them, the low-quality sample's
         # (train.py:734-740: result unused, Q2 -- only the BatchNorm running statistics move, after the other four's): ONE batch,
         # put together in one launch
         us, mt, lbr = F.row_ptrs(ulb_x_s), F.row_ptrs(move_transx), F.row_ptrs(lb_x_w)
-        rows = [(p, 0, 0) for p in lbr] + [(us[i], mt[i], bx[i]) for i in range(B)] + \
-               [(mt[i], us[i], bx[i]) for i in range(B)] + [(p, 0, 0) for p in us]
+        rows = ([(p, 0, 0) for p in uw] if fold_weak else []) + [(p, 0, 0) for p in lbr] + \
+               [(us[i], mt[i], bx[i]) for i in range(B)] + [(mt[i], us[i], bx[i]) for i in range(B)] + [(p, 0, 0) for p in us]
         ib_lq = None
         if new_choice is not None:
             bbox_ev.synchronize()
@@ -395,14 +396,18 @@ class SSLTrainer:
         x_all = F.assemble(rows, lb_x_w, HW)
         n4 = nlb + 3 * B
         lg_all = None
-        if self.batch_passes and nlb == B and B > 1:
-            lg_all = model.forward_batched(x_all, 4, tail=len(x_all) - n4)
-            lg_lb, lg_ul, lg_lu, lg_s = lg_all.detach().split(B)
+        if fold_weak:
+            lg_all = model.forward_batched(x_all, 5, tail=len(x_all) - n4 - B, lead=1)
+            lg_weak, lg_lb, lg_ul, lg_lu, lg_s = lg_all.detach().split(B)
+            stu_pl, _ = self._pl(lg_weak)
         else:
             lg_lb, lg_ul, lg_lu, lg_s = (model(t) for t in x_all[:n4].split([nlb, B, B, B]))
             if ib_lq is not None:
                 with torch.no_grad():
                     model(x_all[n4:])
+        # the per-sample Dice behind the hardness ranking: counted and copied to pinned memory here, read at the END of the step
+        # (nothing before the next step depends on it)
+        dice_host, dice_ev = self._sample_dice_async(stu_pl, pl)
         self._mark("student fwd issued")
 
         # losses and backward (train.py:816-848; Q5, Q6): loss = sup + w*(ul + lu + w*s)
@@ -416,7 +421,7 @@ class SSLTrainer:
             outs.append(out)
             dl = F.seg_loss_bwd(lg.detach(), tgt, msk, mode, out, gscale=coef,
                                 gdev=self.scaler.state if self.scaler is not None else None,       # scaler.scale(loss)
-                                out=dl_all[k * B:(k + 1) * B] if dl_all is not None else None)
+                                out=dl_all[(k + 1) * B:(k + 2) * B] if dl_all is not None else None)     # (rows of the leading pass: ignored)
             if lg_all is None:
                 lg.backward(dl)
         overlap = self.grad_allreduce is not None and hasattr(self.grad_allreduce, "start_tail")
