@@ -145,6 +145,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C ust-run_amd/csrc`. There is no CPU fallback for this path.")
+        # torch first: its wheel carries the HIP runtime the device memory and streams come from, and libustrun.so must bind to THAT
+        # copy -- loaded on its own it pulls in /opt/rocm's, and a process with both sees "no ROCm-capable device" at the first launch
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError if the library lacks a declared symbol
