@@ -69,13 +69,18 @@ def pack16(w):
 
 
 def variant(th, tw, bn, mi, nt, *rest):
-    """rest = [build tag,] pool, xf; build tag "m16" = the 16x16x32 build (bit 7 of the code)"""
+    """rest = [build tag,] pool, xf; build tag "m16" = the 16x16x32 build (bit 7 of the code).
+    ("lin", W, 128, 4, 1): the linear tiles of round 5 (256 consecutive positions of the flat padded space, row length W)"""
+    if th == "lin":
+        return 1 << 30 | tw << 16 | bn << 8 | (0 if rest[-1] else 0x80) | mi << 4 | nt << 2 | (1 if rest[-1] else 0)
     m16 = 0x80 if (rest and rest[0] == "m16") else 0
     pool, xf = rest[-2], rest[-1]
     return th << 24 | tw << 16 | bn << 8 | m16 | mi << 4 | nt << 2 | (2 if pool else 0) | (1 if xf else 0)
 
 
 def vstr(v):
+    if v >> 30 & 1:
+        return "linear W%d BN%d MI%d%s xf%d" % ((v >> 16) & 255, (v >> 8) & 255, (v >> 4) & 7, " m16" if v & 0x80 else "", v & 1)
     return "TH%d TW%d BN%d MI%d%s NT%d pool%d xf%d" % (v >> 24, (v >> 16) & 255, (v >> 8) & 255, (v >> 4) & 7, " m16" if v & 0x80 else "",
                                                     (v >> 2) & 3, (v >> 1) & 1, v & 1)
 
@@ -117,8 +122,9 @@ CASES = [
     # the 8 x 32 tile: the rule takes 16 x 16 tiles; 18 x 18 and 24 x 24 pad to 32 on 16 x 16 tiles: 8 x 16 MI 2;
     # 144 x 144 (= 4.5 x 32): 16 x 16 as well
     ("pad_48_512", 16, (512,), 512, 48, 48, 2, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1)),
-    ("pad_18_1024", 64, (1024,), 1024, 18, 18, 4, (8, 16, 128, 2, 2), (8, 16, 128, 2, 2)),
-    ("pad_24_1024", 64, (1024,), 1024, 24, 24, 4, (8, 16, 128, 2, 2), (8, 16, 128, 2, 2)),
+    # (since round 5 these two maps run on the linear tiles -- the LIN cases below; ustrun_debug_flags bit 26 keeps the rule's tile)
+    ("pad_18_1024", 64, (1024,), 1024, 18, 18, 4, (8, 16, 128, 2, 2), (8, 16, 128, 2, 2), 1 << 26),
+    ("pad_24_1024", 64, (1024,), 1024, 24, 24, 4, (8, 16, 128, 2, 2), (8, 16, 128, 2, 2), 1 << 26),
     ("pad_144_128", 8, (128,), 128, 144, 144, 2, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1)),
     # ---- the 512-pixel x 64-channel tile (16 x 32 px, wave tile 128 px x 64 ch, one block per CU; ustrun_debug_flags bit 13):
     # the concat conv of up4 forward, and the input gradient of a 64 -> 128 layer (a 128 -> 64 product on a plain source)
@@ -140,7 +146,22 @@ CASES = [c[:8] + ((c[8] + ("m16",)) if (isinstance(c[8], tuple) and c[8][3] == 4
 for _c in list(CASES):
     if _c[0] in ("tall_wide_128", "cat_128_to_64", "tall_narrow_512", "c64_wide", "c64_narrow", "mid_grid_512", "pad_18_1024", "pad_144_128"):
         tag = lambda v: v if not isinstance(v, tuple) or (len(v) > 5 and v[5] == "m16") else v[:5] + ("m16",)
-        CASES.append(("m16all_" + _c[0],) + _c[1:7] + (_c[7], tag(_c[8]), 32768))
+        CASES.append(("m16all_" + _c[0],) + _c[1:7] + (_c[7], tag(_c[8]), 32768 | (_c[9] if len(_c) > 9 else 0)))
+# ---- linear tiles (round 5, conv_halo_bf16.hip LINW: VERDICT r4 next 4): the maps of configs[2] / configs[3] whose sides no
+# rectangular tile divides -- 18 / 36 / 72 pixels (M&Ms 288 x 288, train_mnms.py:397-399), 24 (prostate 384 x 384, train.py:416-418).
+# A tile is 256 consecutive positions of a pass's flat padded space: tiles cross rows and images (never passes), the last tile of a
+# pass is partial, pad positions are computed and dropped.  Forward through BatchNorm + ReLU on load (32x32x16 build) with
+# statistics, input gradient on the 16x16x32 build; a two-source concat with an offset window and the two-destination input
+# gradient; a map with H != W in one pass
+LIN = lambda w: ("lin", w, 128, 4, 1)
+CASES += [
+    ("lin_18_1024", 64, (1024,), 1024, 18, 18, 4, LIN(18), LIN(18)),
+    ("lin_24_1024", 64, (1024,), 1024, 24, 24, 4, LIN(24), LIN(24)),
+    ("lin_36_512", 20, (512,), 512, 36, 36, 4, LIN(36), LIN(36)),
+    ("lin_72_256", 8, (256,), 256, 72, 72, 2, LIN(72), LIN(72)),
+    ("lin_cat_36", 24, (128, 128), 256, 36, 36, 2, LIN(36), LIN(36)),
+    ("lin_18x20_512", 48, (512,), 512, 20, 18, 1, LIN(18), LIN(18)),
+]
 
 WS_CODE = {"ws4": 0x57530000, "ws8": 0x57530100, "ws": 0x57530200}      # four waves / eight waves / consumer + producer waves (default)
 
@@ -244,6 +265,55 @@ def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):
     assert rel(dw.cpu(), wr.grad) < 1e-6
     l.check(lib.ustrun_conv3x3_wgrad(sarr, len(srcs), dyg.data_ptr(), n, h, w, co, dw.data_ptr(), 1, part.data_ptr(), nb, E.code, None), "wgrad acc")
     assert rel(dw.cpu(), 2 * wr.grad) < 1e-6
+
+
+def test_linear_tiles_shorter_last_pass_exact():
+    """Linear tiles with a last pass shorter than the others (the student's batched call: G passes of B images + the one-image
+    low-quality pass, ustrun_unet_desc_t::tail): 4 x 5 + 2 images of 36 x 36, 512 -> 512; the last pass has its own tile count, its
+    BatchNorm constants, and its statistics rows at the end (the count ustrun_unet_forward splits them by is checked through the
+    per-pass sums)."""
+    l = L()
+    lib = l.lib()
+    n, gn, c, h, w = 22, 5, 512, 36, 36
+    G = (n + gn - 1) // gn
+    g = torch.Generator().manual_seed(77)
+    ri = lambda lo, hi, *s_: torch.randint(lo, hi + 1, s_, generator=g).float()
+    y0 = ri(-3, 3, n, c, h, w)
+    sc = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (G, c), generator=g)]
+    sh = ri(-1, 1, G, c)
+    scn = sc.repeat_interleave(gn, 0)[:n, :, None, None]
+    shn = sh.repeat_interleave(gn, 0)[:n, :, None, None]
+    a0 = torch.relu(y0 * scn + shn)
+    wt = ri(-2, 2, c, c, 3, 3)
+    ref = F.conv2d(a0, wt, None, 1, 1)
+    assert float(ref.abs().max()) < 2 ** 24
+    aff = torch.zeros(G, 4, c)
+    aff[:, 0], aff[:, 1] = sc, sh
+    affg, y0g = aff.cuda(), nhwc16(y0)
+    src = l.nhwc_src(y0g.data_ptr(), c, h, w, affg.data_ptr(), affg.data_ptr() + 4 * c, relu=1, gN=gn, gstride=4 * c)
+    sarr = (l.Src * 1)(src)
+    wf, _ = pack16(wt)
+    ZO = 8192
+    obuf = torch.full((ZO + n * h * w * c + ZO,), 9.0, device="cuda", dtype=E.t)
+    out = obuf[ZO:ZO + n * h * w * c].view(n, h, w, c)
+    rows_max = lib.ustrun_conv_mtiles(n, h, w, c)
+    stat = torch.full((rows_max + 64, 2, c), 5.0, device="cuda")
+    rows = C.c_int(0)
+    l.check(lib.ustrun_conv3x3_fwd_rows(sarr, 1, wf.data_ptr(), n, h, w, c, out.data_ptr(), stat.data_ptr(), C.byref(rows), E.code, None), "fwd")
+    assert lib.ustrun_debug_last_conv_variant() == variant("lin", 36, 128, 4, 1, False, True), vstr(lib.ustrun_debug_last_conv_variant())
+    yc = from_nhwc(out.float())
+    assert rel(yc, r16(ref)) < 1e-6
+    assert bool((obuf[:ZO] == 9.0).all()) and bool((obuf[-ZO:] == 9.0).all()) and bool((stat[rows.value:] == 5.0).all())
+    per = lambda imgs: -(-imgs * (h + 1) * (w + 1) // 256)
+    assert rows.value == (G - 1) * per(gn) + per(n - (G - 1) * gn)
+    r0 = 0
+    for p_ in range(G):
+        imgs = min(gn, n - p_ * gn)
+        st = stat[r0:r0 + per(imgs)].double().sum(0).cpu()
+        r0 += per(imgs)
+        ys = yc[p_ * gn:p_ * gn + imgs].double()
+        assert float((st[0] - ys.sum((0, 2, 3))).abs().max()) <= 1e-6 * float(ys.abs().sum((0, 2, 3)).max())
+        np.testing.assert_allclose(st[1].numpy(), ys.square().sum((0, 2, 3)).numpy(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("n,G,ci,co,h,w", [
@@ -440,7 +510,10 @@ def test_wgrad_all_taps_builds_exact(case):
     ("wide_128", 16, 2, 128, 128, 128, 128, (8, 32, 128, 4, 1, "m16")),       # 8 x 32 tiles, two passes
     ("narrow_512_ragged", 16, 1, 512, 512, 56, 24, (16, 16, 128, 4, 1, "m16")),   # 16 x 16 tiles, ragged right / bottom edges
     ("bottleneck", 64, 4, 1024, 512, 16, 16, (16, 16, 128, 4, 1, "m16")),     # N = 64, four passes, 512 -> 1024 channels back
-    ("too_small", 2, 1, 128, 128, 32, 32, None),                                # a grid the fused epilogue does not cover: rows = 0, no launch
+    ("too_small", 2, 1, 128, 128, 32, 32, None),
+    # linear tiles (round 5): 18 x 18 at the bottleneck's width, four passes; 36 x 36 with a partial last tile per pass
+    ("lin_18", 64, 4, 1024, 512, 18, 18, ("lin", 18, 128, 4, 1)),
+    ("lin_36", 20, 4, 512, 512, 36, 36, ("lin", 36, 128, 4, 1)),                                # a grid the fused epilogue does not cover: rows = 0, no launch
     # the 64 -> 64 streaming kernel (consumer / producer build; the sums ride on the producers' stores): two passes; then four
     # passes on a ragged map (9 row-steps in segments, 2.5 strips of 32 px)
     ("ws64_n8_128", 8, 2, 64, 64, 128, 128, "ws"),

@@ -64,18 +64,33 @@ template <bool B> struct more_value<std::integral_constant<bool, B>> { static co
 // in the four registers of a tile -> 2 cvt_pk + one ds_write_b64 in the epilogue instead of four 2-byte writes.  Same fragment
 // bytes from LDS, same weight loads, same accumulator count; what differs is the clock the chip holds (MI355X_MICROARCH.md,
 // "DVFS give-back" item 7).
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false, bool M16 = false, bool BNS = false>
+// LINW (round 5; maps whose sides the rectangular tiles do not divide: 18 / 36 / 72 pixels of the 288 x 288 workload, 24 of the
+// 384 x 384 one -- an 8 x 16 tile covers an 18 x 18 map at 42 % useful MFMAs): the M dimension is the FLAT PADDED space of one
+// pass -- image stride (H + 1)(W + 1), row pitch RP = W + 1: one zero column behind every row and one zero row behind every
+// image serve as right AND left, lower AND upper padding of the neighbours -- cut into tiles of TH x TW = 256 consecutive
+// positions, whatever image or row they fall in.  Tap (ty, tx) is then the constant shift ty RP + tx for every position, so the
+// patch is the 256 + 2 RP + 2 positions around the tile, a fragment is still one base register + a compile-time immediate, and
+// nothing in the stage body changes; what changes is where a patch position comes from (src_setup: position -> image, row,
+// column, once per tile) and where an output position goes (epilogue: the pad positions are computed and dropped).  Useful
+// MFMAs: H W / ((H + 1)(W + 1)) = 90 % at 18 x 18, 95 % at 36 x 36.  tiles_x = tiles per full pass, tiles_y = images per pass
+// (BatchNorm constants are per pass: a tile never crosses one; a shorter last pass has its own tile count).
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false, bool M16 = false, bool BNS = false,
+          int LINW = 0>
 __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)) void conv3x3_halo_bf16_kernel(const IgemmArgs a, const int tiles_x, const int tiles_y,
                                                                    const int nt_total) {
     static_assert(BK == 32, "80-byte patch rows hold one 32-channel chunk");
+    constexpr bool LIN = LINW > 0;
+    constexpr int RP = LINW + 1;                // LIN: row pitch of the flat padded space
+    constexpr int TM = TH * TW;
+    static_assert(!LIN || (DIL == 1 && !POOL && TW == 32 && BREG && RP > 8), "linear tiles: un-dilated, un-pooled, 32-position sub-tiles");
     static_assert(!M16 || (BREG && !XF), "the 16x16x32 build: plain sources, weights through registers");
     static_assert(!BNS || M16, "BatchNorm-backward sums ride on the 16x16x32 epilogue (8 channels of a pixel per lane)");
     static_assert(!BREG || NT <= 2, "register-fed weights: 16 registers per tap and set");
-    constexpr int HW2 = TW + 2 * DIL;
+    constexpr int HW2 = LIN ? RP : TW + 2 * DIL;
     constexpr int SR = 32 / TW;                 // tile rows per 32-pixel sub-tile (2 or 1)
     constexpr int WM = TH / (SR * MI), WN = 4 / WM;
     static_assert(WM * WN == 4 && BN == WN * 64, "4 waves, 64 channels per wave");
-    constexpr int HP = (TH + 2 * DIL) * HW2;    // halo pixels
+    constexpr int HP = LIN ? TM + 2 * RP + 2 : (TH + 2 * DIL) * HW2;    // halo pixels
     constexpr int PITCH = 80;                   // patch row: 4 x 16 B of channels + 16 B pad
     constexpr int DSLOTS = (HP * 5 + 63) / 64 * 64;   // direct staging: 16-byte LDS slots incl. the pad slots, whole waves
     constexpr int XSLOTS = (HP * 4 + 63) / 64 * 64;   // transform staging: (pixel, channel group) items, whole waves
@@ -103,7 +118,9 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
     char* Raw = Bs + BBYTES;                    // NRAW x raw slot
     char* Cst = Raw + NRAW * RAWB;              // 2 x {32 scales, 32 shifts} f32 of a chunk (kept out of vmcnt's way)
 
-    const int mt_total = a.N * tiles_y * tiles_x;
+    const int IS = LIN ? (a.Ho + 1) * RP : 1;                                   // LIN: positions per image
+    const int lin_full = LIN ? a.N / tiles_y : 0;                               //      full passes
+    const int mt_total = LIN ? lin_full * tiles_x + ((a.N - lin_full * tiles_y) * IS + TM - 1) / TM : a.N * tiles_y * tiles_x;
     const int ntiles = mt_total * nt_total;
     int bid = blockIdx.x;
     {
@@ -112,9 +129,12 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
     }
     const int mtile = bid / nt_total, ntile = bid % nt_total;
     const int n0 = ntile * BN;
-    const int img = mtile / (tiles_y * tiles_x);
-    const int trem = mtile - img * tiles_y * tiles_x;
-    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const int lpass = LIN ? min(mtile / tiles_x, lin_full) : 0;
+    const int img = LIN ? lpass * tiles_y : mtile / (tiles_y * tiles_x);        // LIN: the first image of the tile's pass,
+    const int nimg = LIN ? min(tiles_y, a.N - img) : 1;                         //      the images of that pass,
+    const int P0 = LIN ? (mtile - lpass * tiles_x) * TM : 0;                    //      the tile's first position in it
+    const int trem = LIN ? 0 : mtile - img * tiles_y * tiles_x;
+    const int y0 = LIN ? 0 : (trem / tiles_x) * TH, x0 = LIN ? 0 : (trem % tiles_x) * TW;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS-DMA bases and role tests stay scalar
@@ -160,6 +180,15 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
             const int q = tq + 256 * i;
             const int hp = XF ? (q >> 2) : q / 5;
             const int g = XF ? (tq & 3) : q - 5 * hp;
+            if constexpr (LIN) {     // patch position hp = flat position P0 - RP - 1 + hp of the pass: input pixel (r, c) of image il
+                const int F = P0 - RP - 1 + hp, Fc = F < 0 ? 0 : F;
+                const int il = Fc / IS, rem = Fc - il * IS, r = rem / RP, c = rem - r * RP;
+                const int ly = r - S.off_y, lx = c - S.off_x;
+                const bool ok = hp < HP && g < 4 && F >= 0 && il < nimg && r < a.Ho && c < LINW && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
+                aoff[i] = ok ? 2 * ((int)((long)il * S.sN + (long)ly * S.sH + (long)lx * S.sW) + 8 * g) : OOB;
+                aokm |= (ok ? 1u : 0u) << i;
+                continue;
+            }
             const int hy = hp / HW2, hx = hp - hy * HW2;
             const int ly = by + hy, lx = bx + hx;
             const bool ok = hp < HP && g < 4 && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
@@ -311,7 +340,8 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
             for (int g = 0; g < 4; ++g) acc16[i][h][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // this lane's fragment bases: patch pixel of sub-tile 0 at tap (0,0), K half lh; weight column wn*64 + l31
-    const int afrag0 = M16 ? ((wm * SR * MI) * HW2 + (lane & 15)) * PITCH + (lane >> 4) * 16      // pixel l & 15 of a half, k group l >> 4
+    const int afrag0 = LIN ? (M16 ? (wm * MI * 32 + (lane & 15)) * PITCH + (lane >> 4) * 16 : (wm * MI * 32 + l31) * PITCH + lh * 16)
+                     : M16 ? ((wm * SR * MI) * HW2 + (lane & 15)) * PITCH + (lane >> 4) * 16      // pixel l & 15 of a half, k group l >> 4
                            : ((wm * SR * MI + (TW == 16 ? (l31 >> 4) : 0)) * HW2 + (l31 & (TW - 1))) * PITCH + lh * 16;
     const int bfrag0 = (lh * BN + wn * 64 + l31) * 16;
     const int nstage = nchunk * NSTG;
@@ -446,7 +476,9 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
             }
             // middle: every fragment is base + immediate
             auto afrag = [&](int tap, int ks, int i) __attribute__((always_inline)) {
-                if constexpr (M16)       // ks = the 16-pixel half: the right half of a 32-pixel row, or the second row of a 2 x 16 sub-tile
+                if constexpr (LIN)       // position 32 i (+ 16 ks) of the wave's run, shifted by the tap
+                    return *(const bf16x8*)(Afrag + (32 * i + (M16 ? 16 * ks : 0) + (tap / 3) * RP + tap % 3) * PITCH + (M16 ? 0 : ks * 32));
+                else if constexpr (M16)       // ks = the 16-pixel half: the right half of a 32-pixel row, or the second row of a 2 x 16 sub-tile
                     return *(const bf16x8*)(Afrag + ((DIL * (tap / 3) + SR * i + (TW == 16 ? ks : 0)) * HW2 + DIL * (tap % 3) + (TW == 16 ? 0 : 16 * ks)) * PITCH);
                 else
                 return *(const bf16x8*)(Afrag + ((DIL * (tap / 3) + SR * i) * HW2 + DIL * (tap % 3)) * PITCH + ks * 32);
@@ -690,7 +722,13 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
     };
     constexpr int EPITCH = 144;
     char* ep = smem + wave * (32 * EPITCH);         // the A patches are dead after the last barrier
-    const bool full = y0 + TH <= a.Ho && x0 + TW <= a.Wo;     // interior tile: no per-pixel masks
+    const bool full = !LIN && y0 + TH <= a.Ho && x0 + TW <= a.Wo;     // interior tile: no per-pixel masks
+    // LIN: (image of the pass, row, column) of the position the lane stores next -- P0 + 128 wm + (lane >> 3), then 8 further per
+    // store step (RP > 8: one carry) -- and, for the statistics taken from the accumulators, the sub-tile's valid positions as a mask
+    int e_il = 0, e_r = 0, e_c = 0;
+    unsigned vmask = 0xffffffffu;
+    auto lin_pos = [&](int P, int& il, int& r, int& c) { il = P / IS; const int rem = P - il * IS; r = rem / RP; c = rem - r * RP; };
+    if constexpr (LIN) lin_pos(P0 + wm * MI * 32 + (lane >> 3), e_il, e_r, e_c);
     // sub-tile i -> LDS scratch (bf16) + statistics; MASK = false on interior tiles (a wave-uniform branch, not selects)
     auto park = [&](int i, auto mask_c, auto stat_c) {
         constexpr bool MASK = decltype(mask_c)::value, STAT = decltype(stat_c)::value;
@@ -717,7 +755,10 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
                 *(elt_t*)(ep + (row + 1) * EPITCH + (j * 32 + l31) * 2) = h[1];
                 if (!STAT) continue;
                 f32x2 f = __builtin_convertvector(h, f32x2);               // statistics see the stored values
-                if (MASK) {
+                if (MASK && LIN) {
+                    if (!((vmask >> row) & 1u)) f[0] = 0.f;
+                    if (!((vmask >> (row + 1)) & 1u)) f[1] = 0.f;
+                } else if (MASK) {
                     const int oy0 = oyb + (TW == 16 ? (row >> 4) : 0), ox0 = x0 + (row & (TW - 1));
                     const int oy1 = oyb + (TW == 16 ? ((row + 1) >> 4) : 0), ox1 = x0 + ((row + 1) & (TW - 1));
                     if (!(oy0 < a.Ho && ox0 < a.Wo)) f[0] = 0.f;
@@ -732,6 +773,13 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int oyb = y0 + wm * SR * MI + SR * i;
+        if constexpr (LIN && !M16) {
+            if (a.stat) {
+                int il, r, c;
+                lin_pos(P0 + wm * MI * 32 + 32 * i + l31, il, r, c);
+                vmask = (unsigned)__builtin_amdgcn_ballot_w64(il < nimg && r < a.Ho && c < LINW);
+            }
+        }
         if constexpr (M16) park(i, std::false_type{}, std::false_type{});
         else {
         if (!a.stat) park(i, std::false_type{}, std::false_type{});        // input-gradient: no statistics
@@ -760,20 +808,26 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
         for (int t = 0; t < 4; ++t) {
             const int idx = lane + 64 * t, row = idx >> 3, ch = idx & 7;
             const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
-            const int oy = oyb + (TW == 16 ? (row >> 4) : 0), ox = x0 + (row & (TW - 1));
+            const int oy = LIN ? e_r : oyb + (TW == 16 ? (row >> 4) : 0), ox = LIN ? e_c : x0 + (row & (TW - 1));
+            const int oimg = LIN ? img + e_il : img;
+            const bool inb = LIN ? (e_il < nimg && e_r < a.Ho && e_c < LINW) : (oy < a.Ho && ox < a.Wo);
+            if constexpr (LIN) {     // the next step's position: 8 further
+                e_c += 8;
+                if (e_c >= RP) { e_c -= RP; if (++e_r > a.Ho) { e_r = 0; ++e_il; } }
+            }
             const int col = n0 + wn * 64 + ch * 8;
             if constexpr (BNS) {     // (single destination: the launcher admits nothing else)
-                const bool ok = oy < a.Ho && ox < a.Wo && col < a.C0;
-                const long eo = ok ? (((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col : 0;
+                const bool ok = inb && col < a.C0;
+                const long eo = ok ? (((long)oimg * a.Ho + oy) * a.Wo + ox) * a.C0 + col : 0;
                 bns_piece(v8, *(const bf16x8*)((const elt_t*)a.bny + eo), ok);
-            } else if constexpr (M16) { if (a.stat) stat_piece(v8, oy < a.Ho && ox < a.Wo); }
-            if (oy < a.Ho && ox < a.Wo) {
+            } else if constexpr (M16) { if (a.stat) stat_piece(v8, inb); }
+            if (inb) {
                 if (col < a.C0) {
-                    *(bf16x8*)((elt_t*)a.out0 + (((long)img * a.Ho + oy) * a.Wo + ox) * a.C0 + col) = v8;
+                    *(bf16x8*)((elt_t*)a.out0 + (((long)oimg * a.Ho + oy) * a.Wo + ox) * a.C0 + col) = v8;
                 } else {
                     const int y1 = oy - a.o1y, x1 = ox - a.o1x;
                     if (y1 >= 0 && y1 < a.H1 && x1 >= 0 && x1 < a.W1)
-                        *(bf16x8*)((elt_t*)a.out1 + (((long)img * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0)) = v8;
+                        *(bf16x8*)((elt_t*)a.out1 + (((long)oimg * a.H1 + y1) * a.W1 + x1) * C1 + (col - a.C0)) = v8;
                 }
             }
         }
@@ -818,22 +872,39 @@ __global__ __launch_bounds__(256, (TH * TW * BN >= 512 * 64 && BN == 64 ? 1 : 2)
 }
 
 thread_local int g_last_variant = 0;    // (per calling thread) TH<<24 | TW<<16 | BN<<8 | MI<<4 | NT<<2 | POOL<<1 | XF of the last launch (tests: ustrun_debug_last_conv_variant)
+                                        // (linear tiles: bit 30 | W << 16 | ...)
 
-template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false, bool M16 = false, bool BNS = false>
+// linear tiles (LINW): passes and tiles of a launch.  A pass = the images that share BatchNorm constants (the sources' gN, or the
+// gN of the BatchNorm-backward sums the launch forms; the whole batch without either); tiles never cross one.
+struct LinPlan { int gN, tpp, mtiles, last_rows; };
+static LinPlan lin_plan(const IgemmArgs& a) {
+    int g = 0;
+    for (int i = 0; i < a.nsrc; ++i)
+        if (a.src[i].gN > 0) g = a.src[i].gN;
+    if (!g && a.bn_gN > 0) g = a.bn_gN;
+    if (g <= 0 || g > a.N) g = a.N;
+    const long IS = (long)(a.Ho + 1) * (a.Wo + 1);
+    const int tpp = (int)cdiv(g * IS, 256L), full = a.N / g, tailN = a.N - full * g, tail = (int)cdiv(tailN * IS, 256L);
+    return {g, tpp, full * tpp + tail, tailN ? tail : (full > 1 ? tpp : -1)};
+}
+
+template <int TH, int TW, int BN, int BK, int MI, bool POOL, int NT, bool XF, int DIL = 1, bool BREG = false, bool M16 = false, bool BNS = false,
+          int LINW = 0>
 int launch_xf(const IgemmArgs& a, hipStream_t st) {
-    g_last_variant = TH << 24 | TW << 16 | BN << 8 | (M16 ? 0x80 : 0) | MI << 4 | NT << 2 | (POOL ? 2 : 0) | (XF ? 1 : 0);
-    const int tx = cdiv(a.Wb, TW), ty = cdiv(a.Hb, TH), nt = a.Cout / BN;
-    constexpr int DSLOTS = ((TH + 2 * DIL) * (TW + 2 * DIL) * 5 + 63) / 64 * 64;
+    g_last_variant = (LINW ? (1 << 30 | LINW << 16) : (TH << 24 | TW << 16)) | BN << 8 | (M16 ? 0x80 : 0) | MI << 4 | NT << 2 | (POOL ? 2 : 0) | (XF ? 1 : 0);
+    const LinPlan lp = LINW ? lin_plan(a) : LinPlan{0, 0, 0, -1};
+    const int tx = LINW ? lp.tpp : cdiv(a.Wb, TW), ty = LINW ? lp.gN : cdiv(a.Hb, TH), nt = a.Cout / BN;
+    constexpr int DSLOTS = ((LINW ? TH * TW + 2 * (LINW + 1) + 2 : (TH + 2 * DIL) * (TW + 2 * DIL)) * 5 + 63) / 64 * 64;
     constexpr int AIT = (DSLOTS + 255) / 256, NSTG = (9 + NT - 1) / NT, BATCH = (AIT + NSTG - 2) / (NSTG - 1);
     const size_t rawb = XF ? (size_t)BATCH * (POOL ? 4 : 1) * 4096 : 0;
     const size_t fixed = 2 * (size_t)(BREG ? AIT * 256 : DSLOTS) * 16 + (BREG ? 0 : 2 * NT * (size_t)(BK / 8) * BN * 16) + 512;
     const size_t lds = fixed + (XF && fixed + 2 * rawb <= 81920 ? 2 : 1) * rawb;
-    dim3 grid(a.N * ty * tx * nt), block(256);
+    dim3 grid((LINW ? lp.mtiles : a.N * ty * tx) * nt), block(256);
     // above the 64 KB default (the dilation-4 patch pair: 93 KB; the 16 x 16 x 128 transforming tile: 66 KB): raise the limit
     // whatever the dilation is (the un-dilated 16 x 16 tile used to launch without the attribute)
     if (lds > 64 * 1024)
-        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG, M16, BNS>, (int)lds, "conv3x3_halo_bf16"));
-    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG, M16, BNS>), grid, block, lds, st, a, tx, ty, nt);
+        USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG, M16, BNS, LINW>, (int)lds, "conv3x3_halo_bf16"));
+    hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<TH, TW, BN, BK, MI, POOL, NT, XF, DIL, BREG, M16, BNS, LINW>), grid, block, lds, st, a, tx, ty, nt);
     USTRUN_LAUNCH_CHECK("conv3x3_halo_bf16");
     return 0;
 }
@@ -899,12 +970,40 @@ bool halo_supported(const IgemmArgs& a) {
 }
 
 int halo_tile128(const IgemmArgs& a);
+static double halo_rect_score(const IgemmArgs& a);
+
+// Linear tiles (LINW builds: 18, 24, 36, 72-pixel rows): the row length if this launch runs on them, else 0.  They serve
+// 128-column outputs of un-pooled, un-dilated sources when (a) the rectangular tiles would waste more of their MFMAs on padding --
+// useful fraction x the tiles' measured relative rates, as in halo_tile128 -- and (b) the launch still has a block per CU.
+// (ustrun_debug_flags bit 26: off, for A/B runs)
+int halo_linear_w(const IgemmArgs& a) {
+    if ((g_debug_flags & (1 << 26)) || (g_debug_flags & (8 | 2097152 | 32768)) || ((g_debug_flags >> 10) & 3)) return 0;
+    if (!halo_supported(a) || halo_dilation(a) != 1 || a.Cout % 128 || a.Hb != a.Ho || a.Wb != a.Wo) return 0;
+    const int w = a.Wo;
+    if (!(w == 18 || w == 24 || w == 36 || w == 72)) return 0;
+    int g = 0;
+    for (int i = 0; i < a.nsrc; ++i) {
+        if (a.src[i].pool) return 0;
+        if (a.src[i].gN > 0) { if (g && g != a.src[i].gN) return 0; g = a.src[i].gN; }
+    }
+    if (a.bny && a.bn_gN > 0 && g && g != a.bn_gN) return 0;
+    const LinPlan lp = lin_plan(a);
+    for (int i = 0; i < a.nsrc; ++i)
+        if ((long)lp.gN * a.src[i].sN * 2 >= (1L << 31) - 4096) return 0;          // 32-bit byte offsets inside a pass
+    if ((long)lp.mtiles * (a.Cout / 128) < 256) return 0;
+    const double lin = (double)a.N * a.Ho * a.Wo / (lp.mtiles * 256.0);
+    return lin > 1.05 * halo_rect_score(a) ? w : 0;
+}
+// statistics rows of the last pass of a linear-tile launch (-1: not one, or a single pass)
+int halo_linear_last_pass_rows(const IgemmArgs& a) { return halo_linear_w(a) ? lin_plan(a).last_rows : -1; }
+
 // can this input-gradient launch also form the BatchNorm-backward sums of the layer whose da it writes?  (one plain source, one
 // destination, the two 256-pixel x 128-channel tiles on the 16x16x32 build)
 bool halo_bnsum_supported(const IgemmArgs& a) {
     if (!halo_supported(a) || halo_dilation(a) != 1 || a.nsrc != 1 || a.out1 || a.C0 != a.Cout || a.Cout % 128) return false;
     if (a.src[0].scale || a.src[0].relu || a.src[0].pool) return false;
     if ((g_debug_flags & (8 | 2097152))) return false;
+    if (halo_linear_w(a)) return true;
     const int t = halo_tile128(a);
     return t == 0 || t == 1;
 }
@@ -916,6 +1015,17 @@ bool halo_tall_tile(const IgemmArgs& a) {
 
 // Tile of the 128-column, un-pooled, un-dilated case: 0 = 8 x 32 px (MI 4), 1 = 16 x 16 px (MI 4), 2 = 8 x 16 px (MI 2, 128 columns),
 // 3 = 8 x 16 px, 64 columns (less than one block per CU).  ustrun_debug_flags bits 10-11 force 0..2 (+1) for A/B runs.
+// useful MFMA fraction x relative rate of the rectangular tile conv3x3_halo_launch_bf16 would pick (128-column, un-pooled case)
+static double halo_rect_score(const IgemmArgs& a) {
+    const double h8 = cdiv(a.Hb, 8) * 8.0, h16 = cdiv(a.Hb, 16) * 16.0, w16 = cdiv(a.Wb, 16) * 16.0, w32 = cdiv(a.Wb, 32) * 32.0;
+    const double hw = (double)a.Hb * a.Wb;
+    switch (halo_tile128(a)) {
+        case 0: return hw / (h8 * w32);
+        case 1: return 0.93 * hw / (h16 * w16);
+        default: return 0.80 * hw / (h8 * w16);
+    }
+}
+
 int halo_tile128(const IgemmArgs& a) {
     const int force = (g_debug_flags >> 10) & 3;
     const bool wide = a.Wb >= 32;
@@ -935,6 +1045,7 @@ int halo_tile128(const IgemmArgs& a) {
 
 // BatchNorm-statistics rows written by the configuration conv3x3_halo_launch_bf16 picks
 int halo_stat_rows_used(const IgemmArgs& a) {
+    if (halo_linear_w(a)) return lin_plan(a).mtiles;          // one row per 256-position tile
     if (halo_dilation(a) == 4 && a.Cout % 128 == 0) return a.N * cdiv(a.Hb, 16) * 2 * cdiv(a.Wb, 16);       // 16 x 16 tiles, two rows each
     if (halo_dilation(a) > 1) return a.N * cdiv(a.Hb, 8) * cdiv(a.Wb, 16);
     bool pool = false;
@@ -971,9 +1082,28 @@ static int launch_dilated(const IgemmArgs& a, hipStream_t st) {
     return xf ? launch_xf<8, 16, 64, 32, 1, false, 2, true, DIL>(a, st) : launch_xf<8, 16, 64, 32, 1, false, 2, false, DIL>(a, st);
 }
 
+template <int W>
+static int launch_linear(const IgemmArgs& a, hipStream_t st) {
+    bool xf = false;
+    for (int i = 0; i < a.nsrc; ++i) xf |= a.src[i].scale != nullptr || a.src[i].relu != 0;
+    if (a.bny) {
+        USTRUN_CHECK(!xf && a.stat && a.bnsc && a.bnsh, "conv3x3_halo: BatchNorm-backward sums need a plain source");
+        return launch_xf<8, 32, 128, 32, 4, false, 1, false, 1, true, true, true, W>(a, st);
+    }
+    return xf ? launch_xf<8, 32, 128, 32, 4, false, 1, true, 1, true, false, false, W>(a, st)
+              : launch_xf<8, 32, 128, 32, 4, false, 1, false, 1, true, true, false, W>(a, st);
+}
+
 int conv3x3_halo_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     if (halo_dilation(a) == 2) return launch_dilated<2>(a, st);
     if (halo_dilation(a) == 4) return launch_dilated<4>(a, st);
+    switch (halo_linear_w(a)) {
+        case 18: return launch_linear<18>(a, st);
+        case 24: return launch_linear<24>(a, st);
+        case 36: return launch_linear<36>(a, st);
+        case 72: return launch_linear<72>(a, st);
+        default: break;
+    }
     bool pool = false;
     for (int i = 0; i < a.nsrc; ++i) pool |= a.src[i].pool != 0;
     const bool wide = a.Wb >= 32;                 // 32-pixel rows: conflict-free A fragment reads

@@ -238,7 +238,8 @@ extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const
         if (stat_rows) *stat_rows = total;
         return 0;
     }
-    g_last_pass_rows = -1;          // one launch: rows per image are uniform
+    // one launch: rows per image are uniform -- or, on the halo kernel's linear tiles, per pass with the last pass's count here
+    g_last_pass_rows = (dtype == USTRUN_D16 && !first && G > 1) ? halo_linear_last_pass_rows(a) : -1;
     if (stat) {
         const int rows = ustrun_conv_mtiles(N, H, W, Cout);
         const int used = first ? conv_first_stat_rows(N, H, W, dtype) : igemm_stat_rows_used(a, dtype);
