@@ -94,7 +94,8 @@ CASES = [
     # 128-channel tall tile with the two-destination epilogue for its input gradient
     ("cat_128_to_64", 8, (64, 64), 64, 128, 128, 2, (8, 32, 64, 2, 2), (8, 32, 128, 4, 1)),
     # 256 px x 128 ch with 16-pixel rows (extent < 32 px), ragged right / bottom edges
-    ("tall_narrow_512", 16, (512,), 512, 56, 24, 1, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1)),
+    # (24-pixel rows run on the linear tiles since round 5: ustrun_debug_flags bit 26 keeps this case on the tile it was written for)
+    ("tall_narrow_512", 16, (512,), 512, 56, 24, 1, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1), 1 << 26),
     # the bottleneck of the student's four batched passes as the step runs it: N = 64, 16 x 16, 1024 -> 1024
     ("bottleneck_n64", 64, (1024,), 1024, 16, 16, 4, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1)),
     # 64 -> 64 full-resolution layers (inc.conv2, up4.conv2): wide and narrow 64-channel tiles
@@ -381,13 +382,18 @@ def test_convT_bf16_batched_passes_exact(n, G, ci, co, h, w):
 # the kernel that ran is asserted, the slabs' consumer (dw, db) sits between sentinel zones.
 CONVT_WGRAD_CASES = [
     # (id, N, Cin, Cout, H, W, passes, transform, flags, expected variant)
-    ("t256_w16", 4, 256, 128, 16, 16, 2, True, 0, 0x54320100),
-    ("t256_w18_tail", 3, 512, 256, 18, 18, 1, True, 0, 0x54320100),
-    ("t256_w24_plain", 2, 256, 64, 24, 24, 1, False, 0, 0x54320100),
-    ("t256_w48", 2, 1024, 512, 12, 48, 1, True, 0, 0x54320100),
-    ("t128_w36", 4, 128, 64, 36, 36, 2, True, 0, 0x54320080),
-    ("t128_w144_tail", 1, 128, 64, 9, 144, 1, True, 0, 0x54320080),
-    ("t128_w256", 2, 128, 64, 64, 256, 2, True, 0, 0x54320080),
+    # 'T3' (0x5433....): the round-5 kernel with the next stage's activation under the MFMAs (the default); 'T2': the same kernel with
+    # the activation behind them (ustrun_debug_flags bit 24); 'T1': the round-1 kernel (bit 27)
+    ("t256_w16", 4, 256, 128, 16, 16, 2, True, 0, 0x54330100),
+    ("t256_w18_tail", 3, 512, 256, 18, 18, 1, True, 0, 0x54330100),
+    ("t256_w24_plain", 2, 256, 64, 24, 24, 1, False, 0, 0x54330100),
+    ("t256_w48", 2, 1024, 512, 12, 48, 1, True, 0, 0x54330100),
+    ("t256_short", 1, 256, 64, 4, 16, 1, True, 0, 0x54330100),       # two stages: fewer than the buffers in flight
+    ("t128_w36", 4, 128, 64, 36, 36, 2, True, 0, 0x54330080),
+    ("t128_w144_tail", 1, 128, 64, 9, 144, 1, True, 0, 0x54330080),
+    ("t128_w256", 2, 128, 64, 64, 256, 2, True, 0, 0x54330080),
+    ("t2_t256_w18_tail", 3, 512, 256, 18, 18, 1, True, 1 << 24, 0x54320100),
+    ("t2_t128_w36", 4, 128, 64, 36, 36, 2, True, 1 << 24, 0x54320080),
     ("old_forced", 4, 256, 128, 16, 16, 2, True, 1 << 27, 0x54310000),
 ]
 
@@ -508,7 +514,7 @@ def test_wgrad_all_taps_builds_exact(case):
 
 @pytest.mark.parametrize("name,n,G,cin,cout,h,w,tile", [
     ("wide_128", 16, 2, 128, 128, 128, 128, (8, 32, 128, 4, 1, "m16")),       # 8 x 32 tiles, two passes
-    ("narrow_512_ragged", 16, 1, 512, 512, 56, 24, (16, 16, 128, 4, 1, "m16")),   # 16 x 16 tiles, ragged right / bottom edges
+    ("narrow_512_ragged", 16, 1, 512, 512, 56, 40, (16, 16, 128, 4, 1, "m16")),   # 16 x 16 tiles, ragged right / bottom edges
     ("bottleneck", 64, 4, 1024, 512, 16, 16, (16, 16, 128, 4, 1, "m16")),     # N = 64, four passes, 512 -> 1024 channels back
     ("too_small", 2, 1, 128, 128, 32, 32, None),
     # linear tiles (round 5): 18 x 18 at the bottleneck's width, four passes; 36 x 36 with a partial last tile per pass
