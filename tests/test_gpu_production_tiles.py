@@ -162,6 +162,10 @@ CASES += [
     ("lin_72_256", 8, (256,), 256, 72, 72, 2, LIN(72), LIN(72)),
     ("lin_cat_36", 24, (128, 128), 256, 36, 36, 2, LIN(36), LIN(36)),
     ("lin_18x20_512", 48, (512,), 512, 20, 18, 1, LIN(18), LIN(18)),
+    # a plain first source that still carries the pass structure (the pooled operand of a Down block in a batched call): the
+    # statistics rows must split by pass although no constants are read
+    ("plain_lin_24_512", 30, (512,), 1024, 24, 24, 3, LIN(24), LIN(24)),
+    ("plain_lin_cat_36", 24, (128, 128), 256, 36, 36, 2, LIN(36), LIN(36)),
 ]
 
 WS_CODE = {"ws4": 0x57530000, "ws8": 0x57530100, "ws": 0x57530200}      # four waves / eight waves / consumer + producer waves (default)
@@ -198,8 +202,14 @@ def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):
     affg = aff.cuda()
     y0g = nhwc16(y0)
     keep += [affg, y0g]
-    srcs.append(l.nhwc_src(y0g.data_ptr(), cs[0], h, w, affg.data_ptr(), affg.data_ptr() + 4 * cs[0], relu=1,
-                           gN=gn if G > 1 else 0, gstride=4 * cs[0]))
+    plain = name.startswith("plain_")      # source 0 as a finished activation (a pooled / materialised operand): no constants, but passes
+    if plain:
+        a0g = nhwc16(a0)
+        keep.append(a0g)
+        srcs.append(l.nhwc_src(a0g.data_ptr(), cs[0], h, w, gN=gn if G > 1 else 0, gstride=4 * cs[0]))
+    else:
+        srcs.append(l.nhwc_src(y0g.data_ptr(), cs[0], h, w, affg.data_ptr(), affg.data_ptr() + 4 * cs[0], relu=1,
+                               gN=gn if G > 1 else 0, gstride=4 * cs[0]))
     if len(cs) == 2:
         uh, uw, oy, ox = h - 2, w - 4, 1, 2
         u = ri(-3, 3, n, cs[1], uh, uw)
@@ -227,7 +237,7 @@ def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):
     l.check(lib.ustrun_conv3x3_fwd_rows(sarr, len(srcs), wf.data_ptr(), n, h, w, co, out.data_ptr(), stat.data_ptr(),
                                         C.byref(rows), E.code, None), "fwd")
     got = lib.ustrun_debug_last_conv_variant()
-    assert got == (WS_CODE[vf] | 1 if vf in WS_CODE else variant(*vf, False, True)), f"forward ran {vstr(got)}"
+    assert got == (WS_CODE[vf] | 1 if vf in WS_CODE else variant(*vf, False, not plain)), f"forward ran {vstr(got)}"
     yc = from_nhwc(out.float())
     assert rel(yc, r16(ref.detach())) < 1e-6
     # statistics rows: per pass, sums of the STORED (bf16-rounded) outputs
@@ -382,18 +392,13 @@ def test_convT_bf16_batched_passes_exact(n, G, ci, co, h, w):
 # the kernel that ran is asserted, the slabs' consumer (dw, db) sits between sentinel zones.
 CONVT_WGRAD_CASES = [
     # (id, N, Cin, Cout, H, W, passes, transform, flags, expected variant)
-    # 'T3' (0x5433....): the round-5 kernel with the next stage's activation under the MFMAs (the default); 'T2': the same kernel with
-    # the activation behind them (ustrun_debug_flags bit 24); 'T1': the round-1 kernel (bit 27)
-    ("t256_w16", 4, 256, 128, 16, 16, 2, True, 0, 0x54330100),
-    ("t256_w18_tail", 3, 512, 256, 18, 18, 1, True, 0, 0x54330100),
-    ("t256_w24_plain", 2, 256, 64, 24, 24, 1, False, 0, 0x54330100),
-    ("t256_w48", 2, 1024, 512, 12, 48, 1, True, 0, 0x54330100),
-    ("t256_short", 1, 256, 64, 4, 16, 1, True, 0, 0x54330100),       # two stages: fewer than the buffers in flight
-    ("t128_w36", 4, 128, 64, 36, 36, 2, True, 0, 0x54330080),
-    ("t128_w144_tail", 1, 128, 64, 9, 144, 1, True, 0, 0x54330080),
-    ("t128_w256", 2, 128, 64, 64, 256, 2, True, 0, 0x54330080),
-    ("t2_t256_w18_tail", 3, 512, 256, 18, 18, 1, True, 1 << 24, 0x54320100),
-    ("t2_t128_w36", 4, 128, 64, 36, 36, 2, True, 1 << 24, 0x54320080),
+    ("t256_w16", 4, 256, 128, 16, 16, 2, True, 0, 0x54320100),
+    ("t256_w18_tail", 3, 512, 256, 18, 18, 1, True, 0, 0x54320100),
+    ("t256_w24_plain", 2, 256, 64, 24, 24, 1, False, 0, 0x54320100),
+    ("t256_w48", 2, 1024, 512, 12, 48, 1, True, 0, 0x54320100),
+    ("t128_w36", 4, 128, 64, 36, 36, 2, True, 0, 0x54320080),
+    ("t128_w144_tail", 1, 128, 64, 9, 144, 1, True, 0, 0x54320080),
+    ("t128_w256", 2, 128, 64, 64, 256, 2, True, 0, 0x54320080),
     ("old_forced", 4, 256, 128, 16, 16, 2, True, 1 << 27, 0x54310000),
 ]
 

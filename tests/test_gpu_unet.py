@@ -367,6 +367,62 @@ def test_leading_passes_without_gradient(dtype, base, n, hw, passes, lead, tail)
     print("leading passes: worst relative gradient difference against the zero-fed full backward %.2e" % worst)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_linear_tiles_in_the_network(dtype):
+    """configs[3]'s shape (M&Ms 288^2, 4 classes, 8 + 8: train_mnms.py:397-399) as the step calls the student: one leading pass
+    without gradient, four gradient passes, the one-image tail -- 41 images in one call.  Its 72 / 36 / 18-pixel levels run on the
+    halo kernel's linear tiles (round 5: tiles of 256 consecutive positions that cross rows and images but never passes); the same
+    call with ustrun_debug_flags bit 26 runs them on rectangular tiles.  Every convolution output is the same either way (the
+    operator tests compare them bitwise); what differs is how the BatchNorm statistics rows partition the pixels, i.e. the order of
+    f32 partial sums: running statistics to 1e-5, logits to 16-bit rounding, gradients alike."""
+    import copy
+    from networks.unet_model import UNet
+    from ustrun import _lib
+    lib = _lib.lib()
+    torch.manual_seed(5)
+    m1 = UNet(1, 4, dtype=dtype).cuda().train()
+    m2 = copy.deepcopy(m1)
+    g = torch.Generator().manual_seed(9)
+    B = 8
+    x = torch.randn(5 * B + 1, 1, 288, 288, generator=g).cuda()
+    dl = torch.randn(5 * B, 4, 288, 288, generator=g).cuda()       # (the leading pass's part is skipped by the backward)
+    m3 = copy.deepcopy(m1)
+    outs = []
+    # (the third run is the yardstick: rectangular tiles again, but the 16 x 16 one forced where the rule picks another -- bits 10-11 --,
+    # i.e. one more partition of the same pixels into statistics rows)
+    for m, flags in ((m1, 0), (m2, 1 << 26), (m3, 1 << 26 | 2 << 10)):
+        old = lib.ustrun_debug_flags(flags)
+        try:
+            lg = m.forward_batched(x, 5, tail=1, lead=1)
+            lg.backward(dl)
+        finally:
+            lib.ustrun_debug_flags(old)
+        outs.append(lg.detach().float())
+    rel = lambda u, v: float((u - v).norm() / (v.norm() + 1e-30))
+    e_lin, e_ref = rel(outs[0], outs[1]), rel(outs[2], outs[1])
+    print("linear tiles in the network: logits rel-L2 %.2e (between two rectangular tilings: %.2e)" % (e_lin, e_ref))
+    assert torch.isfinite(outs[0]).all() and e_lin < 2e-2 and e_lin < 3 * e_ref + 1e-4
+    worst = 0.0
+    for (k, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        if k.endswith("num_batches_tracked"):
+            assert int(b1) == int(b2), k
+        else:
+            e = rel(b1, b2)
+            worst = max(worst, e)
+            assert e < 2e-3, (k, e)
+    print("linear tiles in the network: running statistics worst rel %.2e" % worst)
+    g_lin, g_ref = [], []
+    for (k, p1), (_, p2), (_, p3) in zip(m1.named_parameters(), m2.named_parameters(), m3.named_parameters()):
+        assert torch.isfinite(p1.grad).all(), k
+        g_lin.append(rel(p1.grad, p2.grad))
+        g_ref.append(rel(p3.grad, p2.grad))
+    g_lin.sort(); g_ref.sort()
+    print("linear tiles in the network: gradients rel-L2 median %.2e, worst %.2e (between two rectangular tilings: %.2e, %.2e)"
+          % (g_lin[len(g_lin) // 2], g_lin[-1], g_ref[len(g_ref) // 2], g_ref[-1]))
+    # 16-bit gradients of a random-init net amplify a flipped rounding (test_bf16_compute_tracks_f32): the bar is the yardstick's level
+    assert g_lin[len(g_lin) // 2] < 2 * g_ref[len(g_ref) // 2] + 1e-3 and g_lin[-1] < 2 * g_ref[-1] + 1e-3
+
+
 @pytest.mark.parametrize("dtype,base,n,hw,passes,tail,exact", [("bf16", 64, 4, 64, 4, 1, False), ("f16", 32, 3, 128, 2, 2, True),
                                                                ("f32", 16, 2, 40, 3, 1, True), ("bf16", 64, 2, 256, 4, 1, False),
                                                                ("bf16", 16, 3, 72, 1, 1, True), ("bf16", 64, 16, 128, 4, 1, False)])

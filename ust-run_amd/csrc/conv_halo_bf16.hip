@@ -878,8 +878,8 @@ thread_local int g_last_variant = 0;    // (per calling thread) TH<<24 | TW<<16 
 // gN of the BatchNorm-backward sums the launch forms; the whole batch without either); tiles never cross one.
 struct LinPlan { int gN, tpp, mtiles, last_rows; };
 static LinPlan lin_plan(const IgemmArgs& a) {
-    int g = 0;
-    for (int i = 0; i < a.nsrc; ++i)
+    int g = a.pass_gN > 0 ? a.pass_gN : 0;
+    for (int i = 0; i < a.nsrc && !g; ++i)
         if (a.src[i].gN > 0) g = a.src[i].gN;
     if (!g && a.bn_gN > 0) g = a.bn_gN;
     if (g <= 0 || g > a.N) g = a.N;
@@ -981,7 +981,7 @@ int halo_linear_w(const IgemmArgs& a) {
     if (!halo_supported(a) || halo_dilation(a) != 1 || a.Cout % 128 || a.Hb != a.Ho || a.Wb != a.Wo) return 0;
     const int w = a.Wo;
     if (!(w == 18 || w == 24 || w == 36 || w == 72)) return 0;
-    int g = 0;
+    int g = a.pass_gN > 0 ? a.pass_gN : 0;
     for (int i = 0; i < a.nsrc; ++i) {
         if (a.src[i].pool) return 0;
         if (a.src[i].gN > 0) { if (g && g != a.src[i].gN) return 0; g = a.src[i].gN; }

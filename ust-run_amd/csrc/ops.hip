@@ -222,6 +222,7 @@ extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const
     int gN = 0;
     const int G = src_groups(srcs, nsrc, N, &gN);
     USTRUN_CHECK(G >= 1, "conv3x3_fwd: inconsistent pass groups");
+    a.pass_gN = gN;
     if (G > 1 && !(dtype == USTRUN_D16 && halo_supported(a))) {      // one launch per pass
         USTRUN_CHECK(!stat || stat_rows, "conv3x3_fwd: batched passes need ustrun_conv3x3_fwd_rows");
         int total = 0;

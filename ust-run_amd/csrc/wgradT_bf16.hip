@@ -280,16 +280,9 @@ template <int TM> struct T2 {
     static constexpr int BIT = KP2 * 32 / NTH;               // du items: 2 / 4
     static constexpr int WM = TM / 64, WN = 2;               // waves along ci / along the columns (one 32-co half each)
     static constexpr int NT = 4;                             // du fragments (8 co x 4 taps each) per wave
-    static constexpr int NBUF = TM == 256 ? 4 : 3;           // PIPE: stage buffers (256 ci: 4 x 32 KB, one block per CU either way;
-                                                             // 128 ci: a fourth 24 KB buffer would cost the second block)
 };
 
-// PIPE (the default; ustrun_debug_flags bit 24: off): the block's eight waves meet at one barrier per stage, so they all multiply
-// at the same time and all activate at the same time -- with the activation BEHIND the MFMAs the matrix pipe idled through it (SQ
-// counters of the build without: 25 % busy at 8 VALU per MFMA).  Here the stage s + 1 a wave activates is waited for at the TOP of
-// stage s (one more stage buffer where LDS has room keeps two stages of flight time), its cells are read with the fragments, and
-// the arithmetic of one cell rides between the eight MFMAs of each 16-pixel step; the cells are written back before the barrier.
-template <int TM, bool PIPE>
+template <int TM>
 __global__ __launch_bounds__(2 * TM, 2) void wgradT2_bf16_kernel(const WgradArgs a, const int ntn) {
     typedef T2<TM> G;
     constexpr int ARB = G::ARB, ATILE = G::ATILE, STAGE = G::STAGE, AIT = G::AIT, BIT = G::BIT, WN = G::WN, NT = G::NT, NTH = G::NTH;
@@ -431,81 +424,8 @@ __global__ __launch_bounds__(2 * TM, 2) void wgradT2_bf16_kernel(const WgradArgs
     };
 
     auto wait_all_but_one_stage = [&]() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(AIT + BIT) : "memory"); };
-    const int nstage = (int)((kend - kbeg + KP2 - 1) / KP2);
-    if constexpr (PIPE) {
-        static_assert(AIT == KP2 / 16, "one cell per 16-pixel step");
-        constexpr int NB = G::NBUF;
-        char* sb[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) sb[b] = smem + b * STAGE;
-        if (nstage > 0) {
-            load_consts(kbeg);
-#pragma unroll
-            for (int b = 0; b < NB - 1; ++b)
-                if (b < nstage) issue_stage(sb[b]);
-            if (nstage >= NB - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NB - 2) * (AIT + BIT)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            activate(sb[0], kbeg);
-        }
-        __syncthreads();
-        const short floorbits = S.relu ? (short)0 : (short)0x8000;
-#pragma unroll 1
-        for (int s = 0; s < nstage; ++s) {
-            const bool issue = s + NB - 1 < nstage;
-            if (issue) issue_stage(sb[NB - 1]);
-            const long m1 = kbeg + (long)(s + 1) * KP2;
-            if (s + 1 < nstage) load_consts(m1);
-            if (issue) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NB - 2) * (AIT + BIT)) : "memory");      // stage s + 1 has landed
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const long left = kend - m1;
-            const int rem1 = left < 0 ? 0 : (left < KP2 ? (int)left : KP2);
-            u32x4 cell[AIT];
-#pragma unroll
-            for (int i = 0; i < AIT; ++i) cell[i] = *(const u32x4*)(sb[1] + (tid + NTH * i) * 16);
-#pragma unroll
-            for (int kk = 0; kk < KP2 / 16; ++kk) {
-                bf16x8 af[2], bf[NT];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = fragA(sb[0], i, 16 * kk);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bf[j] = fragB(sb[0], j, 16 * kk);
-                if (do_bias) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) accb[j] = USTRUN_DOT2_ONES(((elt2_t){bf[j][2 * q], bf[j][2 * q + 1]}), accb[j]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = USTRUN_MFMA_32x32x16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                {   // the cell of this step: identity constants for a plain source (bf16 -> f32 -> bf16 is exact); rows past the range zero
-                    u32x4 u = act8_bf16(cell[kk], asc0, asc1, ash0, ash1, floorbits);
-                    const bool dead = arow[kk] >= rem1;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) u[q] = dead ? 0u : u[q];
-                    cell[kk] = u;
-                }
-#pragma unroll
-                for (int m = 0; m < 2 * NT; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int i = 0; i < AIT; ++i) *(u32x4*)(sb[1] + (tid + NTH * i) * 16) = cell[i];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            char* tmp = sb[0];
-#pragma unroll
-            for (int b = 0; b + 1 < NB; ++b) sb[b] = sb[b + 1];
-            sb[NB - 1] = tmp;
-        }
-    } else {
     char* st[3] = {smem, smem + STAGE, smem + 2 * STAGE};
+    const int nstage = (int)((kend - kbeg + KP2 - 1) / KP2);
     if (nstage > 0) {
         load_consts(kbeg);
         issue_stage(st[0]);
@@ -548,7 +468,6 @@ __global__ __launch_bounds__(2 * TM, 2) void wgradT2_bf16_kernel(const WgradArgs
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         { char* tmp = st[0]; st[0] = st[1]; st[1] = st[2]; st[2] = tmp; }
-    }
     }
 
     // slab in the torch layout [Cin][Cout][2][2]: rows of D are ci (registers); lane 16 g + 4 tap + c is column (co, tap)
@@ -642,20 +561,12 @@ int wgradT_launch_bf16(const WgradArgs& a, hipStream_t st) {
     if (tm) {
         dim3 grid((a.Cin / tm) * (a.Cout / 64) * a.ksplit), block(2 * tm);
         set_last_wgrad_variant(0x54320000 | tm);                   // 'T2' | ci tile
-        const bool pipe = !(g_debug_flags & (1 << 24));
-        if (pipe) set_last_wgrad_variant(0x54330000 | tm);         // 'T3': activation under the MFMAs
-        if (tm == 256 && pipe) {
-            USTRUN_TRY(ensure_dynamic_lds((const void*)wgradT2_bf16_kernel<256, true>, T2<256>::NBUF * T2<256>::STAGE, "wgradT2_bf16"));
-            hipLaunchKernelGGL((wgradT2_bf16_kernel<256, true>), grid, block, T2<256>::NBUF * T2<256>::STAGE, st, a, a.Cout / 64);
-        } else if (tm == 256) {
-            USTRUN_TRY(ensure_dynamic_lds((const void*)wgradT2_bf16_kernel<256, false>, 3 * T2<256>::STAGE, "wgradT2_bf16"));
-            hipLaunchKernelGGL((wgradT2_bf16_kernel<256, false>), grid, block, 3 * T2<256>::STAGE, st, a, a.Cout / 64);
-        } else if (pipe) {
-            USTRUN_TRY(ensure_dynamic_lds((const void*)wgradT2_bf16_kernel<128, true>, T2<128>::NBUF * T2<128>::STAGE, "wgradT2_bf16"));
-            hipLaunchKernelGGL((wgradT2_bf16_kernel<128, true>), grid, block, T2<128>::NBUF * T2<128>::STAGE, st, a, a.Cout / 64);
+        if (tm == 256) {
+            USTRUN_TRY(ensure_dynamic_lds((const void*)wgradT2_bf16_kernel<256>, 3 * T2<256>::STAGE, "wgradT2_bf16"));
+            hipLaunchKernelGGL(wgradT2_bf16_kernel<256>, grid, block, 3 * T2<256>::STAGE, st, a, a.Cout / 64);
         } else {
-            USTRUN_TRY(ensure_dynamic_lds((const void*)wgradT2_bf16_kernel<128, false>, 3 * T2<128>::STAGE, "wgradT2_bf16"));
-            hipLaunchKernelGGL((wgradT2_bf16_kernel<128, false>), grid, block, 3 * T2<128>::STAGE, st, a, a.Cout / 64);
+            USTRUN_TRY(ensure_dynamic_lds((const void*)wgradT2_bf16_kernel<128>, 3 * T2<128>::STAGE, "wgradT2_bf16"));
+            hipLaunchKernelGGL(wgradT2_bf16_kernel<128>, grid, block, 3 * T2<128>::STAGE, st, a, a.Cout / 64);
         }
         USTRUN_LAUNCH_CHECK("wgradT2_bf16");
         return 0;
