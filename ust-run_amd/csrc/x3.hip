@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, c
 
     // ---- staging: item i = patch pixel (tid + 256 i) >> 3, 4-channel group tid & 7; geometry per source, not per chunk ----
     const int c4 = tid & 7;
-    long goff[CIT];
+    int goff[CIT];                                  // element offsets inside the source (< 2^31: conv3x3_x3_supported)
     unsigned gok = 0;
     int cur_second = -1, cbase = 0, s_relu = 0;
     const float* sptr = nullptr;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, c
             const int ly = y0 - 1 + py - S.off_y, lx = x0 - 1 + pxx - S.off_x;
             const bool ok = px < CPP && ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
             gok |= (ok ? 1u : 0u) << i;
-            goff[i] = ok ? img * S.sN + (long)ly * S.sH + (long)lx * S.sW : 0;
+            goff[i] = ok ? (int)(img * S.sN + (long)ly * S.sH + (long)lx * S.sW) : 0;
         }
     };
     f32x4 av[CIT];
@@ -368,17 +368,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, c
             }
         }
     };
-    // weight fragments of (chunk, tap): [k step][column tile][plane]
-    auto load_b = [&](u32x4 (&b)[2][2][3], int c, int tap) {
-        const __bf16* ws = W3 + (long)tap * 3 * plane;
+    // weight fragments of step u of a chunk -- G = 1: (tap u / 2, 16-channel half u % 2), G = 2: tap u, both halves: [half][column tile][plane]
+    constexpr int G = RT == 2 ? 1 : 2, NSTEP = 18 / G;
+    auto load_b = [&](u32x4 (&b)[G][2][3], int c, int u) {
+        const __bf16* ws = W3 + (long)(G == 1 ? u >> 1 : u) * 3 * plane;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 64 + j * 32 + l31;
-                const long o = ((long)(c * (XBK / 8) + 2 * ks + lh) * a.Cout + (n < a.Cout ? n : 0)) * 8;
+                const long o = ((long)(c * (XBK / 8) + 2 * (G == 1 ? u & 1 : g) + lh) * a.Cout + (n < a.Cout ? n : 0)) * 8;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[ks][j][p] = *(const u32x4*)(ws + p * plane + o);
+                for (int p = 0; p < 3; ++p) b[g][j][p] = *(const u32x4*)(ws + p * plane + o);
             }
     };
 
@@ -392,11 +393,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, c
 
     // this lane's A-fragment base: tile row 2 RT wm + 2 i + (l31 >> 4), column l31 & 15, at patch offset (+1, +1); k half lh
     const char* Ap = smem + ((2 * RT * wm + (l31 >> 4) + 1) * CPW + (l31 & 15) + 1) * XAP + lh * 16;
-    u32x4 bfr[2][2][2][3];
+    // The fragments of a step load one step ahead into the other of two register sets.  64-row wave tiles (RT = 2) step by (tap,
+    // 16-channel half): 24 MFMAs per step, 48 fragment registers -- two whole taps' worth, 96, put that build 60 registers past the
+    // file (scratch reloads in every tap).  32-row wave tiles step by tap (24 MFMAs as well; steps of 12 with a ring of three sets
+    // measured 13-20 % slower).  An even step count (18) lands every chunk on the same set; nine taps alternate, so that build has two
+    // copies of the chunk body with the parity a compile-time constant.
+    u32x4 bfr[2][G][2][3];
     fetch(0);
     load_b(bfr[0], 0, 0);
-    // nine taps per chunk alternate between the two fragment sets, so a chunk starts on the set its predecessor ended on: the set
-    // index is (tap + PAR) & 1 with PAR the chunk's parity -- a compile-time constant of two copies of the body
     auto chunk_body = [&](int c, auto par_c) {
         constexpr int PAR = decltype(par_c)::value;
         if (c) __syncthreads();                       // every wave is done reading the previous chunk's patch
@@ -404,15 +408,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, c
         __syncthreads();
         if (c + 1 < nchunk) fetch(c + 1);             // registers, in flight under the nine taps below
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            // the NEXT tap's fragments (the next chunk's first tap behind the last one) load under this tap's 48 / 24 MFMAs
-            if (t < 8) load_b(bfr[(t + 1 + PAR) & 1], c, t + 1);
-            else if (c + 1 < nchunk) load_b(bfr[(t + 1 + PAR) & 1], c + 1, 0);
+        for (int u = 0; u < NSTEP; ++u) {
+            constexpr int dummy = 0; (void)dummy;
+            if (u + 1 < NSTEP) load_b(bfr[(u + 1 + PAR) & 1], c, u + 1);
+            else if (c + 1 < nchunk) load_b(bfr[(u + 1 + PAR) & 1], c + 1, 0);
+            const int t = G == 1 ? u >> 1 : u;
             const int kh = t / 3, kw = t % 3;
             const int dy = FLIP ? 1 - kh : kh - 1, dx = FLIP ? 1 - kw : kw - 1;
             const char* At = Ap + (dy * CPW + dx) * XAP;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int g = 0; g < G; ++g) {
+                const int ks = G == 1 ? u & 1 : g;
                 b16x8 af[RT][3];
 #pragma unroll
                 for (int i = 0; i < RT; ++i)
@@ -422,20 +428,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, c
                 for (int j = 0; j < 2; ++j) {
                     b16x8 bf[3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(b16x8, bfr[(t + PAR) & 1][ks][j][p]);
+                    for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(b16x8, bfr[(u + PAR) & 1][g][j][p]);
 #pragma unroll
                     for (int i = 0; i < RT; ++i) acc[i][j] = mfma6(af[i], bf, acc[i][j]);
                 }
             }
         }
     };
-    int c = 0;
+    if constexpr (NSTEP % 2 == 0) {
 #pragma unroll 1
-    for (; c + 1 < nchunk; c += 2) {
-        chunk_body(c, std::integral_constant<int, 0>{});
-        chunk_body(c + 1, std::integral_constant<int, 1>{});
+        for (int c = 0; c < nchunk; ++c) chunk_body(c, std::integral_constant<int, 0>{});
+    } else {
+        int c = 0;
+#pragma unroll 1
+        for (; c + 1 < nchunk; c += 2) {
+            chunk_body(c, std::integral_constant<int, 0>{});
+            chunk_body(c + 1, std::integral_constant<int, 1>{});
+        }
+        if (c < nchunk) chunk_body(c, std::integral_constant<int, 0>{});
     }
-    if (c < nchunk) chunk_body(c, std::integral_constant<int, 0>{});
 
     // ---- epilogue: D[row = pixel][col = channel]; col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the 32-row tile
     const int C1 = a.Cout - a.C0;
@@ -785,6 +796,8 @@ bool conv3x3_x3_supported(const IgemmArgs& a) {
     if (a.nseg != 9 || a.segw != 3 || a.nz != 1 || a.s_in != 1 || a.s_out != 1 || a.bias) return false;
     if (!((a.d0 == -1 && a.dstep == 1) || (a.d0 == 1 && a.dstep == -1))) return false;
     if (a.Ho != a.Hb || a.Wo != a.Wb) return false;
+    for (int i = 0; i < a.nsrc; ++i)
+        if ((long)a.N * a.src[i].sN >= (1L << 31) - 64) return false;              // 32-bit element offsets of the staging items
     return true;
 }
 int conv3x3_x3_stat_rows(const IgemmArgs& a) { return a.N * cdiv(a.Hb, CTH) * cdiv(a.Wb, CTW); }
