@@ -368,19 +368,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, c
             }
         }
     };
-    // weight fragments of step u of a chunk -- G = 1: (tap u / 2, 16-channel half u % 2), G = 2: tap u, both halves: [half][column tile][plane]
-    constexpr int G = RT == 2 ? 1 : 2, NSTEP = 18 / G;
-    auto load_b = [&](u32x4 (&b)[G][2][3], int c, int u) {
-        const __bf16* ws = W3 + (long)(G == 1 ? u >> 1 : u) * 3 * plane;
+    // weight fragments of step u = 2 tap + (16-channel half) of a chunk: [column tile][plane]
+    auto load_b = [&](u32x4 (&b)[2][3], int c, int u) {
+        const __bf16* ws = W3 + (long)(u >> 1) * 3 * plane;
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            const long o = ((long)(c * (XBK / 8) + 2 * (u & 1) + lh) * a.Cout + (n < a.Cout ? n : 0)) * 8;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + l31;
-                const long o = ((long)(c * (XBK / 8) + 2 * (G == 1 ? u & 1 : g) + lh) * a.Cout + (n < a.Cout ? n : 0)) * 8;
-#pragma unroll
-                for (int p = 0; p < 3; ++p) b[g][j][p] = *(const u32x4*)(ws + p * plane + o);
-            }
+            for (int p = 0; p < 3; ++p) b[j][p] = *(const u32x4*)(ws + p * plane + o);
+        }
     };
 
     f32x16 acc[RT][2];
@@ -393,59 +390,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, c
 
     // this lane's A-fragment base: tile row 2 RT wm + 2 i + (l31 >> 4), column l31 & 15, at patch offset (+1, +1); k half lh
     const char* Ap = smem + ((2 * RT * wm + (l31 >> 4) + 1) * CPW + (l31 & 15) + 1) * XAP + lh * 16;
-    // The fragments of a step load one step ahead into the other of two register sets.  64-row wave tiles (RT = 2) step by (tap,
-    // 16-channel half): 24 MFMAs per step, 48 fragment registers -- two whole taps' worth, 96, put that build 60 registers past the
-    // file (scratch reloads in every tap).  32-row wave tiles step by tap (24 MFMAs as well; steps of 12 with a ring of three sets
-    // measured 13-20 % slower).  An even step count (18) lands every chunk on the same set; nine taps alternate, so that build has two
-    // copies of the chunk body with the parity a compile-time constant.
-    u32x4 bfr[2][G][2][3];
+    // A chunk is 18 steps (tap, 16-channel half): 24 MFMAs on the 64-row wave tile, 12 on the 32-row one.  The fragments of a step
+    // (24 registers) load NSET - 1 steps ahead into a ring of NSET sets -- one step of lead for the former, two for the latter: the
+    // same 24 MFMAs of flight time.  (Two whole taps' worth of registers, 96, put the 64-row build 60 registers past the file.)  18 is
+    // a multiple of 2 and of 3: a step's set is a compile-time constant whatever the chunk.
+    constexpr int NSET = RT == 2 ? 2 : 3;
+    u32x4 bfr[NSET][2][3];
     fetch(0);
-    load_b(bfr[0], 0, 0);
-    auto chunk_body = [&](int c, auto par_c) {
-        constexpr int PAR = decltype(par_c)::value;
+#pragma unroll
+    for (int u = 0; u < NSET - 1; ++u) load_b(bfr[u], 0, u);
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
         if (c) __syncthreads();                       // every wave is done reading the previous chunk's patch
         write_patch();
         __syncthreads();
         if (c + 1 < nchunk) fetch(c + 1);             // registers, in flight under the nine taps below
 #pragma unroll
-        for (int u = 0; u < NSTEP; ++u) {
+        for (int u = 0; u < 18; ++u) {
             constexpr int dummy = 0; (void)dummy;
-            if (u + 1 < NSTEP) load_b(bfr[(u + 1 + PAR) & 1], c, u + 1);
-            else if (c + 1 < nchunk) load_b(bfr[(u + 1 + PAR) & 1], c + 1, 0);
-            const int t = G == 1 ? u >> 1 : u;
+            const int un = u + NSET - 1;              // the step whose fragments load under this one's MFMAs
+            if (un < 18) load_b(bfr[un % NSET], c, un);
+            else if (c + 1 < nchunk) load_b(bfr[un % NSET], c + 1, un - 18);
+            // (left alone, hipcc sinks each of these loads to a few MFMAs in front of its use -- shorter live ranges -- and the step waits
+            // out an L2 round trip per fragment: the matrix pipe was 51 % busy.  Nothing crosses this line.)
+            __builtin_amdgcn_sched_barrier(0);
+            const int t = u >> 1, ks = u & 1;
             const int kh = t / 3, kw = t % 3;
             const int dy = FLIP ? 1 - kh : kh - 1, dx = FLIP ? 1 - kw : kw - 1;
             const char* At = Ap + (dy * CPW + dx) * XAP;
+            b16x8 af[RT][3];
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int ks = G == 1 ? u & 1 : g;
-                b16x8 af[RT][3];
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int i = 0; i < RT; ++i)
+                for (int p = 0; p < 3; ++p) af[i][p] = __builtin_bit_cast(b16x8, *(const u32x4*)(At + p * CPLANE + 2 * i * CPW * XAP + ks * 32));
+            // term by term over all of the wave's accumulators: the six products of one accumulator (small terms first, as in mfma6)
+            // stand 2 RT instructions apart instead of back to back
+            constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) af[i][p] = __builtin_bit_cast(b16x8, *(const u32x4*)(At + p * CPLANE + 2 * i * CPW * XAP + ks * 32));
+            for (int q = 0; q < 6; ++q)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    b16x8 bf[3];
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(b16x8, bfr[(u + PAR) & 1][g][j][p]);
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) acc[i][j] = mfma6(af[i], bf, acc[i][j]);
-                }
-            }
+                    for (int i = 0; i < RT; ++i)
+                        acc[i][j] = X3_MFMA(af[i][TA[q]], __builtin_bit_cast(b16x8, bfr[u % NSET][j][TB[q]]), acc[i][j], 0, 0, 0);
         }
-    };
-    if constexpr (NSTEP % 2 == 0) {
-#pragma unroll 1
-        for (int c = 0; c < nchunk; ++c) chunk_body(c, std::integral_constant<int, 0>{});
-    } else {
-        int c = 0;
-#pragma unroll 1
-        for (; c + 1 < nchunk; c += 2) {
-            chunk_body(c, std::integral_constant<int, 0>{});
-            chunk_body(c + 1, std::integral_constant<int, 1>{});
-        }
-        if (c < nchunk) chunk_body(c, std::integral_constant<int, 0>{});
     }
 
     // ---- epilogue: D[row = pixel][col = channel]; col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the 32-row tile
