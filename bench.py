@@ -412,8 +412,9 @@ def main():
             json.dump(layers, open(a.dump_layers, "w"), indent=0)
         big = max((r["images"] for r in layers), default=0)
         roof["layers"] = [r for r in layers if r["images"] == big and r["op"] == "fwd"]
-        roof["layers_bwd"] = [r for r in layers if r["images"] == big and r["op"] != "fwd" and
-                              r["layer"] in ("inc.conv2", "down1.conv2", "down2.conv2", "up4.conv1", "up4.conv2", "up4.up")]
+        # (the backward covers the gradient passes only: fewer images than the forward since the leading and tail passes ride along)
+        big_bwd = max((r["images"] for r in layers if r["op"] != "fwd"), default=0)
+        roof["layers_bwd"] = [r for r in layers if r["images"] == big_bwd and r["op"] != "fwd"]
         # ... and the two DoubleConv BLOCKS that target names (inc, up4.conv), forward: both convolutions' algorithmic bytes
         # (read x, write y1, read y1, write y2) over both launches' time, against the HBM roof
         dc = []

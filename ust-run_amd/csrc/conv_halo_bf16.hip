@@ -990,7 +990,7 @@ int halo_linear_w(const IgemmArgs& a) {
     const LinPlan lp = lin_plan(a);
     for (int i = 0; i < a.nsrc; ++i)
         if ((long)lp.gN * a.src[i].sN * 2 >= (1L << 31) - 4096) return 0;          // 32-bit byte offsets inside a pass
-    if ((long)lp.mtiles * (a.Cout / 128) < 256) return 0;
+    if ((long)lp.mtiles * (a.Cout / 128) < 160) return 0;
     const double lin = (double)a.N * a.Ho * a.Wo / (lp.mtiles * 256.0);
     return lin > 1.05 * halo_rect_score(a) ? w : 0;
 }

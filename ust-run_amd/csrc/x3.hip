@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const IgemmArgs a, con
     load_stage(0);
     for (int s = 0; s < nstage; ++s) {
         load_b(s);                                   // in flight under the split below
+        __builtin_amdgcn_sched_barrier(0);           // (hipcc otherwise sinks these loads to just in front of their MFMAs: conv3x3_x3_kernel)
         write_stage();
         __syncthreads();
         if (s + 1 < nstage) load_stage(s + 1);
@@ -218,14 +219,14 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const IgemmArgs a, con
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) af[i][p] = __builtin_bit_cast(b16x8, *(const u32x4*)(Ap + p * APLANE + i * 32 * XAP + ks * 32));
+            constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};       // mfma6's order, term by term over the four accumulators
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                b16x8 bf[3];
+            for (int q = 0; q < 6; ++q)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bf[p] = __builtin_bit_cast(b16x8, bfr[ks][j][p]);
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i][j] = mfma6(af[i], bf, acc[i][j]);
-            }
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][j] = X3_MFMA(af[i][TA[q]], __builtin_bit_cast(b16x8, bfr[ks][j][TB[q]]), acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
