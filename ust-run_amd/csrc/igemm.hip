@@ -308,7 +308,8 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     int rc;
     bool grouped = false;
     for (int i = 0; i < a.nsrc; ++i) grouped |= a.src[i].gN > 0;
-    USTRUN_CHECK(!grouped || dtype == USTRUN_D16, "igemm: batched passes reached a kernel without per-pass BatchNorm constants");
+    USTRUN_CHECK(!grouped || dtype == USTRUN_D16 || (dtype == USTRUN_F32X3 && conv3x3_x3_supported(a)),
+                 "igemm: batched passes reached a kernel without per-pass BatchNorm constants");
     if (dtype == USTRUN_D16) {
         if (!(g_debug_flags & 1) && ws64_supported(a)) rc = conv3x3_ws64_launch_bf16(a, st);
         else if (halo_supported(a)) rc = conv3x3_halo_launch_bf16(a, st);
@@ -317,7 +318,7 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
         else if (convT_dgrad_supported(a)) rc = convT_dgrad_launch_bf16(a, st);
         else if (grouped) { set_error("igemm: batched passes reached a kernel without per-pass BatchNorm constants"); rc = 1; }
         else rc = igemm_launch_bf16(a, st);
-    } else if (dtype == USTRUN_F32X3 && !grouped && igemm_x3_supported(a)) {     // three-term bf16 products (x3.hip)
+    } else if (dtype == USTRUN_F32X3 && igemm_x3_supported(a) && (!grouped || conv3x3_x3_supported(a))) {     // three-term bf16 products (x3.hip)
         rc = igemm_x3_launch(a, st);
     } else if (pick_bm(a.Cout) == 128 || pool) {   // (narrow outputs with a pooled source only occur in tiny test nets)
         rc = pool ? launch_cfg<2, 2, true>(a, st) : launch_cfg<2, 2, false>(a, st);

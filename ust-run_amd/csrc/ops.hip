@@ -223,7 +223,8 @@ extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const
     const int G = src_groups(srcs, nsrc, N, &gN);
     USTRUN_CHECK(G >= 1, "conv3x3_fwd: inconsistent pass groups");
     a.pass_gN = gN;
-    if (G > 1 && !(dtype == USTRUN_D16 && halo_supported(a))) {      // one launch per pass
+    // one launch per pass -- unless the kernel picks the pass's constants per image (the 16-bit halo kernel, the halo-tiled x3 kernel)
+    if (G > 1 && !(dtype == USTRUN_D16 && halo_supported(a)) && !(dtype == USTRUN_F32X3 && !first && conv3x3_x3_supported(a) && !(g_debug_flags & (1 << 24)))) {      // (bit 24: x3 per pass, A/B runs)
         USTRUN_CHECK(!stat || stat_rows, "conv3x3_fwd: batched passes need ustrun_conv3x3_fwd_rows");
         int total = 0;
         for (int g = 0; g < G; ++g) {
@@ -441,7 +442,7 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
         int gN = 0;
         const int G = src_groups(srcs, nsrc, N, &gN);
         USTRUN_CHECK(G >= 1, "conv3x3_wgrad: inconsistent pass groups");
-        if (G > 1 && !(dtype == USTRUN_D16 && wgrad_halo_supported(a))) {
+        if (G > 1 && !(dtype == USTRUN_D16 && wgrad_halo_supported(a)) && !(dtype == USTRUN_F32X3 && wgrad_x3_supported(a) && !(g_debug_flags & (1 << 24)))) {
             for (int g = 0; g < G; ++g) {
                 ustrun_src_t sl[2];
                 for (int i = 0; i < nsrc; ++i) sl[i] = src_slice(srcs[i], g, gN, dtype);

@@ -329,7 +329,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, c
     auto geometry = [&](int second) {
         cur_second = second;
         const SrcDev S = pick_src(a.src[0], a.src[1], second != 0);
-        sptr = S.ptr; sscale = S.scale; sshift = S.shift; s_relu = S.relu;
+        // batched passes: a tile lies in one image, its pass picks the BatchNorm constants (gN images per pass, gstride floats apart)
+        const long gofs = (S.scale && S.gN > 0) ? (long)(img / S.gN) * S.gstride : 0;
+        sptr = S.ptr; sscale = S.scale ? S.scale + gofs : nullptr; sshift = S.shift ? S.shift + gofs : nullptr; s_relu = S.relu;
         cbase = second ? a.src[0].C : 0;
         gok = 0;
 #pragma unroll
@@ -525,7 +527,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const WgradArgs a, con
     const SrcDev S = pick_src(a.src[0], a.src[1], second);
     const int cl = cg - (second ? a.src[0].C : 0);
     f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
-    if (S.scale) { asc = *(const f32x4*)(S.scale + cl); ash = *(const f32x4*)(S.shift + cl); }
+    int cur_grp = -1;                              // batched passes: the constants follow the image of the tile being fetched
+    auto load_consts = [&](int img) {
+        const int grp = S.gN > 0 ? img / S.gN : 0;
+        if (S.scale && grp != cur_grp) {
+            const long o = (long)grp * (S.gN > 0 ? S.gstride : 0) + cl;
+            asc = *(const f32x4*)(S.scale + o); ash = *(const f32x4*)(S.shift + o);
+            // (complete HERE, inside the rare branch: pending, they put a full vmcnt drain in front of every tile's split)
+            asm volatile("" : "+v"(asc), "+v"(ash));
+            cur_grp = grp;
+        }
+    };
     const float* sp = S.ptr + cl;
     const float* dyp = a.dy + co0 + 4 * c4;
 
@@ -533,6 +545,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const WgradArgs a, con
     unsigned aok = 0;
     auto fetch_tile = [&](int t) {
         const int img = t / (tiles_y * tiles_x);
+        load_consts(img);                          // (this tile is split at the bottom of the stage that fetches it: after the previous tile's)
         const int rem = t - img * tiles_y * tiles_x;
         const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
         aok = 0;
@@ -824,7 +837,7 @@ bool wgrad_x3_supported(const WgradArgs& a) {
     if (a.Cin % 64 || a.Cout % 64 || a.dyH != a.Hb || a.dyW != a.Wb) return false;
     for (int i = 0; i < a.nsrc; ++i) {
         const SrcDev& s = a.src[i];
-        if (s.esz != 4 || s.sC != 1 || (s.C & 3) || s.pool || s.gN > 0) return false;
+        if (s.esz != 4 || s.sC != 1 || (s.C & 3) || s.pool) return false;
         if ((s.sN | s.sH | s.sW) & 3) return false;
     }
     return true;
