@@ -480,6 +480,13 @@ int ustrun_debug_conv_stat_rows(int N, int Ho, int Wo, int Cin, int Cout, int k,
  * state.  Every thread starts from the value the environment variable USTRUN_DEBUG_FLAGS had when the library was loaded
  * (read once at load, never on a launch path).                                                                    */
 int ustrun_debug_flags(int flags);
+/* a second word of the same kind (the first is full), same rules: per calling thread, returns the previous value, starts from the
+ * environment variable USTRUN_DEBUG_FLAGS2 as read at load.
+ * bit 0 (1): the halo-tiled 3x3 kernel never runs on its linear tiles (round 5: maps with 18 / 24 / 36 / 72-pixel rows; DESIGN.md
+ *   10.9) -- the rectangular tile of the padding rule instead (A/B runs, and the tests that pin those tiles).
+ * bit 1 (2): dtype USTRUN_F32X3 launches its halo-tiled convolution and its weight gradient once per pass of a batched call, as
+ *   before they took the pass's constants per image (A/B runs).                                                        */
+int ustrun_debug_flags2(int flags);
 /* development aid: while a device buffer is set here (per calling thread), the 64 -> 64 streaming kernel and the two-group
  * all-taps weight gradient run their phase-stamping diagnostic builds and write per-wave cycle sums there as
  * [workgroup][8 waves][8] u64 = 64 u64 per workgroup (tools/ab_ws64.py --diag, tools/diag_wgrad.py).  n_u64 = the buffer's

@@ -94,8 +94,8 @@ CASES = [
     # 128-channel tall tile with the two-destination epilogue for its input gradient
     ("cat_128_to_64", 8, (64, 64), 64, 128, 128, 2, (8, 32, 64, 2, 2), (8, 32, 128, 4, 1)),
     # 256 px x 128 ch with 16-pixel rows (extent < 32 px), ragged right / bottom edges
-    # (24-pixel rows run on the linear tiles since round 5: ustrun_debug_flags bit 26 keeps this case on the tile it was written for)
-    ("tall_narrow_512", 16, (512,), 512, 56, 24, 1, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1), 1 << 26),
+    # (24-pixel rows run on the linear tiles since round 5: ustrun_debug_flags2 bit 0 keeps this case on the tile it was written for)
+    ("tall_narrow_512", 16, (512,), 512, 56, 24, 1, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1), (0, 1)),
     # the bottleneck of the student's four batched passes as the step runs it: N = 64, 16 x 16, 1024 -> 1024
     ("bottleneck_n64", 64, (1024,), 1024, 16, 16, 4, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1)),
     # 64 -> 64 full-resolution layers (inc.conv2, up4.conv2): wide and narrow 64-channel tiles
@@ -123,9 +123,10 @@ CASES = [
     # the 8 x 32 tile: the rule takes 16 x 16 tiles; 18 x 18 and 24 x 24 pad to 32 on 16 x 16 tiles: 8 x 16 MI 2;
     # 144 x 144 (= 4.5 x 32): 16 x 16 as well
     ("pad_48_512", 16, (512,), 512, 48, 48, 2, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1)),
-    # (since round 5 these two maps run on the linear tiles -- the LIN cases below; ustrun_debug_flags bit 26 keeps the rule's tile)
-    ("pad_18_1024", 64, (1024,), 1024, 18, 18, 4, (8, 16, 128, 2, 2), (8, 16, 128, 2, 2), 1 << 26),
-    ("pad_24_1024", 64, (1024,), 1024, 24, 24, 4, (8, 16, 128, 2, 2), (8, 16, 128, 2, 2), 1 << 26),
+    # (since round 5 these two maps run on the linear tiles -- the LIN cases below; ustrun_debug_flags2 bit 0 keeps the rule's tile: a
+    # case's flags are one int for ustrun_debug_flags or a pair for (ustrun_debug_flags, ustrun_debug_flags2))
+    ("pad_18_1024", 64, (1024,), 1024, 18, 18, 4, (8, 16, 128, 2, 2), (8, 16, 128, 2, 2), (0, 1)),
+    ("pad_24_1024", 64, (1024,), 1024, 24, 24, 4, (8, 16, 128, 2, 2), (8, 16, 128, 2, 2), (0, 1)),
     ("pad_144_128", 8, (128,), 128, 144, 144, 2, (16, 16, 128, 4, 1), (16, 16, 128, 4, 1)),
     # ---- the 512-pixel x 64-channel tile (16 x 32 px, wave tile 128 px x 64 ch, one block per CU; ustrun_debug_flags bit 13):
     # the concat conv of up4 forward, and the input gradient of a 64 -> 128 layer (a 128 -> 64 product on a plain source)
@@ -147,7 +148,8 @@ CASES = [c[:8] + ((c[8] + ("m16",)) if (isinstance(c[8], tuple) and c[8][3] == 4
 for _c in list(CASES):
     if _c[0] in ("tall_wide_128", "cat_128_to_64", "tall_narrow_512", "c64_wide", "c64_narrow", "mid_grid_512", "pad_18_1024", "pad_144_128"):
         tag = lambda v: v if not isinstance(v, tuple) or (len(v) > 5 and v[5] == "m16") else v[:5] + ("m16",)
-        CASES.append(("m16all_" + _c[0],) + _c[1:7] + (_c[7], tag(_c[8]), 32768 | (_c[9] if len(_c) > 9 else 0)))
+        _f = _c[9] if len(_c) > 9 else 0
+        CASES.append(("m16all_" + _c[0],) + _c[1:7] + (_c[7], tag(_c[8]), (32768 | _f[0], _f[1]) if isinstance(_f, tuple) else 32768 | _f))
 # ---- linear tiles (round 5, conv_halo_bf16.hip LINW: VERDICT r4 next 4): the maps of configs[2] / configs[3] whose sides no
 # rectangular tile divides -- 18 / 36 / 72 pixels (M&Ms 288 x 288, train_mnms.py:397-399), 24 (prostate 384 x 384, train.py:416-418).
 # A tile is 256 consecutive positions of a pass's flat padded space: tiles cross rows and images (never passes), the last tile of a
@@ -176,11 +178,14 @@ def test_production_tile_exact(case):
     name, n, cs, co, h, w, G, vf, vd = case[:9]
     l = L()
     lib = l.lib()
-    old_flags = lib.ustrun_debug_flags(case[9] if len(case) > 9 else {"ws4": 2, "ws8": 4}.get(vf, 0))
+    fl = case[9] if len(case) > 9 else {"ws4": 2, "ws8": 4}.get(vf, 0)
+    f1, f2 = fl if isinstance(fl, tuple) else (fl, 0)
+    old_flags, old_flags2 = lib.ustrun_debug_flags(f1), lib.ustrun_debug_flags2(f2)
     try:
         _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd)
     finally:
         lib.ustrun_debug_flags(old_flags)
+        lib.ustrun_debug_flags2(old_flags2)
 
 
 def _production_tile_exact(l, lib, name, n, cs, co, h, w, G, vf, vd):

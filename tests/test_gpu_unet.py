@@ -372,7 +372,7 @@ def test_linear_tiles_in_the_network(dtype):
     """configs[3]'s shape (M&Ms 288^2, 4 classes, 8 + 8: train_mnms.py:397-399) as the step calls the student: one leading pass
     without gradient, four gradient passes, the one-image tail -- 41 images in one call.  Its 72 / 36 / 18-pixel levels run on the
     halo kernel's linear tiles (round 5: tiles of 256 consecutive positions that cross rows and images but never passes); the same
-    call with ustrun_debug_flags bit 26 runs them on rectangular tiles.  Every convolution output is the same either way (the
+    call with ustrun_debug_flags2 bit 0 runs them on rectangular tiles.  Every convolution output is the same either way (the
     operator tests compare them bitwise); what differs is how the BatchNorm statistics rows partition the pixels, i.e. the order of
     f32 partial sums: running statistics to 1e-5, logits to 16-bit rounding, gradients alike."""
     import copy
@@ -388,15 +388,16 @@ def test_linear_tiles_in_the_network(dtype):
     dl = torch.randn(5 * B, 4, 288, 288, generator=g).cuda()       # (the leading pass's part is skipped by the backward)
     m3 = copy.deepcopy(m1)
     outs = []
-    # (the third run is the yardstick: rectangular tiles again, but the 16 x 16 one forced where the rule picks another -- bits 10-11 --,
-    # i.e. one more partition of the same pixels into statistics rows)
-    for m, flags in ((m1, 0), (m2, 1 << 26), (m3, 1 << 26 | 2 << 10)):
-        old = lib.ustrun_debug_flags(flags)
+    # (the third run is the yardstick: rectangular tiles again, but the 16 x 16 one forced where the rule picks another -- bits 10-11
+    # of ustrun_debug_flags --, i.e. one more partition of the same pixels into statistics rows)
+    for m, flags, flags2 in ((m1, 0, 0), (m2, 0, 1), (m3, 2 << 10, 1)):
+        old, old2 = lib.ustrun_debug_flags(flags), lib.ustrun_debug_flags2(flags2)
         try:
             lg = m.forward_batched(x, 5, tail=1, lead=1)
             lg.backward(dl)
         finally:
             lib.ustrun_debug_flags(old)
+            lib.ustrun_debug_flags2(old2)
         outs.append(lg.detach().float())
     rel = lambda u, v: float((u - v).norm() / (v.norm() + 1e-30))
     e_lin, e_ref = rel(outs[0], outs[1]), rel(outs[2], outs[1])

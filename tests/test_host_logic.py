@@ -168,3 +168,7 @@ def test_statistics_rows_never_exceed_the_published_bound():
     assert n > 5000 and worst == 1.0       # the bound is tight somewhere: it is a bound of the kernels, not a padded guess
     # the round-2 overflow shape, by name
     assert lib.ustrun_debug_conv_stat_rows(8, 72, 72, 64, 64, 3, 1, 1, 0, L.BF16) == 432 <= lib.ustrun_conv_mtiles(8, 72, 72, 64)
+    # linear tiles (round 5): one row per 256 positions of the flat padded space (19 x 19 per 18 x 18 image), one pass here
+    assert lib.ustrun_debug_conv_stat_rows(64, 18, 18, 1024, 1024, 3, 1, 1, 0, L.BF16) == -(-64 * 19 * 19 // 256) <= lib.ustrun_conv_mtiles(64, 18, 18, 1024)
+    # ... and not for a grid of a few blocks (one validation image): the 8 x 16 rectangular tile's rows
+    assert lib.ustrun_debug_conv_stat_rows(1, 18, 18, 1024, 1024, 3, 1, 1, 0, L.BF16) == 3 * 2

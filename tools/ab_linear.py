@@ -1,6 +1,6 @@
 """GPU box: the 3x3 layers of the maps no rectangular tile divides (configs[2] / configs[3]: 24 px of prostate 384^2; 72 / 36 / 18 px
 of M&Ms 288^2), forward (BatchNorm + ReLU on load, statistics) and input gradient, on the halo kernel's linear tiles (round 5) and
--- ustrun_debug_flags bit 26 -- on the rectangular tile the padding rule picks.  Same buffers, alternating.
+-- ustrun_debug_flags2 bit 0 -- on the rectangular tile the padding rule picks.  Same buffers, alternating.
 
     python tools/ab_linear.py [--b 8] [--reps 20]
 """
@@ -55,11 +55,11 @@ def main():
         dgr = lambda: l.check(lib.ustrun_conv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), nb, hw, hw, co, ci, da.data_ptr(), ci, None, 0, 0, 0, 0, 1, None))
         res, outs = {}, {}
         for rect in (1, 0, 1, 0):
-            old = lib.ustrun_debug_flags((1 << 26) if rect else 0)
+            old = lib.ustrun_debug_flags2(1 if rect else 0)
             tf, vf = timed(fwd, a.reps), lib.ustrun_debug_last_conv_variant()
             yo = y.clone()
             td, vd = timed(dgr, a.reps), lib.ustrun_debug_last_conv_variant()
-            lib.ustrun_debug_flags(old)
+            lib.ustrun_debug_flags2(old)
             res[rect] = (min(tf, res[rect][0]) if rect in res else tf, min(td, res[rect][1]) if rect in res else td, vf, vd)
             outs[rect] = (yo, da.clone())
         same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -975,9 +975,9 @@ static double halo_rect_score(const IgemmArgs& a);
 // Linear tiles (LINW builds: 18, 24, 36, 72-pixel rows): the row length if this launch runs on them, else 0.  They serve
 // 128-column outputs of un-pooled, un-dilated sources when (a) the rectangular tiles would waste more of their MFMAs on padding --
 // useful fraction x the tiles' measured relative rates, as in halo_tile128 -- and (b) the launch still has a block per CU.
-// (ustrun_debug_flags bit 26: off, for A/B runs)
+// (ustrun_debug_flags2 bit 0: off, for A/B runs)
 int halo_linear_w(const IgemmArgs& a) {
-    if ((g_debug_flags & (1 << 26)) || (g_debug_flags & (8 | 2097152 | 32768)) || ((g_debug_flags >> 10) & 3)) return 0;
+    if ((g_debug_flags2 & 1) || (g_debug_flags & (8 | 2097152 | 32768)) || ((g_debug_flags >> 10) & 3)) return 0;
     if (!halo_supported(a) || halo_dilation(a) != 1 || a.Cout % 128 || a.Hb != a.Ho || a.Wb != a.Wo) return 0;
     const int w = a.Wo;
     if (!(w == 18 || w == 24 || w == 36 || w == 72)) return 0;

@@ -158,6 +158,8 @@ extern "C" int ustrun_debug_last_wgrad_variant(void) { return wgrad_last_variant
 namespace ustrun {
 static const int g_env_debug_flags = getenv("USTRUN_DEBUG_FLAGS") ? atoi(getenv("USTRUN_DEBUG_FLAGS")) : 0;     // read once, at load
 thread_local int g_debug_flags = g_env_debug_flags;
+static const int g_env_debug_flags2 = getenv("USTRUN_DEBUG_FLAGS2") ? atoi(getenv("USTRUN_DEBUG_FLAGS2")) : 0;
+thread_local int g_debug_flags2 = g_env_debug_flags2;       // the second word (ustrun_debug_flags2)
 int env_debug_flags() { return g_env_debug_flags; }     // the process-wide constant: for switches that shape a plan two calls share
 thread_local DebugBuf g_dbg = {nullptr, 0};
 int debug_buffer_for(long blocks, const char* who, unsigned long long** out) {
@@ -175,6 +177,7 @@ extern "C" int ustrun_debug_buffer(void* device_u64, int64_t n_u64) {
     return 0;
 }
 extern "C" int ustrun_debug_flags(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
+extern "C" int ustrun_debug_flags2(int flags) { const int old = g_debug_flags2; g_debug_flags2 = flags; return old; }
 
 // ---- clock probe (tools/clock_probe.py; MI355X_MICROARCH.md "DVFS give-back" item 6): every workgroup records the shader-clock
 // counter (s_memtime: one tick per shader cycle) and the constant 100 MHz counter (s_memrealtime) together with where it ran.
@@ -224,7 +227,7 @@ extern "C" int ustrun_conv3x3_fwd_rows(const ustrun_src_t* srcs, int nsrc, const
     USTRUN_CHECK(G >= 1, "conv3x3_fwd: inconsistent pass groups");
     a.pass_gN = gN;
     // one launch per pass -- unless the kernel picks the pass's constants per image (the 16-bit halo kernel, the halo-tiled x3 kernel)
-    if (G > 1 && !(dtype == USTRUN_D16 && halo_supported(a)) && !(dtype == USTRUN_F32X3 && !first && conv3x3_x3_supported(a) && !(g_debug_flags & (1 << 24)))) {      // (bit 24: x3 per pass, A/B runs)
+    if (G > 1 && !(dtype == USTRUN_D16 && halo_supported(a)) && !(dtype == USTRUN_F32X3 && !first && conv3x3_x3_supported(a) && !(g_debug_flags2 & 2))) {      // (ustrun_debug_flags2 bit 1: x3 per pass, A/B runs)
         USTRUN_CHECK(!stat || stat_rows, "conv3x3_fwd: batched passes need ustrun_conv3x3_fwd_rows");
         int total = 0;
         for (int g = 0; g < G; ++g) {
@@ -442,7 +445,7 @@ extern "C" int ustrun_conv3x3_wgrad(const ustrun_src_t* srcs, int nsrc, const vo
         int gN = 0;
         const int G = src_groups(srcs, nsrc, N, &gN);
         USTRUN_CHECK(G >= 1, "conv3x3_wgrad: inconsistent pass groups");
-        if (G > 1 && !(dtype == USTRUN_D16 && wgrad_halo_supported(a)) && !(dtype == USTRUN_F32X3 && wgrad_x3_supported(a) && !(g_debug_flags & (1 << 24)))) {
+        if (G > 1 && !(dtype == USTRUN_D16 && wgrad_halo_supported(a)) && !(dtype == USTRUN_F32X3 && wgrad_x3_supported(a) && !(g_debug_flags2 & 2))) {
             for (int g = 0; g < G; ++g) {
                 ustrun_src_t sl[2];
                 for (int i = 0; i < nsrc; ++i) sl[i] = src_slice(srcs[i], g, gN, dtype);

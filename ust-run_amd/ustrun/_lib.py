@@ -119,6 +119,7 @@ SIGNATURES = {
     "ustrun_debug_conv_stat_rows": (i32, [i32] * 10),
     "ustrun_debug_last_wgrad_variant": (i32, []),
     "ustrun_debug_flags": (i32, [i32]),
+    "ustrun_debug_flags2": (i32, [i32]),
     "ustrun_debug_buffer": (i32, [vp, i64]),
     "ustrun_debug_last_bn_variant": (i32, []),
     "ustrun_debug_clock_probe": (i32, [vp, i32, vp]),

@@ -94,9 +94,12 @@ def model_params(model):
 
 
 def _current_debug_flags(lib):
+    """both words (ustrun_debug_flags, ustrun_debug_flags2) of the calling thread"""
     f = lib.ustrun_debug_flags(0)
     lib.ustrun_debug_flags(f)
-    return f
+    f2 = lib.ustrun_debug_flags2(0)
+    lib.ustrun_debug_flags2(f2)
+    return f, f2
 
 
 class _UNetFn(torch.autograd.Function):
@@ -117,11 +120,12 @@ class _UNetFn(torch.autograd.Function):
     def backward(ctx, dlogits, *unused):
         model, d = ctx.model, ctx.desc
         lib = L.lib()
-        restore = lib.ustrun_debug_flags(ctx.debug_flags)
+        restore = lib.ustrun_debug_flags(ctx.debug_flags[0]), lib.ustrun_debug_flags2(ctx.debug_flags[1])
         try:
             return _UNetFn._backward(ctx, lib, model, d, dlogits)
         finally:
-            lib.ustrun_debug_flags(restore)
+            lib.ustrun_debug_flags(restore[0])
+            lib.ustrun_debug_flags2(restore[1])
 
     @staticmethod
     def _backward(ctx, lib, model, d, dlogits):
