@@ -492,7 +492,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(const IgemmArgs a, c
 // ---- weight gradient, all nine taps per block ----------------------------------------------------------------------------------
 constexpr int TH = 4, TW = 16, HW2 = TW + 2, HP = (TH + 2) * HW2;   // 4 x 16 tile, 6 x 18 = 108 halo pixels
 constexpr int RB = 192;                                              // LDS row pitch: 64 bf16 + 64 bytes (conflict-free transposing reads)
-constexpr int WATILE = TH * TW * RB, WDTILE = HP * RB;               // one plane of the activation tile / of the dY patch
 constexpr int WAIT = TH * TW * 16 / 256;                             // float4 items per thread: activation 4,
 constexpr int WDIT = (HP * 16 + 255) / 256;                          //                          dY 7
 
@@ -505,120 +504,158 @@ __device__ __forceinline__ b16x8 tr_frag(const char* lane_base, int k0) {
     return f;
 }
 
+// Consumer / producer waves (as the 64 -> 64 streaming kernel of round 3): waves 0-3 read fragments and multiply, waves 4-7 fetch,
+// activate, split and write the NEXT tile into the other of two stage buffers -- one of each per SIMD, so the ~430 VALU instructions of
+// splitting a tile run under the other wave's 216 MFMAs instead of in front of them (one block of four waves per CU did both in turn:
+// the matrix pipe idled through every split and its two barriers).  Rows are 128 bytes with the 64-byte halves swapped where bit 1 of
+// the row is set (the four rows of a transposing read stay on disjoint bank quarters without the 64 bytes of padding per row that
+// left LDS for ONE stage only).
+constexpr int RBW = 128;
+constexpr int WDROWS = (HP * 16 + 255) / 256 * 16;            // 112: every staging item of the dY patch has a row (108 .. 111: slack, never read)
+constexpr int WATILE2 = TH * TW * RBW, WDTILE2 = WDROWS * RBW, WSTAGE2 = 3 * (WATILE2 + WDTILE2);
+
+__device__ __forceinline__ b16x8 tr_fragw(const char* lane_base, int k0) {
+    const b16x4 lo = __builtin_bit_cast(b16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ustrun_lds_s16x4*)(lane_base + k0 * RBW)));
+    const b16x4 hi = __builtin_bit_cast(b16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ustrun_lds_s16x4*)(lane_base + (k0 + 4) * RBW)));
+    b16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
 // grid = (ci tiles * co tiles, ksplit); tiles_per = spatial tiles per split
-__global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const WgradArgs a, const int ntn, const int tiles_x, const int tiles_y,
+__global__ __launch_bounds__(512, 2) void wgrad_x3_kernel(const WgradArgs a, const int ntn, const int tiles_x, const int tiles_y,
                                                           const int tiles_per) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                               // [3][64 px][RB]
-    char* Ds = smem + 3 * WATILE;                  // [3][108 px][RB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave >> 1, wj = wave & 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 x { [3][64 px][RBW], [3][112 px][RBW] }
+    const int lane = threadIdx.x & 63, ptid = threadIdx.x & 255;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave8 >= 4;                // wave-uniform
+    const int wave = wave8 & 3, wi = wave >> 1, wj = wave & 1;
     const int mtile = blockIdx.x / ntn, ntile = blockIdx.x % ntn;
     const int ci0 = mtile * 64, co0 = ntile * 64;
     const int ttotal = a.N * tiles_y * tiles_x;
     const int tbeg = blockIdx.y * tiles_per;
     const int tend = min(ttotal, tbeg + tiles_per);
 
-    // activation item i = pixel (tid + 256 i) >> 4 of the tile, 4-channel group tid & 15 (one source, one set of constants per thread)
-    const int c4 = tid & 15;
-    const int cg = ci0 + 4 * c4;
-    const bool second = (a.nsrc == 2 && cg >= a.src[0].C);
-    const SrcDev S = pick_src(a.src[0], a.src[1], second);
-    const int cl = cg - (second ? a.src[0].C : 0);
-    f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
-    int cur_grp = -1;                              // batched passes: the constants follow the image of the tile being fetched
-    auto load_consts = [&](int img) {
-        const int grp = S.gN > 0 ? img / S.gN : 0;
-        if (S.scale && grp != cur_grp) {
-            const long o = (long)grp * (S.gN > 0 ? S.gstride : 0) + cl;
-            asc = *(const f32x4*)(S.scale + o); ash = *(const f32x4*)(S.shift + o);
-            // (complete HERE, inside the rare branch: pending, they put a full vmcnt drain in front of every tile's split)
-            asm volatile("" : "+v"(asc), "+v"(ash));
-            cur_grp = grp;
-        }
-    };
-    const float* sp = S.ptr + cl;
-    const float* dyp = a.dy + co0 + 4 * c4;
-
-    f32x4 av[WAIT], dv[WDIT];
-    unsigned aok = 0;
-    auto fetch_tile = [&](int t) {
-        const int img = t / (tiles_y * tiles_x);
-        load_consts(img);                          // (this tile is split at the bottom of the stage that fetches it: after the previous tile's)
-        const int rem = t - img * tiles_y * tiles_x;
-        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
-        aok = 0;
-#pragma unroll
-        for (int i = 0; i < WAIT; ++i) {
-            const int px = (tid + 256 * i) >> 4;
-            const int ly = y0 + (px >> 4) - S.off_y, lx = x0 + (px & 15) - S.off_x;
-            const bool ok = ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
-            const f32x4 v = *(const f32x4*)(sp + img * S.sN + (long)(ok ? ly : 0) * S.sH + (long)(ok ? lx : 0) * S.sW);
-            av[i] = v;
-            aok |= (ok ? 1u : 0u) << i;
-        }
-#pragma unroll
-        for (int i = 0; i < WDIT; ++i) {
-            const int hp = (tid + 256 * i) >> 4;
-            const int hy = hp / HW2, hx = hp - hy * HW2;
-            const int ly = y0 - 1 + hy, lx = x0 - 1 + hx;
-            const bool ok = hp < HP && ly >= 0 && ly < a.dyH && lx >= 0 && lx < a.dyW;
-            const f32x4 v = *(const f32x4*)(dyp + (((long)img * a.dyH + (ok ? ly : 0)) * a.dyW + (ok ? lx : 0)) * a.Cout);
-            dv[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto write_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < WAIT; ++i) {
-            const int px = (tid + 256 * i) >> 4;
-            f32x4 v = av[i] * asc + ash;
-            if (S.relu) v = relu4(v);
-            if (!((aok >> i) & 1u)) v = (f32x4){0.f, 0.f, 0.f, 0.f};       // padding is applied after the activation
-            u32x2 p0, p1, p2;
-            split4(v, p0, p1, p2);
-            char* dst = As + px * RB + c4 * 8;
-            *(u32x2*)dst = p0; *(u32x2*)(dst + WATILE) = p1; *(u32x2*)(dst + 2 * WATILE) = p2;
-        }
-#pragma unroll
-        for (int i = 0; i < WDIT; ++i) {
-            const int hp = (tid + 256 * i) >> 4;
-            if (hp < HP) {
-                u32x2 p0, p1, p2;
-                split4(dv[i], p0, p1, p2);
-                char* dst = Ds + hp * RB + c4 * 8;
-                *(u32x2*)dst = p0; *(u32x2*)(dst + WDTILE) = p1; *(u32x2*)(dst + 2 * WDTILE) = p2;
-            }
-        }
-    };
-
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const int lrow = 8 * (lane >> 5) + ((lane & 15) >> 2), lcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    const char* Ab = As + lrow * RB + (wi * 32 + lcol) * 2;
-    const char* Db = Ds + lrow * RB + (wj * 32 + lcol) * 2;
 
-    if (tbeg < tend) { fetch_tile(tbeg); write_tile(); }
-    __syncthreads();
-#pragma unroll 1
+    if (producer) {
+        // activation item i = pixel (ptid + 256 i) >> 4 of the tile, 4-channel group ptid & 15 (one source, one set of constants per thread)
+        const int c4 = ptid & 15;
+        const int cg = ci0 + 4 * c4;
+        const bool second = (a.nsrc == 2 && cg >= a.src[0].C);
+        const SrcDev S = pick_src(a.src[0], a.src[1], second);
+        const int cl = cg - (second ? a.src[0].C : 0);
+        f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+        int cur_grp = -1;                              // batched passes: the constants follow the image of the tile being fetched
+        auto load_consts = [&](int img) {
+            const int grp = S.gN > 0 ? img / S.gN : 0;
+            if (S.scale && grp != cur_grp) {
+                const long o = (long)grp * (S.gN > 0 ? S.gstride : 0) + cl;
+                asc = *(const f32x4*)(S.scale + o); ash = *(const f32x4*)(S.shift + o);
+                cur_grp = grp;
+            }
+        };
+        const float a_floor = S.relu ? 0.f : -__builtin_inff();
+        const float* sp = S.ptr + cl;
+        const float* dyp = a.dy + co0 + 4 * c4;
+        f32x4 av[WAIT], dv[WDIT];
+        unsigned aok = 0;
+        auto fetch_tile = [&](int t) {
+            const int img = t / (tiles_y * tiles_x);
+            const int rem = t - img * tiles_y * tiles_x;
+            const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+            aok = 0;
+#pragma unroll
+            for (int i = 0; i < WAIT; ++i) {
+                const int px = (ptid + 256 * i) >> 4;
+                const int ly = y0 + (px >> 4) - S.off_y, lx = x0 + (px & 15) - S.off_x;
+                const bool ok = ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
+                av[i] = *(const f32x4*)(sp + img * S.sN + (long)(ok ? ly : 0) * S.sH + (long)(ok ? lx : 0) * S.sW);
+                aok |= (ok ? 1u : 0u) << i;
+            }
+#pragma unroll
+            for (int i = 0; i < WDIT; ++i) {
+                const int hp = (ptid + 256 * i) >> 4;
+                const int hy = hp / HW2, hx = hp - hy * HW2;
+                const int ly = y0 - 1 + hy, lx = x0 - 1 + hx;
+                const bool ok = hp < HP && ly >= 0 && ly < a.dyH && lx >= 0 && lx < a.dyW;
+                dv[i] = *(const f32x4*)(dyp + (((long)img * a.dyH + (ok ? ly : 0)) * a.dyW + (ok ? lx : 0)) * a.Cout);
+                aok |= (ok ? 1u : 0u) << (8 + i);
+            }
+        };
+        // (the constants a tile is split with are those of ITS image: loaded here, at its split, not at its fetch one stage earlier)
+        auto write_tile = [&](char* stage, int t) {
+            load_consts(t / (tiles_y * tiles_x));
+#pragma unroll
+            for (int i = 0; i < WAIT; ++i) {
+                const int px = (ptid + 256 * i) >> 4;
+                f32x4 v = av[i] * asc + ash;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = __builtin_fmaxf(v[q], a_floor);
+                if (!((aok >> i) & 1u)) v = (f32x4){0.f, 0.f, 0.f, 0.f};       // padding is applied after the activation
+                u32x2 p0, p1, p2;
+                split4(v, p0, p1, p2);
+                char* dst = stage + px * RBW + ((c4 * 8) ^ (((px >> 1) & 1) << 6));
+                *(u32x2*)dst = p0; *(u32x2*)(dst + WATILE2) = p1; *(u32x2*)(dst + 2 * WATILE2) = p2;
+            }
+#pragma unroll
+            for (int i = 0; i < WDIT; ++i) {
+                const int hp = (ptid + 256 * i) >> 4;
+                const f32x4 v = ((aok >> (8 + i)) & 1u) ? dv[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                u32x2 p0, p1, p2;
+                split4(v, p0, p1, p2);
+                char* dst = stage + 3 * WATILE2 + hp * RBW + ((c4 * 8) ^ (((hp >> 1) & 1) << 6));      // (hp >= HP: the slack rows)
+                *(u32x2*)dst = p0; *(u32x2*)(dst + WDTILE2) = p1; *(u32x2*)(dst + 2 * WDTILE2) = p2;
+            }
+        };
+        if (tbeg < tend) {
+            fetch_tile(tbeg);
+            write_tile(smem, tbeg);
+            if (tbeg + 1 < tend) fetch_tile(tbeg + 1);
+        }
+        __syncthreads();
+        char* nxt = smem + WSTAGE2;
+        for (int t = tbeg; t < tend; ++t) {
+            if (t + 1 < tend) {
+                write_tile(nxt, t + 1);                   // under the consumers' MFMAs of tile t
+                if (t + 2 < tend) fetch_tile(t + 2);      // in flight until the split one stage on
+            }
+            __syncthreads();
+            nxt = smem + (nxt == smem ? WSTAGE2 : 0);
+        }
+        return;                                           // (the slab is the consumers')
+    }
+
+    // ---- consumers.  Fragment bases: rows 8 (lane >> 5) + q (+ 4), columns 32 w + 16 ((lane >> 4) & 1) + 4 (lane & 3); the half-swap of a
+    // row depends on bit 1 of (first row of the fragment + the lane's row): activation fragments start on multiples of 16, dY
+    // fragments anywhere -- four bases by the start's low two bits
+    const int lrow = 8 * (lane >> 5) + ((lane & 15) >> 2), lcolb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int abase = lrow * RBW + ((wi * 64 + lcolb) ^ (((lrow >> 1) & 1) << 6));
+    int dbase4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbase4[c] = 3 * WATILE2 + lrow * RBW + ((wj * 64 + lcolb) ^ ((((c + lrow) >> 1) & 1) << 6));
+    __syncthreads();                                      // the first tile is in place
+    const char* cur = smem;
     for (int t = tbeg; t < tend; ++t) {
-        const bool more = t + 1 < tend;
-        if (more) fetch_tile(t + 1);                     // registers, under this tile's MFMAs
         b16x8 af[TH][3];
 #pragma unroll
         for (int r = 0; r < TH; ++r)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[r][p] = tr_frag(Ab + p * WATILE, r * TW);
+            for (int p = 0; p < 3; ++p) af[r][p] = tr_fragw(cur + abase + p * WATILE2, r * TW);
 #pragma unroll
         for (int pr = 0; pr < TH + 2; ++pr) {
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
+                constexpr int dummy = 0; (void)dummy;
+                const int k0 = pr * HW2 + 2 - kw;
                 b16x8 b[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = tr_frag(Db + p * WDTILE, pr * HW2 + 2 - kw);
+                for (int p = 0; p < 3; ++p) b[p] = tr_fragw(cur + dbase4[k0 & 3] + p * WDTILE2, k0);
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {      // tap (kh, kw) pairs pixel row r with dY row r + 2 - kh of the patch
                     const int r = pr + kh - 2;
@@ -626,9 +663,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_x3_kernel(const WgradArgs a, con
                 }
             }
         }
-        __syncthreads();                                  // every wave is done reading this tile
-        if (more) write_tile();
-        __syncthreads();
+        __syncthreads();                                  // tile t is read, tile t + 1 is written
+        cur = smem + (cur == smem ? WSTAGE2 : 0);
     }
 
     // slab in the torch weight layout [Cout][Cin][3][3]
@@ -883,9 +919,9 @@ int wgradT_x3_launch(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t 
 }
 
 int wgrad_x3_launch(const WgradArgs& a, int ksplit, int tiles_per, hipStream_t st) {
-    const int lds = 3 * (WATILE + WDTILE);
+    const int lds = 2 * WSTAGE2;
     USTRUN_TRY(ensure_dynamic_lds((const void*)wgrad_x3_kernel, lds, "wgrad_x3"));
-    dim3 grid((a.Cin / 64) * (a.Cout / 64), ksplit), block(256);
+    dim3 grid((a.Cin / 64) * (a.Cout / 64), ksplit), block(512);
     hipLaunchKernelGGL(wgrad_x3_kernel, grid, block, lds, st, a, a.Cout / 64, cdiv(a.Wb, TW), cdiv(a.Hb, TH), tiles_per);
     USTRUN_LAUNCH_CHECK("wgrad_x3");
     return 0;
