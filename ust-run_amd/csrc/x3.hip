@@ -565,26 +565,43 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3_kernel(const WgradArgs a, con
         const float* dyp = a.dy + co0 + 4 * c4;
         f32x4 av[WAIT], dv[WDIT];
         unsigned aok = 0;
+        // tile-invariant item geometry: (row, column) inside the tile / the patch and the element offset from the tile's origin --
+        // per tile only two compares and a select per item remain (the 64-bit index arithmetic per item and tile was half of the
+        // producers' ~840 VALU instructions per tile, which compete with the consumers' MFMAs for the SIMD's issue slots)
+        int apy[WAIT], apx[WAIT], aoff[WAIT], dhy[WDIT], dhx[WDIT], doff[WDIT];
+#pragma unroll
+        for (int i = 0; i < WAIT; ++i) {
+            const int px = (ptid + 256 * i) >> 4;
+            apy[i] = px >> 4; apx[i] = px & 15;
+            aoff[i] = (int)(apy[i] * S.sH + apx[i] * S.sW);
+        }
+#pragma unroll
+        for (int i = 0; i < WDIT; ++i) {
+            const int hp = (ptid + 256 * i) >> 4;
+            dhy[i] = hp < HP ? hp / HW2 : -(1 << 20);             // (items past the patch: never inside the image)
+            dhx[i] = hp - (hp / HW2) * HW2;
+            doff[i] = ((hp / HW2) * a.dyW + dhx[i]) * a.Cout;
+        }
         auto fetch_tile = [&](int t) {
-            const int img = t / (tiles_y * tiles_x);
+            const int img = __builtin_amdgcn_readfirstlane(t / (tiles_y * tiles_x));
             const int rem = t - img * tiles_y * tiles_x;
-            const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+            const int y0 = __builtin_amdgcn_readfirstlane((rem / tiles_x) * TH), x0 = __builtin_amdgcn_readfirstlane((rem % tiles_x) * TW);
+            const int ty = y0 - S.off_y, tx = x0 - S.off_x;
+            const int arel = (int)(ty * S.sH + tx * S.sW);              // tile origin inside the image (elements; < 2^31: the host checks)
+            const float* ab = sp + (long)img * S.sN + arel;            // wave-uniform
             aok = 0;
 #pragma unroll
             for (int i = 0; i < WAIT; ++i) {
-                const int px = (ptid + 256 * i) >> 4;
-                const int ly = y0 + (px >> 4) - S.off_y, lx = x0 + (px & 15) - S.off_x;
-                const bool ok = ly >= 0 && ly < S.LH && lx >= 0 && lx < S.LW;
-                av[i] = *(const f32x4*)(sp + img * S.sN + (long)(ok ? ly : 0) * S.sH + (long)(ok ? lx : 0) * S.sW);
+                const bool ok = (unsigned)(ty + apy[i]) < (unsigned)S.LH && (unsigned)(tx + apx[i]) < (unsigned)S.LW;
+                av[i] = *(const f32x4*)(ab + (ok ? aoff[i] : -arel));      // (outside the image: its first pixel, masked at the split)
                 aok |= (ok ? 1u : 0u) << i;
             }
+            const int drel = ((y0 - 1) * a.dyW + (x0 - 1)) * a.Cout;
+            const float* db = dyp + (long)img * a.dyH * a.dyW * a.Cout + drel;
 #pragma unroll
             for (int i = 0; i < WDIT; ++i) {
-                const int hp = (ptid + 256 * i) >> 4;
-                const int hy = hp / HW2, hx = hp - hy * HW2;
-                const int ly = y0 - 1 + hy, lx = x0 - 1 + hx;
-                const bool ok = hp < HP && ly >= 0 && ly < a.dyH && lx >= 0 && lx < a.dyW;
-                dv[i] = *(const f32x4*)(dyp + (((long)img * a.dyH + (ok ? ly : 0)) * a.dyW + (ok ? lx : 0)) * a.Cout);
+                const bool ok = (unsigned)(y0 - 1 + dhy[i]) < (unsigned)a.dyH && (unsigned)(x0 - 1 + dhx[i]) < (unsigned)a.dyW;
+                dv[i] = *(const f32x4*)(db + (ok ? doff[i] : -drel));
                 aok |= (ok ? 1u : 0u) << (8 + i);
             }
         };
@@ -875,7 +892,9 @@ bool wgrad_x3_supported(const WgradArgs& a) {
         const SrcDev& s = a.src[i];
         if (s.esz != 4 || s.sC != 1 || (s.C & 3) || s.pool) return false;
         if ((s.sN | s.sH | s.sW) & 3) return false;
+        if (s.sN >= (1L << 31) - 64 || (s.H + 8L) * s.sH >= (1L << 31) - 64) return false;      // 32-bit element offsets inside an image
     }
+    if ((long)(a.dyH + 8) * a.dyW * a.Cout >= (1L << 31) - 64) return false;
     return true;
 }
 
