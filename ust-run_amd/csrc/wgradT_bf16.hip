@@ -282,8 +282,21 @@ template <int TM> struct T2 {
     static constexpr int NT = 4;                             // du fragments (8 co x 4 taps each) per wave
 };
 
-template <int TM>
-__global__ __launch_bounds__(2 * TM, 2) void wgradT2_bf16_kernel(const WgradArgs a, const int ntn) {
+// DIAG (a development build, launched only while ustrun_debug_buffer is set; tools/diag_wgradT.py): phase stamps per wave into
+// dbg[block][wave 0..7][8] -- cycles (s_memtime) summed over the stages: 0 issuing the transfers two stages ahead, 1 fragment reads +
+// MFMAs, 2 the counted wait for the next stage, 3 its activation in place, 4 the barrier; 5 = stages.  Measured (1024 -> 512 at 16 x
+// 16, N = 64, per 32-pixel stage and wave): 646 / 1197 / 103 / 722 / 387 cycles -- the 16 MFMAs' phase is pipe-bound (two waves per
+// SIMD: 1024), everything else runs with the waves in step and nothing multiplying.  Tried on that evidence, both without effect
+// (0.568 ms over the four layers either way): the stage's transfers issued one by one between the MFMAs; two 128-ci blocks per CU.
+__device__ __forceinline__ unsigned long long stamp_t2() {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+template <int TM, bool DIAG = false>
+__global__ __launch_bounds__(2 * TM, 2) void wgradT2_bf16_kernel(const WgradArgs a, const int ntn, unsigned long long* __restrict__ dbg = nullptr) {
     typedef T2<TM> G;
     constexpr int ARB = G::ARB, ATILE = G::ATILE, STAGE = G::STAGE, AIT = G::AIT, BIT = G::BIT, WN = G::WN, NT = G::NT, NTH = G::NTH;
     constexpr int OOB = (int)0x80000000;
@@ -434,10 +447,13 @@ __global__ __launch_bounds__(2 * TM, 2) void wgradT2_bf16_kernel(const WgradArgs
         activate(st[0], kbeg);
     }
     __syncthreads();
+    unsigned long long dsum[5] = {0, 0, 0, 0, 0}, d0 = 0, d1 = 0;
 #pragma unroll 1
     for (int s = 0; s < nstage; ++s) {
         const bool issue = s + 2 < nstage;
+        if constexpr (DIAG) d0 = stamp_t2();
         if (issue) issue_stage(st[2]);
+        if constexpr (DIAG) { d1 = stamp_t2(); dsum[0] += d1 - d0; d0 = d1; }
 #pragma unroll
         for (int kk = 0; kk < KP2 / 16; ++kk) {
             bf16x8 af[2], bf[NT];
@@ -457,17 +473,25 @@ __global__ __launch_bounds__(2 * TM, 2) void wgradT2_bf16_kernel(const WgradArgs
                 for (int j = 0; j < NT; ++j) acc[i][j] = USTRUN_MFMA_32x32x16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DIAG) { d1 = stamp_t2(); dsum[1] += d1 - d0; d0 = d1; }
         if (s + 1 < nstage) {
             if (issue) wait_all_but_one_stage();
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (DIAG) { d1 = stamp_t2(); dsum[2] += d1 - d0; d0 = d1; }
             const long m1 = kbeg + (long)(s + 1) * KP2;
             load_consts(m1);
             activate(st[1], m1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (DIAG) { d1 = stamp_t2(); dsum[3] += d1 - d0; d0 = d1; }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (DIAG) { d1 = stamp_t2(); dsum[4] += d1 - d0; }
         { char* tmp = st[0]; st[0] = st[1]; st[1] = st[2]; st[2] = tmp; }
+    }
+    if constexpr (DIAG) {
+        if (lane == 0 && dbg)
+            for (int k = 0; k < 8; ++k) dbg[((long)blockIdx.x * 8 + wave) * 8 + k] = k < 5 ? dsum[k] : (k == 5 ? (unsigned long long)nstage : 0ull);
     }
 
     // slab in the torch layout [Cin][Cout][2][2]: rows of D are ci (registers); lane 16 g + 4 tap + c is column (co, tap)
@@ -561,12 +585,17 @@ int wgradT_launch_bf16(const WgradArgs& a, hipStream_t st) {
     if (tm) {
         dim3 grid((a.Cin / tm) * (a.Cout / 64) * a.ksplit), block(2 * tm);
         set_last_wgrad_variant(0x54320000 | tm);                   // 'T2' | ci tile
-        if (tm == 256) {
+        unsigned long long* dbg = nullptr;
+        USTRUN_TRY(debug_buffer_for((long)grid.x, "wgradT2", &dbg));
+        if (tm == 256 && dbg) {                  // ustrun_debug_buffer set: the stamped build (tools/diag_wgradT.py)
+            USTRUN_TRY(ensure_dynamic_lds((const void*)wgradT2_bf16_kernel<256, true>, 3 * T2<256>::STAGE, "wgradT2_bf16"));
+            hipLaunchKernelGGL((wgradT2_bf16_kernel<256, true>), grid, block, 3 * T2<256>::STAGE, st, a, a.Cout / 64, dbg);
+        } else if (tm == 256) {
             USTRUN_TRY(ensure_dynamic_lds((const void*)wgradT2_bf16_kernel<256>, 3 * T2<256>::STAGE, "wgradT2_bf16"));
-            hipLaunchKernelGGL(wgradT2_bf16_kernel<256>, grid, block, 3 * T2<256>::STAGE, st, a, a.Cout / 64);
+            hipLaunchKernelGGL((wgradT2_bf16_kernel<256>), grid, block, 3 * T2<256>::STAGE, st, a, a.Cout / 64, (unsigned long long*)nullptr);
         } else {
             USTRUN_TRY(ensure_dynamic_lds((const void*)wgradT2_bf16_kernel<128>, 3 * T2<128>::STAGE, "wgradT2_bf16"));
-            hipLaunchKernelGGL(wgradT2_bf16_kernel<128>, grid, block, 3 * T2<128>::STAGE, st, a, a.Cout / 64);
+            hipLaunchKernelGGL((wgradT2_bf16_kernel<128>), grid, block, 3 * T2<128>::STAGE, st, a, a.Cout / 64, (unsigned long long*)nullptr);
         }
         USTRUN_LAUNCH_CHECK("wgradT2_bf16");
         return 0;
