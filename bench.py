@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event roofline leg")
     ap.add_argument("--dump-layers", default="", help="write every tagged launch class (layer, op, images) of the sampled steps to this JSON file")
+    ap.add_argument("--dump-full", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="the FULL result (per-layer roofline tables, every secondary field) goes to this file; stdout carries "
+                         "only the compact line (\"\" = no file)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` entries (the other BASELINE.json shapes, the f32 parity path, DeepLabV2-ResNet101 @512^2)")
     return ap.parse_args()
@@ -278,15 +281,76 @@ def spawn_ranks(a):
 
 
 PARITY_NOTE = {
-    "bf16": "value is the bf16 path (bf16 operands and stored activations, f32 accumulate): logits within 3e-2 rel-L2 and <= 2 % "
-            "arg-max flips of the reference fixtures (tests/test_gpu_unet.py); the north_star's 1e-4 / bit-exact arg-max "
-            "tolerance is met by dtypes f32 and f32x3 -- their rates are the first two `secondary` entries; the fp16 + loss-scale path (the "
-            "reference's --amp arithmetic: 5e-3 rel-L2, <= 0.3 % flips) is the `secondary` entry with dtype f16",
-    "f16": "dtype f16: fp16 operands and stored activations, f32 accumulate, dynamic loss scale with GradScaler's schedule -- "
-           "the reference's --amp arithmetic; logits within 5e-3 rel-L2 and <= 0.3 % arg-max flips of the reference fixtures",
-    "f32": "dtype f32: the exact parity path (1e-4 rel, arg-max bit-exact outside 1e-6 margins)",
-    "f32x3": "dtype f32x3: f32 tensors, convolution products as six bf16 MFMAs over three-term operand splits: the reference's "
-             "full-size logits to 3e-6 rel-L2, arg-max flips only at margins < 3e-6 (tests/test_gpu_unet.py) -- the north_star tolerance"}
+    "bf16": "bf16 operands + stored activations, f32 accumulate: logits <= 3e-2 rel-L2, <= 2 % arg-max flips vs the reference "
+            "fixtures; the north_star's 1e-4 / bit-exact arg-max bar is met by f32 and f32x3 (secondary[0,1]); secondary[2] = "
+            "f16 + loss scale, the reference's --amp arithmetic (5e-3, <= 0.3 %)",
+    "f16": "f16 operands + stored activations, f32 accumulate, GradScaler's loss-scale schedule (the reference's --amp): logits "
+           "<= 5e-3 rel-L2, <= 0.3 % arg-max flips vs the reference fixtures",
+    "f32": "the exact parity path (1e-4 rel, arg-max bit-exact outside 1e-6 margins)",
+    "f32x3": "f32 tensors, products as six bf16 MFMAs over three-term splits: reference logits to 3e-6 rel-L2, arg-max flips only "
+             "at margins < 3e-6 -- the north_star tolerance"}
+
+
+LINE_LIMIT = 6000          # characters of the ONE stdout line (the driver parses a bounded tail of stdout: VERDICT r5, weak 1)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact_line(out):
+    """The ONE JSON line the driver parses, from the full result dict: headline fields, `config`, `roofline` (scalars, the
+    weight-gradient class, the two DoubleConv blocks the north_star names, the traffic fields), `cpu_baseline`, a short
+    `parity_note`, and `secondary` reduced to workload / dtype / ms / images per s / class fractions.  The per-layer tables
+    (`roofline.layers`, `layers_bwd`) never travel on this line: they go to --dump-full / --dump-layers files and stderr."""
+    o = {k: v for k, v in out.items() if k not in ("roofline", "cpu_baseline", "secondary", "parity_note")}
+    r = out.get("roofline")
+    if r is not None:
+        c = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_ms",
+                      "alg_flops_per_launch", "alg_bytes_per_launch", "time_share_of_step", "clock_mhz", "sustained_peak",
+                      "frac_sustained", "traffic_per_step", "alg_bytes_per_step_all_streams", "traffic_ratio_by_totals"))
+        for k in ("alg_flops_per_launch", "alg_bytes_per_launch", "alg_bytes_per_step_all_streams"):
+            if k in c:
+                c[k] = float(f"{c[k]:.5g}")
+        if r.get("wgrad"):
+            c["wgrad"] = _pick(r["wgrad"], ("achieved", "unit", "frac", "traffic", "time_share_of_step", "traffic_ratio_by_totals"))
+        if r.get("doubleconv"):
+            c["doubleconv"] = [_pick(b, ("block", "op", "images", "ms", "gbps", "frac_hbm", "frac_mfma")) for b in r["doubleconv"]]
+        if r.get("traffic_note"):
+            c["traffic_note"] = "profiles/traffic file is of another library build: dropped"
+        if r.get("layers_file"):
+            c["layers_file"] = r["layers_file"]
+        o["roofline"] = c
+    else:
+        o["roofline"] = None
+    b = out.get("cpu_baseline")
+    if b is not None:
+        c = _pick(b, ("value", "unit", "cores", "kind", "sample", "cpu", "step_seconds"))
+        if b.get("one_thread"):
+            c["one_thread_extrapolated"] = b["one_thread"].get("value")
+        o["cpu_baseline"] = c
+    else:
+        o["cpu_baseline"] = None
+    o["parity_note"] = out.get("parity_note")
+    if "secondary" in out:
+        sec = []
+        for s in out["secondary"]:
+            e = _pick(s, ("workload", "dtype", "ms_per_step", "images_per_s", "peak_mem_gib"))
+            if "error" in s:
+                e["error"] = s["error"][:120]
+            for cls in ("conv", "wgrad"):
+                if cls in s.get("roofline", {}):
+                    e[cls + "_frac"] = s["roofline"][cls]["frac"]
+            sec.append(e)
+        o["secondary"] = sec
+    line = json.dumps(o, allow_nan=False)
+    if len(line) > LINE_LIMIT:         # never print a line the driver cannot parse: shed the optional parts, largest first
+        for k in ("secondary", "parity_note"):
+            o.pop(k, None)
+            line = json.dumps(o, allow_nan=False)
+            if len(line) <= LINE_LIMIT:
+                break
+    return line
 
 
 def held_clock_mhz(pa, pb, nb):
@@ -486,7 +550,16 @@ def main():
             out["secondary"] = secondary_runs(dev, lib)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.dataset)
-        print(json.dumps(out), flush=True)
+        if a.dump_full:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(a.dump_full)), exist_ok=True)
+                with open(a.dump_full, "w") as f:
+                    json.dump(out, f)
+                if out["roofline"] is not None:
+                    out["roofline"]["layers_file"] = os.path.relpath(a.dump_full, ROOT)
+            except OSError as e:
+                print(f"[bench] --dump-full {a.dump_full}: {e}", file=sys.stderr, flush=True)
+        print(compact_line(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -172,3 +172,42 @@ def test_statistics_rows_never_exceed_the_published_bound():
     assert lib.ustrun_debug_conv_stat_rows(64, 18, 18, 1024, 1024, 3, 1, 1, 0, L.BF16) == -(-64 * 19 * 19 // 256) <= lib.ustrun_conv_mtiles(64, 18, 18, 1024)
     # ... and not for a grid of a few blocks (one validation image): the 8 x 16 rectangular tile's rows
     assert lib.ustrun_debug_conv_stat_rows(1, 18, 18, 1024, 1024, 3, 1, 1, 0, L.BF16) == 3 * 2
+
+
+def test_bench_prints_one_compact_parseable_line():
+    """VERDICT r5 weak 1 / ADVICE r5: the driver parses a bounded tail of stdout, so the line bench.py prints is built by
+    compact_line() from the full result and must stay small, strict JSON, and carry `roofline` + `cpu_baseline` -- checked on
+    a RECORDED full result of a real run (profiles/r05c_bench.json: 21 KB with the per-layer tables)."""
+    import importlib.util
+    import json
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05c_bench.json")))
+    assert len(json.dumps(full)) > 15000 and "layers_bwd" in full["roofline"]
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line) < bench.LINE_LIMIT <= 6000
+    got = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))     # no NaN / Infinity
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in got, k
+    assert got["value"] == full["value"] and got["ms_per_step"] == full["ms_per_step"]
+    r = got["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "wgrad", "doubleconv"):
+        assert k in r, k
+    assert "layers" not in r and "layers_bwd" not in r
+    assert {b["block"] for b in r["doubleconv"]} == {"inc", "up4.conv"}
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in got["cpu_baseline"], k
+    assert len(got["secondary"]) == len(full["secondary"])
+    assert all("images_per_s" in s and "conv_frac" in s for s in got["secondary"])
+    # a result that would still be too long sheds its optional parts instead of printing an unparseable line
+    fat = dict(full, secondary=full["secondary"] * 40)
+    line2 = bench.compact_line(fat)
+    assert len(line2) < bench.LINE_LIMIT and "roofline" in json.loads(line2) and "cpu_baseline" in json.loads(line2)
+    # a non-finite number must fail loudly here, not at the driver
+    import pytest
+    with pytest.raises(ValueError):
+        bench.compact_line(dict(full, value=float("nan")))

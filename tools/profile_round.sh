@@ -5,7 +5,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profile_round
 mkdir -p $O
 cd $R
-timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err
+timeout -k 10 400 python bench.py --dump-full $O/bench_full.json > $O/bench.json 2> $O/bench.err
+wc -c $O/bench.json
 tail -c 600 $O/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 8 --warmup 2 --no-secondary --no-cpu-baseline > $O/kt.log 2>&1
