@@ -383,6 +383,25 @@ def test_leading_passes_without_gradient(dtype, base, n, hw, passes, lead, tail)
     print("leading passes: worst relative gradient difference against the zero-fed full backward %.2e" % worst)
 
 
+def test_leading_passes_with_features():
+    """forward_batched(lead > 0, feature=True) takes the pass-by-pass route; every pass returns (logits, feat) and the
+    result is the per-component concatenation -- equal to the passes run one after the other."""
+    import copy
+    from networks.unet_model import UNet
+    torch.manual_seed(31)
+    m1 = UNet(3, 2, base_channels=16, dtype="f32").cuda().train()
+    m2 = copy.deepcopy(m1)
+    x = torch.randn(2 * 3 + 1, 3, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
+    lg, ft = m1.forward_batched(x, 3, tail=1, feature=True, lead=1)
+    assert lg.shape == (6, 2, 32, 32) and ft.shape == (6, 16, 32, 32)
+    with torch.no_grad():
+        l0, f0 = m2(x[:2], True)
+    l1, f1 = m2.forward_passes([x[2:4], x[4:6]], True, tail=x[6:])
+    assert torch.equal(lg.detach(), torch.cat([l0, l1.detach()])) and torch.equal(ft.detach(), torch.cat([f0, f1.detach()]))
+    for (k, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        assert torch.equal(b1, b2), k
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_linear_tiles_in_the_network(dtype):
     """configs[3]'s shape (M&Ms 288^2, 4 classes, 8 + 8: train_mnms.py:397-399) as the step calls the student: one leading pass
@@ -443,7 +462,10 @@ def test_linear_tiles_in_the_network(dtype):
 @pytest.mark.parametrize("dtype,base,n,hw,passes,tail,exact", [("bf16", 64, 4, 64, 4, 1, False), ("f16", 32, 3, 128, 2, 2, True),
                                                                ("f32", 16, 2, 40, 3, 1, True), ("bf16", 64, 2, 256, 4, 1, False),
                                                                ("bf16", 16, 3, 72, 1, 1, True), ("bf16", 64, 16, 128, 4, 1, False),
-                                                               ("f32x3", 64, 2, 64, 3, 1, True)])
+                                                               ("f32x3", 64, 2, 64, 3, 1, True),
+                                                               # a tail whose own row split needs MORE stage-1 blocks than
+                                                               # the equal passes' (4 x 50 rows -> 29 splits, 3 x 50 -> 30; 5 x 72 -> 30, 4 x 72 -> 32)
+                                                               ("bf16", 32, 4, 80, 2, 3, False), ("bf16", 32, 5, 96, 1, 4, False)])
 def test_tail_pass_equals_a_call_of_its_own(dtype, base, n, hw, passes, tail, exact):
     """`passes` equal forward passes with a shorter tail pass behind them in ONE call (ustrun_unet_desc_t::tail -- the reference's
     low-quality-sample forward, train.py:740, riding behind the student's four gradient passes) against the same passes as

@@ -99,13 +99,15 @@ def test_driver_command_lines_keep_the_reference_flags_and_defaults():
 
 
 def test_amp_flag_selects_the_precision_like_the_reference():
-    """train.py:54,551-552,842-847: `--amp 1` (the default) = fp16 autocast + GradScaler, `--amp 0` = fp32.  Here: --amp 1 ->
-    the IEEE-half build with the device-side loss scale, --amp_dtype bf16 -> bfloat16, --amp 0 -> the exact f32 path;
-    --backend_dtype overrides."""
+    """train.py:54,551-552,842-848: `--amp 1` (the default) = fp16 autocast + GradScaler, `--amp 0` = fp32.  Here: --amp 1 ->
+    the IEEE-half build with the device-side loss scale, --amp_dtype bf16 -> bfloat16, --amp 0 -> the exact path: f32 tensors
+    with three-term products on the matrix cores for the U-Net (f32x3, VERDICT r5 next 7), the f32-MFMA path for DeepLabV2;
+    --backend_dtype overrides (f32 stays reachable)."""
     T = _load_driver("train")
     dt = lambda *argv: T.compute_dtype(T.parser.parse_args(list(argv)))
-    assert dt() == "f16" and dt("--amp", "1") == "f16" and dt("--amp", "0") == "f32"
-    assert dt("--amp_dtype", "bf16") == "bf16" and dt("--amp", "0", "--amp_dtype", "bf16") == "f32"
+    assert dt() == "f16" and dt("--amp", "1") == "f16" and dt("--amp", "0") == "f32x3"
+    assert dt("--amp", "0", "--model", "deeplabv2") == "f32" and dt("--amp", "0", "--backend_dtype", "f32") == "f32"
+    assert dt("--amp_dtype", "bf16") == "bf16" and dt("--amp", "0", "--amp_dtype", "bf16") == "f32x3"
     assert dt("--backend_dtype", "bf16") == "bf16" and dt("--amp", "0", "--backend_dtype", "f16") == "f16"
 
 

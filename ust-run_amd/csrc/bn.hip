@@ -19,10 +19,8 @@ namespace {
 __global__ __launch_bounds__(256) void bn_stat_stage1_kernel(float* stat, int rows, int C, int R, int passes, BnTail tail) {
     __shared__ double red[2][8][32];
     stat += (long)blockIdx.z * rows * 2 * C;            // blockIdx.z = forward pass (its own rows)
-    if ((int)blockIdx.z == passes) {                    // the tail pass
-        rows = tail.rows; R = tail.R;
-        if ((int)blockIdx.y * R >= rows) return;
-    }
+    if ((int)blockIdx.z == passes) { rows = tail.rows; R = tail.R; }      // the tail pass: its own rows and split
+    if ((int)blockIdx.y * R >= rows) return;            // (grid.y covers the larger of the two split counts)
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl, r0 = blockIdx.y * R, r1 = min(rows, r0 + R);
     double s1 = 0.0, s2 = 0.0;
@@ -878,7 +876,10 @@ int bn_finalize_passes(float* stat, int mtiles, int passes, int C, int64_t count
             USTRUN_LAUNCH_CHECK("bn_stat_fused");
             return 0;
         }
-        hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, cdiv(mtiles, R), passes + (tail.R > 0 ? 1 : 0)), dim3(256), 0, s,
+        // the tail's split is its own (fewer rows, smaller R): it can need MORE y-blocks than the equal passes (ADVICE r5:
+        // 144 rows -> R 5 -> 29 blocks, a 96-row tail -> R 3 -> 32), so the grid covers both and each block checks its range
+        const int ysplits = std::max(cdiv(mtiles, R), tail.R > 0 ? cdiv(tail.rows, tail.R) : 0);
+        hipLaunchKernelGGL(bn_stat_stage1_kernel, dim3(C / 32, ysplits, passes + (tail.R > 0 ? 1 : 0)), dim3(256), 0, s,
                            (float*)stat, mtiles, C, R, passes, tail);
         USTRUN_LAUNCH_CHECK("bn_stat_stage1");
         hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3(C / 32), dim3(1024), 0, s, stat, mtiles, C, (double)count, R, gamma,

@@ -128,6 +128,7 @@ static int check_srcs(const ustrun_src_t* srcs, int nsrc, const char* who) {
 
 // ---- several forward passes batched into one call (ustrun_src_t::gN): the fast bf16 kernels pick the BatchNorm
 // constants per image; every other kernel is run once per pass on the corresponding slices -------------------------
+namespace ustrun { thread_local bool g_short_last_pass = false; }
 static int src_groups(const ustrun_src_t* srcs, int nsrc, int N, int* gN) {
     int g = 0;
     for (int i = 0; i < nsrc; ++i)
@@ -137,7 +138,10 @@ static int src_groups(const ustrun_src_t* srcs, int nsrc, int N, int* gN) {
         }
     *gN = g;
     if (g == 0) return 1;
-    return (N + g - 1) / g;         // (the last pass may be shorter: ustrun_unet_desc_t::tail)
+    // a shorter last pass exists only where the caller DECLARED one (ustrun_unet_desc_t::tail -> ShortLastPass in unet.hip, which
+    // sized a (G+1)-th constants table for it); a mis-sized batch through the operator API is an error, not a tail
+    if (N % g != 0 && !g_short_last_pass) return -1;
+    return (N + g - 1) / g;
 }
 static inline int pass_images(int g, int gN, int N) { return N - g * gN < gN ? N - g * gN : gN; }
 static ustrun_src_t src_slice(const ustrun_src_t& s, int g, int gN, int dtype) {

@@ -283,6 +283,7 @@ extern "C" int ustrun_unet_pack(const ustrun_unet_desc_t* d, ustrun_stream_t s) 
 extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, float* logits, float* feat,
                                    void* workspace, ustrun_stream_t s) {
     Plan p; USTRUN_TRY(make_plan(d, p));
+    ShortLastPass declared_tail(p.T > 0);
     USTRUN_CHECK(x && logits && workspace && d->packed, "unet_forward: null pointer");
     char* ws = (char*)workspace;
     const float* pk = (const float*)d->packed;
@@ -394,6 +395,7 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
                                          void* scratch, float* const* grads, int accumulate, int which, ustrun_stream_t s) {
     USTRUN_CHECK(which >= 0 && which <= 4, "unet_backward: part %d", which);
     Plan p; USTRUN_TRY(make_plan(d, p));
+    ShortLastPass declared_tail(p.T > 0);
     USTRUN_CHECK(x && dlogits && workspace && scratch && grads && d->packed, "unet_backward: null pointer");
     USTRUN_CHECK(d->train, "unet_backward: forward must have run in train mode");
     const char* ws = (const char*)workspace;

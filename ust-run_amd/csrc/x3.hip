@@ -839,7 +839,7 @@ bool igemm_x3_supported(const IgemmArgs& a) {
     if (a.nsrc == 2 && a.src[0].C % XBK) return false;             // a chunk never straddles the two sources
     for (int i = 0; i < a.nsrc; ++i) {
         const SrcDev& s = a.src[i];
-        if (s.esz != 4 || s.sC != 1 || (s.C & 3) || s.pool || s.gN > 0) return false;
+        if (s.esz != 4 || s.sC != 1 || (s.C & 3) || s.pool) return false;     // (batched passes, gN > 0: the halo-tiled kernel only -- igemm.hip)
         if ((s.sN | s.sH | s.sW) & 3) return false;                // 16-byte loads
     }
     return true;

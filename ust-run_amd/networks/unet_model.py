@@ -68,11 +68,13 @@ class UNet(nn.Module):
             raise RuntimeError(f"forward_batched: {len(x)} images are not {groups} equal passes + a shorter tail of {tail}")
         if self.bilinear or lead and feature:
             parts = list(x[:n * groups].split(n))
-            with torch.no_grad():
-                head = [self._forward_blocks(t, False) if self.bilinear else self(t) for t in parts[:lead]]
+            with torch.no_grad():           # (with `feature` every pass returns (logits, feat): concatenated per component)
+                head = [self._forward_blocks(t, feature) if self.bilinear else self(t, feature) for t in parts[:lead]]
             rest = self.forward_passes(parts[lead:], feature, tail=x[n * groups:] if tail else None)
             if not lead:
                 return rest
+            if feature:
+                return tuple(torch.cat([h[k] for h in head] + [rest[k]], 0) for k in range(2))
             return torch.cat(head + [rest], 0)
         from ustrun import engine
         return engine.unet_forward(self, x, feature, groups=groups, tail=tail, lead=lead)

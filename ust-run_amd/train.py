@@ -65,7 +65,7 @@ parser.add_argument('--amp_dtype', default='fp16', choices=['fp16', 'bf16'],
                     help="storage / matrix-core type under --amp 1: 'fp16' = the reference's torch.cuda.amp autocast + GradScaler "
                          "(train.py:30,551-552,842-845: IEEE half, dynamic loss scale on the device), 'bf16' = bfloat16, no loss scale")
 parser.add_argument('--backend_dtype', default='', choices=['', 'f32', 'f32x3', 'bf16', 'f16'],
-                    help="explicit override of what --amp / --amp_dtype select ('' = follow them; --amp 0 = f32, the exact path)")
+                    help="explicit override of what --amp / --amp_dtype select ('' = follow them; --amp 0 = f32x3 for the U-Net, f32 for DeepLabV2: the exact paths)")
 parser.add_argument('--fft', default='device', choices=['host', 'device'])
 parser.add_argument('--data_root', type=str, default='../../data')
 parser.add_argument('--log_every', type=int, default=50)
@@ -80,7 +80,13 @@ def compute_dtype(args):
     autocast with a GradScaler; --amp 0 is its fp32 path (train.py:551-552,842-847)."""
     if args.backend_dtype:
         return args.backend_dtype
-    return {"fp16": "f16", "bf16": "bf16"}[args.amp_dtype] if args.amp else "f32"
+    if args.amp:
+        return {"fp16": "f16", "bf16": "bf16"}[args.amp_dtype]
+    # --amp 0, the reference's fp32 branch (train.py:846-848): f32 tensors throughout.  For the U-Net the convolutions' products
+    # run as three-term bf16 splits on the matrix cores (f32x3: the reference's logits to 3e-6 rel-L2, arg-max flips only at
+    # margins < 3e-6 -- the same bars as `f32`, at ~3x its rate); the f32-MFMA path stays reachable as --backend_dtype f32 and is
+    # what DeepLabV2 (no x3 kernels for its 1x1 / dilated / strided convolutions) takes
+    return "f32x3" if args.model == "unet" else "f32"
 
 
 def make_loaders(args, C, H, dev=None):
