@@ -407,6 +407,16 @@ int ustrun_conv2d_wgrad(const ustrun_src_t* srcs, int nsrc, const void* dy, int 
 /* weight gradient of ustrun_conv_rowwin_fwd: dw[Cout][src->C][nrows] (the layout its weights were packed from)               */
 int ustrun_conv_rowwin_wgrad(const ustrun_src_t* src, const void* dy, int N, int Ho, int Wo, int Cout, int nrows, int stride, float* dw,
                              int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s);
+/* the input gradient of a bottleneck's conv1 (1x1, stride 1: resnet.py:87-89 under autograd) with the residual join that follows it
+ * in the backward, in one launch: g[N,H,W,Cin] = (dy (*) w_dgrad + add) * (ref > 0) -- what ustrun_conv2d_fwd over dy followed by
+ * ustrun_relu_bwd_add computes, rounding included (add / ref may be NULL as there) -- and, with y != NULL, the BatchNorm-backward
+ * sums of the layer whose OUTPUT gradient g is (a BatchNorm that no ReLU follows: the previous block's bn3, resnet.py:96) as
+ * *stat_rows rows of [2][Cin] = {sum(g), sum(g y)} for ustrun_bn_bwd_finalize_stat (stat: ustrun_conv_mtiles(N, H, W, Cin) rows).
+ * *fused = 0 and NO launch when the shape is not covered (16-bit storage, Cin % 128 == 0, Cout % 64 == 0): the caller then runs
+ * the three separate calls.                                                                                                   */
+int ustrun_conv1x1_dgrad_join(const void* dy, const void* w_dgrad, int N, int H, int W, int Cout, int Cin, const void* add,
+                              const void* ref, void* g, const void* y, float* stat, int* stat_rows, int* fused, int dtype,
+                              ustrun_stream_t s);
 /* gradient of the bottleneck's join with respect to its pre-ReLU sum: g = (a + b) * (ref > 0) over n elements (n % 4 == 0);
  * b = NULL: one contribution, ref = NULL: no ReLU (the max-pool output feeding layer1)                                       */
 int ustrun_relu_bwd_add(const void* a, const void* b, const void* ref, int64_t n, void* g, int dtype, ustrun_stream_t s);
@@ -485,8 +495,16 @@ int ustrun_debug_flags(int flags);
  * bit 0 (1): the halo-tiled 3x3 kernel never runs on its linear tiles (round 5: maps with 18 / 24 / 36 / 72-pixel rows; DESIGN.md
  *   10.9) -- the rectangular tile of the padding rule instead (A/B runs, and the tests that pin those tiles).
  * bit 1 (2): dtype USTRUN_F32X3 launches its halo-tiled convolution and its weight gradient once per pass of a batched call, as
- *   before they took the pass's constants per image (A/B runs).                                                        */
+ *   before they took the pass's constants per image (A/B runs).
+ * bit 2 (4): the 64 -> 64 streaming kernel keeps its uniform strip split (round 6: the flat plan gives every block the same number
+ *   of row steps at any image count) -- A/B runs.
+ * bit 3 (8): ustrun_conv1x1_dgrad_join never fuses (*fused = 0) -- A/B runs and the tests of the unfused path.                 */
 int ustrun_debug_flags2(int flags);
+/* Operator-level declaration (per calling thread; returns the previous value): while `allow` is nonzero, the convolution entry
+ * points accept a batch whose LAST pass is shorter than ustrun_src_t::gN (N % gN != 0 -- the caller then owns a constants table of
+ * ceil(N / gN) entries and splits the statistics rows accordingly).  Otherwise N % gN != 0 is an error ("inconsistent pass
+ * groups"): a mis-sized batch is not a tail.  ustrun_unet_forward / _backward set it themselves from ustrun_unet_desc_t::tail.   */
+int ustrun_short_last_pass(int allow);
 /* development aid: while a device buffer is set here (per calling thread), the 64 -> 64 streaming kernel and the two-group
  * all-taps weight gradient run their phase-stamping diagnostic builds and write per-wave cycle sums there as
  * [workgroup][8 waves][8] u64 = 64 u64 per workgroup (tools/ab_ws64.py --diag, tools/diag_wgrad.py).  n_u64 = the buffer's

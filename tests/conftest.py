@@ -24,3 +24,47 @@ def load_golden(name):
 @pytest.fixture
 def golden():
     return load_golden
+
+
+# ---- the default GPU set vs. the full one (`pytest -m gpu` must finish well inside the driver's step limit) ----
+# USTRUN_TEST_FULL=1 runs every case.  The default leaves out (reported as SKIPPED, with this reason) only cases that re-run a kernel
+# some other default case already pins bit-exactly:
+#   * builds no product path launches (debug-flag variants kept for A/B runs: the first convolution's kernels of rounds 1-4, the
+#     four- / eight-wave builds of the 64 -> 64 streaming kernel, the 512-pixel tile, the "old_*" weight-gradient builds);
+#   * the IEEE-half compile of a SOURCE-IDENTICAL kernel (the same .hip built with elt_t = _Float16) beyond a core set per family
+#     -- every family keeps at least one f16 case, and the f16 path as a whole is pinned by the golden / oracle / trajectory tests.
+# No SURVEY.md 8 row loses its oracle / golden test: those tests are never in the extended set.
+FULL = os.environ.get("USTRUN_TEST_FULL", "0") == "1"
+_F16_CORE_TILES = {"tall_wide_128", "cat_128_to_64", "bottleneck_n64", "c64_wide", "mid_grid_512", "ws64_ragged", "ws64f_ragged", "pad_48_512",
+                   "m16_tall_wide_128", "m16all_tall_wide_128", "lin_36_512", "plain_lin_24_512"}
+
+
+def extended_only(item):
+    """True: the case runs only with USTRUN_TEST_FULL=1 (see above)."""
+    cs = getattr(item, "callspec", None)
+    if cs is None:
+        return False
+    p = cs.params
+    fn = getattr(item, "originalname", item.name)
+    if fn == "test_conv_first_bf16_mfma_exact":
+        return p["flags"] != 0 or (p["elt"] == "f16" and not p["with_stat"])
+    if fn == "test_conv_first_weight_gradient_exact":
+        return p["flags"] != 0 or (p["elt"] == "f16" and p["h"] * p["w"] * p["n"] < 4000)
+    if fn == "test_production_tile_exact":
+        name = p["case"][0]
+        if name.startswith(("ws64w4", "ws64w8", "t512_")):
+            return True
+        return p.get("elt") == "f16" and name not in _F16_CORE_TILES
+    if fn in ("test_convT_weight_gradient_round5_kernel_exact", "test_wgrad_all_taps_builds_exact"):
+        name = p["name"] if "name" in p else p["case"][0]
+        return name.startswith("old_") or (p.get("elt") == "f16" and name not in ("t256_w16", "t128_w36", "pp_512", "buf_cat_64_64"))
+    return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if FULL:
+        return
+    skip = pytest.mark.skip(reason="extended set: run with USTRUN_TEST_FULL=1 (tests/conftest.py)")
+    for it in items:
+        if extended_only(it):
+            it.add_marker(skip)

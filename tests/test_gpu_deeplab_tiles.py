@@ -111,6 +111,68 @@ def _conv1x1_production_tiles(ci, co, want):
     np.testing.assert_allclose(stat[:used.value, 1].double().sum(0).cpu().numpy(), stored.double().square().sum((0, 2, 3)).numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("cw,cx,n,h,w,has_add,has_ref,has_y,bn", [
+    (256, 1024, 4, 64, 64, True, True, True, 256),     # layer3's conv1 under autograd: 256-column tiles (256 row tiles x 4 column tiles)
+    (128, 512, 2, 33, 35, True, True, True, 128),      # ragged last row tile, 128-column tiles
+    (64, 256, 2, 40, 24, True, False, False, 128),     # behind the max-pool: no ReLU in between, no BatchNorm sums
+    (512, 2048, 1, 16, 20, False, True, True, 128)])   # the head's gradient through the last block's ReLU: one contribution
+def test_conv1x1_dgrad_join_exact(dt, cw, cx, n, h, w, has_add, has_ref, has_y, bn):
+    """ustrun_conv1x1_dgrad_join (round 6): the input gradient of a bottleneck's conv1 with the residual join in the GEMM's epilogue
+    and the BatchNorm-backward sums of the previous block's bn3 from the stored pieces -- against torch-CPU on integer data (exact),
+    against the three separate calls it replaces (bit-identical output), the kernel that ran asserted, outputs between sentinels."""
+    l = L()
+    lib = l.lib()
+    t16 = torch.bfloat16 if dt == 1 else torch.float16
+    g = torch.Generator().manual_seed(cw + cx + h)
+    ri = lambda lo, hi, *s_: torch.randint(lo, hi + 1, s_, generator=g).float()
+    dy = ri(-1, 1, n, cw, h, w)
+    wt = ri(-1, 1, cw, cx, 1, 1)                       # conv1's weight [Cout = cw][Cin = cx]
+    add, ref, y3 = ri(-3, 3, n, cx, h, w), ri(-1, 1, n, cx, h, w), ri(-3, 3, n, cx, h, w)
+    want = F.conv_transpose2d(dy, wt)                  # the 1x1 input gradient
+    assert float(want.abs().max()) + 3 < 2 ** 8        # sums and the join stay exact in both 16-bit types
+    if has_add:
+        want = want + add
+    if has_ref:
+        want = want * (ref > 0)
+    to = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda().to(t16)
+    wd = torch.zeros(lib.ustrun_pack_conv_elems(cx, cw, 1), dtype=t16, device="cuda")
+    wtt = wt.flip(2, 3).transpose(0, 1).contiguous().cuda()
+    l.check(lib.ustrun_pack_conv(wtt.data_ptr(), cx, cw, 1, wd.data_ptr(), dt, None))
+    dyg, addg, refg, y3g = to(dy), to(add), to(ref), to(y3)
+    out, oflat = guarded(torch.zeros(n, h, w, cx, device="cuda", dtype=t16), 7.0)
+    rows_max = lib.ustrun_conv_mtiles(n, h, w, cx)
+    stat, sflat = guarded(torch.zeros(rows_max, 2, cx, device="cuda"), 7.0)
+    rows, fused = C.c_int(0), C.c_int(0)
+    l.check(lib.ustrun_conv1x1_dgrad_join(dyg.data_ptr(), wd.data_ptr(), n, h, w, cw, cx, addg.data_ptr() if has_add else None,
+                                          refg.data_ptr() if has_ref else None, out.data_ptr(), y3g.data_ptr() if has_y else None,
+                                          stat.data_ptr() if has_y else None, C.byref(rows), C.byref(fused), dt, None), "join")
+    assert fused.value == 1
+    assert lib.ustrun_debug_last_conv_variant() == (ct_variant(bn, 64, 2, True) | 0x4000 | (0x2000 if has_y else 0)), hex(lib.ustrun_debug_last_conv_variant())
+    got = from_nhwc(out)
+    assert torch.equal(got, want)
+    assert guards_intact(oflat, out.numel(), 7.0) and guards_intact(sflat, stat.numel(), 7.0)
+    if has_y:
+        assert rows.value == -(-n * h * w // 128) <= rows_max
+        np.testing.assert_allclose(stat[:rows.value, 0].double().sum(0).cpu().numpy(), want.double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+        np.testing.assert_allclose(stat[:rows.value, 1].double().sum(0).cpu().numpy(), (want * y3).double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+    # the unfused path (ustrun_debug_flags2 bit 3 declines the fusion): the same bits from conv2d_fwd + relu_bwd_add
+    old2 = lib.ustrun_debug_flags2(8)
+    try:
+        l.check(lib.ustrun_conv1x1_dgrad_join(dyg.data_ptr(), wd.data_ptr(), n, h, w, cw, cx, addg.data_ptr() if has_add else None,
+                                              refg.data_ptr() if has_ref else None, out.data_ptr(), None, None, None, C.byref(fused), dt, None), "join")
+        assert fused.value == 0
+    finally:
+        lib.ustrun_debug_flags2(old2)
+    src = l.nhwc_src(dyg.data_ptr(), cw, h, w)
+    dxa = torch.empty(n, h, w, cx, device="cuda", dtype=t16)
+    l.check(lib.ustrun_conv2d_fwd(C.byref(src), 1, wd.data_ptr(), None, n, h, w, cx, 1, 1, 1, dxa.data_ptr(), 0, None, None, dt, None), "dgrad")
+    g2 = torch.empty_like(dxa)
+    l.check(lib.ustrun_relu_bwd_add(dxa.data_ptr(), addg.data_ptr() if has_add else None, refg.data_ptr() if has_ref else None, dxa.numel(),
+                                    g2.data_ptr(), dt, None), "join pass")
+    assert torch.equal(g2, out)
+
+
 def wt_variant(tm, tn, loader, ksplit):
     return 0x54000000 | (tm // 64) << 20 | (tn // 64) << 16 | loader << 12 | ksplit
 

@@ -109,7 +109,8 @@ def convT_layer(lib, n, ci, co, h, w, reps):
 def ab_flags(a, lib):
     """the conv3x3 layers under each debug-flag value, interleaved (rule 24): median of --rounds rounds per (layer, flag)"""
     import numpy as np
-    flags = [int(v) for v in a.flags.split(",")]
+    flags = a.flags.split(",")          # each "F" or "F:F2" = (ustrun_debug_flags, ustrun_debug_flags2)
+    pair = lambda f: (int(f.split(":")[0]), int(f.split(":")[1]) if ":" in f else 0)
     S = a.hw
     layers = [("inc.2   64->64", 64, 64, S, False, False)]
     c, s = 64, S
@@ -131,9 +132,9 @@ def ab_flags(a, lib):
         res = {f: [] for f in flags}
         for r in range(3):
             for f in flags:
-                lib.ustrun_debug_flags(f)
+                lib.ustrun_debug_flags(pair(f)[0]); lib.ustrun_debug_flags2(pair(f)[1])
                 res[f].append(conv_layer(lib, a.n, ci, co, hw, hw, pool, cat, a.reps))
-        lib.ustrun_debug_flags(0)
+        lib.ustrun_debug_flags(0); lib.ustrun_debug_flags2(0)
         cells = []
         for f in flags:
             fl = res[f][0][0]

@@ -40,10 +40,16 @@ __device__ __forceinline__ int fastmod(int v, int d, float inv) {      // v mod 
 // fragments of its 64 columns straight from L2 into registers one stage (two k-steps = 4 MI MFMAs) ahead -- no weight
 // tile in LDS, no LDS-DMA beside the compiler-visible activation loads (which made hipcc drain vmcnt(0) at every chunk) -- and the
 // waves share only the activation tile: one barrier per 64-channel chunk.
-template <int BN, int BK, int MODE, bool BREG, bool BNS = false>
+// JOIN (round 6, MODE 2 only): the 1x1 GEMM is the input gradient of a bottleneck's conv1 (DeepLabV2-ResNet backward, reference
+// networks/backbone/resnet.py:87-105 under autograd) and its epilogue performs the residual join that followed it as a pass of its
+// own: stored = (product + join_add) * (join_ref > 0) -- the gradient of the previous block's pre-ReLU sum -- and, with BNS, the two
+// BatchNorm-backward sums of that block's bn3 (sum(g), sum(g y3): a.bnsc = 0, a.bnsh = 1 make the mask all ones) from the stored
+// pieces.  7 tensor passes over the widest maps of the network become 4.
+template <int BN, int BK, int MODE, bool BREG, bool BNS = false, bool JOIN = false>
 __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, const int mt_total, const int nt_total) {
     constexpr bool DG = MODE == 1, PLAIN = MODE == 2;
-    static_assert(!BNS || DG, "BatchNorm-backward sums ride on the input gradient's epilogue");
+    static_assert(!BNS || DG || JOIN, "BatchNorm-backward sums ride on an input gradient's epilogue");
+    static_assert(!JOIN || PLAIN, "the residual join rides on the 1x1 GEMM");
     static_assert(!BREG || BK == 64, "register-fed weights: two stages of two k-steps per chunk");
     constexpr int BM = 128;
     constexpr int WN = BN / 64, WM = 4 / WN, MI = BM / (32 * WM);
@@ -319,15 +325,30 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     // statistics row per 128-pixel tile (the tile lies inside one pass: the launcher checks) -- conv_halo_bf16.hip, same idea
     float bsc[8], bsh[8];
     __amdgpu_buffer_rsrc_t yrs = ors;
+    if constexpr (BNS && JOIN) {        // a BatchNorm that no ReLU follows (bn3): every position counts
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bsc[q] = 0.f; bsh[q] = 1.f; }
+    }
     if constexpr (BNS) {
+        if constexpr (!JOIN) {
         const long go = a.bn_gN > 0 ? (long)(m0 / (a.bn_gN * a.Hb * a.Wb)) * a.bn_gstride : 0;
         const float* ps = a.bnsc + go + colw + ch * 8;
         const float* pb = a.bnsh + go + colw + ch * 8;
         const f32x4 s0 = *(const f32x4*)ps, s1_ = *(const f32x4*)(ps + 4), b0 = *(const f32x4*)pb, b1 = *(const f32x4*)(pb + 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { bsc[q] = s0[q]; bsc[4 + q] = s1_[q]; bsh[q] = b0[q]; bsh[4 + q] = b1[q]; }
+        }
         yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((elt_t*)a.bny + o_base), 0, (int)(o_left < 0x7fffffffL ? o_left : 0x7fffffffL), 0x00020000);
     }
+    // JOIN: the other contribution and the ReLU reference beside every stored piece (same layout as the output; a null tensor
+    // reads through a zero-length resource: zeros, and "no reference" means no mask)
+    __amdgpu_buffer_rsrc_t jars = ors, jrrs = ors;
+    if constexpr (JOIN) {
+        const int left = (int)(o_left < 0x7fffffffL ? o_left : 0x7fffffffL);
+        jars = __builtin_amdgcn_make_buffer_rsrc((void*)(a.join_add ? (elt_t*)a.join_add + o_base : (elt_t*)a.out0), 0, a.join_add ? left : 0, 0x00020000);
+        jrrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.join_ref ? (elt_t*)a.join_ref + o_base : (elt_t*)a.out0), 0, a.join_ref ? left : 0, 0x00020000);
+    }
+    const bool j_mask = JOIN && a.join_ref != nullptr;
     __syncthreads();                              // every wave is done with the activation tiles the scratch aliases
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -348,10 +369,19 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = r0 + 8 * t;
-            const bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
+            bf16x8 v8 = *(const bf16x8*)(ep + row * EPITCH + ch * 16);
             const int d = d0 + 8 * t;
             const bool ok = m0 + d < a.M;
             const int vo = (DG || PLAIN) ? (d * a.Cout + ch * 8) * 2 : ((4 * d - 2 * x + 2 * W) * a.Cout + ch * 8) * 2;
+            if constexpr (JOIN) {       // (the unfused pair rounds the product to the storage type, adds in f32 and rounds again: so does this)
+                const bf16x8 b8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(jars, ok ? vo : OOBV, 0, 0));
+                const bf16x8 r8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(jrrs, ok ? vo : OOBV, 0, 0));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float g = (float)v8[q] + (float)b8[q];
+                    v8[q] = (elt_t)((!j_mask || (float)r8[q] > 0.f) ? g : 0.f);
+                }
+            }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v8), ors, ok ? vo : OOBV, 0, 0);
             if constexpr (BNS) {
                 const bf16x8 y8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(yrs, ok ? vo : OOBV, 0, 0));
@@ -362,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
                     st1[q] += dz; st2[q] += dz * yf;
                 }
             }
-            if constexpr (PLAIN) {                  // statistics see the stored values; rows past M are not counted
+            if constexpr (PLAIN && !BNS) {          // statistics see the stored values; rows past M are not counted
                 if (a.stat) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) { const float f = ok ? (float)v8[q] : 0.f; st1[q] += f; st2[q] += f * f; }
@@ -402,15 +432,15 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     }
 }
 
-template <int BN, int BK, int MODE, bool BREG = false, bool BNS = false>
+template <int BN, int BK, int MODE, bool BREG = false, bool BNS = false, bool JOIN = false>
 int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const int ncols = MODE == 0 ? 4 * a.Cout : a.Cout;
     const int mt = cdiv(a.M, 128), nt = ncols / BN;
     const size_t lds_a = 2 * (size_t)128 * BK * 2, lds_ep = 4 * 32 * 144;
     const size_t lds = BREG ? (lds_a > lds_ep ? lds_a : lds_ep) : lds_a + 2 * (size_t)(BK / 8) * BN * 16;
     dim3 grid(mt * nt), block(256);
-    set_last_variant(0x43540000 | (BREG ? 0x1000 : 0) | (BN / 32) << 8 | (BK / 32) << 4 | MODE);   // 'CT' | register-fed weights | BN/32 | BK/32 | MODE (tests)
-    hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, MODE, BREG, BNS>), grid, block, lds, st, a, mt, nt);
+    set_last_variant(0x43540000 | (JOIN ? 0x4000 : 0) | (BNS ? 0x2000 : 0) | (BREG ? 0x1000 : 0) | (BN / 32) << 8 | (BK / 32) << 4 | MODE);   // 'CT' | join | sums | register-fed weights | BN/32 | BK/32 | MODE (tests)
+    hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, MODE, BREG, BNS, JOIN>), grid, block, lds, st, a, mt, nt);
     USTRUN_LAUNCH_CHECK("convT_bf16");
     return 0;
 }
@@ -467,6 +497,20 @@ int conv1x1_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     if (a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 256) return old ? launch_cfg<256, 32, 2>(a, st) : launch_cfg<256, 64, 2, true>(a, st);
     if (a.Cout % 128 == 0) return old ? launch_cfg<128, 64, 2>(a, st) : launch_cfg<128, 64, 2, true>(a, st);
     return old ? launch_cfg<64, 64, 2>(a, st) : launch_cfg<64, 64, 2, true>(a, st);
+}
+// the 1x1 GEMM with the residual join in its epilogue (and, with a.bny, the BatchNorm-backward sums of the stored gradient): a plain
+// source, 128-column tiles, one statistics row per 128-pixel tile
+bool conv1x1_join_supported(const IgemmArgs& a) {
+    if (!conv1x1_supported(a) || (g_debug_flags & 512) || a.Cout % 128 || a.bias) return false;
+    if (a.src[0].scale || a.src[0].relu) return false;
+    return (long)a.M * a.Cout < (1L << 30);          // (32-bit byte offsets behind a tile base)
+}
+int conv1x1_join_launch_bf16(const IgemmArgs& a, hipStream_t st) {
+    USTRUN_CHECK(conv1x1_join_supported(a) && (a.join_add || a.join_ref), "conv1x1_join: unsupported shape");
+    USTRUN_CHECK(!a.bny || a.stat, "conv1x1_join: BatchNorm-backward sums need their statistics rows");
+    const bool wide = a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 256;
+    if (a.bny) return wide ? launch_cfg<256, 64, 2, true, true, true>(a, st) : launch_cfg<128, 64, 2, true, true, true>(a, st);
+    return wide ? launch_cfg<256, 64, 2, true, false, true>(a, st) : launch_cfg<128, 64, 2, true, false, true>(a, st);
 }
 // the input gradient that also forms the BatchNorm-backward sums of the layer whose da it writes (a.bny set): one statistics row per
 // 128-pixel tile; the register-fed builds only, tiles inside one pass

@@ -45,12 +45,18 @@ constexpr int NR = (GITEMS + 255) / 256;       // staging rounds per group: 9 (t
 
 __device__ __attribute__((aligned(16))) const unsigned g_zero16w[4] = {0u, 0u, 0u, 0u};
 
-struct WsPlan { int sx, sy, seg, items, ipb; unsigned long long* dbg; };
+// Uniform plan: every strip is cut into sy segments of seg rows, item = (image, segment, strip), ipb items per block.
+// Flat plan (L > 0; the consumer / producer build only): the strips' 8-row steps form ONE sequence of N * sx * steps steps and
+// block b takes steps [b L, (b + 1) L) of it, whatever strips they fall in -- equal work per block at ANY image count (81 images of
+// 256^2: 648 strips over 256 CUs are 3 rounds of items with the last one half empty, but 81 steps per block exactly).  L >= steps,
+// so a strip is cut at most once: item slot = 2 strip + (the piece does not start at the strip's first row).
+struct WsPlan { int sx, sy, seg, items, ipb, L, steps; unsigned long long* dbg; };
 
 template <int V> using ic = std::integral_constant<int, V>;
 
 struct Cur {            // one group of 8 input rows of one item (or nothing)
     int valid, item, img, x0, ybeg, S, k;
+    int left;           // flat plan: steps of the block's range behind this item
 };
 
 // One iteration u of a block's group sequence (groups = 8 input rows of an item, S + 1 per item):
@@ -748,10 +754,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
     const int img_bytes = (int)(S.sN * 2), out_bytes = H * W * 128;
 
     // ---- cursors over the block's sequence of groups (all eight waves keep them: the trip count must agree) ----
+    const bool flat = p.L > 0;
     const int it0 = blockIdx.x * p.ipb, it1 = min(it0 + p.ipb, p.items);
     auto decode = [&](int item, int k) __attribute__((always_inline)) {
         Cur c;
-        c.valid = item < it1; c.k = k;
+        c.k = k; c.left = 0;
+        if (flat) {             // the block's first piece: wherever step blockIdx.x * L falls
+            const int total = a.N * p.sx * p.steps;
+            const int pos = blockIdx.x * p.L, end = min(pos + p.L, total);
+            const int strip = pos / p.steps, st = pos - strip * p.steps;
+            c.valid = pos < end;
+            c.img = strip / p.sx;
+            c.x0 = (strip - c.img * p.sx) * TW;
+            c.ybeg = st * 8;
+            c.S = max(min(p.steps - st, end - pos), 1);
+            c.left = max(end - pos - c.S, 0);
+            c.item = strip * 2 + (st != 0 ? 1 : 0);
+            return c;
+        }
+        c.valid = item < it1;
         item = min(item, it1 - 1);
         c.item = item;
         const int per = p.sx * p.sy;
@@ -769,6 +790,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
     auto advance = [&](const Cur& c) __attribute__((always_inline)) {
         Cur n = c;
         const bool same = c.k < c.S;
+        if (flat) {             // the next piece starts at the next strip's first row and ends with the strip or with the block's range
+            const bool has = c.left > 0;
+            int x0 = c.x0 + TW, img = c.img;
+            const bool wrapx = x0 >= p.sx * TW;
+            x0 = wrapx ? 0 : x0;
+            img = wrapx ? img + 1 : img;
+            const int S = min(p.steps, c.left);
+            if (same) n.k = c.k + 1;
+            else if (has) { n.item = (c.item | 1) + 1; n.img = img; n.x0 = x0; n.ybeg = 0; n.S = S; n.left = c.left - S; n.k = 0; }
+            else { n.valid = 0; n.k = 0; }
+            return c.valid ? n : c;
+        }
         const int item = min(c.item + 1, it1 - 1);
         const bool has = c.item + 1 < it1;
         int x0 = c.x0 + TW, ybeg = c.ybeg, img = c.img;
@@ -975,14 +1008,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
     auto piece_off = [&](int HF, int tt, const Cur& c, bool live) __attribute__((always_inline)) {
         const int i = 2 * HF + (tt >> 1), px = 16 * (tt & 1) + pp;
         const int y = c.ybeg + 8 * (c.k - 1) + 4 * wm + i;
-        const int ylim = min(c.ybeg + p.seg, H);
+        const int ylim = min(c.ybeg + 8 * c.S, H);        // the item's rows (uniform plan: seg = 8 S but for an image's last segment)
         const bool inimg = live & (y < ylim) & (c.x0 + px < W);
         return inimg ? (unsigned)(st_lane + (tt & 1) * 2048 + __builtin_amdgcn_readfirstlane(c.img * out_bytes + (y * W + c.x0) * 128)) : 0x80000000u;
     };
     auto epi_B = [&](int HF, int tt, const Cur& c, bool live, int set = 0) __attribute__((always_inline)) {
         const int i = 2 * HF + (tt >> 1), px = 16 * (tt & 1) + pp;
         const int y = c.ybeg + 8 * (c.k - 1) + 4 * wm + i;
-        const int ylim = min(c.ybeg + p.seg, H);
+        const int ylim = min(c.ybeg + 8 * c.S, H);        // the item's rows (uniform plan: seg = 8 S but for an image's last segment)
         u32x4 u = *(const u32x4*)(Ew + (i * 32 + px) * EPITCH + o * 16);
         const bool inimg = live & (y < ylim) & (c.x0 + px < W);
         // (row offset in the vector offset, soffset 0: see the four-wave kernel's epi_B)
@@ -1028,6 +1061,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
                 *(f32x4*)(row + 4) = (f32x4){s1[4], s1[5], s1[6], s1[7]};
                 *(f32x4*)(row + 64) = (f32x4){s2[0], s2[1], s2[2], s2[3]};
                 *(f32x4*)(row + 68) = (f32x4){s2[4], s2[5], s2[6], s2[7]};
+                if (flat && c.ybeg == 0 && c.S == p.steps) {        // a strip nobody cut: its second slot's rows are zeros, written here
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    float* row1 = row + 2 * 2 * 64;
+                    *(f32x4*)row1 = z; *(f32x4*)(row1 + 4) = z; *(f32x4*)(row1 + 64) = z; *(f32x4*)(row1 + 68) = z;
+                }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -1105,7 +1143,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64cp_kernel(const IgemmArgs 
     }
 }
 
-// segments per strip: whole waves of blocks over the 256 CUs, few bubbles (one staging-only iteration per item)
+// which build serves a launch (conv3x3_ws64_launch_bf16): the consumer / producer waves unless a debug flag forces another
+static bool ws_cp_build() { return (g_debug_flags & 32) ? true : (g_debug_flags & (16 | 4 | 2)) ? false : true; }
+
+// segments per strip: whole waves of blocks over the 256 CUs, few bubbles (one staging-only iteration per item) -- or, where that
+// leaves a round of items half empty, the flat plan (WsPlan): equal step counts per block
 WsPlan ws_plan(const IgemmArgs& a) {
     WsPlan p;
     p.sx = cdiv(a.Wb, TW);
@@ -1123,8 +1165,20 @@ WsPlan ws_plan(const IgemmArgs& a) {
     p.seg = cdiv(steps, p.sy) * 8;
     p.items = a.N * p.sx * p.sy;
     p.ipb = (p.items + 255) / 256;
+    p.L = 0; p.steps = steps;
     p.dbg = nullptr;
+    // the flat plan: L steps per block, its range touching at most cdiv(L - 1, steps) + 1 strips (ustrun_debug_flags2 bit 2 keeps
+    // the uniform plan: A/B runs)
+    const long total = (long)a.N * p.sx * steps;
+    const int L = (int)((total + 255) / 256);
+    if (ws_cp_build() && !(g_debug_flags2 & 4) && L >= steps && total < (1L << 30)) {
+        const double cost = L + 1.5 * (cdiv(L - 1, steps) + 1);
+        if (cost < 0.97 * best) p.L = L;
+    }
     return p;
+}
+static int ws_grid(const IgemmArgs& a, const WsPlan& p) {
+    return p.L > 0 ? (int)cdiv((long)a.N * p.sx * p.steps, (long)p.L) : cdiv(p.items, p.ipb);
 }
 
 }  // namespace
@@ -1142,7 +1196,8 @@ bool ws64_supported(const IgemmArgs& a) {
     return p.items >= 192;              // smaller problems (the batch-1 forward): the tiled kernel fills the chip better
 }
 
-int ws64_stat_rows(const IgemmArgs& a) { return ws_plan(a).items * 2; }
+// two rows (one per consumer-wave pair) per item; flat plan: per slot, two slots per strip
+int ws64_stat_rows(const IgemmArgs& a) { const WsPlan p = ws_plan(a); return p.L > 0 ? a.N * p.sx * 4 : p.items * 2; }
 
 // can the streaming kernel's input gradient also form the BatchNorm-backward sums of the layer whose da it writes?
 bool ws64_bnsum_supported(const IgemmArgs& a) {
@@ -1154,7 +1209,7 @@ bool ws64_bnsum_supported(const IgemmArgs& a) {
 
 int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     WsPlan p = ws_plan(a);
-    const int grid = cdiv(p.items, p.ipb);
+    const int grid = ws_grid(a, p);
     USTRUN_TRY(debug_buffer_for(grid, "conv3x3_ws64_bf16", &p.dbg));     // set: the DIAG build runs and writes [block][wave][8] u64 there
     bool xf = false;
     set_last_variant(0x57530000 | ((a.src[0].scale != nullptr || a.src[0].relu != 0) ? 1 : 0));     // 'WS' | XF
@@ -1170,7 +1225,9 @@ int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     // hides half as many of them.  debug flag bit 1 forces four waves everywhere, bit 2 eight waves everywhere.
     const bool eight = (g_debug_flags & 4) ? true : (g_debug_flags & 2) ? false : !(xf || a.stat);
     // consumer / producer waves (round 3, second form): debug flag bit 4 forces it off, bit 5 on everywhere
-    const bool cpw = (g_debug_flags & 32) ? true : (g_debug_flags & (16 | 4 | 2)) ? false : true;
+    const bool cpw = ws_cp_build();
+    USTRUN_CHECK(cpw || p.L == 0, "conv3x3_ws64: the flat plan belongs to the consumer / producer build");
+    const int flatbit = p.L > 0 ? 0x800 : 0;          // variant code: | 0x800 = flat plan
     if (cpw && p.dbg) {          // stamped build: [block][wave 0..7][8] u64 (0/2: work of the two segments, 1/3: waits at B1 / B2, 5: iterations)
         USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<true, true, true>, LDSBCP, "conv3x3_ws64cp_bf16 (diag)"));
         USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<false, false, true>, LDSBCP, "conv3x3_ws64cp_bf16 (diag)"));
@@ -1181,14 +1238,14 @@ int conv3x3_ws64_launch_bf16(const IgemmArgs& a, hipStream_t st) {
     }
     if (a.bny) {                  // input gradient + BatchNorm-backward sums: the consumer / producer build only (ws64_bnsum_supported)
         USTRUN_CHECK(cpw && !p.dbg && !xf && a.stat && a.bnsc && a.bnsh, "conv3x3_ws64: BatchNorm-backward sums need the plain consumer / producer build");
-        set_last_variant(0x57530000 | 0x200 | 0x400);                 // 'WS' | consumer/producer | sums
+        set_last_variant(0x57530000 | 0x200 | 0x400 | flatbit);                 // 'WS' | consumer/producer | sums
         USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<false, false, false, true>, LDSBCP, "conv3x3_ws64cp_bf16"));
         hipLaunchKernelGGL((conv3x3_ws64cp_kernel<false, false, false, true>), dim3(grid), dim3(512), LDSBCP, st, a, p);
         USTRUN_LAUNCH_CHECK("conv3x3_ws64cp_bf16");
         return 0;
     }
     if (cpw && !p.dbg) {
-        set_last_variant(0x57530000 | 0x200 | (xf ? 1 : 0));       // 'WS' | consumer/producer | XF
+        set_last_variant(0x57530000 | 0x200 | flatbit | (xf ? 1 : 0));       // 'WS' | consumer/producer | XF
         USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<true, true>, LDSBCP, "conv3x3_ws64cp_bf16"));
         USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<true, false>, LDSBCP, "conv3x3_ws64cp_bf16"));
         USTRUN_TRY(ensure_dynamic_lds((const void*)conv3x3_ws64cp_kernel<false, true>, LDSBCP, "conv3x3_ws64cp_bf16"));

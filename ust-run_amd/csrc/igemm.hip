@@ -303,14 +303,16 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     const double w_elems = (double)a.nseg * a.nz * a.Cin * a.Cout;
     const double aesz = dtype == USTRUN_D16 ? 2.0 : 4.0;     // stored element size of activations and packed weights
     // (an input gradient that also forms the BatchNorm-backward sums reads y beside every output element it stores)
-    const double y_elems = a.bny ? out_elems : 0.0;
+    const double y_elems = (a.bny ? out_elems : 0.0) + (a.join_add ? out_elems : 0.0) + (a.join_ref ? out_elems : 0.0);
     prof_begin(0, 2.0 * a.M * a.nz * a.Cout * a.nseg * a.Cin, aesz * (in_elems + out_elems + y_elems + w_elems), st);
     int rc;
     bool grouped = false;
     for (int i = 0; i < a.nsrc; ++i) grouped |= a.src[i].gN > 0;
     USTRUN_CHECK(!grouped || dtype == USTRUN_D16 || (dtype == USTRUN_F32X3 && conv3x3_x3_supported(a)),
                  "igemm: batched passes reached a kernel without per-pass BatchNorm constants");
-    if (dtype == USTRUN_D16) {
+    if (dtype == USTRUN_D16 && (a.join_add || a.join_ref)) {
+        rc = conv1x1_join_launch_bf16(a, st);
+    } else if (dtype == USTRUN_D16) {
         if (!(g_debug_flags & 1) && ws64_supported(a)) rc = conv3x3_ws64_launch_bf16(a, st);
         else if (halo_supported(a)) rc = conv3x3_halo_launch_bf16(a, st);
         else if (convT_fwd_supported(a)) rc = convT_fwd_launch_bf16(a, st);

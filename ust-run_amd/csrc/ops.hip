@@ -182,6 +182,7 @@ extern "C" int ustrun_debug_buffer(void* device_u64, int64_t n_u64) {
 }
 extern "C" int ustrun_debug_flags(int flags) { const int old = g_debug_flags; g_debug_flags = flags; return old; }
 extern "C" int ustrun_debug_flags2(int flags) { const int old = g_debug_flags2; g_debug_flags2 = flags; return old; }
+extern "C" int ustrun_short_last_pass(int allow) { const int old = g_short_last_pass; g_short_last_pass = allow != 0; return old; }
 
 // ---- clock probe (tools/clock_probe.py; MI355X_MICROARCH.md "DVFS give-back" item 6): every workgroup records the shader-clock
 // counter (s_memtime: one tick per shader cycle) and the constant 100 MHz counter (s_memrealtime) together with where it ran.

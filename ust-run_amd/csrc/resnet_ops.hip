@@ -337,6 +337,42 @@ extern "C" int ustrun_conv2d_fwd(const ustrun_src_t* srcs, int nsrc, const void*
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
 
+// The input gradient of a bottleneck's conv1 (1x1, stride 1) with the residual join that follows it in the backward, in ONE launch:
+//   g = (dy (*) w_dgrad + add) * (ref > 0)         [N,H,W,Cin]; add / ref may be NULL (one contribution / no ReLU in between)
+// and, with y, the BatchNorm-backward sums of the layer whose OUTPUT gradient g is (a BatchNorm no ReLU follows: the previous block's
+// bn3) as rows of [2][Cin] = {sum(g), sum(g y)} per 128 pixels, for ustrun_bn_bwd_finalize_stat.  *fused = 0 and NO launch when the
+// shape is not covered: the caller then runs ustrun_conv2d_fwd, ustrun_relu_bwd_add and ustrun_bn_bwd_reduce.
+extern "C" int ustrun_conv1x1_dgrad_join(const void* dy, const void* w_dgrad, int N, int H, int W, int Cout, int Cin, const void* add,
+                                         const void* ref, void* g, const void* y, float* stat, int* stat_rows, int* fused, int dtype,
+                                         ustrun_stream_t s) {
+    USTRUN_CHECK(dy && w_dgrad && g && fused && N > 0 && H > 0 && W > 0 && Cout > 0 && Cin > 0, "conv1x1_dgrad_join: bad args");
+    USTRUN_CHECK(!y || (stat && stat_rows), "conv1x1_dgrad_join: the sums need their rows");
+    *fused = 0;
+    if (stat_rows) *stat_rows = 0;
+    if (dtype != USTRUN_D16 || (!add && !ref) || (g_debug_flags2 & 8)) return 0;         // (ustrun_debug_flags2 bit 3: never fused, A/B runs)
+    IgemmArgs a = {};
+    ustrun_src_t sd = {};
+    sd.ptr = dy; sd.C = Cout; sd.H = H; sd.W = W;
+    sd.sC = 1; sd.sW = Cout; sd.sH = (int64_t)W * Cout; sd.sN = (int64_t)H * W * Cout;
+    a.nsrc = 1; a.src[0] = make_src(sd, dtype); a.Cin = Cout;
+    a.W = (const float*)w_dgrad; a.Cout = Cin;
+    a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
+    a.s_in = 1; a.nseg = 1; a.segw = 1; a.d0 = 0; a.dstep = 1;
+    a.nz = 1; a.s_out = 1;
+    a.out0 = (float*)g; a.C0 = Cin; a.Ho = H; a.Wo = W; a.out_esz = 2;
+    if (!conv1x1_join_supported(a)) return 0;
+    a.join_add = add; a.join_ref = ref;
+    if (y) {
+        a.bny = y; a.stat = stat;
+        const int used = cdiv(a.M, 128);
+        USTRUN_TRY(stat_rows_within_bound(used, N, H, W, Cin, "conv1x1_dgrad_join"));
+        *stat_rows = used;
+    }
+    USTRUN_TRY(igemm_launch(a, dtype, (hipStream_t)s));
+    *fused = 1;
+    return 0;
+}
+
 // A k x k convolution over few input channels as `nrows` row segments: with an NHWC source of C channels, the k horizontally
 // adjacent pixels of one kernel row are k * C CONTIGUOUS elements, so the caller describes the source with "channels" = that
 // window (rounded up to a multiple of 8: the extra elements meet zero weights), pixel stride = C elements, and a border it has

@@ -55,7 +55,10 @@ __device__ __forceinline__ int fdiv(int v, int d, float invd, int& rem) {
 // grid = (ci tiles * co tiles * taps * ksplit)
 // SWAP (1x1 convolutions): the MFMA operands trade places, D rows are co and its lanes ci, so the slab comes out as [co][ci] --
 // the torch layout of a 1x1 weight -- and the fixed-order streaming sum finishes it without a transposing pass.
-template <int TM, int TN, bool PLAIN, bool SWAP>
+// AFF (round 6): the source carries BatchNorm constants / a ReLU.  A finished activation (AFF = false) skips the f32 round trip of
+// every staged item -- ~40 VALU instructions per 16-byte item, which each of the Cout / TN column tiles (and each of the nine taps)
+// repeated on the same values and which, not the MFMAs, paced the stage (8 VALU per MFMA in the SQ counters).
+template <int TM, int TN, bool PLAIN, bool SWAP, bool AFF>
 __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs a, const int mtn, const int ntn) {
     constexpr int RBA = TM * 2, RBB = TN * 2;                 // LDS row pitches (bytes)
     constexpr int AQ = TM / 8, AROWS = 256 / AQ, AP = KP / AROWS;      // 16-byte items per row, rows per pass, passes
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
     const SrcDev& S = a.src[0];
     const int c8 = tid % AQ;
     const int cl = ci0 + 8 * c8;
-    const bool aff = S.scale != nullptr;
+    const bool aff = AFF && S.scale != nullptr;
     f32x4 asc0 = {1.f, 1.f, 1.f, 1.f}, asc1 = asc0, ash0 = {0.f, 0.f, 0.f, 0.f}, ash1 = ash0;
     if (aff) {
         asc0 = *(const f32x4*)(S.scale + cl); asc1 = *(const f32x4*)(S.scale + cl + 4);
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tap_bf16_kernel(const WgradArgs 
             const int row = arow + AROWS * i;
             const bool ok = (aok >> i) & 1u;
             bf16x8 h = av[i];
-            {   // branch-free: identity constants (1, 0, floor = -inf) for a finished activation -- bf16 -> f32 -> bf16 is exact
+            if constexpr (AFF) {
                 f32x4 lo = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]} * asc0 + ash0;
                 f32x4 hi = (f32x4){(float)h[4], (float)h[5], (float)h[6], (float)h[7]} * asc1 + ash1;
 #pragma unroll
@@ -300,16 +303,21 @@ int wgrad_tap_plan(const WgradArgs& a, int* ksplit, long* kchunk) {
     return 0;
 }
 
-template <int TM, int TN>
-static int launch_tile(const WgradArgs& a, hipStream_t st) {
+template <int TM, int TN, bool AFF>
+static int launch_tile_aff(const WgradArgs& a, hipStream_t st) {
     const int mtn = a.Cin / TM, ntn = a.Cout / TN;
     dim3 grid(mtn * ntn * a.nseg * a.ksplit), block(256);
     constexpr int lds = 2 * KP * (TM + TN) * 2;
-    if (pixel_linear(a)) hipLaunchKernelGGL((wgrad_tap_bf16_kernel<TM, TN, true, true>), grid, block, lds, st, a, mtn, ntn);
-    else if (a.nseg == 1) hipLaunchKernelGGL((wgrad_tap_bf16_kernel<TM, TN, false, true>), grid, block, lds, st, a, mtn, ntn);
-    else hipLaunchKernelGGL((wgrad_tap_bf16_kernel<TM, TN, false, false>), grid, block, lds, st, a, mtn, ntn);
+    if (pixel_linear(a)) hipLaunchKernelGGL((wgrad_tap_bf16_kernel<TM, TN, true, true, AFF>), grid, block, lds, st, a, mtn, ntn);
+    else if (a.nseg == 1) hipLaunchKernelGGL((wgrad_tap_bf16_kernel<TM, TN, false, true, AFF>), grid, block, lds, st, a, mtn, ntn);
+    else hipLaunchKernelGGL((wgrad_tap_bf16_kernel<TM, TN, false, false, AFF>), grid, block, lds, st, a, mtn, ntn);
     USTRUN_LAUNCH_CHECK("wgrad_tap_bf16");
     return 0;
+}
+template <int TM, int TN>
+static int launch_tile(const WgradArgs& a, hipStream_t st) {
+    const bool aff = a.src[0].scale != nullptr || a.src[0].relu;
+    return aff ? launch_tile_aff<TM, TN, true>(a, st) : launch_tile_aff<TM, TN, false>(a, st);
 }
 
 thread_local int g_last_wgrad_variant = 0;     // (per calling thread)
@@ -319,7 +327,7 @@ void set_last_wgrad_variant(int v) { g_last_wgrad_variant = v; }
 int wgrad_tap_launch_bf16(const WgradArgs& a, hipStream_t st) {
     const int tm = tile_m(a), tn = tile_n(a);
     // 'T' | TM/64 | TN/64 | loader (2 = pixel-linear 1x1, 1 = one tap, 0 = taps) | ksplit   (tests: ustrun_debug_last_wgrad_variant)
-    g_last_wgrad_variant = 0x54000000 | (tm / 64) << 20 | (tn / 64) << 16 | (pixel_linear(a) ? 2 : (a.nseg == 1 ? 1 : 0)) << 12 | (a.ksplit & 0xfff);
+    g_last_wgrad_variant = 0x54000000 | (tm / 64) << 20 | (tn / 64) << 16 | (pixel_linear(a) ? 2 : (a.nseg == 1 ? 1 : 0)) << 12 | (a.ksplit & 0xfff);       // (ksplit < 2^11 by the plan)
     if (tm == 128 && tn == 128) return launch_tile<128, 128>(a, st);
     if (tm == 128) return launch_tile<128, 64>(a, st);
     if (tn == 128) return launch_tile<64, 128>(a, st);

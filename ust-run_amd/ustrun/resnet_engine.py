@@ -17,6 +17,7 @@ image receives no gradient, as in the reference's training loops).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -45,6 +46,8 @@ def _tdtype(dt):
 
 
 _GEN = [0]
+# A/B switch (tools/bench_deeplab.py): weight gradients read BatchNorm + ReLU sources through a materialised activation
+_MATERIALISE_WGRAD_OPERAND = os.environ.get("USTRUN_DEEPLAB_WGRAD_ONLOAD", "0") != "1"
 
 
 def invalidate_packs():
@@ -325,6 +328,12 @@ def _conv_wgrad(x, dy, y, conv, grads, dt):
     part = _scratch.get("wgrad", pb, dy.device)
     dw = torch.empty_like(conv.weight)
     src = x.src()
+    if x.aff is not None and dt != L.F32 and _MATERIALISE_WGRAD_OPERAND:
+        # the operand relu(bn(x)) written out once (4 B per element at the HBM rate) instead of being formed per staged item in
+        # every one of the Cout / 128 column tiles and k * k taps of the weight gradient (2-18 times over: round 6)
+        act = _scratch.get("wgrad_act", x.t.numel() * 2, dy.device)
+        L.check(lib.ustrun_act16(C.byref(src), x.N, act.data_ptr(), dt, stream_ptr()), "ustrun_act16")
+        src = L.nhwc_src(act.data_ptr(), x.C, x.H, x.W)
     L.check(lib.ustrun_conv2d_wgrad(C.byref(src), 1, dy.data_ptr(), y.N, y.H, y.W, co, k, s, d, dw.data_ptr(), 0, part.data_ptr(), pb, dt,
                                     stream_ptr()), "ustrun_conv2d_wgrad")
     grads[conv.weight] = dw
@@ -367,10 +376,55 @@ def _join(a, b, ref, dt):
     return g
 
 
-def _block_backward(rec, G, dt, grads):
-    """G = gradient of the block's pre-ReLU join sum -> the two gradients reaching the block input (conv1 path, identity path)"""
+def _bn_apply(y, da, coef, dt):
+    """the apply half of _bn_backward for a BatchNorm that no ReLU follows, from coefficients already formed (fused sums)"""
+    lib = L.lib()
+    sc, sh = _scratch.noact(y.C, y.t.device)
+    dy = torch.empty_like(y.t)
+    L.check(lib.ustrun_bn_bwd_apply(da.data_ptr(), None, y.t.data_ptr(), sc.data_ptr(), sh.data_ptr(), coef.data_ptr(), y.N, y.H, y.W,
+                                    y.C, dy.data_ptr(), dt, stream_ptr()), "ustrun_bn_bwd_apply")
+    return dy
+
+
+def _conv1_dgrad_join(dy1, y1, x, conv, dxb, ref, prev, dt, grads):
+    """Gradient of the PREVIOUS block's pre-ReLU sum: (dgrad(conv1)(dy1) + dxb) * (ref > 0), ref = this block's input (the previous
+    block's output; None behind the max-pool).  One launch where the library fuses the join into the 1x1 input gradient's epilogue
+    (ustrun_conv1x1_dgrad_join: 16-bit storage, round 6), which then also forms the sums of the previous block's bn3 backward:
+    -> (G_prev, coef of prev.bn3 or None)."""
+    lib = L.lib()
+    co, ci, k, _ = conv.weight.shape
+    if k == 1 and conv.stride[0] == 1 and dt != L.F32:
+        dev = dy1.device
+        g = torch.empty_like(x.t)
+        y3p, bn3p = (prev[5], prev[1].bn3) if prev is not None else (None, None)
+        rows, fused = C.c_int(0), C.c_int(0)
+        stat = None
+        if y3p is not None:
+            stat = _scratch.get("join_stat", lib.ustrun_conv_mtiles(x.N, x.H, x.W, ci) * 2 * ci * 4, dev)
+        L.check(lib.ustrun_conv1x1_dgrad_join(dy1.data_ptr(), _packed_dgrad(conv, dt).data_ptr(), x.N, x.H, x.W, co, ci,
+                                              None if dxb is None else dxb.data_ptr(), None if ref is None else ref.data_ptr(), g.data_ptr(),
+                                              None if y3p is None else y3p.t.data_ptr(), None if stat is None else stat.data_ptr(),
+                                              C.byref(rows), C.byref(fused), dt, stream_ptr()), "ustrun_conv1x1_dgrad_join")
+        if fused.value:
+            if y3p is None:
+                return g, None
+            coef = torch.empty(3, ci, device=dev)
+            dg, db = torch.empty(ci, device=dev), torch.empty(ci, device=dev)
+            L.check(lib.ustrun_bn_bwd_finalize_stat(stat.data_ptr(), rows.value, 1, ci, x.N * x.H * x.W, bn3p.weight.data_ptr(),
+                                                    y3p.aff[2].data_ptr(), y3p.aff[3].data_ptr(), 0, dg.data_ptr(), db.data_ptr(), 0,
+                                                    coef.data_ptr(), stream_ptr()), "ustrun_bn_bwd_finalize_stat")
+            grads[bn3p.weight], grads[bn3p.bias] = dg, db
+            return g, coef
+    dxa = _conv_dgrad(dy1, y1, x, conv, dt)
+    return _join(dxa, dxb, ref, dt), None
+
+
+def _block_backward(rec, G, dt, grads, prev=None, coef3=None, first=False):
+    """G = gradient of the block's pre-ReLU join sum -> (gradient of the PREVIOUS block's pre-ReLU sum -- or of the max-pool output
+    for the first block --, the coefficients of the previous block's bn3 backward when the join's launch formed its sums).
+    coef3: this block's own bn3 coefficients, when the join that produced G formed them."""
     _, blk, x, y1, y2, y3, yd, _ = rec
-    dy3 = _bn_backward(y3, G, False, blk.bn3, grads, dt)
+    dy3 = _bn_apply(y3, G, coef3, dt) if coef3 is not None else _bn_backward(y3, G, False, blk.bn3, grads, dt)
     _conv_wgrad(y2, dy3, y3, blk.conv3, grads, dt)
     da2 = _conv_dgrad(dy3, y3, y2, blk.conv3, dt)
     dy2 = _bn_backward(y2, da2, True, blk.bn2, grads, dt)
@@ -378,12 +432,16 @@ def _block_backward(rec, G, dt, grads):
     da1 = _conv_dgrad(dy2, y2, y1, blk.conv2, dt)
     dy1 = _bn_backward(y1, da1, True, blk.bn1, grads, dt)
     _conv_wgrad(x, dy1, y1, blk.conv1, grads, dt)
-    dxa = _conv_dgrad(dy1, y1, x, blk.conv1, dt)
     if yd is None:
-        return dxa, G
-    dyd = _bn_backward(yd, G, False, blk.downsample[1], grads, dt)
-    _conv_wgrad(x, dyd, yd, blk.downsample[0], grads, dt)
-    return dxa, _conv_dgrad(dyd, yd, x, blk.downsample[0], dt)
+        dxb = G
+    else:
+        dyd = _bn_backward(yd, G, False, blk.downsample[1], grads, dt)
+        _conv_wgrad(x, dyd, yd, blk.downsample[0], grads, dt)
+        dxb = _conv_dgrad(dyd, yd, x, blk.downsample[0], dt)
+    # the previous block's ReLU (none after the max-pool); a previous block WITH a projection shortcut needs G for two BatchNorms:
+    # its sums stay with _bn_backward there (4 of ResNet-101's 33 blocks)
+    return _conv1_dgrad_join(dy1, y1, x, blk.conv1, dxb, None if first else x.t, None if (first or prev is None or prev[6] is not None) else prev,
+                             dt, grads)
 
 
 def _head_backward(rec, dlogits, dt, grads):
@@ -458,11 +516,9 @@ def deeplabv2_backward(net, tape, dlogits):
     assert rec[0] == "head"
     dc4 = _head_backward(rec, dlogits, dt, grads)
     G = _join(dc4, None, rec[2].t, dt)                           # through the last block's ReLU
-    for rec in reversed(tape[1:-1]):
-        dxa, dxb = _block_backward(rec, G, dt, grads)
-        x = rec[2]
-        prev_is_block = rec is not tape[1]
-        G = _join(dxa, dxb, x.t if prev_is_block else None, dt)   # the previous block's ReLU; none after the max-pool
+    coef3 = None
+    for i in range(len(tape) - 2, 0, -1):
+        G, coef3 = _block_backward(tape[i], G, dt, grads, prev=tape[i - 1] if i > 1 else None, coef3=coef3, first=(i == 1))
     _stem_backward(tape[0], G, dt, grads)
     return grads
 
