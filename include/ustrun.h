@@ -407,16 +407,24 @@ int ustrun_conv2d_wgrad(const ustrun_src_t* srcs, int nsrc, const void* dy, int 
 /* weight gradient of ustrun_conv_rowwin_fwd: dw[Cout][src->C][nrows] (the layout its weights were packed from)               */
 int ustrun_conv_rowwin_wgrad(const ustrun_src_t* src, const void* dy, int N, int Ho, int Wo, int Cout, int nrows, int stride, float* dw,
                              int accumulate, float* partials, int64_t partials_bytes, int dtype, ustrun_stream_t s);
-/* the input gradient of a bottleneck's conv1 (1x1, stride 1: resnet.py:87-89 under autograd) with the residual join that follows it
- * in the backward, in one launch: g[N,H,W,Cin] = (dy (*) w_dgrad + add) * (ref > 0) -- what ustrun_conv2d_fwd over dy followed by
- * ustrun_relu_bwd_add computes, rounding included (add / ref may be NULL as there) -- and, with y != NULL, the BatchNorm-backward
- * sums of the layer whose OUTPUT gradient g is (a BatchNorm that no ReLU follows: the previous block's bn3, resnet.py:96) as
- * *stat_rows rows of [2][Cin] = {sum(g), sum(g y)} for ustrun_bn_bwd_finalize_stat (stat: ustrun_conv_mtiles(N, H, W, Cin) rows).
- * *fused = 0 and NO launch when the shape is not covered (16-bit storage, Cin % 128 == 0, Cout % 64 == 0): the caller then runs
- * the three separate calls.                                                                                                   */
+/* the input gradient of a 1x1, stride-1 convolution with what follows it in a bottleneck's backward (resnet.py:87-105 under
+ * autograd), in one launch: g[N,H,W,Cin] = (dy (*) w_dgrad + add) * (ref > 0) -- what ustrun_conv2d_fwd over dy followed by
+ * ustrun_relu_bwd_add computes, rounding included (add / ref may be NULL as there: conv1's input gradient and the residual join)
+ * -- and, with y != NULL, the BatchNorm-backward sums of the layer whose OUTPUT gradient g is, as *stat_rows rows of [2][Cin] =
+ * {sum(g mask), sum(g mask y)} for ustrun_bn_bwd_finalize_stat (stat: ustrun_conv_mtiles(N, H, W, Cin) rows): mask = y scale +
+ * shift > 0 (a BatchNorm + ReLU layer: conv3's input gradient feeding bn2), or all ones with scale = shift = NULL (a BatchNorm no
+ * ReLU follows: the previous block's bn3, resnet.py:96, behind the join).  *fused = 0 and NO launch when the shape is not covered
+ * (16-bit storage, Cin % 128 == 0, Cout % 64 == 0): the caller then runs the separate calls.                                   */
 int ustrun_conv1x1_dgrad_join(const void* dy, const void* w_dgrad, int N, int H, int W, int Cout, int Cin, const void* add,
-                              const void* ref, void* g, const void* y, float* stat, int* stat_rows, int* fused, int dtype,
-                              ustrun_stream_t s);
+                              const void* ref, void* g, const void* y, const float* scale, const float* shift, float* stat,
+                              int* stat_rows, int* fused, int dtype, ustrun_stream_t s);
+/* space-to-batch for a dilated 3x3 convolution's weight gradient: out[(n r + a) r + b][i][j][c] = act(src[n][i r + a][j r + b][c]),
+ * every residue class (a, b) of the r x r pixel lattice as an image of its own, all padded with ZEROS to ceil(H / r) x ceil(W / r)
+ * (out: N r r images); act = relu(x scale + shift) when the source carries constants, else a copy (src: plain contiguous NHWC,
+ * 16-bit storage, C % 8 == 0).  With BOTH operands laid out this way ustrun_conv2d_wgrad(k = 3, dilation = 1) over N r r images
+ * returns the weight gradient of the dilation-r convolution (networks/backbone/resnet.py:92-93 with replace_stride_with_dilation)
+ * on the all-taps kernel.                                                                                                        */
+int ustrun_space_to_batch(const ustrun_src_t* src, int N, int r, void* out, int dtype, ustrun_stream_t s);
 /* gradient of the bottleneck's join with respect to its pre-ReLU sum: g = (a + b) * (ref > 0) over n elements (n % 4 == 0);
  * b = NULL: one contribution, ref = NULL: no ReLU (the max-pool output feeding layer1)                                       */
 int ustrun_relu_bwd_add(const void* a, const void* b, const void* ref, int64_t n, void* g, int dtype, ustrun_stream_t s);

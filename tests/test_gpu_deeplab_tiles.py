@@ -145,7 +145,7 @@ def test_conv1x1_dgrad_join_exact(dt, cw, cx, n, h, w, has_add, has_ref, has_y, 
     stat, sflat = guarded(torch.zeros(rows_max, 2, cx, device="cuda"), 7.0)
     rows, fused = C.c_int(0), C.c_int(0)
     l.check(lib.ustrun_conv1x1_dgrad_join(dyg.data_ptr(), wd.data_ptr(), n, h, w, cw, cx, addg.data_ptr() if has_add else None,
-                                          refg.data_ptr() if has_ref else None, out.data_ptr(), y3g.data_ptr() if has_y else None,
+                                          refg.data_ptr() if has_ref else None, out.data_ptr(), y3g.data_ptr() if has_y else None, None, None,
                                           stat.data_ptr() if has_y else None, C.byref(rows), C.byref(fused), dt, None), "join")
     assert fused.value == 1
     assert lib.ustrun_debug_last_conv_variant() == (ct_variant(bn, 64, 2, True) | 0x4000 | (0x2000 if has_y else 0)), hex(lib.ustrun_debug_last_conv_variant())
@@ -160,7 +160,7 @@ def test_conv1x1_dgrad_join_exact(dt, cw, cx, n, h, w, has_add, has_ref, has_y, 
     old2 = lib.ustrun_debug_flags2(8)
     try:
         l.check(lib.ustrun_conv1x1_dgrad_join(dyg.data_ptr(), wd.data_ptr(), n, h, w, cw, cx, addg.data_ptr() if has_add else None,
-                                              refg.data_ptr() if has_ref else None, out.data_ptr(), None, None, None, C.byref(fused), dt, None), "join")
+                                              refg.data_ptr() if has_ref else None, out.data_ptr(), None, None, None, None, None, C.byref(fused), dt, None), "join")
         assert fused.value == 0
     finally:
         lib.ustrun_debug_flags2(old2)
@@ -171,6 +171,86 @@ def test_conv1x1_dgrad_join_exact(dt, cw, cx, n, h, w, has_add, has_ref, has_y, 
     l.check(lib.ustrun_relu_bwd_add(dxa.data_ptr(), addg.data_ptr() if has_add else None, refg.data_ptr() if has_ref else None, dxa.numel(),
                                     g2.data_ptr(), dt, None), "join pass")
     assert torch.equal(g2, out)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_conv1x1_dgrad_bnsum_masked_exact(dt):
+    """ustrun_conv1x1_dgrad_join without a join: conv3's input gradient (1024 -> 256 at layer3) with the sums of bn2's backward --
+    sum(da mask), sum(da mask y), mask = y scale + shift > 0 -- from the stored pieces (integer data: exact)."""
+    l = L()
+    lib = l.lib()
+    t16 = torch.bfloat16 if dt == 1 else torch.float16
+    n, h, w, c4, c = 2, 33, 40, 1024, 256
+    g = torch.Generator().manual_seed(5)
+    ri = lambda lo, hi, *s_: torch.randint(lo, hi + 1, s_, generator=g).float()
+    dy, wt, y2 = ri(-1, 1, n, c4, h, w), ri(-1, 1, c4, c, 1, 1), ri(-3, 3, n, c, h, w)
+    sc, sh = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (c,), generator=g)], ri(-1, 1, c)
+    want = F.conv_transpose2d(dy, wt)
+    assert float(want.abs().max()) < 2 ** 8
+    mask = (y2 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) > 0
+    to = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda().to(t16)
+    wd = torch.zeros(lib.ustrun_pack_conv_elems(c, c4, 1), dtype=t16, device="cuda")
+    wtt = wt.flip(2, 3).transpose(0, 1).contiguous().cuda()
+    l.check(lib.ustrun_pack_conv(wtt.data_ptr(), c, c4, 1, wd.data_ptr(), dt, None))
+    dyg, y2g, scg, shg = to(dy), to(y2), sc.cuda(), sh.cuda()
+    out, oflat = guarded(torch.zeros(n, h, w, c, device="cuda", dtype=t16), 7.0)
+    rows_max = lib.ustrun_conv_mtiles(n, h, w, c)
+    stat, sflat = guarded(torch.zeros(rows_max, 2, c, device="cuda"), 7.0)
+    rows, fused = C.c_int(0), C.c_int(0)
+    l.check(lib.ustrun_conv1x1_dgrad_join(dyg.data_ptr(), wd.data_ptr(), n, h, w, c4, c, None, None, out.data_ptr(), y2g.data_ptr(), scg.data_ptr(),
+                                          shg.data_ptr(), stat.data_ptr(), C.byref(rows), C.byref(fused), dt, None), "dgrad + sums")
+    assert fused.value == 1 and rows.value == -(-n * h * w // 128)
+    assert lib.ustrun_debug_last_conv_variant() == (ct_variant(128, 64, 2, True) | 0x6000), hex(lib.ustrun_debug_last_conv_variant())
+    assert torch.equal(from_nhwc(out), want)
+    assert guards_intact(oflat, out.numel(), 7.0) and guards_intact(sflat, stat.numel(), 7.0)
+    np.testing.assert_allclose(stat[:rows.value, 0].double().sum(0).cpu().numpy(), (want * mask).double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(stat[:rows.value, 1].double().sum(0).cpu().numpy(), (want * mask * y2).double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("n,ci,co,h,w,r", [(2, 256, 256, 33, 35, 2), (3, 64, 128, 21, 18, 4), (1, 128, 64, 16, 24, 2)])
+def test_space_to_batch_weight_gradient_exact(dt, n, ci, co, h, w, r):
+    """Round 6: the weight gradient of a dilation-r 3x3 convolution as an ORDINARY 3x3 weight gradient over the r x r sub-grid images
+    (ustrun_space_to_batch on both operands, then ustrun_conv2d_wgrad with dilation 1 over N r r images: the all-taps kernel) --
+    against torch-CPU's dilated convolution on integer data (exact): sub-grids of unequal extent (33 = 17 + 16, 35 = 18 + 17, 21 =
+    6 + 5 + 5 + 5), BatchNorm + ReLU applied by the re-laying pass, zero padding written by it, outputs between sentinels."""
+    l = L()
+    lib = l.lib()
+    t16 = torch.bfloat16 if dt == 1 else torch.float16
+    g = torch.Generator().manual_seed(n * 100 + h)
+    ri = lambda lo, hi, *s_: torch.randint(lo, hi + 1, s_, generator=g).float()
+    y0 = ri(-3, 3, n, ci, h, w)
+    sc, sh = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (ci,), generator=g)], ri(-1, 1, ci)
+    x = torch.relu(y0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    dy = ri(-1, 1, n, co, h, w)
+    wr = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    F.conv2d(x, wr, None, 1, r, r).backward(dy)
+    assert float(wr.grad.abs().max()) < 2 ** 24
+    to = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda().to(t16)
+    y0g, dyg, scg, shg = to(y0), to(dy), sc.cuda(), sh.cuda()
+    hs, ws = -(-h // r), -(-w // r)
+    n2 = n * r * r
+    xs, xflat = guarded(torch.full((n2, hs, ws, ci), 3.0, device="cuda", dtype=t16), 7.0)
+    ds, dflat = guarded(torch.full((n2, hs, ws, co), 3.0, device="cuda", dtype=t16), 7.0)
+    src = l.nhwc_src(y0g.data_ptr(), ci, h, w, scg.data_ptr(), shg.data_ptr(), relu=1)
+    l.check(lib.ustrun_space_to_batch(C.byref(src), n, r, xs.data_ptr(), dt, None), "s2b x")
+    dsrc = l.nhwc_src(dyg.data_ptr(), co, h, w)
+    l.check(lib.ustrun_space_to_batch(C.byref(dsrc), n, r, ds.data_ptr(), dt, None), "s2b dy")
+    assert guards_intact(xflat, xs.numel(), 7.0) and guards_intact(dflat, ds.numel(), 7.0)
+    # the layout itself: sub-grid (a, b) of image k, zeros beyond its extent
+    xs_ref = torch.zeros(n, r, r, hs, ws, ci)
+    for a in range(r):
+        for b in range(r):
+            sub = x[:, :, a::r, b::r].permute(0, 2, 3, 1)
+            xs_ref[:, a, b, :sub.shape[1], :sub.shape[2]] = sub
+    assert torch.equal(xs.float().cpu().view(n, r, r, hs, ws, ci), xs_ref)
+    pb = lib.ustrun_wgrad_partials_bytes(9, ci, co, n2 * hs * ws)
+    part = torch.empty(pb // 4, device="cuda")
+    dw, wflat = guarded(torch.zeros(co, ci, 3, 3, device="cuda"), 7.0)
+    psrc = l.nhwc_src(xs.data_ptr(), ci, hs, ws)
+    l.check(lib.ustrun_conv2d_wgrad(C.byref(psrc), 1, ds.data_ptr(), n2, hs, ws, co, 3, 1, 1, dw.data_ptr(), 0, part.data_ptr(), pb, dt, None), "wgrad")
+    assert rel(dw.cpu(), wr.grad) < 1e-6
+    assert guards_intact(wflat, dw.numel(), 7.0)
 
 
 def wt_variant(tm, tn, loader, ksplit):

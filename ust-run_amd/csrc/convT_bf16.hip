@@ -325,18 +325,17 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     // statistics row per 128-pixel tile (the tile lies inside one pass: the launcher checks) -- conv_halo_bf16.hip, same idea
     float bsc[8], bsh[8];
     __amdgpu_buffer_rsrc_t yrs = ors;
-    if constexpr (BNS && JOIN) {        // a BatchNorm that no ReLU follows (bn3): every position counts
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { bsc[q] = 0.f; bsh[q] = 1.f; }
-    }
     if constexpr (BNS) {
-        if constexpr (!JOIN) {
-        const long go = a.bn_gN > 0 ? (long)(m0 / (a.bn_gN * a.Hb * a.Wb)) * a.bn_gstride : 0;
-        const float* ps = a.bnsc + go + colw + ch * 8;
-        const float* pb = a.bnsh + go + colw + ch * 8;
-        const f32x4 s0 = *(const f32x4*)ps, s1_ = *(const f32x4*)(ps + 4), b0 = *(const f32x4*)pb, b1 = *(const f32x4*)(pb + 4);
+        if (JOIN && !a.bnsc) {          // a BatchNorm that no ReLU follows (bn3): every position counts
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { bsc[q] = s0[q]; bsc[4 + q] = s1_[q]; bsh[q] = b0[q]; bsh[4 + q] = b1[q]; }
+            for (int q = 0; q < 8; ++q) { bsc[q] = 0.f; bsh[q] = 1.f; }
+        } else {
+            const long go = a.bn_gN > 0 ? (long)(m0 / (a.bn_gN * a.Hb * a.Wb)) * a.bn_gstride : 0;
+            const float* ps = a.bnsc + go + colw + ch * 8;
+            const float* pb = a.bnsh + go + colw + ch * 8;
+            const f32x4 s0 = *(const f32x4*)ps, s1_ = *(const f32x4*)(ps + 4), b0 = *(const f32x4*)pb, b1 = *(const f32x4*)(pb + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { bsc[q] = s0[q]; bsc[4 + q] = s1_[q]; bsh[q] = b0[q]; bsh[4 + q] = b1[q]; }
         }
         yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((elt_t*)a.bny + o_base), 0, (int)(o_left < 0x7fffffffL ? o_left : 0x7fffffffL), 0x00020000);
     }
@@ -439,7 +438,7 @@ int launch_cfg(const IgemmArgs& a, hipStream_t st) {
     const size_t lds_a = 2 * (size_t)128 * BK * 2, lds_ep = 4 * 32 * 144;
     const size_t lds = BREG ? (lds_a > lds_ep ? lds_a : lds_ep) : lds_a + 2 * (size_t)(BK / 8) * BN * 16;
     dim3 grid(mt * nt), block(256);
-    set_last_variant(0x43540000 | (JOIN ? 0x4000 : 0) | (BNS ? 0x2000 : 0) | (BREG ? 0x1000 : 0) | (BN / 32) << 8 | (BK / 32) << 4 | MODE);   // 'CT' | join | sums | register-fed weights | BN/32 | BK/32 | MODE (tests)
+    set_last_variant(0x43540000 | (JOIN ? 0x4000 : 0) | (JOIN && BNS ? 0x2000 : 0) | (BREG ? 0x1000 : 0) | (BN / 32) << 8 | (BK / 32) << 4 | MODE);   // 'CT' | join | sums | register-fed weights | BN/32 | BK/32 | MODE (tests)
     hipLaunchKernelGGL((convT_bf16_kernel<BN, BK, MODE, BREG, BNS, JOIN>), grid, block, lds, st, a, mt, nt);
     USTRUN_LAUNCH_CHECK("convT_bf16");
     return 0;
@@ -506,7 +505,8 @@ bool conv1x1_join_supported(const IgemmArgs& a) {
     return (long)a.M * a.Cout < (1L << 30);          // (32-bit byte offsets behind a tile base)
 }
 int conv1x1_join_launch_bf16(const IgemmArgs& a, hipStream_t st) {
-    USTRUN_CHECK(conv1x1_join_supported(a) && (a.join_add || a.join_ref), "conv1x1_join: unsupported shape");
+    USTRUN_CHECK(conv1x1_join_supported(a) && (a.join_add || a.join_ref || a.bny), "conv1x1_join: unsupported shape");
+    USTRUN_CHECK((a.bnsc == nullptr) == (a.bnsh == nullptr), "conv1x1_join: scale / shift come together");
     USTRUN_CHECK(!a.bny || a.stat, "conv1x1_join: BatchNorm-backward sums need their statistics rows");
     const bool wide = a.Cout % 256 == 0 && (long)cdiv(a.M, 128) * (a.Cout / 256) >= 256;
     if (a.bny) return wide ? launch_cfg<256, 64, 2, true, true, true>(a, st) : launch_cfg<128, 64, 2, true, true, true>(a, st);

@@ -310,7 +310,7 @@ int igemm_launch(const IgemmArgs& a, int dtype, hipStream_t st) {
     for (int i = 0; i < a.nsrc; ++i) grouped |= a.src[i].gN > 0;
     USTRUN_CHECK(!grouped || dtype == USTRUN_D16 || (dtype == USTRUN_F32X3 && conv3x3_x3_supported(a)),
                  "igemm: batched passes reached a kernel without per-pass BatchNorm constants");
-    if (dtype == USTRUN_D16 && (a.join_add || a.join_ref)) {
+    if (dtype == USTRUN_D16 && (a.join_add || a.join_ref || (a.bny && conv1x1_join_supported(a) && a.nseg == 1 && a.s_in == 1))) {
         rc = conv1x1_join_launch_bf16(a, st);
     } else if (dtype == USTRUN_D16) {
         if (!(g_debug_flags & 1) && ws64_supported(a)) rc = conv3x3_ws64_launch_bf16(a, st);

@@ -337,19 +337,22 @@ extern "C" int ustrun_conv2d_fwd(const ustrun_src_t* srcs, int nsrc, const void*
     return igemm_launch(a, dtype, (hipStream_t)s);
 }
 
-// The input gradient of a bottleneck's conv1 (1x1, stride 1) with the residual join that follows it in the backward, in ONE launch:
+// The input gradient of a 1x1, stride-1 convolution with what follows it in a bottleneck's backward, in ONE launch:
 //   g = (dy (*) w_dgrad + add) * (ref > 0)         [N,H,W,Cin]; add / ref may be NULL (one contribution / no ReLU in between)
-// and, with y, the BatchNorm-backward sums of the layer whose OUTPUT gradient g is (a BatchNorm no ReLU follows: the previous block's
-// bn3) as rows of [2][Cin] = {sum(g), sum(g y)} per 128 pixels, for ustrun_bn_bwd_finalize_stat.  *fused = 0 and NO launch when the
-// shape is not covered: the caller then runs ustrun_conv2d_fwd, ustrun_relu_bwd_add and ustrun_bn_bwd_reduce.
+// -- the residual join behind conv1's input gradient -- and, with y, the BatchNorm-backward sums of the layer whose OUTPUT gradient g
+// is, as rows of [2][Cin] = {sum(g mask), sum(g mask y)} per 128 pixels for ustrun_bn_bwd_finalize_stat: mask = y scale + shift > 0
+// for a BatchNorm + ReLU layer (conv3's input gradient feeding bn2), all ones with scale = shift = NULL (the previous block's bn3
+// behind the join).  *fused = 0 and NO launch when the shape is not covered: the caller then runs ustrun_conv2d_fwd,
+// ustrun_relu_bwd_add and ustrun_bn_bwd_reduce.
 extern "C" int ustrun_conv1x1_dgrad_join(const void* dy, const void* w_dgrad, int N, int H, int W, int Cout, int Cin, const void* add,
-                                         const void* ref, void* g, const void* y, float* stat, int* stat_rows, int* fused, int dtype,
-                                         ustrun_stream_t s) {
+                                         const void* ref, void* g, const void* y, const float* scale, const float* shift, float* stat,
+                                         int* stat_rows, int* fused, int dtype, ustrun_stream_t s) {
     USTRUN_CHECK(dy && w_dgrad && g && fused && N > 0 && H > 0 && W > 0 && Cout > 0 && Cin > 0, "conv1x1_dgrad_join: bad args");
     USTRUN_CHECK(!y || (stat && stat_rows), "conv1x1_dgrad_join: the sums need their rows");
+    USTRUN_CHECK((scale == nullptr) == (shift == nullptr) && (!scale || y), "conv1x1_dgrad_join: scale / shift come together, with y");
     *fused = 0;
     if (stat_rows) *stat_rows = 0;
-    if (dtype != USTRUN_D16 || (!add && !ref) || (g_debug_flags2 & 8)) return 0;         // (ustrun_debug_flags2 bit 3: never fused, A/B runs)
+    if (dtype != USTRUN_D16 || (!add && !ref && !y) || (g_debug_flags2 & 8)) return 0;         // (ustrun_debug_flags2 bit 3: never fused, A/B runs)
     IgemmArgs a = {};
     ustrun_src_t sd = {};
     sd.ptr = dy; sd.C = Cout; sd.H = H; sd.W = W;
@@ -363,7 +366,7 @@ extern "C" int ustrun_conv1x1_dgrad_join(const void* dy, const void* w_dgrad, in
     if (!conv1x1_join_supported(a)) return 0;
     a.join_add = add; a.join_ref = ref;
     if (y) {
-        a.bny = y; a.stat = stat;
+        a.bny = y; a.bnsc = scale; a.bnsh = shift; a.stat = stat;
         const int used = cdiv(a.M, 128);
         USTRUN_TRY(stat_rows_within_bound(used, N, H, W, Cin, "conv1x1_dgrad_join"));
         *stat_rows = used;
@@ -449,6 +452,49 @@ extern "C" int ustrun_aspp_gather(const float* z, int N, int h, int w, int K, in
     return 0;
 }
 
+// Space-to-batch for the weight gradient of a dilated 3x3 convolution (round 6).  With dilation r and padding r, output pixel
+// (y, x) only meets input pixels of its own residue class (y mod r, x mod r): on the r x r sub-grids the convolution is an ORDINARY
+// 3x3 (padding 1), and its weight gradient is the sum of the sub-grids' -- which the all-taps kernel (wgrad_halo_bf16.hip: the dY
+// tile read once for nine taps) forms at 2-3 x the rate of nine one-tap GEMMs that each stream both operands again.  This pass
+// writes out[(n r + a) r + b][i][j][c] = act(src[n][i r + a][j r + b][c]) for every sub-grid (a, b), all padded to ceil(H / r) x
+// ceil(W / r) with ZEROS (the positions past a shorter sub-grid's edge, and what the 3x3's own padding reads there): zeros in both
+// operands add nothing to the sums.  act = relu(x scale + shift) with constants (it then replaces ustrun_act16), else a copy.
+// thread = (output pixel, 8 channels): 16-byte loads and stores.
+__global__ __launch_bounds__(256) void space_to_batch_kernel(const elt_t* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int relu, int N, int H, int W, int C, int r,
+                                                             int Hs, int Ws, elt_t* __restrict__ out) {
+    typedef __attribute__((ext_vector_type(8))) elt_t v8;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    const int C8 = C / 8;
+    const long total = (long)N * r * r * Hs * Ws * C8;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c8 = (int)(e % C8);
+        long t = e / C8;
+        const int j = (int)(t % Ws); t /= Ws;
+        const int i = (int)(t % Hs); t /= Hs;
+        const int b = (int)(t % r); t /= r;
+        const int a = (int)(t % r);
+        const int n = (int)(t / r);
+        const int yy = i * r + a, xx = j * r + b;
+        u4 o = {0u, 0u, 0u, 0u};
+        if (yy < H && xx < W) {
+            v8 v = *(const v8*)(x + (((long)n * H + yy) * W + xx) * C + c8 * 8);
+            if (scale) {
+                const f32x4 s0 = *(const f32x4*)(scale + c8 * 8), s1 = *(const f32x4*)(scale + c8 * 8 + 4);
+                const f32x4 b0 = *(const f32x4*)(shift + c8 * 8), b1 = *(const f32x4*)(shift + c8 * 8 + 4);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float f = (float)v[q] * (q < 4 ? s0[q & 3] : s1[q & 3]) + (q < 4 ? b0[q & 3] : b1[q & 3]);
+                    f = relu ? fmaxf(f, 0.f) : f;
+                    v[q] = (elt_t)f;
+                }
+            }
+            o = __builtin_bit_cast(u4, v);
+        }
+        *(u4*)(out + e * 8) = o;
+    }
+}
+
 // ---- backward entry points --------------------------------------------------------------------------------------------------
 #define USTRUN_BY_DTYPE(KERNEL, BLOCKS, ...)                                                                                    \
     do {                                                                                                                        \
@@ -460,6 +506,20 @@ extern "C" int ustrun_relu_bwd_add(const void* a, const void* b, const void* ref
     USTRUN_CHECK(a && g && n > 0 && n % 4 == 0 && dtype_ok(dtype), "relu_bwd_add: bad args");
     USTRUN_BY_DTYPE(relu_bwd_add_kernel, stream_blocks(n / 4), (const float*)a, (const float*)b, (const float*)ref, (long)(n / 4), (float*)g);
     USTRUN_LAUNCH_CHECK("relu_bwd_add");
+    return 0;
+}
+
+extern "C" int ustrun_space_to_batch(const ustrun_src_t* src, int N, int r, void* out, int dtype, ustrun_stream_t s) {
+    USTRUN_CHECK(dtype == USTRUN_D16, "space_to_batch: 16-bit storage only (dtype %d)", dtype);
+    USTRUN_CHECK(src && src->ptr && out && N > 0 && r >= 2 && r <= 8, "space_to_batch: bad args");
+    const int C = src->C, H = src->H, W = src->W;
+    USTRUN_CHECK(src->sC == 1 && src->sW == C && src->sH == (int64_t)W * C && src->sN == (int64_t)H * W * C && !src->pool && !src->off_y &&
+                 !src->off_x && !src->f32 && src->gN == 0, "space_to_batch: source must be a plain contiguous NHWC activation");
+    USTRUN_CHECK((src->scale == nullptr) == (src->shift == nullptr) && (!src->relu || src->scale) && C % 8 == 0, "space_to_batch: C=%d / constants", C);
+    const int Hs = (H + r - 1) / r, Ws = (W + r - 1) / r;
+    hipLaunchKernelGGL(space_to_batch_kernel, dim3(stream_blocks((long)N * r * r * Hs * Ws * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                       (const elt_t*)src->ptr, src->scale, src->shift, src->relu, N, H, W, C, r, Hs, Ws, (elt_t*)out);
+    USTRUN_LAUNCH_CHECK("space_to_batch");
     return 0;
 }
 

@@ -48,6 +48,7 @@ def _tdtype(dt):
 _GEN = [0]
 # A/B switch (tools/bench_deeplab.py): weight gradients read BatchNorm + ReLU sources through a materialised activation
 _MATERIALISE_WGRAD_OPERAND = os.environ.get("USTRUN_DEEPLAB_WGRAD_ONLOAD", "0") != "1"
+_SPACE_TO_BATCH_WGRAD = os.environ.get("USTRUN_DEEPLAB_WGRAD_TAPS", "0") != "1"      # "1": dilated 3x3 weight gradients tap by tap (rounds 2-5)
 
 
 def invalidate_packs():
@@ -328,6 +329,23 @@ def _conv_wgrad(x, dy, y, conv, grads, dt):
     part = _scratch.get("wgrad", pb, dy.device)
     dw = torch.empty_like(conv.weight)
     src = x.src()
+    if k == 3 and d > 1 and s == 1 and dt != L.F32 and _SPACE_TO_BATCH_WGRAD and ci % 64 == 0 and co % 64 == 0:
+        # dilated 3x3: both operands re-laid as d x d sub-grid images (zero-padded to one extent; the activation pass does the
+        # re-laying, so only dy costs a pass of its own) -> an ORDINARY 3x3 weight gradient over N d d images on the all-taps kernel
+        Hs, Ws = -(-x.H // d), -(-x.W // d)
+        n2 = x.N * d * d
+        xs = _scratch.get("s2b_x", n2 * Hs * Ws * ci * 2, dy.device)
+        ds = _scratch.get("s2b_dy", n2 * Hs * Ws * co * 2, dy.device)
+        L.check(lib.ustrun_space_to_batch(C.byref(src), x.N, d, xs.data_ptr(), dt, stream_ptr()), "ustrun_space_to_batch")
+        dsrc = L.nhwc_src(dy.data_ptr(), co, y.H, y.W)
+        L.check(lib.ustrun_space_to_batch(C.byref(dsrc), y.N, d, ds.data_ptr(), dt, stream_ptr()), "ustrun_space_to_batch")
+        pb = lib.ustrun_wgrad_partials_bytes(9, ci, co, n2 * Hs * Ws)
+        part = _scratch.get("wgrad", pb, dy.device)
+        src = L.nhwc_src(xs.data_ptr(), ci, Hs, Ws)
+        L.check(lib.ustrun_conv2d_wgrad(C.byref(src), 1, ds.data_ptr(), n2, Hs, Ws, co, 3, 1, 1, dw.data_ptr(), 0, part.data_ptr(), pb, dt,
+                                        stream_ptr()), "ustrun_conv2d_wgrad")
+        grads[conv.weight] = dw
+        return
     if x.aff is not None and dt != L.F32 and _MATERIALISE_WGRAD_OPERAND:
         # the operand relu(bn(x)) written out once (4 B per element at the HBM rate) instead of being formed per staged item in
         # every one of the Cout / 128 column tiles and k * k taps of the weight gradient (2-18 times over: round 6)
@@ -376,14 +394,45 @@ def _join(a, b, ref, dt):
     return g
 
 
-def _bn_apply(y, da, coef, dt):
-    """the apply half of _bn_backward for a BatchNorm that no ReLU follows, from coefficients already formed (fused sums)"""
+def _bn_apply(y, da, coef, dt, relu=False):
+    """the apply half of _bn_backward from coefficients already formed (sums fused into the launch that produced da)"""
     lib = L.lib()
-    sc, sh = _scratch.noact(y.C, y.t.device)
+    sc, sh = (y.aff[0], y.aff[1]) if relu else _scratch.noact(y.C, y.t.device)
     dy = torch.empty_like(y.t)
     L.check(lib.ustrun_bn_bwd_apply(da.data_ptr(), None, y.t.data_ptr(), sc.data_ptr(), sh.data_ptr(), coef.data_ptr(), y.N, y.H, y.W,
                                     y.C, dy.data_ptr(), dt, stream_ptr()), "ustrun_bn_bwd_apply")
     return dy
+
+
+def _finalize_fused_sums(stat, rows, y, bn, grads):
+    """rows of {sum(g mask), sum(g mask y)} a fused epilogue wrote -> dgamma, dbeta (into grads) and the apply coefficients"""
+    lib = L.lib()
+    dev = y.t.device
+    coef = torch.empty(3, y.C, device=dev)
+    dg, db = torch.empty(y.C, device=dev), torch.empty(y.C, device=dev)
+    L.check(lib.ustrun_bn_bwd_finalize_stat(stat.data_ptr(), rows, 1, y.C, y.N * y.H * y.W, bn.weight.data_ptr(), y.aff[2].data_ptr(),
+                                            y.aff[3].data_ptr(), 0, dg.data_ptr(), db.data_ptr(), 0, coef.data_ptr(), stream_ptr()),
+            "ustrun_bn_bwd_finalize_stat")
+    grads[bn.weight], grads[bn.bias] = dg, db
+    return coef
+
+
+def _conv3_dgrad_bn2(dy3, y3, y2, conv, bn, dt, grads):
+    """da2 = dgrad(conv3)(dy3) and dy2 = BatchNorm + ReLU backward of bn2: with the sums of bn2's backward formed in the 1x1 input
+    gradient's epilogue where the library covers the shape (one launch instead of the gradient + a reduce pass over da2 and y2)"""
+    lib = L.lib()
+    co, ci, k, _ = conv.weight.shape
+    if k == 1 and conv.stride[0] == 1 and dt != L.F32:
+        da2 = torch.empty_like(y2.t)
+        rows, fused = C.c_int(0), C.c_int(0)
+        stat = _scratch.get("join_stat", lib.ustrun_conv_mtiles(y2.N, y2.H, y2.W, ci) * 2 * ci * 4, dy3.device)
+        L.check(lib.ustrun_conv1x1_dgrad_join(dy3.data_ptr(), _packed_dgrad(conv, dt).data_ptr(), y2.N, y2.H, y2.W, co, ci, None, None,
+                                              da2.data_ptr(), y2.t.data_ptr(), y2.aff[0].data_ptr(), y2.aff[1].data_ptr(), stat.data_ptr(),
+                                              C.byref(rows), C.byref(fused), dt, stream_ptr()), "ustrun_conv1x1_dgrad_join")
+        if fused.value:
+            return _bn_apply(y2, da2, _finalize_fused_sums(stat, rows.value, y2, bn, grads), dt, relu=True)
+    da2 = _conv_dgrad(dy3, y3, y2, conv, dt)
+    return _bn_backward(y2, da2, True, bn, grads, dt)
 
 
 def _conv1_dgrad_join(dy1, y1, x, conv, dxb, ref, prev, dt, grads):
@@ -403,18 +452,10 @@ def _conv1_dgrad_join(dy1, y1, x, conv, dxb, ref, prev, dt, grads):
             stat = _scratch.get("join_stat", lib.ustrun_conv_mtiles(x.N, x.H, x.W, ci) * 2 * ci * 4, dev)
         L.check(lib.ustrun_conv1x1_dgrad_join(dy1.data_ptr(), _packed_dgrad(conv, dt).data_ptr(), x.N, x.H, x.W, co, ci,
                                               None if dxb is None else dxb.data_ptr(), None if ref is None else ref.data_ptr(), g.data_ptr(),
-                                              None if y3p is None else y3p.t.data_ptr(), None if stat is None else stat.data_ptr(),
+                                              None if y3p is None else y3p.t.data_ptr(), None, None, None if stat is None else stat.data_ptr(),
                                               C.byref(rows), C.byref(fused), dt, stream_ptr()), "ustrun_conv1x1_dgrad_join")
         if fused.value:
-            if y3p is None:
-                return g, None
-            coef = torch.empty(3, ci, device=dev)
-            dg, db = torch.empty(ci, device=dev), torch.empty(ci, device=dev)
-            L.check(lib.ustrun_bn_bwd_finalize_stat(stat.data_ptr(), rows.value, 1, ci, x.N * x.H * x.W, bn3p.weight.data_ptr(),
-                                                    y3p.aff[2].data_ptr(), y3p.aff[3].data_ptr(), 0, dg.data_ptr(), db.data_ptr(), 0,
-                                                    coef.data_ptr(), stream_ptr()), "ustrun_bn_bwd_finalize_stat")
-            grads[bn3p.weight], grads[bn3p.bias] = dg, db
-            return g, coef
+            return g, (None if y3p is None else _finalize_fused_sums(stat, rows.value, y3p, bn3p, grads))
     dxa = _conv_dgrad(dy1, y1, x, conv, dt)
     return _join(dxa, dxb, ref, dt), None
 
@@ -426,8 +467,7 @@ def _block_backward(rec, G, dt, grads, prev=None, coef3=None, first=False):
     _, blk, x, y1, y2, y3, yd, _ = rec
     dy3 = _bn_apply(y3, G, coef3, dt) if coef3 is not None else _bn_backward(y3, G, False, blk.bn3, grads, dt)
     _conv_wgrad(y2, dy3, y3, blk.conv3, grads, dt)
-    da2 = _conv_dgrad(dy3, y3, y2, blk.conv3, dt)
-    dy2 = _bn_backward(y2, da2, True, blk.bn2, grads, dt)
+    dy2 = _conv3_dgrad_bn2(dy3, y3, y2, blk.conv3, blk.bn2, dt, grads)
     _conv_wgrad(y1, dy2, y2, blk.conv2, grads, dt)
     da1 = _conv_dgrad(dy2, y2, y1, blk.conv2, dt)
     dy1 = _bn_backward(y1, da1, True, blk.bn1, grads, dt)
