@@ -1,14 +1,10 @@
 set -o pipefail
-cd $GRAFT_REPO_ROOT
-O=gpurun_out
-python -m pytest tests/test_gpu_deeplab_tiles.py tests/test_gpu_deeplab_bwd.py tests/test_gpu_deeplab.py tests/test_gpu_production_tiles.py -m gpu -q -x --durations=8 > $O/r6_t3.log 2>&1; echo rc=$? >> $O/r6_t3.log
-tail -14 $O/r6_t3.log
-echo "== deeplab fwd+bwd: all new paths" > $O/r6_dl_ab2.log
-python tools/bench_deeplab.py --backward --reps 5 >> $O/r6_dl_ab2.log 2>&1
-echo "== dilated wgrad tap by tap" >> $O/r6_dl_ab2.log
-USTRUN_DEEPLAB_WGRAD_TAPS=1 python tools/bench_deeplab.py --backward --reps 5 >> $O/r6_dl_ab2.log 2>&1
-echo "== fused epilogues off (flags2=8)" >> $O/r6_dl_ab2.log
-USTRUN_DEBUG_FLAGS2=8 python tools/bench_deeplab.py --backward --reps 5 >> $O/r6_dl_ab2.log 2>&1
-echo "== ssl step" >> $O/r6_dl_ab2.log
-python tools/bench_deeplab.py --ssl --reps 3 >> $O/r6_dl_ab2.log 2>&1
-grep -E "==|ms|images" $O/r6_dl_ab2.log | cut -c1-420
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/kt_dl; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dl -- python3 $R/tools/bench_deeplab.py --backward --reps 5 > $O/kt_dl.log 2>&1
+find $O/kt_dl -name "*kernel_stats.csv" -exec cp {} $O/r6a_deeplab_kernel_stats.csv \;
+find $O/kt_dl -name "*.csv" -size +6M -delete
+head -30 $O/r6a_deeplab_kernel_stats.csv | cut -c1-200
+cd $R
+bash tools/pmc_wgrad_tap.sh "l3.conv1" l3c1_plain 1 | cut -c1-200
