@@ -723,3 +723,75 @@ def test_backward_in_two_parts_equals_one_call():
     assert fired == [1, 2, 3]
     for (k, p1), (_, p3) in zip(m1.named_parameters(), m3.named_parameters()):
         assert torch.equal(p1.grad, p3.grad), k
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_domain_specific_batchnorm_selects_by_the_first_label(dtype):
+    """UNet(num_domains = D) with forward(x, domain_label=...) (reference networks/dsbn.py:24-27: `self.bns[domain_label[0]]`;
+    BASELINE.json configs[2]'s per-domain statistics): the call runs with the selected domain's BatchNorm2d members -- logits,
+    running buffers and gradients BIT-IDENTICAL to a plain UNet carrying that domain's parameters, nothing of the other domains
+    moves, and their parameters get no gradient."""
+    import copy
+    from networks.unet_model import UNet
+    D, dom = 3, 2
+    torch.manual_seed(41)
+    plain = UNet(3, 2, base_channels=16, dtype=dtype).cuda().train()
+    torch.manual_seed(41)
+    ds = UNet(3, 2, base_channels=16, dtype=dtype, num_domains=D).cuda().train()
+    g = torch.Generator().manual_seed(8)
+    # give every domain its own affine parameters and running buffers; the plain network gets domain `dom`'s
+    for m in ds.modules():
+        if hasattr(m, "bns"):
+            for bn in m.bns:
+                with torch.no_grad():
+                    bn.weight.copy_(torch.rand(bn.num_features, generator=g) + 0.5)
+                    bn.bias.copy_(torch.randn(bn.num_features, generator=g) * 0.1)
+                    bn.running_mean.copy_(torch.randn(bn.num_features, generator=g) * 0.1)
+    sd = {}
+    for k, v in ds.state_dict().items():
+        if ".bns." in k:
+            head, rest = k.split(".bns.")
+            d_, name = rest.split(".", 1)
+            if int(d_) == dom:
+                sd[f"{head}.{name}"] = v.clone()
+        else:
+            sd[k] = v.clone()
+    plain.load_state_dict(sd)
+    before = copy.deepcopy(ds.state_dict())
+    x = torch.randn(4, 3, 48, 48, generator=g).cuda()
+    dl = torch.randn(4, 2, 48, 48, generator=g).cuda()
+    a = plain(x)
+    a.backward(dl)
+    b = ds(x, domain_label=torch.tensor([dom, 0, 1, 0]))
+    b.backward(dl)
+    assert torch.equal(a.detach(), b.detach())
+    after = ds.state_dict()
+    psd = plain.state_dict()
+    for k, v in after.items():
+        if ".bns." in k:
+            head, rest = k.split(".bns.")
+            d_, name = rest.split(".", 1)
+            if int(d_) == dom:
+                assert torch.equal(v, psd[f"{head}.{name}"]), k
+            else:
+                assert torch.equal(v, before[k]), k             # the other domains' buffers did not move
+    pp = dict(plain.named_parameters())
+    for k, p in ds.named_parameters():
+        if ".bns." in k:
+            head, rest = k.split(".bns.")
+            d_, name = rest.split(".", 1)
+            if int(d_) == dom:
+                assert torch.equal(p.grad, pp[f"{head}.{name}"].grad), k
+            else:
+                assert p.grad is None, k
+        else:
+            assert torch.equal(p.grad, pp[k].grad), k
+    with pytest.raises(RuntimeError):
+        ds(x)                                                   # a domain-specific network needs its label
+    with pytest.raises(RuntimeError):
+        plain(x, domain_label=[0])
+    # eval mode reads the selected domain's running statistics
+    ds.eval(); plain.eval()
+    with torch.no_grad():
+        assert torch.equal(ds(x, domain_label=[dom]), plain(x))
+        assert not torch.equal(ds(x, domain_label=[0]), plain(x))

@@ -213,3 +213,19 @@ def test_bench_prints_one_compact_parseable_line():
     import pytest
     with pytest.raises(ValueError):
         bench.compact_line(dict(full, value=float("nan")))
+
+
+def test_dsbn_mirror_keeps_the_reference_surface():
+    """networks/dsbn.py:4-33: `bns` = one BatchNorm2d per domain (state_dict keys bns.<d>.*), the FIRST label selects; the UNet
+    option replaces every BatchNorm2d and leaves the convolutions' initial weights (RNG order) alone."""
+    import torch
+    from networks.dsbn import DomainSpecificBatchNorm2d
+    from networks.unet_model import UNet
+    m = DomainSpecificBatchNorm2d(8, 3)
+    assert sorted(m.state_dict().keys())[:2] == ["bns.0.bias", "bns.0.num_batches_tracked"] and len(m.bns) == 3
+    assert m.select(torch.tensor([2, 0, 1])) is m.bns[2] and m.select([1]) is m.bns[1]
+    torch.manual_seed(3); a = UNet(3, 2, base_channels=8)
+    torch.manual_seed(3); b = UNet(3, 2, base_channels=8, num_domains=2)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert len(sb) == len(sa) + 18 * 5 and all(torch.equal(sa[k], sb[k]) for k in sa if k in sb)
+    assert "inc.double_conv.1.bns.1.running_var" in sb and "inc.double_conv.1.weight" not in sb

@@ -10,8 +10,9 @@ from .unet_parts import _hip_only
 
 
 class UNet(nn.Module):
-    def __init__(self, n_channels, n_classes, bilinear=False, base_channels=64, dtype="f32"):
+    def __init__(self, n_channels, n_classes, bilinear=False, base_channels=64, dtype="f32", num_domains=0):
         super(UNet, self).__init__()
+        self.num_domains = num_domains           # > 0 (additive): every BatchNorm2d becomes a DomainSpecificBatchNorm2d (networks/dsbn.py)
         self.n_channels = n_channels
         self.n_classes = n_classes
         self.bilinear = bilinear
@@ -30,9 +31,30 @@ class UNet(nn.Module):
         self.up3 = Up(4 * b, 2 * b // factor, bilinear)
         self.up4 = Up(2 * b, b, bilinear)
         self.outc = OutConv(b, n_classes)
+        if num_domains:
+            if bilinear:
+                raise ValueError("UNet(num_domains > 0): the fused plan only (bilinear=False)")
+            from .dsbn import DomainSpecificBatchNorm2d
+            for dc in (self.inc, self.down1.maxpool_conv[1], self.down2.maxpool_conv[1], self.down3.maxpool_conv[1],
+                       self.down4.maxpool_conv[1], self.up1.conv, self.up2.conv, self.up3.conv, self.up4.conv):
+                for k in (1, 4):                 # BatchNorm2d draws nothing from the RNG: the convolutions' initial weights are unchanged
+                    bn = dc.double_conv[k]
+                    dc.double_conv[k] = DomainSpecificBatchNorm2d(bn.num_features, num_domains, bn.eps, bn.momentum)
+            self._ustrun_domain = 0
 
-    def forward(self, x, feature=False):
+    def forward(self, x, feature=False, domain_label=None):
+        """domain_label (networks with num_domains > 0 only): the batch's domain; its FIRST entry selects the BatchNorm2d of every
+        DomainSpecificBatchNorm2d for this call (reference networks/dsbn.py:24-27) -- batch statistics, running buffers and
+        gradients all belong to that domain's members."""
         _hip_only(x)
+        if self.num_domains:
+            if domain_label is None:
+                raise RuntimeError("UNet(num_domains > 0): forward needs domain_label")
+            if self.bilinear:
+                raise RuntimeError("UNet(num_domains > 0) runs the fused plan only (bilinear=False)")
+            self._ustrun_domain = int(domain_label[0]) if hasattr(domain_label, "__getitem__") else int(domain_label)
+        elif domain_label is not None:
+            raise RuntimeError("UNet: domain_label given to a network without domain-specific BatchNorm (num_domains = 0)")
         if self.bilinear:
             return self._forward_blocks(x, feature)
         from ustrun import engine

@@ -23,9 +23,11 @@ def conv_bn_list(model):
     dcs = [model.inc, model.down1.maxpool_conv[1], model.down2.maxpool_conv[1], model.down3.maxpool_conv[1],
            model.down4.maxpool_conv[1], model.up1.conv, model.up2.conv, model.up3.conv, model.up4.conv]
     pairs = []
+    dom = getattr(model, "_ustrun_domain", 0) if getattr(model, "num_domains", 0) else None
+    pick = (lambda bn: bn) if dom is None else (lambda bn: bn.bns[dom])       # domain-specific BatchNorm: the call's domain (networks/dsbn.py)
     for dc in dcs:
         s = dc.double_conv
-        pairs += [(s[0], s[1]), (s[3], s[4])]
+        pairs += [(s[0], pick(s[1])), (s[3], pick(s[4]))]
     ups = [model.up1.up, model.up2.up, model.up3.up, model.up4.up]
     return pairs, ups, model.outc.conv
 
@@ -90,7 +92,18 @@ def _ensure_packed(model, d):
 
 
 def model_params(model):
-    return list(model.parameters())
+    """the parameters ustrun_unet_backward writes gradients for, in the order its grads[] array expects: model.parameters() -- of a
+    network with domain-specific BatchNorm, the call's domain's members in their place (the other domains' get no gradient)"""
+    if not getattr(model, "num_domains", 0):
+        return list(model.parameters())
+    pairs, ups, head = conv_bn_list(model)
+    out = []
+    for i, (cv, bn) in enumerate(pairs):
+        if i >= 10 and i % 2 == 0:                # a decoder block: its ConvTranspose comes first (Up.up before Up.conv)
+            u = ups[(i - 10) // 2]
+            out += [u.weight, u.bias]
+        out += [cv.weight, bn.weight, bn.bias]
+    return out + [head.weight, head.bias]
 
 
 def _current_debug_flags(lib):

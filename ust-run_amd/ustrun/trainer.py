@@ -181,6 +181,11 @@ class SSLTrainer:
         self.patch = patch_size or cfg[1]
         self.max_iterations = max_iterations or cfg[5]
         self.model, self.ema_model = model, ema_model
+        if getattr(model, "num_domains", 0) or getattr(ema_model, "num_domains", 0):
+            # the reference's loop never builds such a network; the step's flat gradient / SGD / EMA buffers are
+            # laid out over model.parameters() and the student's passes are batched across domains
+            raise ValueError("SSLTrainer drives networks with plain BatchNorm2d; UNet(num_domains > 0) is for forward / backward through "
+                             "autograd with a per-call domain_label")
         for p in ema_model.parameters():
             p.detach_()                                  # train.py:501-502
         model.train()
