@@ -26,21 +26,23 @@ def golden():
     return load_golden
 
 
-# ---- the default GPU set vs. the full one (`pytest -m gpu` must finish well inside the driver's step limit) ----
-# USTRUN_TEST_FULL=1 runs every case.  The default leaves out (reported as SKIPPED, with this reason) only cases that re-run a kernel
-# some other default case already pins bit-exactly:
+# ---- the full GPU set (default) and a quick one (`pytest -m gpu` must finish well inside the driver's step limit) ----
+# Every case runs by default: 586 cases in 223 s on a gpurun box (profiles/r06_pytest_gpu_full_set.log) once the torch-CPU side of
+# the tests stopped oversubscribing the box's CPU share (below) -- that, not the case count, had made round 5's run take 765 s.
+# USTRUN_TEST_QUICK=1 leaves out (reported as SKIPPED, with this reason) cases that re-run a kernel some other case already pins
+# bit-exactly -- 462 cases in 153 s (profiles/r06_pytest_gpu_quick_set.log):
 #   * builds no product path launches (debug-flag variants kept for A/B runs: the first convolution's kernels of rounds 1-4, the
-#     four- / eight-wave builds of the 64 -> 64 streaming kernel, the 512-pixel tile, the "old_*" weight-gradient builds);
-#   * the IEEE-half compile of a SOURCE-IDENTICAL kernel (the same .hip built with elt_t = _Float16) beyond a core set per family
-#     -- every family keeps at least one f16 case, and the f16 path as a whole is pinned by the golden / oracle / trajectory tests.
-# No SURVEY.md 8 row loses its oracle / golden test: those tests are never in the extended set.
-FULL = os.environ.get("USTRUN_TEST_FULL", "0") == "1"
+#     four- / eight-wave builds of the 64 -> 64 streaming kernel, the 512-pixel tile, the "old_*" weight-gradient builds, the 200-step
+#     trajectory on the f32-MFMA kernels that `--amp 0` no longer selects);
+#   * the IEEE-half compile of a SOURCE-IDENTICAL kernel (the same .hip built with elt_t = _Float16) beyond a core set per family.
+# No SURVEY.md 8 row loses its oracle / golden test in the quick set either.
+FULL = os.environ.get("USTRUN_TEST_QUICK", "0") != "1"
 _F16_CORE_TILES = {"tall_wide_128", "cat_128_to_64", "bottleneck_n64", "c64_wide", "mid_grid_512", "ws64_ragged", "ws64f_ragged", "pad_48_512",
                    "m16_tall_wide_128", "m16all_tall_wide_128", "lin_36_512", "plain_lin_24_512"}
 
 
 def extended_only(item):
-    """True: the case runs only with USTRUN_TEST_FULL=1 (see above)."""
+    """True: the case is left out under USTRUN_TEST_QUICK=1 (see above)."""
     cs = getattr(item, "callspec", None)
     if cs is None:
         return False
@@ -66,7 +68,7 @@ def extended_only(item):
 def pytest_collection_modifyitems(config, items):
     if FULL:
         return
-    skip = pytest.mark.skip(reason="extended set: run with USTRUN_TEST_FULL=1 (tests/conftest.py)")
+    skip = pytest.mark.skip(reason="USTRUN_TEST_QUICK=1: extended case (tests/conftest.py)")
     for it in items:
         if extended_only(it):
             it.add_marker(skip)
