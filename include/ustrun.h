@@ -425,6 +425,13 @@ int ustrun_conv1x1_dgrad_join(const void* dy, const void* w_dgrad, int N, int H,
  * returns the weight gradient of the dilation-r convolution (networks/backbone/resnet.py:92-93 with replace_stride_with_dilation)
  * on the all-taps kernel.                                                                                                        */
 int ustrun_space_to_batch(const ustrun_src_t* src, int N, int r, void* out, int dtype, ustrun_stream_t s);
+/* the input gradient of a (dilated) 3x3, stride-1 convolution as ustrun_conv2d_fwd forms it (a convolution of dy with the pack of
+ * w.flip(2,3).transpose(0,1)) that also forms the BatchNorm-backward sums of the BatchNorm + ReLU layer whose output gradient da
+ * is -- conv2's input gradient feeding bn1 (resnet.py:89-93 under autograd): rows and mask as ustrun_conv3x3_dgrad_bnsum.
+ * *stat_rows = 0 and NO launch when the fused epilogue does not cover the shape (16-bit storage, Cin % 128 == 0, dilation 1 / 2 / 4). */
+int ustrun_conv2d_dgrad_bnsum(const void* dy, const void* w_flipped, int N, int H, int W, int Cout, int Cin, int dilation, void* da,
+                              const void* y, const float* scale, const float* shift, float* stat, int* stat_rows, int dtype,
+                              ustrun_stream_t s);
 /* gradient of the bottleneck's join with respect to its pre-ReLU sum: g = (a + b) * (ref > 0) over n elements (n % 4 == 0);
  * b = NULL: one contribution, ref = NULL: no ReLU (the max-pool output feeding layer1)                                       */
 int ustrun_relu_bwd_add(const void* a, const void* b, const void* ref, int64_t n, void* g, int dtype, ustrun_stream_t s);

@@ -253,6 +253,48 @@ def test_space_to_batch_weight_gradient_exact(dt, n, ci, co, h, w, r):
     assert guards_intact(wflat, dw.numel(), 7.0)
 
 
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("n,c,h,w,d", [(2, 256, 33, 40, 2), (2, 128, 40, 36, 4), (1, 128, 19, 21, 2)])
+def test_dilated_dgrad_with_batchnorm_backward_sums_exact(dt, n, c, h, w, d):
+    """ustrun_conv2d_dgrad_bnsum (round 6): conv2's input gradient in a dilated bottleneck (rate 2: the 8 x 16 tile, rate 4: the 16 x
+    16 tile, both on their 16x16x32 builds) with bn1's backward sums -- sum(da mask), sum(da mask y), mask = y scale + shift > 0 --
+    from the stored pieces: against torch-CPU on integer data (exact), ragged tiles, output and rows between sentinels."""
+    l = L()
+    lib = l.lib()
+    t16 = torch.bfloat16 if dt == 1 else torch.float16
+    g = torch.Generator().manual_seed(n + c + h + d)
+    ri = lambda lo, hi, *s_: torch.randint(lo, hi + 1, s_, generator=g).float()
+    dy, y1 = ri(-1, 1, n, c, h, w), ri(-3, 3, n, c, h, w)
+    wt = (torch.rand(c, c, 3, 3, generator=g) < 0.15).float() * ri(-1, 1, c, c, 3, 3)      # sparse: sums stay below 2^8
+    sc, sh = torch.tensor([0.5, 1.0, 2.0, -1.0])[torch.randint(0, 4, (c,), generator=g)], ri(-1, 1, c)
+    want = F.conv_transpose2d(dy, wt, None, 1, d, 0, 1, d)
+    assert float(want.abs().max()) < 2 ** 8
+    mask = (y1 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) > 0
+    to = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda().to(t16)
+    wd = torch.zeros(lib.ustrun_pack_conv_elems(c, c, 9), dtype=t16, device="cuda")
+    wtt = wt.flip(2, 3).transpose(0, 1).contiguous().cuda()
+    l.check(lib.ustrun_pack_conv(wtt.data_ptr(), c, c, 9, wd.data_ptr(), dt, None))
+    dyg, y1g, scg, shg = to(dy), to(y1), sc.cuda(), sh.cuda()
+    out, oflat = guarded(torch.zeros(n, h, w, c, device="cuda", dtype=t16), 7.0)
+    rows_max = lib.ustrun_conv_mtiles(n, h, w, c)
+    stat, sflat = guarded(torch.zeros(rows_max, 2, c, device="cuda"), 7.0)
+    rows = C.c_int(0)
+    l.check(lib.ustrun_conv2d_dgrad_bnsum(dyg.data_ptr(), wd.data_ptr(), n, h, w, c, c, d, out.data_ptr(), y1g.data_ptr(), scg.data_ptr(), shg.data_ptr(),
+                                          stat.data_ptr(), C.byref(rows), dt, None), "dgrad + sums")
+    assert 0 < rows.value <= rows_max
+    v = lib.ustrun_debug_last_conv_variant()
+    assert v & 0x80 and ((v >> 24, (v >> 16) & 255) == ((16, 16) if d == 4 else (8, 16))), hex(v)      # the rate's tile on the 16x16x32 build
+    assert torch.equal(from_nhwc(out), want)
+    assert guards_intact(oflat, out.numel(), 7.0) and guards_intact(sflat, stat.numel(), 7.0)
+    np.testing.assert_allclose(stat[:rows.value, 0].double().sum(0).cpu().numpy(), (want * mask).double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(stat[:rows.value, 1].double().sum(0).cpu().numpy(), (want * mask * y1).double().sum((0, 2, 3)).numpy(), rtol=1e-6, atol=1e-3)
+    # and the plain input gradient (ustrun_conv2d_fwd over dy) writes the same bits
+    src = l.nhwc_src(dyg.data_ptr(), c, h, w)
+    da = torch.empty(n, h, w, c, device="cuda", dtype=t16)
+    l.check(lib.ustrun_conv2d_fwd(C.byref(src), 1, wd.data_ptr(), None, n, h, w, c, 3, 1, d, da.data_ptr(), 0, None, None, dt, None), "dgrad")
+    assert torch.equal(da, out)
+
+
 def wt_variant(tm, tn, loader, ksplit):
     return 0x54000000 | (tm // 64) << 20 | (tn // 64) << 16 | loader << 12 | ksplit
 

@@ -107,8 +107,8 @@ def phase_times(step):
     """torch.cuda.Event pairs around the engine's backward helpers for one step: {helper: ms} (the events serialise nothing,
     the helpers already run back to back on one stream)"""
     from ustrun import resnet_engine as E
-    names = ["_bn_backward", "_conv_wgrad", "_conv_dgrad", "_join", "_zero_insert", "_head_backward", "_stem_backward", "conv_bn",
-             "stem", "bottleneck"]
+    names = ["_bn_backward", "_bn_apply", "_conv_wgrad", "_conv_dgrad", "_conv3_dgrad_bn2", "_conv2_dgrad_bn1", "_conv1_dgrad_join", "_finalize_fused_sums", "_join",
+             "_zero_insert", "_head_backward", "_stem_backward", "conv_bn", "stem", "bottleneck"]
     recs, orig = {k: [] for k in names}, {k: getattr(E, k) for k in names}
 
     def wrap(k):
@@ -167,7 +167,7 @@ def bench_backward(a, m, x, lib, _lib):
     print(f"DeepLabV2-{a.arch} train-mode forward + backward, N={a.n} {a.hw}x{a.hw}, {a.dtype}: {dt * 1e3:.2f} ms = {a.n / dt:.1f} images/s; "
           + "; ".join(out) + f"; peak device memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     ph = phase_times(step)
-    print("   stream time by engine helper (ms; bottleneck = the whole forward block, conv_bn inside it; _conv_dgrad includes _zero_insert): "
+    print("   stream time by engine helper (ms; bottleneck = the whole forward block, conv_bn inside it; _conv_dgrad includes _zero_insert; _conv3_dgrad_bn2 / _conv1_dgrad_join include their _bn_apply / _finalize_fused_sums / fallbacks): "
           + ", ".join(f"{k} {v:.2f}" for k, v in ph.items()))
 
 

@@ -1000,9 +1000,10 @@ int halo_linear_last_pass_rows(const IgemmArgs& a) { return halo_linear_w(a) ? l
 // can this input-gradient launch also form the BatchNorm-backward sums of the layer whose da it writes?  (one plain source, one
 // destination, the two 256-pixel x 128-channel tiles on the 16x16x32 build)
 bool halo_bnsum_supported(const IgemmArgs& a) {
-    if (!halo_supported(a) || halo_dilation(a) != 1 || a.nsrc != 1 || a.out1 || a.C0 != a.Cout || a.Cout % 128) return false;
+    if (!halo_supported(a) || a.nsrc != 1 || a.out1 || a.C0 != a.Cout || a.Cout % 128) return false;
     if (a.src[0].scale || a.src[0].relu || a.src[0].pool) return false;
     if ((g_debug_flags & (8 | 2097152))) return false;
+    if (halo_dilation(a) != 1) return a.bn_gN == 0;      // (round 6) the dilated tiles of DeepLabV2-ResNet: launch_dilated's 16x16x32 builds
     if (halo_linear_w(a)) return true;
     const int t = halo_tile128(a);
     return t == 0 || t == 1;
@@ -1066,6 +1067,11 @@ static int launch_dilated(const IgemmArgs& a, hipStream_t st) {
     bool xf = false;
     for (int i = 0; i < a.nsrc; ++i) xf |= a.src[i].scale != nullptr || a.src[i].relu != 0;
     const bool breg = !(g_debug_flags & 8);          // weights through registers, one barrier per chunk (round 3)
+    if (a.bny) {        // input gradient + BatchNorm-backward sums (halo_bnsum_supported): the 16x16x32 build of the rate's tile
+        USTRUN_CHECK(breg && !xf && a.stat && a.bnsc && a.bnsh && a.Cout % 128 == 0, "conv3x3_halo: BatchNorm-backward sums need a plain source on the 16x16x32 build");
+        if (DIL == 4) return launch_xf<16, 16, 128, 32, 4, false, 1, false, DIL, true, true, true>(a, st);
+        return launch_xf<8, 16, 128, 32, 2, false, 2, false, DIL, true, true, true>(a, st);
+    }
     if (a.Cout % 128 == 0) {
         // rate 4: the (8 + 8) x (16 + 8) patch of an 8 x 16 tile is three times its output and its pair of buffers leaves room
         // for ONE block per CU anyway -- a 16 x 16 tile (24 x 24 patch: 2.25 x) with the 4 x 2 wave tile does twice the MFMA

@@ -376,6 +376,36 @@ extern "C" int ustrun_conv1x1_dgrad_join(const void* dy, const void* w_dgrad, in
     return 0;
 }
 
+// The input gradient of a (dilated) 3x3, stride-1 convolution as ustrun_conv2d_fwd forms it -- a 3x3 convolution of dy with the pack
+// of w.flip(2, 3).transpose(0, 1) -- that also forms the BatchNorm-backward sums of the BatchNorm + ReLU layer whose output gradient
+// da is (conv2's input gradient feeding bn1): rows of [2][Cin] = {sum(da mask), sum(da mask y)}, mask = y scale + shift > 0, as
+// ustrun_conv3x3_dgrad_bnsum.  *stat_rows = 0 and NO launch when the fused epilogue does not cover the shape.
+extern "C" int ustrun_conv2d_dgrad_bnsum(const void* dy, const void* w_flipped, int N, int H, int W, int Cout, int Cin, int dilation, void* da,
+                                         const void* y, const float* scale, const float* shift, float* stat, int* stat_rows, int dtype,
+                                         ustrun_stream_t s) {
+    USTRUN_CHECK(dy && w_flipped && da && y && scale && shift && stat && stat_rows && N > 0 && H > 0 && W > 0 && Cout > 0 && Cin > 0 && dilation >= 1,
+                 "conv2d_dgrad_bnsum: bad args");
+    *stat_rows = 0;
+    if (dtype != USTRUN_D16 || (g_debug_flags2 & 8)) return 0;
+    IgemmArgs a = {};
+    ustrun_src_t sd = {};
+    sd.ptr = dy; sd.C = Cout; sd.H = H; sd.W = W;
+    sd.sC = 1; sd.sW = Cout; sd.sH = (int64_t)W * Cout; sd.sN = (int64_t)H * W * Cout;
+    a.nsrc = 1; a.src[0] = make_src(sd, dtype); a.Cin = Cout;
+    a.W = (const float*)w_flipped; a.Cout = Cin;
+    a.N = N; a.Hb = H; a.Wb = W; a.M = N * H * W;
+    a.s_in = 1; a.nseg = 9; a.segw = 3; a.d0 = -dilation; a.dstep = dilation;
+    a.nz = 1; a.s_out = 1;
+    a.out0 = (float*)da; a.C0 = Cin; a.Ho = H; a.Wo = W; a.out_esz = 2;
+    if (!halo_supported(a) || !halo_bnsum_supported(a)) return 0;
+    a.bny = y; a.bnsc = scale; a.bnsh = shift; a.stat = stat;
+    const int used = halo_stat_rows_used(a);
+    USTRUN_TRY(stat_rows_within_bound(used, N, H, W, Cin, "conv2d_dgrad_bnsum"));
+    USTRUN_TRY(igemm_launch(a, dtype, (hipStream_t)s));
+    *stat_rows = used;
+    return 0;
+}
+
 // A k x k convolution over few input channels as `nrows` row segments: with an NHWC source of C channels, the k horizontally
 // adjacent pixels of one kernel row are k * C CONTIGUOUS elements, so the caller describes the source with "channels" = that
 // window (rounded up to a multiple of 8: the extra elements meet zero weights), pixel stride = C elements, and a border it has

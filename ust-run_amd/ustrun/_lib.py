@@ -108,6 +108,7 @@ SIGNATURES = {
     "ustrun_rowwin_patches": (i32, [PSrc, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "ustrun_relu_bwd_add": (i32, [vp, vp, vp, i64, vp, i32, vp]),
     "ustrun_space_to_batch": (i32, [PSrc, i32, i32, vp, i32, vp]),
+    "ustrun_conv2d_dgrad_bnsum": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, fp, fp, fp, C.POINTER(C.c_int), i32, vp]),
     "ustrun_conv1x1_dgrad_join": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, fp, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int), i32, vp]),
     "ustrun_maxpool3x3s2_bwd": (i32, [vp, vp, fp, fp, i32, i32, i32, i32, vp, i32, vp]),
     "ustrun_sum_resize_bilinear_bwd": (i32, [fp, i32, i32, i32, i32, i32, i32, fp, vp]),

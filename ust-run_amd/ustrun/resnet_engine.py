@@ -435,6 +435,24 @@ def _conv3_dgrad_bn2(dy3, y3, y2, conv, bn, dt, grads):
     return _bn_backward(y2, da2, True, bn, grads, dt)
 
 
+def _conv2_dgrad_bn1(dy2, y2, y1, conv, bn, dt, grads):
+    """da1 = dgrad(conv2)(dy2) and dy1 = BatchNorm + ReLU backward of bn1, the sums formed in the (dilated) 3x3 input gradient's
+    epilogue where the library covers the shape (stride 1, 16-bit storage, >= 128 channels)"""
+    lib = L.lib()
+    co, ci, k, _ = conv.weight.shape
+    if k == 3 and conv.stride[0] == 1 and dt != L.F32:
+        da1 = torch.empty_like(y1.t)
+        rows = C.c_int(0)
+        stat = _scratch.get("join_stat", lib.ustrun_conv_mtiles(y1.N, y1.H, y1.W, ci) * 2 * ci * 4, dy2.device)
+        L.check(lib.ustrun_conv2d_dgrad_bnsum(dy2.data_ptr(), _packed_dgrad(conv, dt).data_ptr(), y1.N, y1.H, y1.W, co, ci, conv.dilation[0],
+                                              da1.data_ptr(), y1.t.data_ptr(), y1.aff[0].data_ptr(), y1.aff[1].data_ptr(), stat.data_ptr(),
+                                              C.byref(rows), dt, stream_ptr()), "ustrun_conv2d_dgrad_bnsum")
+        if rows.value:
+            return _bn_apply(y1, da1, _finalize_fused_sums(stat, rows.value, y1, bn, grads), dt, relu=True)
+    da1 = _conv_dgrad(dy2, y2, y1, conv, dt)
+    return _bn_backward(y1, da1, True, bn, grads, dt)
+
+
 def _conv1_dgrad_join(dy1, y1, x, conv, dxb, ref, prev, dt, grads):
     """Gradient of the PREVIOUS block's pre-ReLU sum: (dgrad(conv1)(dy1) + dxb) * (ref > 0), ref = this block's input (the previous
     block's output; None behind the max-pool).  One launch where the library fuses the join into the 1x1 input gradient's epilogue
@@ -469,8 +487,7 @@ def _block_backward(rec, G, dt, grads, prev=None, coef3=None, first=False):
     _conv_wgrad(y2, dy3, y3, blk.conv3, grads, dt)
     dy2 = _conv3_dgrad_bn2(dy3, y3, y2, blk.conv3, blk.bn2, dt, grads)
     _conv_wgrad(y1, dy2, y2, blk.conv2, grads, dt)
-    da1 = _conv_dgrad(dy2, y2, y1, blk.conv2, dt)
-    dy1 = _bn_backward(y1, da1, True, blk.bn1, grads, dt)
+    dy1 = _conv2_dgrad_bn1(dy2, y2, y1, blk.conv2, blk.bn1, dt, grads)
     _conv_wgrad(x, dy1, y1, blk.conv1, grads, dt)
     if yd is None:
         dxb = G
