@@ -1,7 +1,2 @@
-set -o pipefail
-R=$GRAFT_REPO_ROOT
-cd $R
-bash tools/profile_round.sh > gpurun_out/profile_round.log 2>&1
-tail -3 gpurun_out/profile_round.log | cut -c1-300
-bash tools/profile_configs.sh > gpurun_out/profile_configs.log 2>&1
-tail -8 gpurun_out/profile_configs.log
+cd $GRAFT_REPO_ROOT
+python tools/diag_x3_grouped.py 2>&1 | grep -v amdgpu.ids
