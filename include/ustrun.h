@@ -192,6 +192,11 @@ int ustrun_convT2x2_wgrad(const ustrun_src_t* src, const void* du, int N, int H,
  * x[N,H,W,C] -> y[N,2H,2W,C] (NHWC f32, C % 4 == 0); _bwd is its exact adjoint (dy -> dx), fixed summation order. */
 int ustrun_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, ustrun_stream_t s);
 int ustrun_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, ustrun_stream_t s);
+/* the same two passes in a plan's storage dtype (the fused U-Net with bilinear = 1): the forward reads a plain contiguous NHWC
+ * source through its BatchNorm constants + ReLU (pass groups honoured) and stores the interpolated activation; the backward is the
+ * adjoint over dy [N,2H,2W,C] -> dx [N,H,W,C]                                                                                   */
+int ustrun_upsample2x_act(const ustrun_src_t* src, int N, void* out, int dtype, ustrun_stream_t s);
+int ustrun_upsample2x_bwd_t(const void* dy, int N, int H, int W, int C, void* dx, int dtype, ustrun_stream_t s);
 
 /* ---- pseudo-labels: replaces train.py:648-667 (teacher) and :669-674 (student) ---------------
  * softmax: conf,label = max(softmax(logits,1),1); mask = conf > th   (label int64, mask f32)
@@ -332,6 +337,9 @@ typedef struct ustrun_unet_desc {
     const float* up_w[4];   const float* up_b[4];
     const float* head_w;    const float* head_b;
     void* packed;                /* packed-weight arena, ustrun_unet_packed_bytes()           */
+    int32_t bilinear;            /* 1: the reference's UNet(bilinear=True) (unet_model.py:17-22, unet_parts.py:48-51): Up upsamples its
+                                  * input 2x (bilinear, align_corners=True) instead of a ConvTranspose2d -- no up_w / up_b, down4 and the
+                                  * decoder on the halved channel plan (DoubleConv(in, out, in // 2)), 56 parameter tensors           */
 } ustrun_unet_desc_t;
 
 int64_t ustrun_unet_packed_bytes(const ustrun_unet_desc_t* d);
@@ -342,7 +350,7 @@ int ustrun_unet_pack(const ustrun_unet_desc_t* d, ustrun_stream_t s);
 int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, float* logits, float* feat,
                         void* workspace, ustrun_stream_t s);
 /* grads[] follow the parameter order of the reference's model.parameters() (64 tensors for
- * bilinear=False): accumulate != 0 adds into them.                                           */
+ * bilinear=False, 56 for bilinear=True): accumulate != 0 adds into them.                     */
 int ustrun_unet_backward(const ustrun_unet_desc_t* d, const float* x, const float* dlogits,
                          void* workspace, void* scratch, float* const* grads, int accumulate,
                          ustrun_stream_t s);

@@ -27,6 +27,13 @@ struct Plan {
     int Hs[5], Ws[5];            // extent per level
     int cin[18], cout[18], lvl[18];
     int up_cin[4], up_cout[4];   // convT j: level of its input = 4-j (j = 0..3), output level 3-j
+    int bil;                     // bilinear Up (unet_parts.py:48-51): no ConvTranspose -- u = the 2x-interpolated input, up_cout = up_cin
+    int gi_head;                 // index of outc.conv.weight in model.parameters() order (62, bilinear: 54)
+    int gi_conv(int i) const {   // index of conv i's weight in model.parameters() order; +1 gamma, +2 beta
+        if (i < 10) return (i / 2) * 6 + (i % 2) * 3;
+        const int j = (i - 10) / 2;
+        return bil ? 30 + j * 6 + (i % 2) * 3 : 30 + j * 8 + 2 + (i % 2) * 3;
+    }
     // BYTE offsets (activations are esz bytes per element, everything else f32)
     int esz;
     long y_off[18], aff_off[18]; // aff: scale, shift, mean, rstd (4*cout)
@@ -65,7 +72,9 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     p.Hs[0] = d->H; p.Ws[0] = d->W;
     for (int l = 1; l < 5; ++l) { p.Hs[l] = p.Hs[l - 1] / 2; p.Ws[l] = p.Ws[l - 1] / 2; }
     const int b = d->base;
-    const int ch[5] = {b, 2 * b, 4 * b, 8 * b, 16 * b};
+    p.bil = d->bilinear ? 1 : 0;
+    p.gi_head = p.bil ? 54 : 62;
+    const int ch[5] = {b, 2 * b, 4 * b, 8 * b, p.bil ? 8 * b : 16 * b};       // (bilinear: Down(8b, 16b // 2), unet_model.py:17-18)
     for (int l = 0; l < 5; ++l) {                 // encoder double convs
         p.cin[2 * l] = l == 0 ? d->C : ch[l - 1]; p.cout[2 * l] = ch[l];
         p.cin[2 * l + 1] = ch[l]; p.cout[2 * l + 1] = ch[l];
@@ -73,11 +82,19 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
     }
     for (int j = 0; j < 4; ++j) {                 // decoder: up(j+1) works at level 3-j
         const int l = 3 - j;
+        if (p.bil) {        // Up(in, out, bilinear) = Upsample + DoubleConv(in, out, in // 2) with out = in // 4 (up4: in // 2), unet_model.py:19-22
+            const int x1ch = j == 0 ? ch[4] : p.cout[9 + 2 * j];
+            p.up_cin[j] = p.up_cout[j] = x1ch;
+            p.cin[10 + 2 * j] = ch[l] + x1ch; p.cout[10 + 2 * j] = p.cin[10 + 2 * j] / 2;
+            p.cin[11 + 2 * j] = p.cout[10 + 2 * j]; p.cout[11 + 2 * j] = j < 3 ? ch[l] / 2 : ch[0];
+        } else {
         p.up_cin[j] = ch[l + 1]; p.up_cout[j] = ch[l + 1] / 2;
         p.cin[10 + 2 * j] = ch[l] + p.up_cout[j]; p.cout[10 + 2 * j] = ch[l];
         p.cin[11 + 2 * j] = ch[l]; p.cout[11 + 2 * j] = ch[l];
+        }
         p.lvl[10 + 2 * j] = p.lvl[11 + 2 * j] = l;
     }
+    USTRUN_CHECK(!p.bil || b % 8 == 0, "unet: bilinear needs base %% 8 == 0 (base=%d)", b);
     p.esz = act_esz(d->dtype);
     const long E = p.esz;
     long o = 0;
@@ -130,7 +147,7 @@ int make_plan(const ustrun_unet_desc_t* d, Plan& p) {
         p.wd_off[i] = o; o = align_up(o + n, 64);
     }
     for (int j = 0; j < 4; ++j) {
-        const long n = 4L * align_up(p.up_cin[j], 8) * align_up(p.up_cout[j], 8) * (d->dtype == USTRUN_F32X3 ? 3 : 1);
+        const long n = p.bil ? 0 : 4L * align_up(p.up_cin[j], 8) * align_up(p.up_cout[j], 8) * (d->dtype == USTRUN_F32X3 ? 3 : 1);
         p.uf_off[j] = o; o = align_up(o + n, 64);
         p.ud_off[j] = o; o = align_up(o + n, 64);
     }
@@ -229,12 +246,6 @@ int conv_sources_fwd(const Plan& p, const float* x, const char* ws, int i, ustru
     return 2;
 }
 
-int grad_index_conv(int i) {    // index of conv i's weight in model.parameters() order; +1 gamma, +2 beta
-    if (i < 10) return (i / 2) * 6 + (i % 2) * 3;
-    const int j = (i - 10) / 2;
-    return 30 + j * 8 + 2 + (i % 2) * 3;
-}
-
 }  // namespace
 }  // namespace ustrun
 
@@ -263,17 +274,17 @@ extern "C" int ustrun_unet_pack(const ustrun_unet_desc_t* d, ustrun_stream_t s) 
             USTRUN_CHECK(d->conv_w[i], "unet_pack: conv weight %d missing", i);
             jobs.j[i] = PackJob{d->conv_w[i], pk + p.wf_off[i], pk + p.wd_off[i], p.cout[i], p.cin[i], 9, 0};
         }
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4 && !p.bil; ++j) {
             USTRUN_CHECK(d->up_w[j], "unet_pack: up weight %d missing", j);
             jobs.j[18 + j] = PackJob{d->up_w[j], pk + p.uf_off[j], pk + p.ud_off[j], p.up_cout[j], p.up_cin[j], 4, 1};
         }
-        return pack_bf16_multi(jobs, 22, (hipStream_t)s);
+        return pack_bf16_multi(jobs, p.bil ? 18 : 22, (hipStream_t)s);
     }
     for (int i = 0; i < 18; ++i) {
         USTRUN_CHECK(d->conv_w[i], "unet_pack: conv weight %d missing", i);
         USTRUN_TRY(ustrun_pack_conv3x3(d->conv_w[i], p.cout[i], p.cin[i], pk + p.wf_off[i], pk + p.wd_off[i], d->dtype, s));
     }
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4 && !p.bil; ++j) {
         USTRUN_CHECK(d->up_w[j], "unet_pack: up weight %d missing", j);
         USTRUN_TRY(ustrun_pack_convT2x2(d->up_w[j], p.up_cin[j], p.up_cout[j], pk + p.uf_off[j], pk + p.ud_off[j], d->dtype, s));
     }
@@ -311,6 +322,8 @@ extern "C" int ustrun_unet_forward(const ustrun_unet_desc_t* d, const float* x, 
             ustrun_src_t a = nhwc_src(ws + p.y_off[prev], affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0,
                                       p.pg);
             prof_set_tag(20 + j, p.N);
+            if (p.bil) USTRUN_TRY(ustrun_upsample2x_act(&a, p.N, ws + p.u_off[j], d->dtype == USTRUN_F32X3 ? USTRUN_F32 : d->dtype, s));
+            else
             USTRUN_TRY(ustrun_convT2x2_fwd(&a, pk + p.uf_off[j], d->up_b[j], p.N, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j],
                                            ws + p.u_off[j], d->dtype, s));
         }
@@ -414,7 +427,7 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
         const int C = p.cout[17];
         const long gpix = (long)p.gN * p.H * p.W;
         USTRUN_TRY(head_bwd_passes(dlogits, yb(17), affp(17), affp(17) + C, gpix, p.H * p.W, C, p.K, d->head_w,
-                                   sc + p.da_off[17], grads[62], grads[63], accumulate, part, p.part_bytes, dt, p.Gb, 4L * C,
+                                   sc + p.da_off[17], grads[p.gi_head], grads[p.gi_head + 1], accumulate, part, p.part_bytes, dt, p.Gb, 4L * C,
                                    (hipStream_t)s, (g_debug_flags & 8388608) ? nullptr : &head_bn_rows));
     }
     // layers 17..10 = decoder, 9..8 = down4 (57 of the encoder's 75 MB of gradients, and the first to finish), 7..0 = the rest
@@ -426,7 +439,7 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
 
         const int l = p.lvl[i], H = p.Hs[l], W = p.Ws[l], C = p.cout[i];
         const float* aff = affp(i);
-        const int gi = grad_index_conv(i);
+        const int gi = p.gi_conv(i);
         // the encoder outputs x1..x4 (convs 1,3,5,7) also feed a MaxPool: add the routed pooled grad
         const bool pooled = (i < 8) && (i % 2 == 1);
         const void* dp = pooled ? sc + p.dp_off[3 - l] : nullptr;
@@ -468,6 +481,12 @@ extern "C" int ustrun_unet_backward_part(const ustrun_unet_desc_t* d, const floa
             USTRUN_TRY(ustrun_conv3x3_dgrad(da, wd, p.Nb, H, W, C, p.cin[i], sc + p.da_off[skip], p.cout[skip],
                                             sc + p.du_off[j], uh, uw, (H - uh) / 2, (W - uw) / 2, dt, s));
             const int prev = (j == 0) ? 9 : i - 1;
+            if (p.bil) {                       // the interpolation's adjoint: du -> da of the block below (no parameters)
+                prof_set_tag(120 + j, p.Nb);
+                USTRUN_TRY(ustrun_upsample2x_bwd_t(sc + p.du_off[j], p.Nb, p.Hs[l + 1], p.Ws[l + 1], p.up_cout[j], sc + p.da_off[prev],
+                                                   dt == USTRUN_F32X3 ? USTRUN_F32 : dt, s));
+                continue;
+            }
             ustrun_src_t a = nhwc_src(yb(prev), affp(prev), p.cout[prev], p.Hs[l + 1], p.Ws[l + 1], 1, 0,
                                       p.pgb);
             const int ub = 30 + j * 8;

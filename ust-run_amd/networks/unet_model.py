@@ -32,8 +32,6 @@ class UNet(nn.Module):
         self.up4 = Up(2 * b, b, bilinear)
         self.outc = OutConv(b, n_classes)
         if num_domains:
-            if bilinear:
-                raise ValueError("UNet(num_domains > 0): the fused plan only (bilinear=False)")
             from .dsbn import DomainSpecificBatchNorm2d
             for dc in (self.inc, self.down1.maxpool_conv[1], self.down2.maxpool_conv[1], self.down3.maxpool_conv[1],
                        self.down4.maxpool_conv[1], self.up1.conv, self.up2.conv, self.up3.conv, self.up4.conv):
@@ -50,22 +48,18 @@ class UNet(nn.Module):
         if self.num_domains:
             if domain_label is None:
                 raise RuntimeError("UNet(num_domains > 0): forward needs domain_label")
-            if self.bilinear:
-                raise RuntimeError("UNet(num_domains > 0) runs the fused plan only (bilinear=False)")
             self._ustrun_domain = int(domain_label[0]) if hasattr(domain_label, "__getitem__") else int(domain_label)
         elif domain_label is not None:
             raise RuntimeError("UNet: domain_label given to a network without domain-specific BatchNorm (num_domains = 0)")
-        if self.bilinear:
-            return self._forward_blocks(x, feature)
         from ustrun import engine
         return engine.unet_forward(self, x, feature)
 
     def _forward_blocks(self, x, feature=False):
         """unet_model.py:25-39 composed from the block modules (each one HIP kernels through the operator-level ABI,
-        f32).  The bilinear variant runs this way: no reference call site uses it (train.py:499 takes the
-        ConvTranspose2d default), so it has no fused whole-network plan."""
+        f32): the parity surface of the blocks, and what the bilinear variant ran on before the fused plan took it
+        (round 6: ustrun_unet_desc_t::bilinear, every storage dtype).  Kept for the tests that compare the two."""
         if self.compute_dtype != "f32":
-            raise RuntimeError("UNet(bilinear=True) runs through the f32 block modules; construct it with dtype='f32'")
+            raise RuntimeError("the block modules run in f32; construct the network with dtype='f32'")
         x1 = self.inc(x)
         x2 = self.down1(x1)
         x3 = self.down2(x2)
@@ -88,10 +82,10 @@ class UNet(nn.Module):
         n = (len(x) - tail) // max(groups, 1)
         if groups < 1 or n * groups + tail != len(x) or (tail and tail >= n):
             raise RuntimeError(f"forward_batched: {len(x)} images are not {groups} equal passes + a shorter tail of {tail}")
-        if self.bilinear or lead and feature:
+        if lead and feature:
             parts = list(x[:n * groups].split(n))
             with torch.no_grad():           # (with `feature` every pass returns (logits, feat): concatenated per component)
-                head = [self._forward_blocks(t, feature) if self.bilinear else self(t, feature) for t in parts[:lead]]
+                head = [self(t, feature) for t in parts[:lead]]
             rest = self.forward_passes(parts[lead:], feature, tail=x[n * groups:] if tail else None)
             if not lead:
                 return rest
@@ -118,11 +112,5 @@ class UNet(nn.Module):
             raise RuntimeError("forward_passes: the tail pass must have the passes' image shape and fewer images")
         x = torch.cat(xs + ([tail] if tail is not None else []), 0) if len(xs) > 1 or tail is not None else xs[0]
         _hip_only(x)
-        if self.bilinear:                                   # no batched plan: pass by pass, in order
-            outs = [self._forward_blocks(t, feature) for t in xs]
-            if tail is not None:
-                with torch.no_grad():
-                    self._forward_blocks(tail, False)
-            return tuple(torch.cat(o, 0) for o in zip(*outs)) if feature else torch.cat(outs, 0)
         from ustrun import engine
         return engine.unet_forward(self, x, feature, groups=len(xs), tail=0 if tail is None else len(tail))

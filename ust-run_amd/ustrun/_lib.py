@@ -28,7 +28,7 @@ class UNetDesc(C.Structure):
                 ("train", i32), ("update_running", i32), ("groups", i32), ("tail", i32), ("lead", i32), ("momentum", f32), ("eps", f32),
                 ("conv_w", vp * 18), ("bn_w", vp * 18), ("bn_b", vp * 18), ("bn_rm", vp * 18),
                 ("bn_rv", vp * 18), ("bn_nbt", vp * 18), ("up_w", vp * 4), ("up_b", vp * 4),
-                ("head_w", vp), ("head_b", vp), ("packed", vp)]
+                ("head_w", vp), ("head_b", vp), ("packed", vp), ("bilinear", i32)]
 
 
 class AsmRow(C.Structure):
@@ -107,6 +107,8 @@ SIGNATURES = {
     "ustrun_sum_resize_bilinear": (i32, [C.POINTER(vp), i32, i32, i32, i32, i32, i32, i32, fp, vp]),
     "ustrun_rowwin_patches": (i32, [PSrc, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "ustrun_relu_bwd_add": (i32, [vp, vp, vp, i64, vp, i32, vp]),
+    "ustrun_upsample2x_act": (i32, [PSrc, i32, vp, i32, vp]),
+    "ustrun_upsample2x_bwd_t": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "ustrun_space_to_batch": (i32, [PSrc, i32, i32, vp, i32, vp]),
     "ustrun_conv2d_dgrad_bnsum": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, fp, fp, fp, C.POINTER(C.c_int), i32, vp]),
     "ustrun_conv1x1_dgrad_join": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, fp, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int), i32, vp]),

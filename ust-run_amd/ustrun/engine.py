@@ -28,7 +28,8 @@ def conv_bn_list(model):
     for dc in dcs:
         s = dc.double_conv
         pairs += [(s[0], pick(s[1])), (s[3], pick(s[4]))]
-    ups = [model.up1.up, model.up2.up, model.up3.up, model.up4.up]
+    # (bilinear=True: Up.up is a parameter-free nn.Upsample -- the plan interpolates, there is no ConvTranspose to hand over)
+    ups = [] if getattr(model, "bilinear", False) else [model.up1.up, model.up2.up, model.up3.up, model.up4.up]
     return pairs, ups, model.outc.conv
 
 
@@ -43,6 +44,7 @@ def _desc(model, N, H, W, train, groups=1, tail=0, lead=0):
     d.N, d.C, d.H, d.W, d.K = N, model.n_channels, H, W, model.n_classes
     d.groups, d.tail, d.lead = groups, tail, lead
     d.base, d.dtype = model.base_channels, _DT[model.compute_dtype]
+    d.bilinear = int(bool(getattr(model, "bilinear", False)))
     d.train, d.update_running = int(train), int(train)
     bn0 = pairs[0][1]
     d.momentum, d.eps = float(bn0.momentum), float(bn0.eps)
