@@ -135,6 +135,41 @@ def test_unet_full_size_forward(name):
     assert diff <= 2, diff
 
 
+def test_unet_bilinear_against_the_reference():
+    """G13 (round 6): the reference's UNet(bilinear=True) itself -- unet_model.py:17-22, unet_parts.py:48-51 -- at full width on a
+    2 x 3 x 96 x 136 input (136 -> 17 -> 8: an odd halving, so MaxPool2d drops a column and F.pad places the interpolated map):
+    the oracle reproduces its initial weights (RNG order, parameter shapes, key count), train-mode logits, arg-max map, loss,
+    gradients and BatchNorm running statistics."""
+    g = load_golden("g13_unet_bilinear_3_2_n2_96x136")
+    n, c, h, w, k = [int(v) for v in g["shape"]]
+    torch.manual_seed(int(g["model_seed"]))
+    sd = U.make_state_dict(c, k, bilinear=True)
+    assert len(sd) == int(g["n_state_keys"])
+    pk = U.param_keys(sd)
+    assert len(pk) == 56 == len(g["param_shapes"])
+    for kk, shp in zip(pk, g["param_shapes"]):
+        assert list(sd[kk].shape) == [int(v) for v in shp[:sd[kk].dim()]], kk
+    np.testing.assert_allclose([float(sd[kk].double().sum()) for kk in pk], g["weight_sums"], rtol=1e-6, atol=1e-6)
+    gen = torch.Generator().manual_seed(int(g["input_seed"]))
+    x = torch.randint(0, 256, (n, c, h, w), generator=gen).float() / 127.5 - 1
+    ref = U.clone_sd(sd, requires_grad=True)
+    logits = U.unet_forward(x, ref, train=True, bilinear=True)
+    loss = logits.square().mean()
+    loss.backward()
+    flat = logits.detach().flatten()
+    close(flat[t(g["sample_idx"])], g["sample_val"], rtol=1e-4, atol=1e-5)
+    assert abs(float(flat.double().norm()) - float(g["logit_l2"])) <= 1e-5 * float(g["logit_l2"])
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    diff = np.unpackbits(np.packbits(logits.detach().argmax(1).numpy().astype(np.uint8)) ^ g["argmax"]).sum()
+    assert diff <= 2, diff
+    norms = np.array([float(ref[kk].grad.double().norm()) for kk in pk])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-9)
+    rm = np.array([float(v.double().sum()) for kk, v in ref.items() if kk.endswith("running_mean")])
+    rv = np.array([float(v.double().sum()) for kk, v in ref.items() if kk.endswith("running_var")])
+    np.testing.assert_allclose(rm, g["rm_sums"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv, g["rv_sums"], rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("K", [2, 4])
 def test_dice_loss_with_mask(K):
     g = load_golden("g4_losses")

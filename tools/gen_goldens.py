@@ -156,6 +156,38 @@ def g3b_unet_backward(name, c, k, n, h):
          rv_sums=np.array([float(v.double().sum()) for kk, v in bufs.items() if kk.endswith("running_var")]))
 
 
+def g13_unet_bilinear(name, c, k, n, h, w):
+    """The reference's UNet(bilinear=True) (unet_model.py:17-22, unet_parts.py:48-51) at full width on a seeded input whose width
+    halves to an odd extent (136 -> 17 -> 8: MaxPool2d drops a column, F.pad places the 16-wide interpolated map in the 17-wide skip):
+    train-mode logits (checksums, 4096 samples, the arg-max map), then gradient norms + 16 samples per parameter tensor for
+    loss = logits.square().mean() and the BatchNorm running-statistic sums -- the state_dict's key list rides along (56 parameters, no
+    up.weight): pins the halved channel plan and the interpolation against the reference itself (round 6)."""
+    torch.manual_seed(1337)
+    model = UNet(n_channels=c, n_classes=k, bilinear=True)
+    wsum = weight_sums(model)
+    g = torch.Generator().manual_seed(1337)
+    x = torch.randint(0, 256, (n, c, h, w), generator=g).float() / 127.5 - 1
+    model.train()
+    logits = model(x)
+    loss = logits.square().mean()
+    loss.backward()
+    flat = logits.detach().flatten()
+    idx = torch.randperm(flat.numel(), generator=g)[:4096]
+    amax = logits.detach().argmax(1).numpy().astype(np.uint8)
+    norms, samples = [], []
+    for p in model.parameters():
+        gflat = p.grad.flatten()
+        norms.append(float(gflat.double().norm()))
+        samples.append(gflat[torch.linspace(0, gflat.numel() - 1, 16).long()].numpy())
+    bufs = model.state_dict()
+    shapes = np.array([list(v.shape) + [0] * (4 - v.dim()) for v in model.parameters()])
+    save(name, model_seed=1337, input_seed=1337, shape=np.array([n, c, h, w, k]), weight_sums=wsum, param_shapes=shapes,
+         n_state_keys=len(bufs), logit_sum=float(flat.double().sum()), logit_l2=float(flat.double().norm()), sample_idx=idx,
+         sample_val=flat[idx], argmax=np.packbits(amax), loss=loss.detach(), grad_norms=np.array(norms), grad_samples=np.stack(samples),
+         rm_sums=np.array([float(v.double().sum()) for kk, v in bufs.items() if kk.endswith("running_mean")]),
+         rv_sums=np.array([float(v.double().sum()) for kk, v in bufs.items() if kk.endswith("running_var")]))
+
+
 def g10_deeplab(name, arch, nclass, n, h, w, seed=1337):
     """The reference's DeepLabV2 (networks/deeplabv2.py) on a seeded input: train-mode logits (samples + checksums), the
     backbone feature norms, running-statistic sums after that call, then eval-mode logits.  The constructor always loads
@@ -425,6 +457,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g4b":
         g4b_dice_rest()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g13":          # only the round-6 addition
+        g13_unet_bilinear("g13_unet_bilinear_3_2_n2_96x136", 3, 2, 2, 96, 136)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g3b":          # only the round-2 addition
         g3b_unet_backward("g3b_unet_3_2_n4_256_bwd", 3, 2, 4, 256)
         sys.exit(0)
@@ -434,6 +469,7 @@ if __name__ == "__main__":
     g3_unet_full("g3_unet_1_2_n2_384", 1, 2, 2, 384)
     g3_unet_full("g3_unet_1_4_n2_288", 1, 4, 2, 288)
     g3b_unet_backward("g3b_unet_3_2_n4_256_bwd", 3, 2, 4, 256)
+    g13_unet_bilinear("g13_unet_bilinear_3_2_n2_96x136", 3, 2, 2, 96, 136)
     g10_deeplab("g10_deeplabv2_r50_n2_96x80", "resnet50", 2, 2, 96, 80)
     g10_deeplab("g10_deeplabv2_r101_n1_128", "resnet101", 2, 1, 128, 128)
     g10b_deeplab_backward("g10b_deeplabv2_r50_n2_96x80_bwd", "resnet50", 2, 2, 96, 80)
