@@ -320,7 +320,36 @@ def _bn_backward(y, da, relu, bn, grads, dt):
     return dy
 
 
+_SIDE = {}          # device -> the weight gradients' stream
+_WGRAD_SIDE_STREAM = os.environ.get("USTRUN_DEEPLAB_WGRAD_STREAM", "1") != "0"       # "0": everything on the caller's stream (rounds 2-5; A/B runs)
+
+
 def _conv_wgrad(x, dy, y, conv, grads, dt):
+    """grads[conv.weight], on a stream of its own (round 6): a layer's weight gradient and its input gradient both only READ dy, and
+    nothing waits for dW before the backward returns -- the main chain's HBM-bound passes (BatchNorm apply, the join's GEMM) and small
+    launches (finalizes, reduces) leave matrix pipes idle that the weight-gradient kernels use: 38.9-39.3 -> 35.9-36.0 ms per forward +
+    backward at n = 16, same box (profiles/r06_ab_deeplab_wgrad_stream.log).  The side stream waits for dy's producer;
+    deeplabv2_backward joins it before it returns."""
+    if not _WGRAD_SIDE_STREAM:
+        return _conv_wgrad_here(x, dy, y, conv, grads, dt)
+    dev = dy.device
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE.get(dev)
+    if side is None:
+        side = _SIDE[dev] = torch.cuda.Stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        _conv_wgrad_here(x, dy, y, conv, grads, dt)
+    for t in (dy, x.t) + ((x.aff[0], x.aff[1]) if x.aff is not None else ()):
+        t.record_stream(side)           # (the caching allocator must not hand these to the main stream while the side stream reads them)
+
+
+def _join_side_stream(dev):
+    if _WGRAD_SIDE_STREAM and dev in _SIDE:
+        torch.cuda.current_stream(dev).wait_stream(_SIDE[dev])
+
+
+def _conv_wgrad_here(x, dy, y, conv, grads, dt):
     """grads[conv.weight] from the loader's view of the input Act x and the raw-output gradient dy (shape of y)"""
     lib = L.lib()
     co, ci, k, _ = conv.weight.shape
@@ -577,6 +606,7 @@ def deeplabv2_backward(net, tape, dlogits):
     for i in range(len(tape) - 2, 0, -1):
         G, coef3 = _block_backward(tape[i], G, dt, grads, prev=tape[i - 1] if i > 1 else None, coef3=coef3, first=(i == 1))
     _stem_backward(tape[0], G, dt, grads)
+    _join_side_stream(dlogits.device)
     return grads
 
 
