@@ -123,10 +123,12 @@ def phase_times(step):
 
     for k in names:
         setattr(E, k, wrap(k))
+    side, E._WGRAD_SIDE_STREAM = E._WGRAD_SIDE_STREAM, False      # (event pairs on one stream: the weight gradients back on it for this step)
     try:
         step()
         torch.cuda.synchronize()
     finally:
+        E._WGRAD_SIDE_STREAM = side
         for k in names:
             setattr(E, k, orig[k])
     return {k: sum(e0.elapsed_time(e1) for e0, e1 in v) for k, v in recs.items()}
