@@ -168,6 +168,12 @@ def test_statistics_rows_never_exceed_the_published_bound():
                     worst = max(worst, used / cap)
                     n += 1
     assert n > 5000 and worst == 1.0       # the bound is tight somewhere: it is a bound of the kernels, not a padded guess
+    # round 6: the 64 -> 64 streaming kernel's flat plan (two row slots per strip: 4 N sx rows) at the image counts that select it
+    for N in (33, 41, 65, 81, 129, 200):
+        for H, W in ((256, 256), (288, 288), (384, 384), (512, 512), (72, 80), (200, 264), (16, 512)):
+            used, cap = lib.ustrun_debug_conv_stat_rows(N, H, W, 64, 64, 3, 1, 1, 0, L.BF16), lib.ustrun_conv_mtiles(N, H, W, 64)
+            assert 0 < used <= cap, (N, H, W, used, cap)
+    assert lib.ustrun_debug_conv_stat_rows(81, 256, 256, 64, 64, 3, 1, 1, 0, L.BF16) == 81 * 8 * 4       # the student's call of configs[1]: flat
     # the round-2 overflow shape, by name
     assert lib.ustrun_debug_conv_stat_rows(8, 72, 72, 64, 64, 3, 1, 1, 0, L.BF16) == 432 <= lib.ustrun_conv_mtiles(8, 72, 72, 64)
     # linear tiles (round 5): one row per 256 positions of the flat padded space (19 x 19 per 18 x 18 image), one pass here
