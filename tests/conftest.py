@@ -27,7 +27,7 @@ def golden():
 
 
 # ---- the full GPU set (default) and a quick one (`pytest -m gpu` must finish well inside the driver's step limit) ----
-# Every case runs by default: 596 cases in 228 s on a gpurun box (profiles/r06_pytest_gpu_full_set.log) once the torch-CPU side of
+# Every case runs by default: 600 cases in 219-232 s on a gpurun box (profiles/r06_pytest_gpu_full_set.log) once the torch-CPU side of
 # the tests stopped oversubscribing the box's CPU share (below) -- that, not the case count, had made round 5's run take 765 s.
 # USTRUN_TEST_QUICK=1 leaves out (reported as SKIPPED, with this reason) cases that re-run a kernel some other case already pins
 # bit-exactly -- 462 cases in 153 s (profiles/r06_pytest_gpu_quick_set.log):
