@@ -351,6 +351,26 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
     __syncthreads();                              // every wave is done with the activation tiles the scratch aliases
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        const int d0 = wm * 32 * MI + 32 * i + r0;
+        // The tensors read beside the stored pieces (join: the other contribution and the ReLU reference; BNS: y) do not depend on
+        // the product: all of a sub-tile's loads (up to twelve 16-byte pieces per lane) are issued HERE, in front of the LDS
+        // transposition, instead of one piece at a time between the stores -- hipcc kept each load behind the store before it
+        // (it cannot tell the resources apart) and every piece waited out a memory round trip of its own (16 per wave and tile).
+        // (Issued one sub-tile further ahead -- 24 pieces in flight, 256 registers -- measured the same.)
+        u32x4_t pb[4], pr[4], py[4];
+        if constexpr (JOIN || BNS) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int d = d0 + 8 * t;
+                const int vo = (m0 + d < a.M) ? (d * a.Cout + ch * 8) * 2 : OOBV;
+                if constexpr (JOIN) {
+                    pb[t] = __builtin_amdgcn_raw_buffer_load_b128(jars, vo, 0, 0);
+                    pr[t] = __builtin_amdgcn_raw_buffer_load_b128(jrrs, vo, 0, 0);
+                }
+                if constexpr (BNS) py[t] = __builtin_amdgcn_raw_buffer_load_b128(yrs, vo, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -363,7 +383,6 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int d0 = wm * 32 * MI + 32 * i + r0;
         int x = (DG || PLAIN) ? 0 : fastmod(x0r + d0, W, invW);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -373,8 +392,8 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
             const bool ok = m0 + d < a.M;
             const int vo = (DG || PLAIN) ? (d * a.Cout + ch * 8) * 2 : ((4 * d - 2 * x + 2 * W) * a.Cout + ch * 8) * 2;
             if constexpr (JOIN) {       // (the unfused pair rounds the product to the storage type, adds in f32 and rounds again: so does this)
-                const bf16x8 b8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(jars, ok ? vo : OOBV, 0, 0));
-                const bf16x8 r8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(jrrs, ok ? vo : OOBV, 0, 0));
+                const bf16x8 b8 = __builtin_bit_cast(bf16x8, pb[t]);
+                const bf16x8 r8 = __builtin_bit_cast(bf16x8, pr[t]);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const float g = (float)v8[q] + (float)b8[q];
@@ -383,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void convT_bf16_kernel(const IgemmArgs a, c
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v8), ors, ok ? vo : OOBV, 0, 0);
             if constexpr (BNS) {
-                const bf16x8 y8 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(yrs, ok ? vo : OOBV, 0, 0));
+                const bf16x8 y8 = __builtin_bit_cast(bf16x8, py[t]);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const float yf = (float)y8[q];
