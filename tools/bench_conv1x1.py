@@ -3,7 +3,7 @@
 ustrun_conv2d_fwd (train mode: statistics rows out) and ustrun_conv1x1_dgrad_join, one shape at a time: ms, TFLOP/s and the
 algorithmic GB/s of each launch beside the two roofs.  Development tool.
 
-    python3 tools/bench_conv1x1.py [--n 16] [--reps 10] [--only NAME]
+    python3 tools/bench_conv1x1.py [--n 16] [--reps 10] [--only NAME] [--ops "fwd plain,dgrad join"]
 """
 import argparse
 import ctypes as C
@@ -39,8 +39,10 @@ def main():
     ap.add_argument("--n", type=int, default=16)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--ops", default="", help="comma-separated subset of: fwd affine, fwd plain, dgrad plain, dgrad join")
     a = ap.parse_args()
     lib = l.lib()
+    want_ops = [o.strip() for o in a.ops.split(",") if o.strip()]
     bf = torch.bfloat16
     dt = l.BF16
     print(f"{'shape':22s} {'op':>12s} {'GF':>6s} {'MB':>6s} {'ms':>7s} {'TF/s':>6s} {'GB/s':>6s} {'x':>3s}")
@@ -66,6 +68,8 @@ def main():
         used = C.c_int(0)
         fl = 2.0 * M * ci * co
         for op in ("fwd affine", "fwd plain"):
+            if want_ops and op not in want_ops:
+                continue
             src = l.nhwc_src(x.data_ptr(), ci, hw, hw, sc.data_ptr(), sh.data_ptr(), relu=1) if op == "fwd affine" else l.nhwc_src(x.data_ptr(), ci, hw, hw)
             fn = lambda: l.check(lib.ustrun_conv2d_fwd(C.byref(src), 1, wf.data_ptr(), None, N, hw, hw, co, 1, 1, 1, y.data_ptr(), 0,
                                                        stat.data_ptr(), C.byref(used), dt, None), "fwd")
@@ -84,6 +88,8 @@ def main():
         u2, fused = C.c_int(0), C.c_int(0)
         dsrc = l.nhwc_src(dy.data_ptr(), co, hw, hw)
         for op in ("dgrad plain", "dgrad join"):
+            if want_ops and op not in want_ops:
+                continue
             if op == "dgrad join":
                 fn = lambda: l.check(lib.ustrun_conv1x1_dgrad_join(dy.data_ptr(), wd.data_ptr(), N, hw, hw, co, ci, add.data_ptr(), ref.data_ptr(),
                                                                    dx.data_ptr(), y3.data_ptr(), None, None, stat2.data_ptr(), C.byref(u2),
